@@ -1,0 +1,176 @@
+"""Case definitions shared by ``make_golden.py`` (generator, build container)
+and the tests that replay the fixtures.  No reference import happens here."""
+from __future__ import annotations
+
+import os
+import sys
+
+import torch
+from torch import nn
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+from oracle.topology import UNetSpec  # noqa: E402
+from oracle.unet import OracleUNet, synthetic_state_dict  # noqa: E402
+
+# (image, patch, step)
+STEP_CASES = [
+    ([110], [64], 0.5), ([512, 512, 512], [128, 128, 128], 0.5), ([512, 512, 512], [160, 160, 160], 0.5),
+    ([512, 512, 512], [160, 96, 96], 0.5), ([128, 128, 128], [128, 128, 128], 0.5), ([129, 128, 200], [128, 128, 128], 0.5),
+    ([40, 36, 44], [16, 16, 16], 0.5), ([40, 36, 44], [16, 16, 16], 1.0), ([40, 36, 44], [16, 16, 16], 0.25),
+    ([33, 47, 21], [20, 28, 20], 0.5), ([300, 211, 97], [96, 160, 80], 0.5), ([300, 211, 97], [96, 160, 80], 0.75),
+    ([122, 101, 30], [122, 101, 30], 0.5), ([65, 65], [64, 64], 0.5), ([1000, 777], [512, 448], 0.5),
+    ([17], [16], 0.5), ([18], [16], 0.5), ([19], [16], 0.3), ([100], [7], 0.5), ([100], [7], 1.0), ([101], [10], 0.1),
+    ([255, 256, 257], [128, 128, 128], 0.5), ([511], [160], 0.5), ([513], [160], 0.5), ([320], [160], 0.5),
+    ([321], [160], 0.5), ([240], [160], 0.5), ([241], [160], 0.5), ([400, 400, 400], [160, 96, 96], 0.5),
+    ([160, 96, 96], [160, 96, 96], 0.5), ([161, 97, 98], [160, 96, 96], 0.5), ([96, 512, 512], [48, 192, 192], 0.5),
+    ([73], [24], 0.5), ([74], [24], 0.5), ([75], [24], 0.5), ([76], [24], 0.5), ([77], [24], 0.5), ([78], [24], 0.5),
+    ([79], [24], 0.5), ([80], [24], 0.5), ([81], [24], 0.5), ([82], [24], 0.5), ([83], [24], 0.5), ([84], [24], 0.5),
+    ([85], [24], 0.5), ([86], [24], 0.5), ([87], [24], 0.5), ([88], [24], 0.5), ([89], [24], 0.5), ([90], [24], 0.5),
+    ([45, 45, 45], [30, 30, 30], 0.5), ([46, 46, 46], [30, 30, 30], 0.5),
+]
+
+GAUSS_FULL = [[8, 8, 8], [16, 12, 10], [20, 28, 20], [32, 32, 32], [16, 16, 16], [24, 16, 20]]
+GAUSS_SUMMARY = [[128, 128, 128], [160, 96, 96], [160, 160, 160]]
+
+# spacing, patch  (C1..C5)
+TOPOLOGY_CASES = [
+    ([1.0, 1.0, 1.0], [128, 128, 128]), ([2.0, 0.9765625, 0.9765625], [160, 96, 96]),
+    ([1.0, 1.0, 1.0], [160, 160, 160]), ([3.0, 0.8, 0.8], [40, 224, 192]), ([5.0, 0.7, 0.7], [16, 320, 320]),
+    ([1.5, 1.5, 1.5], [96, 160, 160]), ([1.0, 1.0, 1.0], [64, 64, 64]), ([2.5, 2.5, 1.0], [48, 48, 192]),
+]
+
+_ARCH = {
+    'network_class_name': 'dynamic_network_architectures.architectures.unet.PlainConvUNet',
+    'arch_kwargs': {'n_stages': 6, 'features_per_stage': [32, 64, 128, 256, 320, 320],
+                    'conv_op': 'torch.nn.modules.conv.Conv3d',
+                    'kernel_sizes': [[1, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]],
+                    'strides': [[1, 1, 1], [1, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2], [2, 1, 1]],
+                    'n_conv_per_stage': [2, 2, 2, 2, 2, 2], 'n_conv_per_stage_decoder': [2, 2, 2, 2, 2],
+                    'conv_bias': True, 'norm_op': 'torch.nn.modules.instancenorm.InstanceNorm3d',
+                    'norm_op_kwargs': {'eps': 1e-05, 'affine': True}, 'dropout_op': None, 'dropout_op_kwargs': None,
+                    'nonlin': 'torch.nn.LeakyReLU', 'nonlin_kwargs': {'inplace': True}},
+    '_kw_requires_import': ['conv_op', 'norm_op', 'dropout_op', 'nonlin']}
+
+PLANS_NEW = {
+    'dataset_name': 'Dataset999_Golden', 'plans_name': 'nnUNetPlans',
+    'original_median_spacing_after_transp': [2.0, 0.9765625, 0.9765625],
+    'original_median_shape_after_transp': [300, 512, 512], 'image_reader_writer': 'SimpleITKIO',
+    'transpose_forward': [0, 1, 2], 'transpose_backward': [0, 1, 2],
+    'experiment_planner_used': 'ExperimentPlanner', 'label_manager': 'LabelManager',
+    'foreground_intensity_properties_per_channel': {'0': {'mean': 418.68, 'std': 412.19, 'percentile_00_5': -60.0,
+                                                          'percentile_99_5': 3068.0}},
+    'configurations': {
+        '3d_lowres': {'data_identifier': 'nnUNetPlans_3d_lowres', 'preprocessor_name': 'DefaultPreprocessor',
+                      'batch_size': 2, 'patch_size': [128, 128, 128], 'spacing': [3.0, 2.0, 2.0],
+                      'normalization_schemes': ['CTNormalization'], 'use_mask_for_norm': [False],
+                      'architecture': _ARCH, 'next_stage': '3d_cascade_fullres'},
+        '3d_fullres': {'data_identifier': 'nnUNetPlans_3d_fullres', 'preprocessor_name': 'DefaultPreprocessor',
+                       'batch_size': 2, 'patch_size': [160, 96, 96], 'spacing': [2.0, 0.9765625, 0.9765625],
+                       'normalization_schemes': ['CTNormalization'], 'use_mask_for_norm': [False],
+                       'architecture': _ARCH},
+        '3d_fullres_bs4': {'inherits_from': '3d_fullres', 'batch_size': 4, 'patch_size': [96, 96, 96]},
+        '3d_cascade_fullres': {'inherits_from': '3d_fullres', 'previous_stage': '3d_lowres'},
+    }}
+
+PLANS_OLD = {
+    'dataset_name': 'Dataset998_GoldenOld', 'plans_name': 'nnUNetPlans',
+    'original_median_spacing_after_transp': [1.0, 1.0, 1.0], 'original_median_shape_after_transp': [200, 200, 200],
+    'image_reader_writer': 'SimpleITKIO', 'transpose_forward': [0, 1, 2], 'transpose_backward': [0, 1, 2],
+    'experiment_planner_used': 'ExperimentPlanner', 'label_manager': 'LabelManager',
+    'foreground_intensity_properties_per_channel': {'0': {'mean': 0.0, 'std': 1.0}},
+    'configurations': {
+        '3d_fullres': {'data_identifier': 'nnUNetPlans_3d_fullres', 'preprocessor_name': 'DefaultPreprocessor',
+                       'batch_size': 2, 'patch_size': [128, 128, 128], 'spacing': [1.0, 1.0, 1.0],
+                       'normalization_schemes': ['ZScoreNormalization'], 'use_mask_for_norm': [False],
+                       'UNet_class_name': 'PlainConvUNet', 'UNet_base_num_features': 32,
+                       'n_conv_per_stage_encoder': [2, 2, 2, 2, 2, 2], 'n_conv_per_stage_decoder': [2, 2, 2, 2, 2],
+                       'num_pool_per_axis': [5, 5, 5],
+                       'pool_op_kernel_sizes': [[1, 1, 1], [2, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2]],
+                       'conv_kernel_sizes': [[3, 3, 3]] * 6, 'unet_max_num_features': 320},
+    }}
+
+DATASET_JSONS = {
+    'labels3': {'labels': {'background': 0, 'a': 1, 'b': 2}, 'channel_names': {'0': 'CT'}, 'file_ending': '.nii.gz'},
+    'two_mod': {'labels': {'background': 0, 'a': 1, 'b': 2, 'c': 3}, 'channel_names': {'0': 'T1', '1': 'T2'},
+                'file_ending': '.nii.gz'},
+    'regions': {'labels': {'background': 0, 'whole': [1, 2, 3], 'core': [2, 3], 'enh': 3},
+                'regions_class_order': [1, 2, 3], 'channel_names': {'0': 'T1'}, 'file_ending': '.nii.gz'},
+}
+
+
+def _c(name, kind, shape, patch, heads=3, channels=1, step=0.5, gaussian=True, mirror=None, folds=1, seed=0,
+       act=None, **kw):
+    d = dict(name=name, kind=kind, shape=list(shape), patch=list(patch), heads=heads, channels=channels, step=step,
+             gaussian=gaussian, mirror=mirror, folds=folds, seed=seed, act=act)
+    d.update(kw)
+    return d
+
+
+SW_CASES = [
+    _c('exact_basic', 'exact', (40, 36, 44), (16, 16, 16)),
+    _c('exact_nogauss', 'exact', (40, 36, 44), (16, 16, 16), gaussian=False, seed=1),
+    _c('exact_step1', 'exact', (40, 36, 44), (16, 16, 16), step=1.0, seed=2),
+    _c('exact_mirror0', 'exact', (33, 30, 21), (16, 24, 16), mirror=[0], seed=3, heads=4),
+    _c('exact_mirror012', 'exact', (28, 30, 33), (16, 16, 24), mirror=[0, 1, 2], seed=4, heads=2, channels=2),
+    _c('exact_mirror12_lrelu', 'exact', (24, 30, 33), (16, 16, 16), mirror=[1, 2], seed=5, act='lrelu_half'),
+    _c('exact_smaller_than_patch', 'exact', (11, 30, 9), (16, 16, 16), seed=6, heads=5),
+    _c('exact_equal_patch', 'exact', (16, 16, 16), (16, 16, 16), seed=7),
+    _c('exact_3folds', 'exact', (30, 24, 27), (16, 16, 16), folds=3, seed=8, heads=3),
+    _c('exact_1fold_via_folds', 'exact', (30, 24, 27), (16, 16, 16), folds=1, seed=9, via_folds=True),
+    _c('exact_aniso_patch', 'exact', (48, 20, 37), (32, 8, 16), seed=10, heads=3, channels=2, act='lrelu_half'),
+    _c('unet_basic', 'unet', (40, 36, 44), (16, 16, 32), heads=3, seed=11),
+    _c('unet_mirror_folds', 'unet', (24, 40, 24), (16, 32, 16), heads=2, channels=2, mirror=[0, 1, 2], folds=2, seed=12),
+]
+
+
+class ExactConvNet(nn.Module):
+    """Zero-padded 3x3x3 conv (+ optional LeakyReLU(1/2)) with dyadic weights:
+    every fp32 sum is exact, so results do not depend on summation order."""
+
+    def __init__(self, cin, heads, act=None):
+        super().__init__()
+        self.conv = nn.Conv3d(cin, heads, 3, padding=1, bias=True)
+        self.act = act
+
+    def forward(self, x):
+        y = self.conv(x)
+        return nn.functional.leaky_relu(y, 0.5) if self.act == 'lrelu_half' else y
+
+
+def exact_state_dict(cin, heads, seed):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randint(-4, 5, (heads, cin, 3, 3, 3), generator=g).float() / 8
+    b = torch.randint(-8, 9, (heads,), generator=g).float() / 4
+    return {'conv.weight': w, 'conv.bias': b}
+
+
+def toy_unet_spec(cin, heads):
+    return UNetSpec('plain', cin, heads, [8, 16, 16], [(3, 3, 3)] * 3, [(1, 1, 1), (2, 2, 2), (1, 2, 2)],
+                    [2, 2, 2], [2, 2])
+
+
+def make_case_inputs(case):
+    g = torch.Generator().manual_seed(1000 + case['seed'])
+    shape = (case['channels'], *case['shape'])
+    if case['kind'] == 'exact':
+        return torch.randint(-16, 17, shape, generator=g).float() / 8
+    return torch.randn(shape, generator=g)
+
+
+def make_case_networks(case):
+    """-> ([net per fold], [state_dict per fold])"""
+    nets, params = [], []
+    for f in range(case['folds']):
+        seed = 77 * case['seed'] + f
+        if case['kind'] == 'exact':
+            net = ExactConvNet(case['channels'], case['heads'], case['act'])
+            sd = exact_state_dict(case['channels'], case['heads'], seed)
+        else:
+            spec = toy_unet_spec(case['channels'], case['heads'])
+            net = OracleUNet(spec)
+            sd = synthetic_state_dict(spec, seed)
+        net.load_state_dict(sd)
+        nets.append(net.eval())
+        params.append(sd)
+    return nets, params

@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in this directory FROM THE REFERENCE ITSELF.
+
+Run in the build container only (needs ``/root/reference``):
+
+    python tests/golden/make_golden.py
+
+It imports the reference's own ``nnUNetPredictor``, ``compute_gaussian``,
+``compute_steps_for_sliding_window``, ``PlansManager``, ``LabelManager`` and
+``get_pool_and_conv_props`` (through the import shims in ``ref_shims.py``) and
+stores inputs-by-seed + expected outputs as small ``.json`` / ``.npz`` files.
+The fixtures are data only; no reference source travels.
+
+Two kinds of sliding-window case:
+
+* ``exact`` - the "network" is a zero-padded 3x3x3 convolution (optionally
+  followed by a LeakyReLU with slope 1/2) whose weights and inputs are dyadic
+  rationals, so every fp32 sum is exact whatever the summation order / CPU
+  ISA.  Expected logits are compared BIT FOR BIT.
+* ``unet`` - a seeded 3-stage PlainConvUNet (this repo's ``oracle.unet``
+  restatement, handed to the reference predictor through
+  ``manual_initialization``).  InstanceNorm makes the result depend on the
+  CPU's reduction order in the last ulp, so these are compared with a
+  tolerance; they pin the predictor logic around a realistic network.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import ref_shims  # noqa: E402
+
+ref_shims.install()
+
+from nnunetv2.inference.predict_from_raw_data import nnUNetPredictor  # noqa: E402
+from nnunetv2.inference.sliding_window_prediction import (compute_gaussian,  # noqa: E402
+                                                          compute_steps_for_sliding_window)
+from nnunetv2.utilities.plans_handling.plans_handler import PlansManager  # noqa: E402
+from nnunetv2.utilities.label_handling.label_handling import LabelManager, determine_num_input_channels  # noqa: E402
+from nnunetv2.experiment_planning.experiment_planners.network_topology import get_pool_and_conv_props  # noqa: E402
+
+from golden_cases import (SW_CASES, STEP_CASES, GAUSS_FULL, GAUSS_SUMMARY, TOPOLOGY_CASES, PLANS_NEW,  # noqa: E402
+                          PLANS_OLD, DATASET_JSONS, make_case_inputs, make_case_networks)
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def gen_steps():
+    out = []
+    for image, patch, step in STEP_CASES:
+        out.append({'image': image, 'patch': patch, 'step': step,
+                    'steps': compute_steps_for_sliding_window(tuple(image), tuple(patch), step)})
+    with open(os.path.join(HERE, 'steps.json'), 'w') as f:
+        json.dump(out, f)
+
+
+def gen_gaussian():
+    arrays, summary = {}, []
+    for p in GAUSS_FULL:
+        compute_gaussian.cache_clear()
+        g = compute_gaussian(tuple(p), sigma_scale=1. / 8, value_scaling_factor=10, device=torch.device('cpu'))
+        arrays['g_' + '_'.join(map(str, p))] = bits(g)
+    for p in GAUSS_SUMMARY:
+        compute_gaussian.cache_clear()
+        g = compute_gaussian(tuple(p), sigma_scale=1. / 8, value_scaling_factor=10, device=torch.device('cpu'))
+        b = bits(g)
+        c = [i // 2 for i in p]
+        summary.append({'patch': p, 'sha256': hashlib.sha256(b.tobytes()).hexdigest(),
+                        'min_bits': int(b.min()), 'max_bits': int(b.max()),
+                        'count_at_min': int((b == b.min()).sum()),
+                        'line0': b[:, c[1], c[2]].tolist(), 'line1': b[c[0], :, c[2]].tolist(),
+                        'line2': b[c[0], c[1], :].tolist()})
+    np.savez_compressed(os.path.join(HERE, 'gaussian.npz'), **arrays)
+    with open(os.path.join(HERE, 'gaussian_summary.json'), 'w') as f:
+        json.dump(summary, f)
+
+
+def gen_sliding_window():
+    arrays = {}
+    for case in SW_CASES:
+        name = case['name']
+        image = make_case_inputs(case)
+        nets, params = make_case_networks(case)
+        plans = PlansManager({'dataset_name': 'Dataset999_Golden', 'plans_name': 'nnUNetPlans',
+                              'configurations': {'3d_fullres': {'patch_size': list(case['patch']),
+                                                                'architecture': {'network_class_name': 'toy',
+                                                                                 'arch_kwargs': {},
+                                                                                 '_kw_requires_import': []}}}})
+        dataset_json = {'labels': {('background' if i == 0 else f'c{i}'): i for i in range(case['heads'])},
+                        'channel_names': {str(i): 'CT' for i in range(case['channels'])}, 'file_ending': '.nii.gz'}
+        pred = nnUNetPredictor(tile_step_size=case['step'], use_gaussian=case['gaussian'],
+                               use_mirroring=case['mirror'] is not None, perform_everything_on_device=False,
+                               device=torch.device('cpu'), verbose=False, allow_tqdm=False)
+        pred.manual_initialization(nets[0], plans, plans.get_configuration('3d_fullres'), params, dataset_json,
+                                   'nnUNetTrainer', tuple(case['mirror']) if case['mirror'] is not None else None)
+        compute_gaussian.cache_clear()
+        torch.set_num_threads(4)
+        if case['folds'] > 1 or case.get('via_folds', False):
+            out = pred.predict_logits_from_preprocessed_data(image)
+        else:
+            out = pred.predict_sliding_window_return_logits(image)
+        assert out.dtype == torch.half and out.shape == (case['heads'], *image.shape[1:])
+        arrays[name] = bits(out)
+        lm = pred.label_manager
+        arrays[name + '__seg'] = lm.convert_logits_to_segmentation(out).numpy().astype(np.int16)
+        print(name, tuple(out.shape), float(out.float().abs().max()))
+    # region-based label conversion on one case's logits
+    case = SW_CASES[0]
+    logits = torch.from_numpy(arrays[case['name']].view(np.int16)).view(torch.half)
+    lm = LabelManager(DATASET_JSONS['regions']['labels'], DATASET_JSONS['regions']['regions_class_order'])
+    assert lm.num_segmentation_heads == logits.shape[0]
+    arrays['regions__seg'] = lm.convert_logits_to_segmentation(logits).numpy().astype(np.int16)
+    np.savez_compressed(os.path.join(HERE, 'sliding_window.npz'), **arrays)
+
+
+def gen_plans():
+    out = {}
+    for tag, plans in (('new', PLANS_NEW), ('old', PLANS_OLD)):
+        import copy
+        import warnings
+        pm = PlansManager(copy.deepcopy(plans))
+        res = {}
+        for cfg in pm.available_configurations:
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                cm = pm.get_configuration(cfg)
+            res[cfg] = {'patch_size': list(cm.patch_size),
+                        'network_class_name': cm.network_arch_class_name,
+                        'arch_kwargs': json.loads(json.dumps(cm.network_arch_init_kwargs, default=str)),
+                        'pool_op_kernel_sizes': json.loads(json.dumps(cm.pool_op_kernel_sizes)),
+                        'previous_stage': cm.previous_stage_name}
+            for dj_name, dj in DATASET_JSONS.items():
+                lm = pm.get_label_manager(dj)
+                res[cfg][f'heads__{dj_name}'] = lm.num_segmentation_heads
+                res[cfg][f'cin__{dj_name}'] = determine_num_input_channels(pm, cm, dj)
+        out[tag] = res
+    with open(os.path.join(HERE, 'plans_expected.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+
+
+def gen_topology():
+    out = []
+    for spacing, patch in TOPOLOGY_CASES:
+        npool, strides, kernels, new_patch, div = get_pool_and_conv_props(tuple(spacing), tuple(patch), 4, 999999)
+        out.append({'spacing': spacing, 'patch': patch, 'num_pool': [int(i) for i in npool],
+                    'strides': [list(map(int, s)) for s in strides], 'kernels': [list(map(int, k)) for k in kernels],
+                    'patch_out': [int(i) for i in new_patch], 'divisible_by': [int(i) for i in div]})
+    with open(os.path.join(HERE, 'topology.json'), 'w') as f:
+        json.dump(out, f)
+
+
+if __name__ == '__main__':
+    gen_steps()
+    gen_gaussian()
+    gen_topology()
+    gen_plans()
+    gen_sliding_window()
+    print('golden vectors written to', HERE)

@@ -1,0 +1,126 @@
+"""The oracle (CPU restatement) replayed against golden vectors that were
+produced by the reference's own code (tests/golden/make_golden.py).  CPU only."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_cases import SW_CASES, DATASET_JSONS, make_case_inputs, make_case_networks
+from oracle import sliding_window as osw
+from oracle import topology as otopo
+
+
+def _bits(t):
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def test_tile_starts_match_reference(golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, 'steps.json')))
+    assert len(cases) >= 50
+    for c in cases:
+        assert osw.tile_starts(c['image'], c['patch'], c['step']) == c['steps'], c
+
+
+def test_tile_starts_known_answers():
+    # the worked example in the reference's own comment (sliding_window_prediction.py:35-36)
+    assert osw.tile_starts([110], [64], 0.5) == [[0, 23, 46]]
+    assert osw.tile_starts([512], [128], 0.5) == [[0, 64, 128, 192, 256, 320, 384]]
+    assert osw.tile_starts([512], [160], 0.5) == [[0, 70, 141, 211, 282, 352]]
+    assert osw.tile_starts([128], [128], 0.5) == [[0]]
+
+
+def test_gaussian_full_maps_bit_exact(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'gaussian.npz'))
+    for key in z.files:
+        patch = tuple(int(i) for i in key.split('_')[1:])
+        got = _bits(osw.gaussian_weight(patch))
+        assert np.array_equal(got, z[key]), key
+
+
+def test_gaussian_large_maps_hash(golden_dir):
+    for s in json.load(open(os.path.join(golden_dir, 'gaussian_summary.json'))):
+        b = _bits(osw.gaussian_weight(tuple(s['patch'])))
+        assert int(b.max()) == s['max_bits'] and int(b.min()) == s['min_bits']
+        assert int((b == b.min()).sum()) == s['count_at_min']
+        c = [i // 2 for i in s['patch']]
+        assert b[:, c[1], c[2]].tolist() == s['line0']
+        assert b[c[0], :, c[2]].tolist() == s['line1']
+        assert b[c[0], c[1], :].tolist() == s['line2']
+        assert hashlib.sha256(b.tobytes()).hexdigest() == s['sha256']
+
+
+def test_gaussian_clamp_value():
+    g = osw.gaussian_weight((128, 128, 128))
+    assert float(g.max()) == 10.0
+    assert float(g.min()) == pytest.approx(5.96e-8, rel=1e-2)      # smallest fp16 subnormal
+
+
+def test_topology_planner_matches_reference(golden_dir):
+    for c in json.load(open(os.path.join(golden_dir, 'topology.json'))):
+        strides, kernels, npool = otopo.plan_pool_and_kernels(c['spacing'], c['patch'])
+        assert [list(s) for s in strides] == c['strides'], c
+        assert [list(k) for k in kernels] == c['kernels'], c
+        assert npool == c['num_pool']
+
+
+def _run_case(case, accum='fp16'):
+    torch.set_num_threads(4)
+    image = make_case_inputs(case)
+    nets, _ = make_case_networks(case)
+    kw = dict(step=case['step'], use_gaussian=case['gaussian'], mirror_axes=case['mirror'], accum=accum)
+    if case['folds'] > 1 or case.get('via_folds', False):
+        return osw.ensemble_logits(nets, image, case['patch'], case['heads'], **kw)
+    return osw.sliding_window_logits(nets[0], image, case['patch'], case['heads'], **kw)
+
+
+@pytest.mark.parametrize('case', [c for c in SW_CASES if c['kind'] == 'exact'], ids=lambda c: c['name'])
+def test_sliding_window_exact_cases_bit_identical(case, golden_dir):
+    z = np.load(os.path.join(golden_dir, 'sliding_window.npz'))
+    out = _run_case(case)
+    assert out.dtype == torch.half
+    assert np.array_equal(_bits(out), z[case['name']])
+    seg = osw.logits_to_labels(out).numpy().astype(np.int16)
+    assert np.array_equal(seg, z[case['name'] + '__seg'])
+
+
+@pytest.mark.parametrize('case', [c for c in SW_CASES if c['kind'] == 'unet'], ids=lambda c: c['name'])
+def test_sliding_window_unet_cases_close(case, golden_dir):
+    z = np.load(os.path.join(golden_dir, 'sliding_window.npz'))
+    out = _run_case(case).float().numpy()
+    ref = torch.from_numpy(z[case['name']].view(np.int16)).view(torch.half).float().numpy()
+    # same algorithm, same torch primitives; only the CPU's reduction order may differ.
+    # Outside the 5.96e-8-weight border (where the reference's own fp16 accumulators
+    # quantise to +-0.5) agreement is at fp16 resolution.
+    err = np.abs(out - ref)
+    assert np.median(err) < 1e-3
+    assert (err > 0.02 * max(1.0, np.abs(ref).max())).mean() < 2e-3
+
+
+def test_region_label_conversion(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'sliding_window.npz'))
+    logits = torch.from_numpy(z[SW_CASES[0]['name']].view(np.int16)).view(torch.half)
+    seg = osw.logits_to_labels(logits, DATASET_JSONS['regions']['regions_class_order'])
+    assert np.array_equal(seg.numpy(), z['regions__seg'])
+
+
+def test_fp32_accumulator_is_close_to_fp16_reference_away_from_border():
+    case = SW_CASES[0]
+    a = _run_case(case, 'fp16').float()
+    b = _run_case(case, 'fp32')
+    assert b.dtype == torch.float32
+    inner = (slice(None), slice(4, -4), slice(4, -4), slice(4, -4))
+    assert (a[inner] - b[inner]).abs().max() < 0.05
+
+
+def test_inf_check_raises():
+    net = lambda x: torch.full((1, 2, *x.shape[2:]), 7e4)           # overflows fp16 after weighting
+    with pytest.raises(RuntimeError, match='Encountered inf'):
+        osw.sliding_window_logits(net, torch.zeros(1, 16, 16, 16), (8, 8, 8), 2)
+
+
+def test_ndim_assert():
+    with pytest.raises(AssertionError):
+        osw.sliding_window_logits(lambda x: x, torch.zeros(16, 16, 16), (8, 8, 8), 1)
