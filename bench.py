@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""Benchmark of the sliding-window inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): a distilled r=2
+PlainConvUNet student with the fast_nnunet_bone_turbo geometry - patch
+160x96x96, 61 classes, anisotropic kernels/strides planned from the .ini's
+target spacing - predicting one synthetic 512^3 CT with half-overlap tiles and
+Gaussian blending: 600 patches per volume.  Synthetic data, random-init weights
+(seed 1234).  One step = one whole volume through
+``nnUNetPredictor.predict_sliding_window_return_logits`` with the volume already
+resident in HBM.  N > 1 shards the patches of the SAME volume over the ranks
+(strong scaling) with a halo exchange over RCCL.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus ``roofline`` and
+``cpu_baseline`` (N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16, MI355X_MICROARCH.md "Chip-level parameters"
+
+WORKLOADS = {
+    # name: (spacing, patch, heads, reduction)
+    'bone_turbo_r2': ((2.0, 0.9765625, 0.9765625), (160, 96, 96), 61, 2),
+    'iso128_r2': ((1.0, 1.0, 1.0), (128, 128, 128), 2, 2),
+    'iso128_teacher': ((1.0, 1.0, 1.0), (128, 128, 128), 2, 1),
+}
+
+
+def plan_topology(spacing, patch, min_edge=4):
+    """Strides / kernels per stage from spacing + patch (same planning rule the reference uses,
+    experiment_planning/experiment_planners/network_topology.py:30-108; restated in the product because
+    the benchmark must not depend on the oracle)."""
+    dim = len(spacing)
+    sp, size = [float(s) for s in spacing], [float(p) for p in patch]
+    strides, kernels, k, pooled = [[1] * dim], [], [1] * dim, [0] * dim
+    while True:
+        ok = [i for i in range(dim) if size[i] >= 2 * min_edge]
+        if not ok:
+            break
+        finest = min(sp[i] for i in ok)
+        ok = [i for i in ok if sp[i] / finest < 2]
+        if len(ok) == 1 and not size[ok[0]] >= 3 * min_edge:
+            break
+        if not ok:
+            break
+        for d in range(dim):
+            if k[d] != 3 and sp[d] / min(sp) < 2:
+                k[d] = 3
+        st = [1] * dim
+        for i in ok:
+            st[i] = 2
+            pooled[i] += 1
+            sp[i] *= 2
+            size[i] = float(np.ceil(size[i] / 2))
+        strides.append(st)
+        kernels.append(list(k))
+    kernels.append([3] * dim)
+    return strides, kernels
+
+
+def synthetic_checkpoint(features, kernels, strides, in_ch, heads, seed=1234):
+    """Random-init state dict in the checkpoint key schema: He-normal(a=0.01) conv weights like the
+    reference's InitWeights_He (utilities/network_initialization.py:4-12), small biases,
+    InstanceNorm gamma~U(0.5,1.5), beta~N(0,0.1)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    gain = (2.0 / (1 + 0.01 ** 2)) ** 0.5
+
+    def conv(prefix, cout, cin, k):
+        fan_in = cin * k[0] * k[1] * k[2]
+        sd[prefix + '.conv.weight'] = torch.randn(cout, cin, *k, generator=g) * (gain / fan_in ** 0.5)
+        sd[prefix + '.conv.bias'] = torch.randn(cout, generator=g) * 0.05
+        sd[prefix + '.norm.weight'] = torch.rand(cout, generator=g) + 0.5
+        sd[prefix + '.norm.bias'] = torch.randn(cout, generator=g) * 0.1
+
+    n = len(features)
+    cin = in_ch
+    for s in range(n):
+        for i in range(2):
+            conv(f'encoder.stages.{s}.0.convs.{i}', features[s], cin, kernels[s])
+            cin = features[s]
+    for d in range(n - 1):
+        below, skip, st = features[-(d + 1)], features[-(d + 2)], strides[-(d + 1)]
+        fan_in = below * st[0] * st[1] * st[2]
+        sd[f'decoder.transpconvs.{d}.weight'] = torch.randn(below, skip, *st, generator=g) * (gain / fan_in ** 0.5)
+        sd[f'decoder.transpconvs.{d}.bias'] = torch.randn(skip, generator=g) * 0.05
+        conv(f'decoder.stages.{d}.convs.0', skip, 2 * skip, kernels[-(d + 2)])
+        conv(f'decoder.stages.{d}.convs.1', skip, skip, kernels[-(d + 2)])
+        sd[f'decoder.seg_layers.{d}.weight'] = torch.randn(heads, skip, 1, 1, 1, generator=g) * (gain / skip ** 0.5)
+        sd[f'decoder.seg_layers.{d}.bias'] = torch.randn(heads, generator=g) * 0.05
+    return sd
+
+
+def build_predictor(workload, device, batch, accumulate_in):
+    from fast_nnunet_amd import nnUNetPredictor
+    from fast_nnunet_amd.plans import PlansManager
+    spacing, patch, heads, r = WORKLOADS[workload]
+    strides, kernels = plan_topology(spacing, patch)
+    n = len(strides)
+    features = [max(min(320, 32 * 2 ** i) // r, 8) for i in range(n)]
+    sd = synthetic_checkpoint(features, kernels, strides, 1, heads)
+    arch = {'network_class_name': 'dynamic_network_architectures.architectures.unet.PlainConvUNet',
+            'arch_kwargs': {'n_stages': n, 'features_per_stage': [min(320, 32 * 2 ** i) for i in range(n)],
+                            'kernel_sizes': kernels, 'strides': strides, 'n_conv_per_stage': [2] * n,
+                            'n_conv_per_stage_decoder': [2] * (n - 1), 'conv_bias': True,
+                            'norm_op_kwargs': {'eps': 1e-5, 'affine': True}},
+            '_kw_requires_import': []}
+    pm = PlansManager({'dataset_name': 'Dataset000_Synthetic', 'plans_name': 'nnUNetPlans',
+                       'configurations': {'3d_fullres': {'patch_size': list(patch), 'spacing': list(spacing),
+                                                         'architecture': arch}}})
+    dj = {'labels': {('background' if i == 0 else f'class_{i}'): i for i in range(heads)},
+          'channel_names': {'0': 'CT'}, 'file_ending': '.nii.gz'}
+    p = nnUNetPredictor(tile_step_size=0.5, use_gaussian=True, use_mirroring=False, perform_everything_on_device=True,
+                        device=device, allow_tqdm=False, accumulate_in=accumulate_in, patches_per_forward=batch)
+    p._reduction = None
+    p.manual_initialization(None, pm, pm.get_configuration('3d_fullres'), [sd], dj, 'nnUNetDistillationTrainer', None)
+    return p, sd, dict(features=features, kernels=kernels, strides=strides, patch=patch, heads=heads, r=r)
+
+
+def synthetic_volume(size, device):
+    """Preprocessed CT-like tensor: HU ~ N(418.68, 412.19) clipped to [-60, 3068], z-scored with the
+    fast_nnunet_bone_turbo constants (engine/config/fast_nnunet_bone_turbo.ini:15-18)."""
+    g = torch.Generator(device='cpu').manual_seed(0)
+    out = torch.empty((1, size, size, size), dtype=torch.float32)
+    for x in range(0, size, 64):                       # chunked: keeps the host working set small
+        hu = torch.randn((min(64, size - x), size, size), generator=g) * 412.1883239746094 + 418.6798400878906
+        out[0, x:x + hu.shape[0]] = (hu.clamp_(-60.0, 3068.0) - 418.6798400878906) / 412.1883239746094
+    return out.to(device)
+
+
+def cpu_baseline(sd, info, seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference path: fp32 network, fp16 Gaussian accumulate) timed on
+    the host cores on a bounded sample of the same workload."""
+    from oracle import sliding_window as osw
+    from oracle.topology import UNetSpec
+    from oracle.unet import build as build_oracle
+    n = len(info['features'])
+    spec = UNetSpec('plain', 1, info['heads'], info['features'], [tuple(k) for k in info['kernels']],
+                    [tuple(s) for s in info['strides']], [2] * n, [2] * (n - 1))
+    net = build_oracle(spec, sd)
+    patch = info['patch']
+    threads = torch.get_num_threads()
+    # sub-volume that holds exactly 2 x 2 x 2 = 8 patches at step 0.5
+    shape = tuple(int(p * 1.5) for p in patch)
+    image = synthetic_volume(max(shape), torch.device('cpu'))[:, :shape[0], :shape[1], :shape[2]].contiguous()
+    with torch.inference_mode():
+        t0 = time.perf_counter()
+        net(image[:, :patch[0], :patch[1], :patch[2]][None])            # warm-up + per-patch estimate
+        one = time.perf_counter() - t0
+    n_patches = 8
+    if one * 9 > seconds_budget:                                          # slow host: shrink the sample
+        shape = (patch[0], patch[1], int(patch[2] * 1.5))
+        image = image[:, :shape[0], :shape[1], :shape[2]].contiguous()
+        n_patches = 2
+    t0 = time.perf_counter()
+    osw.sliding_window_logits(net, image, patch, info['heads'], step=0.5, use_gaussian=True, accum='fp16')
+    dt = time.perf_counter() - t0
+    return {'value': round(n_patches / dt, 4), 'unit': 'patches/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n_patches} patches ({shape[0]}x{shape[1]}x{shape[2]} sub-volume of the same synthetic CT), '
+                      f'fp32 network + fp16 accumulators, torch {torch.__version__} CPU, '
+                      f'{os.cpu_count()} host cpus visible',
+            's_per_patch': round(dt / n_patches, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='bone_turbo_r2', choices=list(WORKLOADS))
+    ap.add_argument('--volume', type=int, default=512)
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--accum', default='fp16', choices=['fp16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X; the engine has no CPU path')
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+
+    accumulate_in = 'fp32' if distributed else args.accum       # halo sums are exchanged in fp32
+    predictor, sd, info = build_predictor(args.workload, device, args.batch, accumulate_in)
+    vol = synthetic_volume(args.volume, device)
+    from fast_nnunet_amd import capi
+    n_patches = capi.plan_volume(info['patch'], vol.shape[1:], 0.5)[2].shape[0]
+
+    if distributed:
+        from fast_nnunet_amd.dist import ShardedPredictor
+        import torch.distributed as dist
+        runner = ShardedPredictor(predictor, dist.group.WORLD)
+        step_fn = lambda: runner.predict_sliding_window_return_logits(vol)
+        barrier = lambda: dist.barrier()
+    else:
+        step_fn = lambda: predictor.predict_sliding_window_return_logits(vol)
+        barrier = lambda: None
+
+    for _ in range(args.warmup):
+        out = step_fn()
+        del out
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step_fn()
+        del out
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if distributed:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    flops_patch, act_bytes_patch = predictor._engine.patch_work()
+    result = {
+        'metric': '3d_fullres patches/sec (distilled r=2 student, sliding window, one 512^3 CT)',
+        'value': round(n_patches * args.steps / dt, 3),
+        'unit': 'patches/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(dt / args.steps * 1e3, 3),
+        'sec_per_volume': round(dt / args.steps, 4),
+        'higher_is_better': True,
+        'scaling': 'strong',
+        'vs_baseline': None,
+        'dtype': 'f16',
+        'data': 'synthetic',
+        'config': {'workload': f'{args.workload}: PlainConvUNet student r={info["r"]}, features {info["features"]}, '
+                               f'patch {"x".join(map(str, info["patch"]))}, {info["heads"]} classes, '
+                               f'{args.volume}^3 volume, tile_step_size 0.5, Gaussian on, mirroring off, '
+                               f'{n_patches} patches/volume',
+                   'patches_per_forward': args.batch,
+                   'accumulators': accumulate_in,
+                   'gflop_per_patch': round(flops_patch / 1e9, 2),
+                   'parallelism': f'patch-sharded x{world}' if distributed else 'single GPU'},
+    }
+
+    if rank == 0 and not distributed and not args.no_roofline:
+        # one extra, identical step with HIP events around every launch (recorded by the engine on the
+        # launch stream) -> duration of the dominant kernel family (conv3d_mfma_kernel)
+        predictor._engine.set_profiling(True)
+        out = step_fn()
+        del out
+        torch.cuda.synchronize()
+        pr = predictor._engine.profile()
+        predictor._engine.set_profiling(False)
+        achieved = pr.conv_flops / (pr.conv_ms * 1e-3) / 1e12 if pr.conv_ms > 0 else 0.0
+        result['roofline'] = {
+            'kernel': 'conv3d_mfma_kernel', 'bound': 'mfma',
+            'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
+            'traffic': None,
+            'launches': int(pr.conv_launches),
+            'avg_launch_us': round(pr.conv_ms * 1e3 / max(1, pr.conv_launches), 2),
+            'flop_per_launch': round(pr.conv_flops / max(1, pr.conv_launches) / 1e9, 3),
+            'flop_unit': 'GFLOP (2*MACs of the conv layers, SURVEY.md App. D method)',
+            'time_share_ms': {'conv3d_mfma': round(pr.conv_ms, 2), 'stem': round(pr.stem_ms, 2),
+                              'tconv': round(pr.tconv_ms, 2), 'seg_head_accumulate': round(pr.head_ms, 2),
+                              'finalize': round(pr.finalize_ms, 2)},
+            'whole_net_tflops': round(flops_patch * n_patches / (dt / args.steps) / 1e12, 2),
+        }
+    if rank == 0 and not distributed and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(sd, info)
+    if rank == 0:
+        print(json.dumps(result))
+    if distributed:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,183 @@
+"""checkpoint / plans -> engine topology (``fnn_arch_desc``) + canonical weight blob.
+
+The reference rebuilds the network object from ``plans.json`` through
+``get_network_from_plans`` (utilities/get_network_from_plans.py:9-43) and, for a
+distilled student, through ``nnUNetDistillationTrainer.build_network_architecture``
+(training/nnUNetTrainer/variants/nnUNetDistillationTrainer.py:605-758, rule
+``max(f // r, 8)`` at :678) - which its own predictor cannot call.
+The engine does not need a module object, only shapes, so the topology is read
+from the state dict itself: feature widths, kernel sizes, conv counts and (from
+the transposed-conv kernels) the strides.  That is robust for any reduction
+factor and is cross-checked against the plans when they are available.
+
+State-dict key schema; aliases (`all_modules.*`,
+`decoder.encoder.*`) and wrapper prefixes (`module.`, `_orig_mod.`,
+`network.`) are canonicalised away.
+"""
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass, field
+from typing import Dict, List, Mapping, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import capi
+
+_PREFIXES = ('module.', '_orig_mod.', 'network.')
+
+
+@dataclass
+class ArchSpec:
+    kind: int
+    in_channels: int
+    num_heads: int
+    features: List[int]
+    kernels: List[Tuple[int, int, int]]
+    strides: List[Tuple[int, int, int]]
+    n_conv_enc: List[int]
+    n_conv_dec: List[int]
+    patch: Tuple[int, int, int]
+    eps: float = 1e-5
+    slope: float = 0.01
+
+    @property
+    def n_stages(self) -> int:
+        return len(self.features)
+
+    def to_desc(self) -> capi.ArchDesc:
+        if self.n_stages > capi.FNN_MAX_STAGES:
+            raise NotImplementedError(f'{self.n_stages} stages > {capi.FNN_MAX_STAGES}')
+        d = capi.ArchDesc()
+        d.kind, d.n_stages, d.in_channels, d.num_heads = self.kind, self.n_stages, self.in_channels, self.num_heads
+        for s in range(self.n_stages):
+            d.features[s] = self.features[s]
+            d.n_conv_enc[s] = self.n_conv_enc[s]
+            for a in range(3):
+                d.kernels[s][a] = self.kernels[s][a]
+                d.strides[s][a] = self.strides[s][a]
+        for s in range(self.n_stages - 1):
+            d.n_conv_dec[s] = self.n_conv_dec[s]
+        for a in range(3):
+            d.patch[a] = int(self.patch[a])
+        d.eps, d.slope = self.eps, self.slope
+        return d
+
+
+def canonical_state_dict(state_dict: Mapping[str, object]) -> Dict[str, np.ndarray]:
+    """Strip wrapper prefixes, drop alias keys, convert to float32 numpy."""
+    out = {}
+    for k, v in state_dict.items():
+        changed = True
+        while changed:
+            changed = False
+            for p in _PREFIXES:
+                if k.startswith(p):
+                    k, changed = k[len(p):], True
+        if '.all_modules.' in k or k.startswith('decoder.encoder.'):
+            continue
+        arr = v.detach().cpu().float().numpy() if hasattr(v, 'detach') else np.asarray(v, dtype=np.float32)
+        out[k] = np.ascontiguousarray(arr, dtype=np.float32)
+    return out
+
+
+def _count(sd, pattern: str) -> int:
+    rx = re.compile(pattern)
+    idx = {int(m.group(1)) for k in sd for m in [rx.match(k)] if m}
+    return (max(idx) + 1) if idx else 0
+
+
+def spec_from_state_dict(state_dict: Mapping[str, object], patch: Sequence[int], eps: float = 1e-5,
+                         slope: float = 0.01) -> ArchSpec:
+    sd = canonical_state_dict(state_dict)
+    if any(k.startswith('encoder.stem.') or '.blocks.' in k for k in sd):
+        raise NotImplementedError('ResidualEncoderUNet checkpoints are recognised but the residual-encoder blocks '
+                                  'are not implemented in the HIP engine yet')
+    n = _count(sd, r'encoder\.stages\.(\d+)\.')
+    if n < 2:
+        raise RuntimeError('state dict does not look like a PlainConvUNet (no encoder.stages.*)')
+    feats, kernels, n_enc = [], [], []
+    for s in range(n):
+        w = sd[f'encoder.stages.{s}.0.convs.0.conv.weight']
+        if w.ndim != 5:
+            raise NotImplementedError('only 3-D (Conv3d) networks are supported')
+        feats.append(int(w.shape[0]))
+        kernels.append(tuple(int(i) for i in w.shape[2:]))
+        n_enc.append(_count(sd, rf'encoder\.stages\.{s}\.0\.convs\.(\d+)\.'))
+    strides = [(1, 1, 1)] * n
+    n_dec = []
+    for d in range(n - 1):
+        tw = sd[f'decoder.transpconvs.{d}.weight']
+        strides[n - 1 - d] = tuple(int(i) for i in tw.shape[2:])
+        n_dec.append(_count(sd, rf'decoder\.stages\.{d}\.convs\.(\d+)\.'))
+    in_ch = int(sd['encoder.stages.0.0.convs.0.conv.weight'].shape[1])
+    heads = int(sd[f'decoder.seg_layers.{n - 2}.weight'].shape[0])
+    return ArchSpec(capi.FNN_NET_PLAIN, in_ch, heads, feats, kernels, strides, n_enc, n_dec,
+                    tuple(int(i) for i in patch), eps, slope)
+
+
+def check_against_plans(spec: ArchSpec, arch_kwargs: dict, reduction: Optional[int] = None):
+    """Raise if the checkpoint disagrees with the plans' architecture block."""
+    n = int(arch_kwargs['n_stages'])
+    if n != spec.n_stages:
+        raise RuntimeError(f'checkpoint has {spec.n_stages} stages, plans say {n}')
+    ks = arch_kwargs['kernel_sizes']
+    plan_k = [tuple(k) if not isinstance(k, int) else (k,) * 3 for k in (ks if not isinstance(ks, int) else [ks] * n)]
+    if [tuple(k) for k in spec.kernels] != [tuple(int(i) for i in k) for k in plan_k]:
+        raise RuntimeError(f'kernel sizes differ: checkpoint {spec.kernels} vs plans {plan_k}')
+    plan_s = [tuple(int(i) for i in s) for s in arch_kwargs['strides']]
+    if list(spec.strides) != plan_s:
+        raise RuntimeError(f'strides differ: checkpoint {spec.strides} vs plans {plan_s}')
+    if reduction is not None:
+        want = [max(int(f) // reduction, 8) for f in arch_kwargs['features_per_stage']]
+        if want != spec.features:
+            raise RuntimeError(f'features {spec.features} do not match max(f // {reduction}, 8) = {want}')
+
+
+def weight_blob(spec: ArchSpec, state_dict: Mapping[str, object]) -> np.ndarray:
+    """Flatten the parameters in the order ``fnn_load_weights`` documents."""
+    sd = canonical_state_dict(state_dict)
+    parts: List[np.ndarray] = []
+
+    def conv_block(prefix):
+        w = sd[prefix + '.conv.weight']
+        parts.append(w.reshape(-1))
+        b = sd.get(prefix + '.conv.bias')
+        parts.append(b if b is not None else np.zeros(w.shape[0], np.float32))
+        parts.append(sd[prefix + '.norm.weight'])
+        parts.append(sd[prefix + '.norm.bias'])
+
+    n = spec.n_stages
+    for s in range(n):
+        for i in range(spec.n_conv_enc[s]):
+            conv_block(f'encoder.stages.{s}.0.convs.{i}')
+    for d in range(n - 1):
+        tw = sd[f'decoder.transpconvs.{d}.weight']
+        parts.append(tw.reshape(-1))
+        tb = sd.get(f'decoder.transpconvs.{d}.bias')
+        parts.append(tb if tb is not None else np.zeros(tw.shape[1], np.float32))
+        for i in range(spec.n_conv_dec[d]):
+            conv_block(f'decoder.stages.{d}.convs.{i}')
+    parts.append(sd[f'decoder.seg_layers.{n - 2}.weight'].reshape(-1))
+    parts.append(sd[f'decoder.seg_layers.{n - 2}.bias'])
+    return np.concatenate([p.astype(np.float32, copy=False).reshape(-1) for p in parts])
+
+
+def spec_from_plans(arch_class_name: str, arch_kwargs: dict, in_channels: int, num_heads: int, patch: Sequence[int],
+                    reduction: int = 1) -> ArchSpec:
+    """Topology from the plans alone (teacher: reduction 1; student: features ``max(f // r, 8)``)."""
+    if 'Residual' in arch_class_name or 'ResEnc' in arch_class_name:
+        raise NotImplementedError('ResidualEncoderUNet is not implemented in the HIP engine yet')
+    n = int(arch_kwargs['n_stages'])
+    feats = [max(int(f) // reduction, 8) if reduction != 1 else int(f) for f in arch_kwargs['features_per_stage']]
+    ks = arch_kwargs['kernel_sizes']
+    kernels = [(int(ks),) * 3] * n if isinstance(ks, int) else [
+        tuple(int(i) for i in (k[0] if isinstance(k[0], (list, tuple)) else k)) for k in ks]
+    strides = [tuple(int(i) for i in s) for s in arch_kwargs['strides']]
+    enc = arch_kwargs['n_conv_per_stage']
+    enc = [int(enc)] * n if isinstance(enc, int) else [int(i) for i in enc]
+    dec = arch_kwargs['n_conv_per_stage_decoder']
+    dec = [int(dec)] * (n - 1) if isinstance(dec, int) else [int(i) for i in dec]
+    eps = float((arch_kwargs.get('norm_op_kwargs') or {}).get('eps', 1e-5))
+    return ArchSpec(capi.FNN_NET_PLAIN, in_channels, num_heads, feats, kernels, strides, enc, dec,
+                    tuple(int(i) for i in patch), eps)

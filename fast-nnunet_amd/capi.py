@@ -1,0 +1,254 @@
+"""ctypes binding of the C ABI in ``include/fnn.h`` (``csrc/libfnn_hip.so``).
+
+This is the stub a maintainer of the reference would add to call the engine
+from ``nnUNetPredictor``.  There is no CPU fallback: if the
+HIP library is missing or no GPU is visible the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+FNN_MAX_STAGES = 8
+FNN_OK, FNN_E_INVALID, FNN_E_HIP, FNN_E_INF, FNN_E_UNSUPPORTED, FNN_E_STATE = 0, -1, -2, -3, -4, -5
+FNN_NET_PLAIN, FNN_NET_RESENC = 0, 1
+FNN_ACC_FP16_REFERENCE, FNN_ACC_FP32 = 0, 1
+FNN_OUT_F16, FNN_OUT_F32 = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libfnn_hip.so')
+
+
+class ArchDesc(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('n_stages', C.c_int32), ('in_channels', C.c_int32), ('num_heads', C.c_int32),
+                ('features', C.c_int32 * FNN_MAX_STAGES),
+                ('kernels', (C.c_int32 * 3) * FNN_MAX_STAGES),
+                ('strides', (C.c_int32 * 3) * FNN_MAX_STAGES),
+                ('n_conv_enc', C.c_int32 * FNN_MAX_STAGES),
+                ('n_conv_dec', C.c_int32 * FNN_MAX_STAGES),
+                ('patch', C.c_int32 * 3),
+                ('eps', C.c_float), ('slope', C.c_float)]
+
+
+class Opts(C.Structure):
+    _fields_ = [('tile_step_size', C.c_float), ('use_gaussian', C.c_int32), ('n_mirror_axes', C.c_int32),
+                ('mirror_axes', C.c_int32 * 3), ('accum', C.c_int32), ('out_dtype', C.c_int32),
+                ('batch', C.c_int32), ('stream', C.c_void_p)]
+
+
+class Profile(C.Structure):
+    _fields_ = [('total_ms', C.c_double), ('conv_ms', C.c_double), ('stem_ms', C.c_double),
+                ('tconv_ms', C.c_double), ('head_ms', C.c_double), ('finalize_ms', C.c_double),
+                ('conv_launches', C.c_int64), ('conv_flops', C.c_double), ('n_patches', C.c_int64)]
+
+
+EXPORTS = ['fnn_abi_version', 'fnn_last_error', 'fnn_create', 'fnn_destroy', 'fnn_weight_count', 'fnn_load_weights',
+           'fnn_set_gaussian', 'fnn_predict_volume', 'fnn_predict_volume_ensemble', 'fnn_accumulate_patches',
+           'fnn_normalize_slab', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_compute_steps', 'fnn_plan_volume',
+           'fnn_set_profiling', 'fnn_get_profile', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d']
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load_library() -> C.CDLL:
+    """Load ``libfnn_hip.so``; raises if it was not built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise EngineError(f'{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` '
+                          f'(or `python -c "import __graft_entry__ as g; g.build()"`). '
+                          f'There is no CPU fallback for the inference engine.')
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32p = C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_float)
+    lib.fnn_abi_version.restype = i32
+    lib.fnn_last_error.restype = C.c_char_p
+    lib.fnn_last_error.argtypes = [vp]
+    lib.fnn_create.argtypes = [C.POINTER(ArchDesc), i32, i32, C.POINTER(vp)]
+    lib.fnn_destroy.argtypes = [vp]
+    lib.fnn_destroy.restype = None
+    lib.fnn_weight_count.argtypes = [vp]
+    lib.fnn_weight_count.restype = i64
+    lib.fnn_load_weights.argtypes = [vp, i32, vp, i64]
+    lib.fnn_set_gaussian.argtypes = [vp, vp, i64]
+    lib.fnn_predict_volume.argtypes = [vp, i32, vp, C.POINTER(i64), C.POINTER(Opts), vp]
+    lib.fnn_predict_volume_ensemble.argtypes = [vp, i32, vp, C.POINTER(i64), C.POINTER(Opts), vp]
+    lib.fnn_accumulate_patches.argtypes = [vp, i32, vp, C.POINTER(i64), C.POINTER(Opts), i64, i64, i64, i64, vp, vp]
+    lib.fnn_normalize_slab.argtypes = [vp, vp, vp, C.POINTER(i64), C.POINTER(Opts), i64, i64, i64, i64, vp]
+    lib.fnn_forward_patches.argtypes = [vp, i32, vp, i32, vp, vp]
+    lib.fnn_argmax_labels.argtypes = [vp, vp, i32, i32, i64, vp, vp]
+    lib.fnn_compute_steps.argtypes = [i64, i64, C.c_double, C.POINTER(i64), i32]
+    lib.fnn_plan_volume.argtypes = [C.POINTER(C.c_int32), C.POINTER(i64), C.c_double, C.POINTER(i64), C.POINTER(i64),
+                                    C.POINTER(i64), C.POINTER(C.c_int32), i64]
+    lib.fnn_set_profiling.argtypes = [vp, i32]
+    lib.fnn_get_profile.argtypes = [vp, C.POINTER(Profile)]
+    lib.fnn_patch_work.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    I3 = C.POINTER(C.c_int)
+    lib.fnn_op_conv3d.argtypes = [i32, i32, I3, f32p, i32, f32p, f32p, C.c_float, f32p, i32, f32p, f32p, C.c_float,
+                                  f32p, f32p, i32, I3, I3, f32p, C.POINTER(C.c_double)]
+    lib.fnn_op_conv_transpose3d.argtypes = [i32, i32, I3, f32p, i32, f32p, f32p, C.c_float, f32p, f32p, i32, I3, f32p]
+    if lib.fnn_abi_version() != 1:
+        raise EngineError('libfnn_hip.so has an unexpected ABI version')
+    _lib = lib
+    return lib
+
+
+def _err(lib, handle) -> str:
+    msg = lib.fnn_last_error(handle)
+    return msg.decode() if msg else ''
+
+
+def check(rc: int, lib, handle=None):
+    """Map C status codes onto the exception types the reference raises."""
+    if rc >= 0:
+        return rc
+    msg = _err(lib, handle)
+    if rc == FNN_E_INVALID:
+        raise AssertionError(msg)
+    if rc == FNN_E_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)            # FNN_E_INF, FNN_E_HIP, FNN_E_STATE
+
+
+def _f32p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def compute_steps(image_size: int, patch_size: int, step: float):
+    lib = load_library()
+    buf = (C.c_int64 * 4096)()
+    n = check(lib.fnn_compute_steps(int(image_size), int(patch_size), float(step), buf, 4096), lib)
+    return [int(buf[i]) for i in range(n)]
+
+
+def plan_volume(patch: Sequence[int], shape_sp: Sequence[int], step: float):
+    """-> (padded shape, low pads, origins [n,3]) exactly as the engine will visit them."""
+    lib = load_library()
+    p = (C.c_int32 * 3)(*[int(i) for i in patch])
+    s = (C.c_int64 * 3)(*[int(i) for i in shape_sp])
+    padded, lo, n = (C.c_int64 * 3)(), (C.c_int64 * 3)(), C.c_int64(0)
+    check(lib.fnn_plan_volume(p, s, float(step), padded, lo, C.byref(n), None, 0), lib)
+    org = np.zeros((n.value, 3), dtype=np.int32)
+    check(lib.fnn_plan_volume(p, s, float(step), padded, lo, C.byref(n),
+                              org.ctypes.data_as(C.POINTER(C.c_int32)), n.value), lib)
+    return list(padded), list(lo), org
+
+
+def op_conv3d(x, w, bias, k, stride, gamma=None, beta=None, slope=1.0, x2=None, gamma2=None, beta2=None, slope2=1.0,
+              device=0, want_stats=False):
+    """Single conv through the HIP kernel.  x [n,cin,D,H,W] float32 (host)."""
+    lib = load_library()
+    x = np.ascontiguousarray(x, np.float32)
+    n, cin = x.shape[:2]
+    dims = (C.c_int * 3)(*x.shape[2:])
+    w = np.ascontiguousarray(w, np.float32)
+    cout = w.shape[0]
+    kk, ss = (C.c_int * 3)(*k), (C.c_int * 3)(*stride)
+    od = [(x.shape[2 + i] + 2 * ((k[i] - 1) // 2) - k[i]) // stride[i] + 1 for i in range(3)]
+    y = np.zeros((n, cout, *od), np.float32)
+    stats = np.zeros((n, cout, 2), np.float64) if want_stats else None
+    f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
+    x2, gamma, beta, gamma2, beta2, bias = f(x2), f(gamma), f(beta), f(gamma2), f(beta2), f(bias)
+    rc = lib.fnn_op_conv3d(device, n, dims, _f32p(x), cin, _f32p(gamma), _f32p(beta), slope,
+                           _f32p(x2), 0 if x2 is None else x2.shape[1], _f32p(gamma2), _f32p(beta2), slope2,
+                           _f32p(w), _f32p(bias), cout, kk, ss, _f32p(y),
+                           None if stats is None else stats.ctypes.data_as(C.POINTER(C.c_double)))
+    check(rc, lib)
+    return (y, stats) if want_stats else y
+
+
+def op_conv_transpose3d(x, w, bias, stride, gamma=None, beta=None, slope=1.0, device=0):
+    lib = load_library()
+    x = np.ascontiguousarray(x, np.float32)
+    n, cin = x.shape[:2]
+    dims = (C.c_int * 3)(*x.shape[2:])
+    w = np.ascontiguousarray(w, np.float32)
+    cout = w.shape[1]
+    ss = (C.c_int * 3)(*stride)
+    y = np.zeros((n, cout, *[x.shape[2 + i] * stride[i] for i in range(3)]), np.float32)
+    f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
+    gamma, beta, bias = f(gamma), f(beta), f(bias)
+    rc = lib.fnn_op_conv_transpose3d(device, n, dims, _f32p(x), cin, _f32p(gamma), _f32p(beta), slope,
+                                     _f32p(w), _f32p(bias), cout, ss, _f32p(y))
+    check(rc, lib)
+    return y
+
+
+class Engine:
+    """Thin RAII wrapper around an ``fnn_engine*``."""
+
+    def __init__(self, desc: ArchDesc, device: int = 0, max_batch: int = 4):
+        self.lib = load_library()
+        self.handle = C.c_void_p()
+        self.desc = desc
+        check(self.lib.fnn_create(C.byref(desc), int(device), int(max_batch), C.byref(self.handle)), self.lib, None)
+        self.max_batch = max_batch
+        self.device = device
+
+    def close(self):
+        if getattr(self, 'handle', None) is not None and self.handle:
+            self.lib.fnn_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def weight_count(self) -> int:
+        return int(self.lib.fnn_weight_count(self.handle))
+
+    def load_weights(self, fold: int, blob: np.ndarray):
+        blob = np.ascontiguousarray(blob, np.float32)
+        check(self.lib.fnn_load_weights(self.handle, fold, blob.ctypes.data, blob.size), self.lib, self.handle)
+
+    def set_gaussian(self, half_bits: np.ndarray):
+        hb = np.ascontiguousarray(half_bits, np.uint16)
+        check(self.lib.fnn_set_gaussian(self.handle, hb.ctypes.data, hb.size), self.lib, self.handle)
+
+    def set_profiling(self, on: bool):
+        check(self.lib.fnn_set_profiling(self.handle, int(on)), self.lib, self.handle)
+
+    def profile(self) -> Profile:
+        p = Profile()
+        check(self.lib.fnn_get_profile(self.handle, C.byref(p)), self.lib, self.handle)
+        return p
+
+    def patch_work(self):
+        fl, by = C.c_double(), C.c_double()
+        check(self.lib.fnn_patch_work(self.handle, C.byref(fl), C.byref(by)), self.lib, self.handle)
+        return fl.value, by.value
+
+    def predict_volume(self, vol_ptr: int, shape, opts: Opts, out_ptr: int, fold: int = 0, n_folds: int = 0):
+        shp = (C.c_int64 * 4)(*[int(i) for i in shape])
+        if n_folds > 0:
+            rc = self.lib.fnn_predict_volume_ensemble(self.handle, n_folds, vol_ptr, shp, C.byref(opts), out_ptr)
+        else:
+            rc = self.lib.fnn_predict_volume(self.handle, fold, vol_ptr, shp, C.byref(opts), out_ptr)
+        check(rc, self.lib, self.handle)
+
+    def accumulate_patches(self, vol_ptr, shape, opts, pb, pe, x0, x1, acc_ptr, wsum_ptr, fold=0):
+        shp = (C.c_int64 * 4)(*[int(i) for i in shape])
+        check(self.lib.fnn_accumulate_patches(self.handle, fold, vol_ptr, shp, C.byref(opts), pb, pe, x0, x1,
+                                              acc_ptr, wsum_ptr), self.lib, self.handle)
+
+    def normalize_slab(self, acc_ptr, wsum_ptr, shape, opts, x0, x1, out_x0, out_x1, out_ptr):
+        shp = (C.c_int64 * 4)(*[int(i) for i in shape])
+        check(self.lib.fnn_normalize_slab(self.handle, acc_ptr, wsum_ptr, shp, C.byref(opts), x0, x1, out_x0, out_x1,
+                                          out_ptr), self.lib, self.handle)
+
+    def forward_patches(self, x_ptr: int, n: int, out_ptr: int, fold: int = 0, stream: int = 0):
+        check(self.lib.fnn_forward_patches(self.handle, fold, x_ptr, n, out_ptr, stream), self.lib, self.handle)
+
+    def argmax_labels(self, logits_ptr, dtype, heads, n_vox, labels_ptr, stream=0):
+        check(self.lib.fnn_argmax_labels(self.handle, logits_ptr, dtype, heads, n_vox, labels_ptr, stream),
+              self.lib, self.handle)

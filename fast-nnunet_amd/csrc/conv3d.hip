@@ -1,0 +1,396 @@
+// conv3d.hip - Conv3d for gfx950 (MI355X): the K1 kernels of SURVEY.md 2.3.
+//
+//   conv3d_mfma_kernel   generic implicit-GEMM conv on the matrix cores
+//                        (v_mfma_f32_16x16x32_f16), any per-axis kernel 1|3 and
+//                        stride 1|2, one or two channels-last inputs (the second
+//                        input replaces torch.cat((up, skip), 1)), InstanceNorm +
+//                        LeakyReLU of the producer applied while staging, the
+//                        InstanceNorm statistics of THIS conv accumulated in the
+//                        epilogue.
+//   stem_conv_kernel     first conv of the network (1..4 input channels) read
+//                        straight out of the fp32 volume at the patch origin
+//                        (no patch copy), fp32 VALU.
+//
+// Replaces torch.nn.Conv3d + InstanceNorm3d + LeakyReLU as composed by
+// dynamic_network_architectures' ConvDropoutNormReLU, which the reference
+// instantiates at nnUNetDistillationTrainer.py:141-173.
+#include "fnn_device.h"
+
+// ----------------------------------------------------------------------------
+// generic MFMA conv
+// ----------------------------------------------------------------------------
+// GEMM view per workgroup:  D[cout, voxel] = sum_k W[cout, k] * X[k, voxel]
+//   voxel : a 4 x 8 x 8 output tile (256 voxels); wave w owns depth slice w,
+//           its 4 MFMA column blocks are pairs of rows (16 voxels each);
+//   k     : input channels in chunks of 16; one k-step (32) = 2 taps x 16 ch;
+//   cout  : NB blocks of 16 per workgroup (blockIdx.y picks the group).
+// Weights are the MFMA "A" operand so that each lane ends up with 4
+// consecutive output channels of one voxel: an 8-byte channels-last store.
+//
+// LDS: [halo tile of the current 16-channel chunk : voxels x 32 B]
+//      [weight fragments of the chunk : ksteps x NB x 1 KiB]
+//      [global offsets of the halo voxels : int per voxel]
+//      [per-input-channel (scale, shift)] [tap offsets]
+template <int NB>
+__global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    int t = blockIdx.x;
+    const int tw = t % p.tiles_w; t /= p.tiles_w;
+    const int th = t % p.tiles_h; t /= p.tiles_h;
+    const int td = t % p.tiles_d;
+    const int n = t / p.tiles_d;
+    const int cb0 = blockIdx.y * NB;
+
+    const int od0 = td * FNN_TILE_D, oh0 = th * FNN_TILE_H, ow0 = tw * FNN_TILE_W;
+    const int ID = (FNN_TILE_D - 1) * p.sd + p.kd;
+    const int IH = (FNN_TILE_H - 1) * p.sh + p.kh;
+    const int IW = (FNN_TILE_W - 1) * p.sw + p.kw;
+    const int IVOX = ID * IH * IW;
+    const int T = p.kd * p.kh * p.kw;
+    const int cin_total = p.chunks * 16;
+
+    char *sA = smem;
+    char *sB = sA + ((IVOX * 32 + 1023) & ~1023);
+    int *sOff = (int *)(sB + p.ksteps * NB * 1024);
+    float2 *sSS = (float2 *)(sOff + ((IVOX + 3) & ~3));
+    int *sTap = (int *)(sSS + cin_total);
+
+    // ---- prologue: halo voxel -> global element offset, tap offsets, scale/shift
+    {
+        const int id0 = od0 * p.sd - p.pd, ih0 = oh0 * p.sh - p.ph, iw0 = ow0 * p.sw - p.pw;
+        for (int v = tid; v < IVOX; v += 256) {
+            const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
+            const int gd = id0 + zd, gh = ih0 + zh, gw = iw0 + zw;
+            const bool ok = gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 && gw < p.Wi;
+            sOff[v] = ok ? ((n * p.Di + gd) * p.Hi + gh) * p.Wi + gw : -1;      // voxel index
+        }
+        if (tid < 2 * p.ksteps) {
+            int off = 0;
+            if (tid < T) {
+                const int a = tid / (p.kh * p.kw), b = (tid / p.kw) % p.kh, c = tid % p.kw;
+                off = ((a * IH + b) * IW + c) * 32;
+            }
+            sTap[tid] = off;
+        }
+        for (int c = tid; c < cin_total; c += 256) {
+            const int s = (c < p.src[0].C) ? 0 : 1;
+            const int cl = c - (s ? p.src[0].C : 0);
+            float sc = 1.f, sh = 0.f;
+            if (p.src[s].stats) {
+                const double *st = p.src[s].stats + ((size_t)n * FNN_STAT_REPL * p.src[s].C + cl) * 2;
+                double s1 = 0, s2 = 0;
+#pragma unroll
+                for (int r = 0; r < FNN_STAT_REPL; ++r) {
+                    s1 += st[(size_t)r * p.src[s].C * 2];
+                    s2 += st[(size_t)r * p.src[s].C * 2 + 1];
+                }
+                const double mean = s1 * (double)p.inv_count;
+                double var = s2 * (double)p.inv_count - mean * mean;
+                var = var > 0 ? var : 0;
+                const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+                sc = p.src[s].gamma[cl] * rstd;
+                sh = p.src[s].beta[cl] - (float)mean * sc;
+            }
+            sSS[c] = make_float2(sc, sh);
+        }
+    }
+
+    // per-lane LDS byte offsets of the 4 column blocks' voxels (k-group folded in)
+    int base[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int r = lane & 15;
+        const int oh_l = 2 * mb + (r >> 3), ow_l = r & 7;
+        base[mb] = ((wave * p.sd * IH + oh_l * p.sh) * IW + ow_l * p.sw) * 32 + ((lane >> 4) & 1) * 16;
+    }
+
+    f32x4 acc[4][NB];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();
+
+    const int cg = tid & 1;                 // which 8-channel half of the chunk this thread stages
+    for (int ch = 0; ch < p.chunks; ++ch) {
+        const int c_glob = ch * 16;
+        const int s = (c_glob < p.src[0].C) ? 0 : 1;
+        const int c_loc = c_glob - (s ? p.src[0].C : 0) + cg * 8;
+        const f16 *sp = p.src[s].ptr;
+        const int sC = p.src[s].C;
+        const float slope = p.src[s].slope;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float2 v = sSS[c_glob + cg * 8 + j];
+            sc[j] = v.x; sh[j] = v.y;
+        }
+        // stage the halo tile of this chunk: global -> normalise + LeakyReLU -> fp16 -> LDS
+        for (int idx = tid; idx < IVOX * 2; idx += 256) {
+            const int v = idx >> 1;
+            const int off = sOff[v];
+            f16x8 o;
+            if (off >= 0) {
+                const f16x8 x = *(const f16x8 *)(sp + (size_t)off * sC + c_loc);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (f16)leaky((float)x[j] * sc[j] + sh[j], slope);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
+            }
+            *(f16x8 *)(sA + v * 32 + cg * 16) = o;
+        }
+        // stage the weight fragments of this chunk
+        {
+            const int per_nb = p.ksteps * 64;                       // uint4 per cout block
+            for (int idx = tid; idx < NB * per_nb; idx += 256) {
+                const int nb = idx / per_nb, r = idx - nb * per_nb;
+                const uint4 *g = (const uint4 *)(p.wpk + ((size_t)((cb0 + nb) * p.chunks + ch) * p.ksteps) * 512);
+                ((uint4 *)sB)[idx] = g[r];
+            }
+        }
+        __syncthreads();
+
+        for (int ks = 0; ks < p.ksteps; ++ks) {
+            const int toff = sTap[2 * ks + (lane >> 5)];
+            f16x8 xf[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) xf[mb] = *(const f16x8 *)(sA + base[mb] + toff);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const f16x8 wf = *(const f16x8 *)(sB + ((nb * p.ksteps + ks) * 64 + lane) * 16);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[mb], acc[mb][nb], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, fp16 store (4 consecutive channels per lane), statistics
+    const int q = lane >> 4, r = lane & 15;
+    const int od = od0 + wave;
+    float s1[NB][4], s2[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[nb][j] = 0.f; s2[nb][j] = 0.f; }
+
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int oh = oh0 + 2 * mb + (r >> 3), ow = ow0 + (r & 7);
+        const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
+        const size_t vox = ((size_t)(n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int co = (cb0 + nb) * 16 + q * 4;
+            const float4 bv = *(const float4 *)(p.bias + co);
+            f16x4 o;
+            o[0] = (f16)(acc[mb][nb][0] + bv.x);
+            o[1] = (f16)(acc[mb][nb][1] + bv.y);
+            o[2] = (f16)(acc[mb][nb][2] + bv.z);
+            o[3] = (f16)(acc[mb][nb][3] + bv.w);
+            if (ok) {
+                *(f16x4 *)(p.out + vox * p.Cout + co) = o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = (float)o[j];
+                    s1[nb][j] += v; s2[nb][j] += v * v;
+                }
+            }
+        }
+    }
+    if (p.stats_out) {
+        // reduce over the 16 voxel lanes, then over the 4 waves through LDS
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+                    s1[nb][j] += __shfl_xor(s1[nb][j], m, 64);
+                    s2[nb][j] += __shfl_xor(s2[nb][j], m, 64);
+                }
+            }
+        float *sRed = (float *)smem;                 // [4 waves][NB*16][2]
+        if (r == 0) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = nb * 16 + q * 4 + j;
+                    sRed[(wave * NB * 16 + c) * 2] = s1[nb][j];
+                    sRed[(wave * NB * 16 + c) * 2 + 1] = s2[nb][j];
+                }
+        }
+        __syncthreads();
+        if (tid < NB * 16 * 2) {
+            const int c = tid >> 1, which = tid & 1;
+            double v = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += (double)sRed[(w * NB * 16 + c) * 2 + which];
+            double *dst = p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout
+                                         + cb0 * 16 + c) * 2 + which;
+            unsafeAtomicAdd(dst, v);
+        }
+    }
+}
+
+size_t conv3d_lds_bytes(const ConvParams &p, int nb) {
+    const int ID = (FNN_TILE_D - 1) * p.sd + p.kd;
+    const int IH = (FNN_TILE_H - 1) * p.sh + p.kh;
+    const int IW = (FNN_TILE_W - 1) * p.sw + p.kw;
+    const int IVOX = ID * IH * IW;
+    size_t b = (size_t)((IVOX * 32 + 1023) & ~1023);
+    b += (size_t)p.ksteps * nb * 1024;
+    b += (size_t)((IVOX + 3) & ~3) * 4;
+    b += (size_t)p.chunks * 16 * 8;
+    b += 2 * p.ksteps * 4 + 64;
+    const size_t red = (size_t)4 * nb * 16 * 2 * 4;
+    return b > red ? b : red;
+}
+
+int conv3d_pick_nb(int nblk) { return (nblk % 4 == 0) ? 4 : (nblk % 2 == 0) ? 2 : 1; }
+
+template <int NB>
+static int launch_conv_nb(const ConvParams &p, hipStream_t st) {
+    const size_t lds = conv3d_lds_bytes(p, NB);
+    if (lds > 160 * 1024) return -1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)conv3d_mfma_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
+    hipLaunchKernelGGL(conv3d_mfma_kernel<NB>, grid, dim3(256), lds, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_conv3d(const ConvParams &p, hipStream_t st) {
+    const int nb = conv3d_pick_nb(p.Cout / 16);
+    if (nb == 4) {
+        if (conv3d_lds_bytes(p, 4) <= 160 * 1024) return launch_conv_nb<4>(p, st);
+        return launch_conv_nb<2>(p, st);
+    }
+    if (nb == 2) return launch_conv_nb<2>(p, st);
+    return launch_conv_nb<1>(p, st);
+}
+
+// ----------------------------------------------------------------------------
+// stem conv: fp32 volume window -> raw fp16 + statistics
+// ----------------------------------------------------------------------------
+// One thread = one output voxel x 16 output channels, fp32 FMA.  The conv's
+// zero padding is at the PATCH border (each patch is an independent network
+// input), not at the volume border.
+__global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tw = t % p.tiles_w; t /= p.tiles_w;
+    const int th = t % p.tiles_h; t /= p.tiles_h;
+    const int td = t % p.tiles_d;
+    const int n = t / p.tiles_d;
+    const int cb = blockIdx.y;                       // block of 16 output channels
+
+    const int pd = (p.kd - 1) / 2, ph = (p.kh - 1) / 2, pw = (p.kw - 1) / 2;
+    const int ID = FNN_TILE_D - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
+    const int IVOX = ID * IH * IW;
+    const int T = p.kd * p.kh * p.kw;
+
+    float *sIn = (float *)smem;                      // [C][IVOX]
+    float *sW = sIn + ((p.C * IVOX + 3) & ~3);       // [C][T][16]
+    float *sRed = sW + p.C * T * 16;                 // [4][16][2]
+
+    const int ox = p.origins[n * 3 + 0], oy = p.origins[n * 3 + 1], oz = p.origins[n * 3 + 2];
+    const int d0 = td * FNN_TILE_D - pd, h0 = th * FNN_TILE_H - ph, w0 = tw * FNN_TILE_W - pw;
+    for (int idx = tid; idx < p.C * IVOX; idx += 256) {
+        const int c = idx / IVOX, v = idx - c * IVOX;
+        const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
+        int d = d0 + zd, h = h0 + zh, w = w0 + zw;
+        float val = 0.f;
+        if (d >= 0 && d < p.PD && h >= 0 && h < p.PH && w >= 0 && w < p.PW) {
+            if (p.flip_d) d = p.PD - 1 - d;
+            if (p.flip_h) h = p.PH - 1 - h;
+            if (p.flip_w) w = p.PW - 1 - w;
+            val = p.vol[(size_t)n * p.vol_batch_stride + (((size_t)c * p.X + (ox + d)) * p.Y + (oy + h)) * p.Z + (oz + w)];
+        }
+        sIn[idx] = val;
+    }
+    for (int idx = tid; idx < p.C * T * 16; idx += 256) {
+        const int co = idx & 15, ct = idx >> 4;
+        sW[idx] = p.w[(size_t)ct * p.Cout + cb * 16 + co];
+    }
+    __syncthreads();
+
+    const int ow_l = tid & 7, oh_l = (tid >> 3) & 7, od_l = tid >> 6;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int c = 0; c < p.C; ++c) {
+        for (int a = 0; a < p.kd; ++a)
+            for (int b = 0; b < p.kh; ++b)
+                for (int e = 0; e < p.kw; ++e) {
+                    const float x = sIn[c * IVOX + ((od_l + a) * IH + (oh_l + b)) * IW + (ow_l + e)];
+                    const float4 *wv = (const float4 *)(sW + ((c * T) + (a * p.kh + b) * p.kw + e) * 16);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 w4 = wv[g];
+                        acc[4 * g + 0] += x * w4.x; acc[4 * g + 1] += x * w4.y;
+                        acc[4 * g + 2] += x * w4.z; acc[4 * g + 3] += x * w4.w;
+                    }
+                }
+    }
+    const int od = td * FNN_TILE_D + od_l, oh = th * FNN_TILE_H + oh_l, ow = tw * FNN_TILE_W + ow_l;
+    const bool ok = od < p.PD && oh < p.PH && ow < p.PW;
+    f16x8 o0, o1;
+    float v1[16], v2[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const f16 hv = (f16)(acc[j] + p.bias[cb * 16 + j]);
+        if (j < 8) o0[j] = hv; else o1[j - 8] = hv;
+        const float f = ok ? (float)hv : 0.f;
+        v1[j] = f; v2[j] = f * f;
+    }
+    if (ok) {
+        f16 *dst = p.out + ((((size_t)n * p.PD + od) * p.PH + oh) * p.PW + ow) * p.Cout + cb * 16;
+        *(f16x8 *)dst = o0;
+        *(f16x8 *)(dst + 8) = o1;
+    }
+    if (p.stats_out) {
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                v1[j] += __shfl_xor(v1[j], m, 64);
+                v2[j] += __shfl_xor(v2[j], m, 64);
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { sRed[(wave * 16 + j) * 2] = v1[j]; sRed[(wave * 16 + j) * 2 + 1] = v2[j]; }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int c = tid >> 1, which = tid & 1;
+            double v = 0;
+            for (int w = 0; w < 4; ++w) v += (double)sRed[(w * 16 + c) * 2 + which];
+            unsafeAtomicAdd(p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout
+                                           + cb * 16 + c) * 2 + which, v);
+        }
+    }
+}
+
+int launch_stem(const StemParams &p, int N, hipStream_t st) {
+    const int ID = FNN_TILE_D - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
+    const int IVOX = ID * IH * IW, T = p.kd * p.kh * p.kw;
+    const size_t lds = (size_t)((p.C * IVOX + 3) & ~3) * 4 + (size_t)p.C * T * 16 * 4 + 4 * 16 * 2 * 4;
+    if (lds > 64 * 1024) return -1;
+    dim3 grid(N * p.tiles_d * p.tiles_h * p.tiles_w, p.Cout / 16);
+    hipLaunchKernelGGL(stem_conv_kernel, grid, dim3(256), lds, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

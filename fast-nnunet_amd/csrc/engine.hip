@@ -1,0 +1,926 @@
+// engine.hip - host side of the C ABI in include/fnn.h.
+//
+// Owns: the layer plan derived from fnn_arch_desc (what the reference builds
+// in PlainConvEncoder / UNetDecoder, nnUNetDistillationTrainer.py:141-173),
+// fp16 weight packing into MFMA fragment order, the activation / statistics /
+// accumulator arenas in HBM, and the sliding-window driver that replaces
+// predict_from_raw_data.py:560-680 (x-major patch order, Gaussian weighting,
+// accumulate, normalise, un-pad; mirroring; fold ensembling).
+#include "fnn_device.h"
+#include "../../include/fnn.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+struct Layer {
+    enum Type { STEM, CONV, TCONV } type;
+    int n_src = 1;
+    int cin_real[2] = {0, 0}, cin_pad[2] = {0, 0};
+    int cout_real = 0, cout_pad = 0;
+    int k[3] = {1, 1, 1}, s[3] = {1, 1, 1};
+    int in_dims[3], out_dims[3];
+    int src_layer[2] = {-1, -1};      // producing layer (-1 = the volume)
+    bool has_norm = true;             // a conv's output is normalised by its consumers; a tconv's is not
+    // offsets
+    size_t w_off = 0;                 // halves, packed weights (STEM: floats in fparam)
+    size_t bias_off = 0, gamma_off = 0, beta_off = 0;   // floats
+    size_t stats_off = 0;             // doubles
+    size_t out_off = 0;               // halves, activation arena (for batch = 1)
+    int64_t blob_w = 0, blob_b = 0, blob_g = 0, blob_beta = 0;
+    int chunks = 0, ksteps = 0;
+    double flops = 0;                 // 2*MACs per patch
+};
+
+struct FoldWeights {
+    f16 *wpk = nullptr;
+    float *fparam = nullptr;
+    bool loaded = false;
+};
+
+inline int pad16(int c) { return (c + 15) / 16 * 16; }
+
+}  // namespace
+
+struct fnn_engine {
+    fnn_arch_desc arch;
+    int device = 0;
+    int max_batch = 1;
+    std::string err;
+    std::vector<Layer> layers;
+    int head_src = -1;                      // layer feeding the seg head
+    int hblocks = 0, head_ksteps = 0;
+    size_t head_w_off = 0, head_bias_off = 0;
+    int64_t blob_head_w = 0, blob_head_b = 0;
+    int64_t blob_count = 0;
+    size_t wpk_halves = 0, fparam_floats = 0, stats_doubles = 0, act_halves = 0;
+    std::vector<FoldWeights> folds;
+    f16 *act = nullptr;
+    double *stats = nullptr;
+    f16 *gauss = nullptr;
+    int *inf_flag = nullptr;
+    int *origins = nullptr; size_t origins_cap = 0;
+    void *acc = nullptr; size_t acc_bytes = 0;
+    void *wsum = nullptr; size_t wsum_bytes = 0;
+    float *vol_tmp = nullptr; size_t vol_tmp_bytes = 0;
+    float *vol_pad = nullptr; size_t vol_pad_bytes = 0;
+    void *out_tmp = nullptr; size_t out_tmp_bytes = 0;
+    float *patch_buf = nullptr; size_t patch_buf_bytes = 0;
+    double head_flops = 0, patch_flops = 0, patch_act_bytes = 0;
+    // profiling
+    bool profiling = false;
+    struct Ev { hipEvent_t a, b; int family; double flops; };
+    std::vector<Ev> evs; size_t ev_used = 0;
+    fnn_profile prof{};
+};
+
+namespace {
+
+int fail(fnn_engine *e, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    if (e) e->err = buf;
+    return code;
+}
+
+#define HIPCHK(e, call)                                                                              \
+    do {                                                                                             \
+        hipError_t _r = (call);                                                                      \
+        if (_r != hipSuccess) return fail(e, FNN_E_HIP, "%s failed: %s", #call, hipGetErrorString(_r)); \
+    } while (0)
+
+bool is_device_ptr(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+int ensure(fnn_engine *e, void **p, size_t *have, size_t need) {
+    if (*have >= need && *p) return 0;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *have = 0;
+    HIPCHK(e, hipMalloc(p, need));
+    *have = need;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+int build_plan(fnn_engine *e) {
+    const fnn_arch_desc &a = e->arch;
+    if (a.kind != FNN_NET_PLAIN) return fail(e, FNN_E_UNSUPPORTED, "only PlainConvUNet topologies are implemented (kind=%d)", a.kind);
+    if (a.n_stages < 2 || a.n_stages > FNN_MAX_STAGES) return fail(e, FNN_E_INVALID, "n_stages out of range");
+    if (a.in_channels < 1 || a.in_channels > 8) return fail(e, FNN_E_UNSUPPORTED, "in_channels must be 1..8");
+    if (a.num_heads < 1 || a.num_heads > 256) return fail(e, FNN_E_UNSUPPORTED, "num_heads must be 1..256");
+    for (int s = 0; s < a.n_stages; ++s)
+        for (int d = 0; d < 3; ++d) {
+            if (a.kernels[s][d] != 1 && a.kernels[s][d] != 3) return fail(e, FNN_E_UNSUPPORTED, "kernel sizes must be 1 or 3");
+            if (a.strides[s][d] != 1 && a.strides[s][d] != 2) return fail(e, FNN_E_UNSUPPORTED, "strides must be 1 or 2");
+            if (s == 0 && a.strides[s][d] != 1) return fail(e, FNN_E_UNSUPPORTED, "stage 0 must have stride 1");
+        }
+    int dims[FNN_MAX_STAGES][3];
+    for (int d = 0; d < 3; ++d) dims[0][d] = a.patch[d];
+    for (int s = 1; s < a.n_stages; ++s)
+        for (int d = 0; d < 3; ++d) {
+            const int k = a.kernels[s][d], st = a.strides[s][d], pad = (k - 1) / 2;
+            dims[s][d] = (dims[s - 1][d] + 2 * pad - k) / st + 1;
+            if (dims[s][d] * st != dims[s - 1][d])
+                return fail(e, FNN_E_INVALID, "patch size %d is not divisible by the pooling of axis %d", a.patch[d], d);
+        }
+    int64_t blob = 0;
+    auto add_conv = [&](Layer::Type type, int nsrc, const int cin[2], const int src[2], int cout, const int32_t *k,
+                        const int32_t *s, const int *in_d, const int *out_d) {
+        Layer L;
+        L.type = type; L.n_src = nsrc;
+        int cin_tot = 0;
+        for (int i = 0; i < nsrc; ++i) {
+            L.cin_real[i] = cin[i]; L.cin_pad[i] = (type == Layer::STEM) ? cin[i] : pad16(cin[i]);
+            L.src_layer[i] = src[i]; cin_tot += cin[i];
+        }
+        L.cout_real = cout; L.cout_pad = pad16(cout);
+        for (int d = 0; d < 3; ++d) { L.k[d] = k[d]; L.s[d] = s[d]; L.in_dims[d] = in_d[d]; L.out_dims[d] = out_d[d]; }
+        const int T = k[0] * k[1] * k[2];
+        L.blob_w = blob; blob += (int64_t)cout * cin_tot * T;
+        L.blob_b = blob; blob += cout;
+        L.blob_g = blob; blob += cout;
+        L.blob_beta = blob; blob += cout;
+        L.flops = 2.0 * cout * cin_tot * T * out_d[0] * out_d[1] * out_d[2];
+        e->layers.push_back(L);
+        return (int)e->layers.size() - 1;
+    };
+    const int32_t one[3] = {1, 1, 1};
+    int prev = -1, prev_c = a.in_channels;
+    int enc_last[FNN_MAX_STAGES];
+    for (int s = 0; s < a.n_stages; ++s) {
+        if (a.n_conv_enc[s] < 1) return fail(e, FNN_E_INVALID, "n_conv_per_stage must be >= 1");
+        for (int i = 0; i < a.n_conv_enc[s]; ++i) {
+            const int cin[2] = {prev_c, 0}, src[2] = {prev, -1};
+            const bool first = (s == 0 && i == 0);
+            const int *in_d = (i == 0 && s > 0) ? dims[s - 1] : dims[s];
+            prev = add_conv(first ? Layer::STEM : Layer::CONV, 1, cin, src, a.features[s], a.kernels[s],
+                            i == 0 ? a.strides[s] : one, in_d, dims[s]);
+            prev_c = a.features[s];
+        }
+        enc_last[s] = prev;
+    }
+    for (int d = 0; d < a.n_stages - 1; ++d) {
+        const int lvl = a.n_stages - 2 - d;           // encoder stage whose skip is consumed
+        const int below = prev_c, skip = a.features[lvl];
+        const int32_t *st = a.strides[lvl + 1];
+        Layer T;
+        T.type = Layer::TCONV; T.n_src = 1; T.has_norm = false;
+        T.cin_real[0] = below; T.cin_pad[0] = pad16(below); T.src_layer[0] = prev;
+        T.cout_real = skip; T.cout_pad = pad16(skip);
+        for (int q = 0; q < 3; ++q) { T.k[q] = st[q]; T.s[q] = st[q]; T.in_dims[q] = dims[lvl + 1][q]; T.out_dims[q] = dims[lvl][q]; }
+        const int taps = st[0] * st[1] * st[2];
+        T.blob_w = blob; blob += (int64_t)below * skip * taps;
+        T.blob_b = blob; blob += skip;
+        T.flops = 2.0 * below * skip * (double)dims[lvl][0] * dims[lvl][1] * dims[lvl][2];
+        e->layers.push_back(T);
+        const int tl = (int)e->layers.size() - 1;
+        if (a.n_conv_dec[d] < 1) return fail(e, FNN_E_INVALID, "n_conv_per_stage_decoder must be >= 1");
+        for (int i = 0; i < a.n_conv_dec[d]; ++i) {
+            if (i == 0) {
+                const int cin[2] = {skip, skip}, src[2] = {tl, enc_last[lvl]};
+                prev = add_conv(Layer::CONV, 2, cin, src, skip, a.kernels[lvl], one, dims[lvl], dims[lvl]);
+            } else {
+                const int cin[2] = {skip, 0}, src[2] = {prev, -1};
+                prev = add_conv(Layer::CONV, 1, cin, src, skip, a.kernels[lvl], one, dims[lvl], dims[lvl]);
+            }
+        }
+        prev_c = skip;
+    }
+    e->head_src = prev;
+    e->blob_head_w = blob; blob += (int64_t)a.num_heads * a.features[0];
+    e->blob_head_b = blob; blob += a.num_heads;
+    e->blob_count = blob;
+
+    // device offsets
+    size_t wpk = 0, fp = 0, st = 0, act = 0;
+    double flops = 0, bytes = 0;
+    for (Layer &L : e->layers) {
+        const size_t ovox = (size_t)L.out_dims[0] * L.out_dims[1] * L.out_dims[2];
+        if (L.type == Layer::STEM) {
+            const int T = L.k[0] * L.k[1] * L.k[2];
+            L.w_off = fp; fp += (size_t)L.cin_real[0] * T * L.cout_pad;
+        } else if (L.type == Layer::CONV) {
+            const int T = L.k[0] * L.k[1] * L.k[2];
+            L.chunks = (L.cin_pad[0] + (L.n_src > 1 ? L.cin_pad[1] : 0)) / 16;
+            L.ksteps = (T + 1) / 2;
+            L.w_off = wpk; wpk += (size_t)(L.cout_pad / 16) * L.chunks * L.ksteps * 512;
+        } else {
+            const int taps = L.s[0] * L.s[1] * L.s[2];
+            L.ksteps = (L.cin_pad[0] + 31) / 32;
+            L.w_off = wpk; wpk += (size_t)taps * (L.cout_pad / 16) * L.ksteps * 512;
+        }
+        L.bias_off = fp; fp += L.cout_pad;
+        if (L.has_norm) { L.gamma_off = fp; fp += L.cout_pad; L.beta_off = fp; fp += L.cout_pad; }
+        L.stats_off = st; if (L.has_norm) st += (size_t)FNN_STAT_REPL * L.cout_pad * 2;
+        L.out_off = act; act += ovox * L.cout_pad;
+        flops += L.flops;
+        bytes += 2.0 * ovox * L.cout_real * 2.0;            // written once + read once, fp16
+    }
+    e->hblocks = (a.num_heads + 15) / 16;
+    e->head_ksteps = (pad16(a.features[0]) + 31) / 32;
+    e->head_w_off = wpk; wpk += (size_t)e->hblocks * e->head_ksteps * 512;
+    e->head_bias_off = fp; fp += (size_t)e->hblocks * 16;
+    const double P = (double)a.patch[0] * a.patch[1] * a.patch[2];
+    e->head_flops = 2.0 * a.num_heads * a.features[0] * P;
+    e->patch_flops = flops + e->head_flops;
+    // skips are read twice (next encoder stage and decoder); network input read once
+    for (int s = 0; s < a.n_stages - 1; ++s) {
+        const Layer &L = e->layers[enc_last[s]];
+        bytes += (double)L.out_dims[0] * L.out_dims[1] * L.out_dims[2] * L.cout_real * 2.0;
+    }
+    e->patch_act_bytes = bytes;
+    e->wpk_halves = wpk; e->fparam_floats = fp; e->stats_doubles = st; e->act_halves = act;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// weight packing (host)
+// ---------------------------------------------------------------------------
+inline uint16_t f2h_bits(float f) { f16 h = (f16)f; uint16_t b; memcpy(&b, &h, 2); return b; }
+
+void pack_conv(const Layer &L, const float *W, uint16_t *dst) {
+    const int T = L.k[0] * L.k[1] * L.k[2];
+    const int cin_tot = L.cin_real[0] + (L.n_src > 1 ? L.cin_real[1] : 0);
+    const int nblk = L.cout_pad / 16;
+    for (int cb = 0; cb < nblk; ++cb)
+        for (int ch = 0; ch < L.chunks; ++ch)
+            for (int ks = 0; ks < L.ksteps; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = 8 * (lane >> 4) + j;
+                        const int tap = 2 * ks + (k >> 4), c = ch * 16 + (k & 15);
+                        const int co = cb * 16 + (lane & 15);
+                        int src = 0, cl = c;
+                        if (c >= L.cin_pad[0]) { src = 1; cl = c - L.cin_pad[0]; }
+                        float v = 0.f;
+                        if (tap < T && co < L.cout_real && cl < L.cin_real[src]) {
+                            const int ci = (src ? L.cin_real[0] : 0) + cl;
+                            v = W[((size_t)co * cin_tot + ci) * T + tap];
+                        }
+                        dst[((((size_t)cb * L.chunks + ch) * L.ksteps + ks) * 64 + lane) * 8 + j] = f2h_bits(v);
+                    }
+}
+
+void pack_tconv(const Layer &L, const float *W, uint16_t *dst) {
+    const int taps = L.s[0] * L.s[1] * L.s[2];
+    const int nblk = L.cout_pad / 16;
+    for (int tap = 0; tap < taps; ++tap)
+        for (int cb = 0; cb < nblk; ++cb)
+            for (int ks = 0; ks < L.ksteps; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int ci = ks * 32 + 8 * (lane >> 4) + j, co = cb * 16 + (lane & 15);
+                        float v = 0.f;
+                        if (ci < L.cin_real[0] && co < L.cout_real) v = W[((size_t)ci * L.cout_real + co) * taps + tap];
+                        dst[((((size_t)tap * nblk + cb) * L.ksteps + ks) * 64 + lane) * 8 + j] = f2h_bits(v);
+                    }
+}
+
+void pack_head(int heads, int cin, int hblocks, int ksteps, const float *W, uint16_t *dst) {
+    for (int hb = 0; hb < hblocks; ++hb)
+        for (int ks = 0; ks < ksteps; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int ci = ks * 32 + 8 * (lane >> 4) + j, h = hb * 16 + (lane & 15);
+                    float v = 0.f;
+                    if (ci < cin && h < heads) v = W[(size_t)h * cin + ci];
+                    dst[(((size_t)hb * ksteps + ks) * 64 + lane) * 8 + j] = f2h_bits(v);
+                }
+}
+
+// ---------------------------------------------------------------------------
+// profiling helpers
+// ---------------------------------------------------------------------------
+enum { FAM_CONV = 0, FAM_STEM, FAM_TCONV, FAM_HEAD, FAM_FINAL };
+
+struct Scope {
+    fnn_engine *e; hipStream_t st; int idx = -1;
+    Scope(fnn_engine *e_, hipStream_t st_, int family, double flops) : e(e_), st(st_) {
+        if (!e->profiling) return;
+        if (e->ev_used == e->evs.size()) {
+            fnn_engine::Ev ev{};
+            if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return;
+            e->evs.push_back(ev);
+        }
+        idx = (int)e->ev_used++;
+        e->evs[idx].family = family; e->evs[idx].flops = flops;
+        (void)hipEventRecord(e->evs[idx].a, st);
+    }
+    ~Scope() { if (idx >= 0) (void)hipEventRecord(e->evs[idx].b, st); }
+};
+
+void collect_profile(fnn_engine *e, int64_t n_patches) {
+    fnn_profile &p = e->prof;
+    p = fnn_profile{};
+    p.n_patches = n_patches;
+    for (size_t i = 0; i < e->ev_used; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e->evs[i].a, e->evs[i].b) != hipSuccess) continue;
+        p.total_ms += ms;
+        switch (e->evs[i].family) {
+            case FAM_CONV: p.conv_ms += ms; p.conv_launches++; p.conv_flops += e->evs[i].flops; break;
+            case FAM_STEM: p.stem_ms += ms; break;
+            case FAM_TCONV: p.tconv_ms += ms; break;
+            case FAM_HEAD: p.head_ms += ms; break;
+            default: p.finalize_ms += ms; break;
+        }
+    }
+    e->ev_used = 0;
+}
+
+// ---------------------------------------------------------------------------
+// one network forward for `nb` patches (activations only; the head is separate)
+// ---------------------------------------------------------------------------
+SrcDesc make_src(fnn_engine *e, const FoldWeights &fw, int layer, int nb) {
+    const Layer &L = e->layers[layer];
+    SrcDesc s{};
+    s.ptr = e->act + L.out_off * e->max_batch;
+    s.C = L.cout_pad;
+    if (L.has_norm) {
+        s.stats = e->stats + L.stats_off * e->max_batch;
+        s.gamma = fw.fparam + L.gamma_off;
+        s.beta = fw.fparam + L.beta_off;
+        s.slope = e->arch.slope;
+    } else {
+        s.stats = nullptr; s.gamma = nullptr; s.beta = nullptr; s.slope = 1.f;
+    }
+    (void)nb;
+    return s;
+}
+
+int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch_stride, const long long vdim[3],
+                  const int *origins_dev, int nb, const int flip[3], hipStream_t st) {
+    const FoldWeights &fw = e->folds[fold];
+    HIPCHK(e, hipMemsetAsync(e->stats, 0, e->stats_doubles * e->max_batch * sizeof(double), st));
+    for (size_t li = 0; li < e->layers.size(); ++li) {
+        const Layer &L = e->layers[li];
+        f16 *out = e->act + L.out_off * e->max_batch;
+        double *stats_out = L.has_norm ? e->stats + L.stats_off * e->max_batch : nullptr;
+        int rc = 0;
+        if (L.type == Layer::STEM) {
+            StemParams p{};
+            p.vol = vol; p.vol_batch_stride = vol_batch_stride; p.C = L.cin_real[0];
+            p.X = vdim[0]; p.Y = vdim[1]; p.Z = vdim[2];
+            p.origins = origins_dev;
+            p.flip_d = flip[0]; p.flip_h = flip[1]; p.flip_w = flip[2];
+            p.PD = L.out_dims[0]; p.PH = L.out_dims[1]; p.PW = L.out_dims[2];
+            p.kd = L.k[0]; p.kh = L.k[1]; p.kw = L.k[2];
+            p.Cout = L.cout_pad;
+            p.w = fw.fparam + L.w_off; p.bias = fw.fparam + L.bias_off;
+            p.out = out; p.stats_out = stats_out;
+            p.tiles_d = (p.PD + FNN_TILE_D - 1) / FNN_TILE_D;
+            p.tiles_h = (p.PH + FNN_TILE_H - 1) / FNN_TILE_H;
+            p.tiles_w = (p.PW + FNN_TILE_W - 1) / FNN_TILE_W;
+            Scope sc(e, st, FAM_STEM, L.flops * nb);
+            rc = launch_stem(p, nb, st);
+        } else if (L.type == Layer::CONV) {
+            ConvParams p{};
+            p.n_src = L.n_src;
+            for (int i = 0; i < L.n_src; ++i) p.src[i] = make_src(e, fw, L.src_layer[i], nb);
+            if (L.n_src == 1) { p.src[1] = p.src[0]; p.src[1].C = 0; }
+            p.N = nb; p.Di = L.in_dims[0]; p.Hi = L.in_dims[1]; p.Wi = L.in_dims[2];
+            p.Do = L.out_dims[0]; p.Ho = L.out_dims[1]; p.Wo = L.out_dims[2];
+            p.Cout = L.cout_pad;
+            p.kd = L.k[0]; p.kh = L.k[1]; p.kw = L.k[2];
+            p.sd = L.s[0]; p.sh = L.s[1]; p.sw = L.s[2];
+            p.pd = (L.k[0] - 1) / 2; p.ph = (L.k[1] - 1) / 2; p.pw = (L.k[2] - 1) / 2;
+            p.wpk = fw.wpk + L.w_off; p.bias = fw.fparam + L.bias_off;
+            p.out = out; p.stats_out = stats_out;
+            p.tiles_d = (p.Do + FNN_TILE_D - 1) / FNN_TILE_D;
+            p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
+            p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
+            p.chunks = L.chunks; p.ksteps = L.ksteps;
+            p.eps = e->arch.eps; p.inv_count = 1.f / ((float)p.Di * p.Hi * p.Wi);
+            Scope sc(e, st, FAM_CONV, L.flops * nb);
+            rc = launch_conv3d(p, st);
+        } else {
+            TconvParams p{};
+            p.src = make_src(e, fw, L.src_layer[0], nb);
+            p.N = nb; p.Di = L.in_dims[0]; p.Hi = L.in_dims[1]; p.Wi = L.in_dims[2];
+            p.sd = L.s[0]; p.sh = L.s[1]; p.sw = L.s[2];
+            p.Cout = L.cout_pad; p.wpk = fw.wpk + L.w_off; p.bias = fw.fparam + L.bias_off;
+            p.out = out; p.ksteps = L.ksteps; p.nblk = L.cout_pad / 16;
+            p.eps = e->arch.eps; p.inv_count = 1.f / ((float)p.Di * p.Hi * p.Wi);
+            Scope sc(e, st, FAM_TCONV, L.flops * nb);
+            rc = launch_tconv(p, st);
+        }
+        if (rc != 0) return fail(e, rc == -1 ? FNN_E_UNSUPPORTED : FNN_E_HIP, "kernel launch failed at layer %zu (rc=%d)", li, rc);
+    }
+    return 0;
+}
+
+HeadParams make_head(fnn_engine *e, int fold, int b) {
+    const fnn_arch_desc &a = e->arch;
+    const FoldWeights &fw = e->folds[fold];
+    HeadParams h{};
+    h.src = make_src(e, fw, e->head_src, 0);
+    h.b = b; h.PD = a.patch[0]; h.PH = a.patch[1]; h.PW = a.patch[2];
+    h.heads = a.num_heads; h.hblocks = e->hblocks; h.ksteps = e->head_ksteps;
+    h.wpk = fw.wpk + e->head_w_off; h.bias = fw.fparam + e->head_bias_off;
+    h.eps = a.eps; h.inv_count = 1.f / ((float)a.patch[0] * a.patch[1] * a.patch[2]);
+    return h;
+}
+
+int steps_1d(int64_t image, int64_t patch, double step, std::vector<int64_t> &out) {
+    // compute_steps_for_sliding_window (sliding_window_prediction.py:30-54), one axis
+    if (!(step > 0 && step <= 1) || patch <= 0 || image < patch) return -1;
+    const double target = (double)patch * step;
+    const int64_t n = (int64_t)std::ceil((double)(image - patch) / target) + 1;
+    out.clear();
+    if (n > 1) {
+        const double actual = (double)(image - patch) / (double)(n - 1);
+        for (int64_t i = 0; i < n; ++i) out.push_back((int64_t)std::nearbyint(actual * (double)i));   // half-to-even
+    } else {
+        out.push_back(0);
+    }
+    return 0;
+}
+
+struct VolPlan {
+    int64_t padded[3], lo[3];
+    std::vector<int64_t> steps[3];
+    std::vector<int> origins;          // [n][3], x-major (predict_from_raw_data.py:532-537)
+    int64_t n_patches = 0;
+};
+
+int plan_volume_p(const int32_t patch[3], const int64_t sp[3], double step, VolPlan &vp);
+int plan_volume(const fnn_arch_desc &a, const int64_t sp[3], double step, VolPlan &vp) {
+    return plan_volume_p(a.patch, sp, step, vp);
+}
+int plan_volume_p(const int32_t patch[3], const int64_t sp[3], double step, VolPlan &vp) {
+    struct { const int32_t *patch; } a{patch};
+    for (int d = 0; d < 3; ++d) {
+        if (sp[d] < 1 || patch[d] < 1) return -1;
+        const int64_t target = sp[d] > a.patch[d] ? sp[d] : a.patch[d];
+        const int64_t diff = target - sp[d];
+        vp.padded[d] = target; vp.lo[d] = diff / 2;        // the odd voxel goes to the high side
+        if (steps_1d(target, a.patch[d], step, vp.steps[d]) != 0) return -1;
+    }
+    vp.origins.clear();
+    for (int64_t x : vp.steps[0])
+        for (int64_t y : vp.steps[1])
+            for (int64_t z : vp.steps[2]) { vp.origins.push_back((int)x); vp.origins.push_back((int)y); vp.origins.push_back((int)z); }
+    vp.n_patches = (int64_t)vp.origins.size() / 3;
+    return 0;
+}
+
+// mirror-axis subsets in the reference's order: by size, then lexicographic (:551-553)
+std::vector<std::vector<int>> mirror_combos(const fnn_opts &o) {
+    std::vector<std::vector<int>> out;
+    const int n = o.n_mirror_axes;
+    // enumerate combinations of positions in lexicographic order
+    for (int size = 1; size <= n; ++size) {
+        std::vector<int> idx(size);
+        for (int i = 0; i < size; ++i) idx[i] = i;
+        while (true) {
+            std::vector<int> c;
+            for (int i : idx) c.push_back(o.mirror_axes[i]);
+            out.push_back(c);
+            int i = size - 1;
+            while (i >= 0 && idx[i] == n - size + i) --i;
+            if (i < 0) break;
+            ++idx[i];
+            for (int j = i + 1; j < size; ++j) idx[j] = idx[j - 1] + 1;
+        }
+    }
+    return out;
+}
+
+int check_ready(fnn_engine *e, int fold, const fnn_opts *o) {
+    if (!e) return FNN_E_INVALID;
+    if (!o) return fail(e, FNN_E_INVALID, "opts is NULL");
+    if (fold < 0 || fold >= (int)e->folds.size() || !e->folds[fold].loaded) return fail(e, FNN_E_STATE, "weights of fold %d are not loaded", fold);
+    if (!(o->tile_step_size > 0 && o->tile_step_size <= 1)) return fail(e, FNN_E_INVALID, "step_size must be larger than 0 and smaller or equal to 1");
+    if (o->use_gaussian && !e->gauss) return fail(e, FNN_E_STATE, "use_gaussian is set but fnn_set_gaussian was not called");
+    if (o->n_mirror_axes < 0 || o->n_mirror_axes > 3) return fail(e, FNN_E_INVALID, "n_mirror_axes out of range");
+    for (int i = 0; i < o->n_mirror_axes; ++i)
+        if (o->mirror_axes[i] < 0 || o->mirror_axes[i] > 2) return fail(e, FNN_E_INVALID, "mirror_axes does not match the dimension of the input!");
+    return 0;
+}
+
+// Runs patches [pb, pe) and accumulates into (acc, wsum) covering x in [x0, x1).
+int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp, const fnn_opts &o, int64_t pb,
+                int64_t pe, int64_t x0, int64_t x1, void *acc, void *wsum, int acc_fp32, hipStream_t st) {
+    const fnn_arch_desc &a = e->arch;
+    const long long vdim[3] = {(long long)vp.padded[0], (long long)vp.padded[1], (long long)vp.padded[2]};
+    int B = o.batch > 0 ? o.batch : e->max_batch;
+    if (B > e->max_batch) B = e->max_batch;
+    const auto combos = mirror_combos(o);
+    const bool tta = !combos.empty();
+    const size_t P = (size_t)a.patch[0] * a.patch[1] * a.patch[2];
+    if (tta) {
+        void *pbuf = e->patch_buf;
+        if (int rc = ensure(e, &pbuf, &e->patch_buf_bytes, (size_t)B * a.num_heads * P * sizeof(float))) return rc;
+        e->patch_buf = (float *)pbuf;
+    }
+    for (int64_t p0 = pb; p0 < pe; p0 += B) {
+        const int nb = (int)((pe - p0 < B) ? pe - p0 : B);
+        const int *org = e->origins + p0 * 3;
+        for (size_t ci = 0; ci <= (tta ? combos.size() : 0); ++ci) {
+            int flip[3] = {0, 0, 0};
+            if (ci > 0) for (int ax : combos[ci - 1]) flip[ax] = 1;
+            if (int rc = forward_batch(e, fold, vol_dev, 0, vdim, org, nb, flip, st)) return rc;
+            for (int b = 0; b < nb; ++b) {
+                HeadParams h = make_head(e, fold, b);
+                const int *oo = &vp.origins[(p0 + b) * 3];
+                h.gauss = o.use_gaussian ? e->gauss : nullptr;
+                h.acc = acc; h.wsum = wsum; h.AX = x1 - x0; h.Y = vp.padded[1]; h.Z = vp.padded[2];
+                h.ox = oo[0] - (int)x0; h.oy = oo[1]; h.oz = oo[2];
+                if (!tta && (h.ox < 0 || h.ox + a.patch[0] > x1 - x0)) return fail(e, FNN_E_INVALID, "patch %lld lies outside the accumulator x-range", (long long)(p0 + b));
+                h.flip_d = flip[0]; h.flip_h = flip[1]; h.flip_w = flip[2];
+                h.acc_fp32 = acc_fp32;
+                if (tta) { h.mode = ci == 0 ? 1 : 2; h.patch_buf = e->patch_buf + (size_t)b * a.num_heads * P; }
+                Scope sc(e, st, FAM_HEAD, e->head_flops);
+                if (launch_head(h, st) != 0) return fail(e, FNN_E_HIP, "seg head launch failed");
+            }
+        }
+        if (tta) {
+            for (int b = 0; b < nb; ++b) {
+                const int *oo = &vp.origins[(p0 + b) * 3];
+                PatchAccParams q{};
+                q.patch_buf = e->patch_buf + (size_t)b * a.num_heads * P;
+                q.n_div = (int)combos.size() + 1; q.inv_n = 1.f / (float)q.n_div;
+                q.PD = a.patch[0]; q.PH = a.patch[1]; q.PW = a.patch[2]; q.heads = a.num_heads;
+                q.gauss = o.use_gaussian ? e->gauss : nullptr;
+                q.acc = acc; q.wsum = wsum; q.AX = x1 - x0; q.Y = vp.padded[1]; q.Z = vp.padded[2];
+                q.ox = oo[0] - (int)x0; q.oy = oo[1]; q.oz = oo[2];
+                q.acc_fp32 = acc_fp32;
+                Scope sc(e, st, FAM_HEAD, 0);
+                if (launch_patch_acc(q, st) != 0) return fail(e, FNN_E_HIP, "patch accumulate launch failed");
+            }
+        }
+    }
+    return 0;
+}
+
+// Brings the input volume onto the device and pads it when smaller than the patch.
+int stage_volume(fnn_engine *e, const float *vol, const int64_t shape[4], const VolPlan &vp, hipStream_t st,
+                 const float **vol_dev) {
+    const size_t nin = (size_t)shape[0] * shape[1] * shape[2] * shape[3];
+    const float *src = vol;
+    if (!is_device_ptr(vol)) {
+        void *t = e->vol_tmp;
+        if (int rc = ensure(e, &t, &e->vol_tmp_bytes, nin * sizeof(float))) return rc;
+        e->vol_tmp = (float *)t;
+        HIPCHK(e, hipMemcpyAsync(e->vol_tmp, vol, nin * sizeof(float), hipMemcpyHostToDevice, st));
+        src = e->vol_tmp;
+    }
+    const bool need_pad = vp.padded[0] != shape[1] || vp.padded[1] != shape[2] || vp.padded[2] != shape[3];
+    if (need_pad) {
+        const size_t npad = (size_t)shape[0] * vp.padded[0] * vp.padded[1] * vp.padded[2];
+        void *t = e->vol_pad;
+        if (int rc = ensure(e, &t, &e->vol_pad_bytes, npad * sizeof(float))) return rc;
+        e->vol_pad = (float *)t;
+        const long long s[3] = {(long long)shape[1], (long long)shape[2], (long long)shape[3]};
+        const long long d[3] = {(long long)vp.padded[0], (long long)vp.padded[1], (long long)vp.padded[2]};
+        const long long lo[3] = {(long long)vp.lo[0], (long long)vp.lo[1], (long long)vp.lo[2]};
+        if (launch_pad_volume(src, e->vol_pad, (int)shape[0], s, d, lo, st) != 0) return fail(e, FNN_E_HIP, "pad launch failed");
+        src = e->vol_pad;
+    }
+    *vol_dev = src;
+    return 0;
+}
+
+int upload_origins(fnn_engine *e, const VolPlan &vp, hipStream_t st) {
+    const size_t need = vp.origins.size() * sizeof(int);
+    void *t = e->origins;
+    if (int rc = ensure(e, &t, &e->origins_cap, need)) return rc;
+    e->origins = (int *)t;
+    HIPCHK(e, hipMemcpyAsync(e->origins, vp.origins.data(), need, hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipStreamSynchronize(st));       // vp.origins is a host temporary
+    return 0;
+}
+
+int predict_one_fold(fnn_engine *e, int fold, const float *vol_dev, const int64_t shape[4], const VolPlan &vp,
+                     const fnn_opts &o, void *out_dev, int ensemble_mode, hipStream_t st) {
+    const fnn_arch_desc &a = e->arch;
+    const int acc_fp32 = o.accum == FNN_ACC_FP32;
+    const size_t esz = acc_fp32 ? 4 : 2;
+    const size_t nvox = (size_t)vp.padded[0] * vp.padded[1] * vp.padded[2];
+    if (int rc = ensure(e, &e->acc, &e->acc_bytes, nvox * a.num_heads * esz)) return rc;
+    if (int rc = ensure(e, &e->wsum, &e->wsum_bytes, nvox * esz)) return rc;
+    HIPCHK(e, hipMemsetAsync(e->acc, 0, nvox * a.num_heads * esz, st));
+    HIPCHK(e, hipMemsetAsync(e->wsum, 0, nvox * esz, st));
+    if (int rc = run_patches(e, fold, vol_dev, vp, o, 0, vp.n_patches, 0, vp.padded[0], e->acc, e->wsum, acc_fp32, st)) return rc;
+    FinalizeParams f{};
+    f.acc = e->acc; f.wsum = e->wsum; f.AX = vp.padded[0]; f.Y = vp.padded[1]; f.Z = vp.padded[2];
+    f.lo_x = (int)vp.lo[0]; f.lo_y = (int)vp.lo[1]; f.lo_z = (int)vp.lo[2];
+    f.OX = shape[1]; f.OY = shape[2]; f.OZ = shape[3];
+    f.heads = a.num_heads; f.acc_fp32 = acc_fp32; f.out_fp32 = o.out_dtype == FNN_OUT_F32;
+    f.mode = ensemble_mode; f.out = out_dev; f.inf_flag = e->inf_flag;
+    Scope sc(e, st, FAM_FINAL, 0);
+    if (launch_finalize(f, st) != 0) return fail(e, FNN_E_HIP, "finalize launch failed");
+    return 0;
+}
+
+int predict_impl(fnn_engine *e, int fold0, int n_folds, const float *vol, const int64_t shape[4], const fnn_opts *o,
+                 void *out) {
+    for (int f = fold0; f < fold0 + n_folds; ++f)
+        if (int rc = check_ready(e, f, o)) return rc;
+    if (!vol || !out || !shape) return fail(e, FNN_E_INVALID, "NULL argument");
+    const fnn_arch_desc &a = e->arch;
+    if (shape[0] != a.in_channels) return fail(e, FNN_E_INVALID, "input has %lld channels, the network expects %d", (long long)shape[0], a.in_channels);
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)o->stream;
+    VolPlan vp;
+    if (plan_volume(a, shape + 1, o->tile_step_size, vp) != 0) return fail(e, FNN_E_INVALID, "invalid volume shape / step size");
+    const float *vol_dev = nullptr;
+    if (int rc = stage_volume(e, vol, shape, vp, st, &vol_dev)) return rc;
+    if (int rc = upload_origins(e, vp, st)) return rc;
+    const size_t nout = (size_t)a.num_heads * shape[1] * shape[2] * shape[3];
+    const size_t osz = o->out_dtype == FNN_OUT_F32 ? 4 : 2;
+    void *out_dev = out;
+    const bool out_on_dev = is_device_ptr(out);
+    if (!out_on_dev) {
+        if (int rc = ensure(e, &e->out_tmp, &e->out_tmp_bytes, nout * osz)) return rc;
+        out_dev = e->out_tmp;
+    }
+    HIPCHK(e, hipMemsetAsync(e->inf_flag, 0, sizeof(int), st));
+    e->ev_used = 0;
+    for (int f = 0; f < n_folds; ++f)
+        if (int rc = predict_one_fold(e, fold0 + f, vol_dev, shape, vp, *o, out_dev, f > 0 ? 1 : 0, st)) return rc;
+    if (n_folds > 1)
+        if (launch_scale_output(out_dev, o->out_dtype == FNN_OUT_F32, (long long)nout, n_folds, e->inf_flag, st) != 0)
+            return fail(e, FNN_E_HIP, "scale launch failed");
+    int flag = 0;
+    HIPCHK(e, hipMemcpyAsync(&flag, e->inf_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (!out_on_dev) HIPCHK(e, hipMemcpyAsync(out, out_dev, nout * osz, hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    if (e->profiling) collect_profile(e, vp.n_patches * n_folds);
+    if (flag)
+        return fail(e, FNN_E_INF, "Encountered inf in predicted array. Aborting... If this problem persists, reduce "
+                                  "value_scaling_factor in compute_gaussian or increase the dtype of predicted_logits to fp32");
+    return 0;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int fnn_abi_version(void) { return FNN_ABI_VERSION; }
+
+const char *fnn_last_error(const fnn_engine *e) { return e ? e->err.c_str() : g_err.c_str(); }
+
+int fnn_create(const fnn_arch_desc *arch, int device, int max_batch, fnn_engine **out) {
+    if (!arch || !out) return fail(nullptr, FNN_E_INVALID, "NULL argument");
+    if (max_batch < 1 || max_batch > 64) return fail(nullptr, FNN_E_INVALID, "max_batch must be 1..64");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, FNN_E_HIP, "no HIP device is available: the MI355X engine has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(nullptr, FNN_E_INVALID, "device %d out of range (%d visible)", device, ndev);
+    fnn_engine *e = new fnn_engine();
+    e->arch = *arch; e->device = device; e->max_batch = max_batch;
+    if (e->arch.eps <= 0) e->arch.eps = 1e-5f;
+    int rc = build_plan(e);
+    if (rc != 0) { g_err = e->err; delete e; return rc; }
+    auto bail = [&](const char *what, hipError_t r) {
+        fail(nullptr, FNN_E_HIP, "%s failed: %s", what, hipGetErrorString(r));
+        fnn_destroy(e);
+        return FNN_E_HIP;
+    };
+    hipError_t r;
+    if ((r = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", r);
+    if ((r = hipMalloc((void **)&e->act, e->act_halves * max_batch * sizeof(f16))) != hipSuccess) return bail("hipMalloc(activations)", r);
+    if ((r = hipMalloc((void **)&e->stats, e->stats_doubles * max_batch * sizeof(double))) != hipSuccess) return bail("hipMalloc(stats)", r);
+    if ((r = hipMalloc((void **)&e->inf_flag, sizeof(int))) != hipSuccess) return bail("hipMalloc(flag)", r);
+    *out = e;
+    return 0;
+}
+
+void fnn_destroy(fnn_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    for (auto &f : e->folds) { if (f.wpk) (void)hipFree(f.wpk); if (f.fparam) (void)hipFree(f.fparam); }
+    void *ptrs[] = {e->act, e->stats, e->gauss, e->inf_flag, e->origins, e->acc, e->wsum, e->vol_tmp, e->vol_pad, e->out_tmp, e->patch_buf};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &ev : e->evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    delete e;
+}
+
+int64_t fnn_weight_count(const fnn_engine *e) { return e ? e->blob_count : -1; }
+
+int fnn_load_weights(fnn_engine *e, int fold, const float *blob, int64_t count) {
+    if (!e) return FNN_E_INVALID;
+    if (!blob) return fail(e, FNN_E_INVALID, "NULL blob");
+    if (count != e->blob_count) return fail(e, FNN_E_INVALID, "weight blob has %lld values, expected %lld", (long long)count, (long long)e->blob_count);
+    if (fold < 0 || fold >= 64) return fail(e, FNN_E_INVALID, "fold index out of range");
+    HIPCHK(e, hipSetDevice(e->device));
+    if ((int)e->folds.size() <= fold) e->folds.resize(fold + 1);
+    FoldWeights &fw = e->folds[fold];
+    std::vector<uint16_t> wpk(e->wpk_halves, 0);
+    std::vector<float> fp(e->fparam_floats, 0.f);
+    for (const Layer &L : e->layers) {
+        const float *W = blob + L.blob_w;
+        if (L.type == Layer::STEM) {
+            const int T = L.k[0] * L.k[1] * L.k[2], C = L.cin_real[0];
+            for (int c = 0; c < C; ++c)
+                for (int t = 0; t < T; ++t)
+                    for (int co = 0; co < L.cout_real; ++co)
+                        fp[L.w_off + ((size_t)c * T + t) * L.cout_pad + co] = W[((size_t)co * C + c) * T + t];
+        } else if (L.type == Layer::CONV) {
+            pack_conv(L, W, wpk.data() + L.w_off);
+        } else {
+            pack_tconv(L, W, wpk.data() + L.w_off);
+        }
+        for (int c = 0; c < L.cout_real; ++c) {
+            fp[L.bias_off + c] = blob[L.blob_b + c];
+            if (L.has_norm) { fp[L.gamma_off + c] = blob[L.blob_g + c]; fp[L.beta_off + c] = blob[L.blob_beta + c]; }
+        }
+    }
+    pack_head(e->arch.num_heads, e->arch.features[0], e->hblocks, e->head_ksteps, blob + e->blob_head_w, wpk.data() + e->head_w_off);
+    for (int h = 0; h < e->arch.num_heads; ++h) fp[e->head_bias_off + h] = blob[e->blob_head_b + h];
+    if (!fw.wpk) HIPCHK(e, hipMalloc((void **)&fw.wpk, wpk.size() * 2));
+    if (!fw.fparam) HIPCHK(e, hipMalloc((void **)&fw.fparam, fp.size() * 4));
+    HIPCHK(e, hipMemcpy(fw.wpk, wpk.data(), wpk.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(fw.fparam, fp.data(), fp.size() * 4, hipMemcpyHostToDevice));
+    fw.loaded = true;
+    return 0;
+}
+
+int fnn_set_gaussian(fnn_engine *e, const uint16_t *half_bits, int64_t count) {
+    if (!e) return FNN_E_INVALID;
+    const int64_t P = (int64_t)e->arch.patch[0] * e->arch.patch[1] * e->arch.patch[2];
+    if (!half_bits || count != P) return fail(e, FNN_E_INVALID, "gaussian must have %lld values", (long long)P);
+    HIPCHK(e, hipSetDevice(e->device));
+    if (!e->gauss) HIPCHK(e, hipMalloc((void **)&e->gauss, P * 2));
+    HIPCHK(e, hipMemcpy(e->gauss, half_bits, P * 2, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int fnn_predict_volume(fnn_engine *e, int fold, const float *vol, const int64_t shape[4], const fnn_opts *opts, void *out) {
+    if (!e) return FNN_E_INVALID;
+    return predict_impl(e, fold, 1, vol, shape, opts, out);
+}
+
+int fnn_predict_volume_ensemble(fnn_engine *e, int n_folds, const float *vol, const int64_t shape[4], const fnn_opts *opts, void *out) {
+    if (!e) return FNN_E_INVALID;
+    if (n_folds < 1) return fail(e, FNN_E_INVALID, "n_folds must be >= 1");
+    return predict_impl(e, 0, n_folds, vol, shape, opts, out);
+}
+
+int fnn_accumulate_patches(fnn_engine *e, int fold, const float *vol, const int64_t shape[4], const fnn_opts *opts,
+                           int64_t patch_begin, int64_t patch_end, int64_t x0, int64_t x1, float *acc, float *wsum) {
+    if (int rc = check_ready(e, fold, opts)) return rc;
+    if (!vol || !acc || !wsum) return fail(e, FNN_E_INVALID, "NULL argument");
+    if (!is_device_ptr(acc) || !is_device_ptr(wsum)) return fail(e, FNN_E_INVALID, "accumulators must be device memory");
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)opts->stream;
+    VolPlan vp;
+    if (plan_volume(e->arch, shape + 1, opts->tile_step_size, vp) != 0) return fail(e, FNN_E_INVALID, "invalid volume shape / step size");
+    if (patch_begin < 0 || patch_end > vp.n_patches || patch_begin > patch_end) return fail(e, FNN_E_INVALID, "patch range out of bounds");
+    if (x0 < 0 || x1 > vp.padded[0] || x0 >= x1) return fail(e, FNN_E_INVALID, "x-range out of bounds");
+    const float *vol_dev = nullptr;
+    if (int rc = stage_volume(e, vol, shape, vp, st, &vol_dev)) return rc;
+    if (int rc = upload_origins(e, vp, st)) return rc;
+    e->ev_used = 0;
+    if (int rc = run_patches(e, fold, vol_dev, vp, *opts, patch_begin, patch_end, x0, x1, acc, wsum, 1, st)) return rc;
+    if (e->profiling) { HIPCHK(e, hipStreamSynchronize(st)); collect_profile(e, patch_end - patch_begin); }
+    return 0;
+}
+
+int fnn_normalize_slab(fnn_engine *e, const float *acc, const float *wsum, const int64_t shape[4], const fnn_opts *opts,
+                       int64_t x0, int64_t x1, int64_t out_x0, int64_t out_x1, void *out) {
+    if (!e || !opts) return FNN_E_INVALID;
+    if (!acc || !wsum || !out) return fail(e, FNN_E_INVALID, "NULL argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)opts->stream;
+    VolPlan vp;
+    if (plan_volume(e->arch, shape + 1, opts->tile_step_size, vp) != 0) return fail(e, FNN_E_INVALID, "invalid volume shape / step size");
+    // output rows [out_x0, out_x1) (un-padded coordinates) must lie inside the slab
+    if (out_x0 < 0 || out_x1 > shape[1] || out_x0 >= out_x1) return fail(e, FNN_E_INVALID, "output x-range out of bounds");
+    if (out_x0 + vp.lo[0] < x0 || out_x1 + vp.lo[0] > x1) return fail(e, FNN_E_INVALID, "output rows are not covered by the slab");
+    const size_t osz = opts->out_dtype == FNN_OUT_F32 ? 4 : 2;
+    // finalize writes a [heads][OX][OY][OZ] block; to address rows of the full tensor we run it per head
+    HIPCHK(e, hipMemsetAsync(e->inf_flag, 0, sizeof(int), st));
+    const size_t plane_in = (size_t)(x1 - x0) * vp.padded[1] * vp.padded[2];
+    const size_t plane_out = (size_t)shape[1] * shape[2] * shape[3];
+    for (int h = 0; h < e->arch.num_heads; ++h) {
+        FinalizeParams f{};
+        f.acc = acc + (size_t)h * plane_in; f.wsum = wsum;
+        f.AX = x1 - x0; f.Y = vp.padded[1]; f.Z = vp.padded[2];
+        f.lo_x = (int)(out_x0 + vp.lo[0] - x0); f.lo_y = (int)vp.lo[1]; f.lo_z = (int)vp.lo[2];
+        f.OX = out_x1 - out_x0; f.OY = shape[2]; f.OZ = shape[3];
+        f.heads = 1; f.acc_fp32 = 1; f.out_fp32 = opts->out_dtype == FNN_OUT_F32; f.mode = 0;
+        f.out = (char *)out + ((size_t)h * plane_out + (size_t)out_x0 * shape[2] * shape[3]) * osz;
+        f.inf_flag = e->inf_flag;
+        if (launch_finalize(f, st) != 0) return fail(e, FNN_E_HIP, "finalize launch failed");
+    }
+    int flag = 0;
+    HIPCHK(e, hipMemcpyAsync(&flag, e->inf_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    if (flag) return fail(e, FNN_E_INF, "Encountered inf in predicted array.");
+    return 0;
+}
+
+int fnn_forward_patches(fnn_engine *e, int fold, const float *x, int n, float *logits, void *stream) {
+    if (!e) return FNN_E_INVALID;
+    if (fold < 0 || fold >= (int)e->folds.size() || !e->folds[fold].loaded) return fail(e, FNN_E_STATE, "weights of fold %d are not loaded", fold);
+    if (!x || !logits || n < 1) return fail(e, FNN_E_INVALID, "bad argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)stream;
+    const fnn_arch_desc &a = e->arch;
+    const size_t P = (size_t)a.patch[0] * a.patch[1] * a.patch[2];
+    const size_t nin = (size_t)n * a.in_channels * P, nout = (size_t)n * a.num_heads * P;
+    const float *xd = x;
+    if (!is_device_ptr(x)) {
+        void *t = e->vol_tmp;
+        if (int rc = ensure(e, &t, &e->vol_tmp_bytes, nin * 4)) return rc;
+        e->vol_tmp = (float *)t;
+        HIPCHK(e, hipMemcpyAsync(e->vol_tmp, x, nin * 4, hipMemcpyHostToDevice, st));
+        xd = e->vol_tmp;
+    }
+    float *od = logits;
+    const bool out_dev = is_device_ptr(logits);
+    if (!out_dev) {
+        if (int rc = ensure(e, &e->out_tmp, &e->out_tmp_bytes, nout * 4)) return rc;
+        od = (float *)e->out_tmp;
+    }
+    std::vector<int> zeros((size_t)e->max_batch * 3, 0);
+    void *t = e->origins;
+    if (int rc = ensure(e, &t, &e->origins_cap, zeros.size() * sizeof(int))) return rc;
+    e->origins = (int *)t;
+    HIPCHK(e, hipMemcpyAsync(e->origins, zeros.data(), zeros.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    const long long vdim[3] = {a.patch[0], a.patch[1], a.patch[2]};
+    const int flip[3] = {0, 0, 0};
+    e->ev_used = 0;
+    for (int p0 = 0; p0 < n; p0 += e->max_batch) {
+        const int nb = (n - p0 < e->max_batch) ? n - p0 : e->max_batch;
+        if (int rc = forward_batch(e, fold, xd + (size_t)p0 * a.in_channels * P, (long long)(a.in_channels * P), vdim,
+                                   e->origins, nb, flip, st)) return rc;
+        for (int b = 0; b < nb; ++b) {
+            HeadParams h = make_head(e, fold, b);
+            h.mode = 1; h.patch_buf = od + (size_t)(p0 + b) * a.num_heads * P;
+            h.acc_fp32 = 1;
+            Scope sc(e, st, FAM_HEAD, e->head_flops);
+            if (launch_head(h, st) != 0) return fail(e, FNN_E_HIP, "seg head launch failed");
+        }
+    }
+    if (!out_dev) HIPCHK(e, hipMemcpyAsync(logits, od, nout * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    if (e->profiling) collect_profile(e, n);
+    return 0;
+}
+
+int fnn_argmax_labels(fnn_engine *e, const void *logits, int dtype, int heads, int64_t n_vox, uint8_t *labels, void *stream) {
+    if (!e) return FNN_E_INVALID;
+    if (!logits || !labels || heads < 1 || heads > 256) return fail(e, FNN_E_INVALID, "bad argument");
+    if (!is_device_ptr(logits) || !is_device_ptr(labels)) return fail(e, FNN_E_INVALID, "fnn_argmax_labels needs device pointers");
+    HIPCHK(e, hipSetDevice(e->device));
+    if (launch_argmax(logits, dtype == FNN_OUT_F32, heads, n_vox, labels, (hipStream_t)stream) != 0) return fail(e, FNN_E_HIP, "argmax launch failed");
+    return 0;
+}
+
+int fnn_compute_steps(int64_t image_size, int64_t patch_size, double step, int64_t *steps, int cap) {
+    std::vector<int64_t> s;
+    if (steps_1d(image_size, patch_size, step, s) != 0) return fail(nullptr, FNN_E_INVALID, "image size must be as large or larger than patch_size, 0 < step <= 1");
+    if ((int)s.size() > cap) return fail(nullptr, FNN_E_INVALID, "steps buffer too small (%zu needed)", s.size());
+    for (size_t i = 0; i < s.size(); ++i) steps[i] = s[i];
+    return (int)s.size();
+}
+
+int fnn_plan_volume(const int32_t patch[3], const int64_t shape_sp[3], double step, int64_t padded[3], int64_t pad_lo[3],
+                    int64_t *n_patches, int32_t *origins, int64_t origins_cap) {
+    if (!patch || !shape_sp) return fail(nullptr, FNN_E_INVALID, "NULL argument");
+    VolPlan vp;
+    if (plan_volume_p(patch, shape_sp, step, vp) != 0) return fail(nullptr, FNN_E_INVALID, "invalid volume shape / patch / step size");
+    for (int d = 0; d < 3; ++d) { if (padded) padded[d] = vp.padded[d]; if (pad_lo) pad_lo[d] = vp.lo[d]; }
+    if (n_patches) *n_patches = vp.n_patches;
+    if (origins) {
+        if (origins_cap < vp.n_patches) return fail(nullptr, FNN_E_INVALID, "origins buffer too small");
+        for (size_t i = 0; i < vp.origins.size(); ++i) origins[i] = vp.origins[i];
+    }
+    return 0;
+}
+
+int fnn_set_profiling(fnn_engine *e, int enabled) { if (!e) return FNN_E_INVALID; e->profiling = enabled != 0; return 0; }
+
+int fnn_get_profile(const fnn_engine *e, fnn_profile *out) { if (!e || !out) return FNN_E_INVALID; *out = e->prof; return 0; }
+
+int fnn_patch_work(const fnn_engine *e, double *flops, double *act_bytes) {
+    if (!e) return FNN_E_INVALID;
+    if (flops) *flops = e->patch_flops;
+    if (act_bytes) *act_bytes = e->patch_act_bytes;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,149 @@
+// Shared device-side definitions for the gfx950 (MI355X) kernels.
+//
+// Data layout in HBM:
+//   activations   fp16, NDHWC ("channels-last"), channel count padded to a
+//                 multiple of 16 so that one MFMA k-group (8 halves = 16 B) is
+//                 one aligned vector load;
+//   raw conv out  stored BEFORE InstanceNorm; the per-(n, channel) sum and sum
+//                 of squares are accumulated by the producing kernel's epilogue
+//                 into `stats` (double, FNN_STAT_REPL replicas to spread the
+//                 atomics), and the CONSUMER applies
+//                 gamma*(x-mean)*rstd+beta and LeakyReLU while it stages its
+//                 input tile;
+//   weights       fp16, pre-packed on the host into MFMA fragment order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define FNN_STAT_REPL 8          // replicas of every stats row (one per blockIdx & 7)
+#define FNN_TILE_D 4             // conv output tile: 4 x 8 x 8 voxels per 256-thread workgroup
+#define FNN_TILE_H 8
+#define FNN_TILE_W 8
+
+// One input tensor of a conv / transposed conv / seg head, with the fused
+// "normalise + LeakyReLU on load" description.
+struct SrcDesc {
+    const f16 *ptr;              // [N][D][H][W][C]
+    int C;                       // padded channel count (multiple of 16)
+    const double *stats;         // [N][REPL][C][2] (sum, sum of squares) or nullptr = identity
+    const float *gamma;          // [C]
+    const float *beta;           // [C]
+    float slope;                 // LeakyReLU slope applied after the affine (1.0 = none)
+};
+
+struct ConvParams {
+    SrcDesc src[2];
+    int n_src;
+    int N, Di, Hi, Wi;           // input spatial size (both sources)
+    int Do, Ho, Wo;              // output spatial size
+    int Cout;                    // padded
+    int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+    const f16 *wpk;              // [cout_blk][chunk][kstep][64 lanes][8]
+    const float *bias;           // [Cout]
+    f16 *out;                    // [N][Do][Ho][Wo][Cout]
+    double *stats_out;           // [N][REPL][Cout][2] or nullptr
+    int tiles_d, tiles_h, tiles_w;
+    int chunks;                  // 16-channel chunks over all sources
+    int ksteps;                  // MFMA k-steps per chunk = ceil(taps / 2)
+    float eps;
+    float inv_count;             // 1 / (Di*Hi*Wi)
+};
+
+struct StemParams {
+    const float *vol;            // [C][X][Y][Z] fp32 (the padded volume)
+    long long vol_batch_stride;  // elements between the volumes of consecutive batch items (0 = one volume)
+    int C;
+    long long X, Y, Z;
+    const int *origins;          // [N][3] patch origin in the volume
+    int flip_d, flip_h, flip_w;  // test-time mirroring of the network input
+    int PD, PH, PW;              // patch = conv input = conv output size (stride 1)
+    int kd, kh, kw;
+    int Cout;                    // padded
+    const float *w;              // [C][taps][Cout] fp32
+    const float *bias;           // [Cout]
+    f16 *out;                    // [N][PD][PH][PW][Cout]
+    double *stats_out;
+    int tiles_d, tiles_h, tiles_w;
+};
+
+struct TconvParams {
+    SrcDesc src;
+    int N, Di, Hi, Wi;
+    int sd, sh, sw;
+    int Cout;                    // padded
+    const f16 *wpk;              // [tap][cout_blk][kstep][64][8]
+    const float *bias;
+    f16 *out;                    // [N][Di*sd][Hi*sh][Wi*sw][Cout]
+    int ksteps;                  // ceil(Cin / 32)
+    int nblk;                    // Cout / 16
+    float eps, inv_count;
+};
+
+struct HeadParams {
+    SrcDesc src;                 // [N][PD][PH][PW][C]
+    int b;                       // batch item handled by this launch
+    int PD, PH, PW;
+    int heads;
+    int hblocks;                 // ceil(heads / 16)
+    int ksteps;                  // ceil(C / 32)
+    const f16 *wpk;              // [hblock][kstep][64][8]
+    const float *bias;           // [hblocks*16]
+    const f16 *gauss;            // [PD][PH][PW] or nullptr (= weight 1)
+    void *acc;                   // [heads][AX][Y][Z] fp16 or fp32, AX = x1 - x0
+    void *wsum;                  // [AX][Y][Z]
+    long long AX, Y, Z;
+    int ox, oy, oz;              // patch origin relative to the accumulator
+    int flip_d, flip_h, flip_w;
+    int mode;                    // 0 fused accumulate, 1 patch buffer '=', 2 patch buffer '+='
+    float *patch_buf;            // [heads][PD*PH*PW] fp32 (modes 1, 2)
+    int acc_fp32;
+    float eps, inv_count;
+};
+
+struct PatchAccParams {          // patch buffer -> volume accumulators (mirroring path)
+    const float *patch_buf;      // [heads][P]
+    float inv_n;                 // 1 / (number of mirrored evaluations)
+    int n_div;                   // the integer divisor (reference divides, not multiplies)
+    int PD, PH, PW, heads;
+    const f16 *gauss;
+    void *acc; void *wsum;
+    long long AX, Y, Z;
+    int ox, oy, oz;
+    int acc_fp32;
+};
+
+struct FinalizeParams {
+    const void *acc; const void *wsum;
+    long long AX, Y, Z;          // accumulator (padded) size
+    int lo_x, lo_y, lo_z;        // un-pad offsets
+    long long OX, OY, OZ;        // output size
+    int heads;
+    int acc_fp32;
+    int out_fp32;
+    int mode;                    // 0 write, 1 add to existing output (fold ensembling)
+    void *out;                   // [heads][OX][OY][OZ]
+    int *inf_flag;
+};
+
+static __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
+
+// launchers (implemented in the .hip files)
+int launch_conv3d(const ConvParams &p, hipStream_t st);
+size_t conv3d_lds_bytes(const ConvParams &p, int nb);
+int conv3d_pick_nb(int nblk);
+int launch_stem(const StemParams &p, int N, hipStream_t st);
+int launch_tconv(const TconvParams &p, hipStream_t st);
+int launch_head(const HeadParams &p, hipStream_t st);
+int launch_patch_acc(const PatchAccParams &p, hipStream_t st);
+int launch_finalize(const FinalizeParams &p, hipStream_t st);
+int launch_scale_output(void *out, int out_fp32, long long n, int divisor, int *inf_flag, hipStream_t st);
+int launch_argmax(const void *logits, int fp32, int heads, long long nvox, uint8_t *labels, hipStream_t st);
+int launch_pad_volume(const float *src, float *dst, int C, const long long s[3], const long long d[3],
+                      const long long lo[3], hipStream_t st);

@@ -1,0 +1,201 @@
+// ops_api.hip - single-op entry points of include/fnn.h (fnn_op_*).
+//
+// Parity tests drive the HIP kernels one at a time through these: host float32
+// NCDHW tensors in, host float32 out.  The wrapper does what the engine does
+// around a kernel: convert to fp16 channels-last with padded channels, pack the
+// weights into MFMA fragment order, provide the producer-side InstanceNorm
+// statistics, launch, convert back.
+#include "fnn_device.h"
+#include "../../include/fnn.h"
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+inline int pad16(int c) { return (c + 15) / 16 * 16; }
+inline uint16_t f2h_bits(float f) { f16 h = (f16)f; uint16_t b; memcpy(&b, &h, 2); return b; }
+inline float h2f_bits(uint16_t b) { f16 h; memcpy(&h, &b, 2); return (float)h; }
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool alloc(size_t n) { return hipMalloc(&p, n ? n : 16) == hipSuccess; }
+    template <class T> T *as() { return (T *)p; }
+};
+
+// NCDHW fp32 -> NDHWC fp16 with channel padding; also the per-(n,c) statistics of the rounded values
+void to_ndhwc(const float *x, int n, int c, int cp, size_t vox, std::vector<uint16_t> &out, std::vector<double> *stats) {
+    out.assign((size_t)n * vox * cp, 0);
+    if (stats) stats->assign((size_t)n * FNN_STAT_REPL * cp * 2, 0.0);
+    for (int b = 0; b < n; ++b)
+        for (int ch = 0; ch < c; ++ch) {
+            double s1 = 0, s2 = 0;
+            const float *src = x + ((size_t)b * c + ch) * vox;
+            for (size_t v = 0; v < vox; ++v) {
+                const uint16_t hb = f2h_bits(src[v]);
+                out[((size_t)b * vox + v) * cp + ch] = hb;
+                const double f = h2f_bits(hb);
+                s1 += f; s2 += f * f;
+            }
+            if (stats) {
+                // spread over two replicas to exercise the replica sum
+                double *st = stats->data() + ((size_t)b * FNN_STAT_REPL * cp + ch) * 2;
+                st[0] = s1 * 0.25; st[1] = s2 * 0.25;
+                st[(size_t)3 * cp * 2] = s1 * 0.75; st[(size_t)3 * cp * 2 + 1] = s2 * 0.75;
+            }
+        }
+}
+
+struct SrcHolder {
+    DevBuf act, stats, gamma, beta;
+    SrcDesc d{};
+};
+
+bool make_src(SrcHolder &h, const float *x, int n, int c, size_t vox, const float *gamma, const float *beta, float slope) {
+    const int cp = pad16(c);
+    std::vector<uint16_t> a;
+    std::vector<double> st;
+    to_ndhwc(x, n, c, cp, vox, a, gamma ? &st : nullptr);
+    if (!h.act.alloc(a.size() * 2)) return false;
+    if (hipMemcpy(h.act.p, a.data(), a.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return false;
+    h.d.ptr = h.act.as<f16>(); h.d.C = cp; h.d.slope = 1.f;
+    if (gamma) {
+        std::vector<float> g(cp, 0.f), b(cp, 0.f);
+        for (int i = 0; i < c; ++i) { g[i] = gamma[i]; b[i] = beta ? beta[i] : 0.f; }
+        if (!h.stats.alloc(st.size() * 8) || !h.gamma.alloc(cp * 4) || !h.beta.alloc(cp * 4)) return false;
+        (void)hipMemcpy(h.stats.p, st.data(), st.size() * 8, hipMemcpyHostToDevice);
+        (void)hipMemcpy(h.gamma.p, g.data(), cp * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(h.beta.p, b.data(), cp * 4, hipMemcpyHostToDevice);
+        h.d.stats = h.stats.as<double>(); h.d.gamma = h.gamma.as<float>(); h.d.beta = h.beta.as<float>();
+        h.d.slope = slope;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fnn_op_conv3d(int device, int n, const int dims[3],
+                  const float *x, int cin, const float *gamma1, const float *beta1, float slope1,
+                  const float *x2, int cin2, const float *gamma2, const float *beta2, float slope2,
+                  const float *w, const float *bias, int cout, const int k[3], const int stride[3],
+                  float *y, double *stats_out) {
+    if (!x || !w || !y || !dims || !k || !stride || n < 1 || cin < 1 || cout < 1) return FNN_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return FNN_E_HIP;
+    const size_t vox = (size_t)dims[0] * dims[1] * dims[2];
+    const int nsrc = x2 ? 2 : 1;
+    SrcHolder s1, s2;
+    if (!make_src(s1, x, n, cin, vox, gamma1, beta1, slope1)) return FNN_E_HIP;
+    if (x2 && !make_src(s2, x2, n, cin2, vox, gamma2, beta2, slope2)) return FNN_E_HIP;
+    const int cp1 = pad16(cin), cp2 = x2 ? pad16(cin2) : 0, cop = pad16(cout);
+    const int T = k[0] * k[1] * k[2], cin_tot = cin + (x2 ? cin2 : 0);
+    ConvParams p{};
+    p.n_src = nsrc; p.src[0] = s1.d;
+    if (x2) p.src[1] = s2.d; else { p.src[1] = s1.d; p.src[1].C = 0; }
+    p.N = n; p.Di = dims[0]; p.Hi = dims[1]; p.Wi = dims[2];
+    p.kd = k[0]; p.kh = k[1]; p.kw = k[2]; p.sd = stride[0]; p.sh = stride[1]; p.sw = stride[2];
+    p.pd = (k[0] - 1) / 2; p.ph = (k[1] - 1) / 2; p.pw = (k[2] - 1) / 2;
+    p.Do = (p.Di + 2 * p.pd - p.kd) / p.sd + 1; p.Ho = (p.Hi + 2 * p.ph - p.kh) / p.sh + 1; p.Wo = (p.Wi + 2 * p.pw - p.kw) / p.sw + 1;
+    p.Cout = cop; p.chunks = (cp1 + cp2) / 16; p.ksteps = (T + 1) / 2;
+    p.tiles_d = (p.Do + FNN_TILE_D - 1) / FNN_TILE_D; p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
+    p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
+    p.eps = 1e-5f; p.inv_count = 1.f / (float)vox;
+    // pack weights [cout][cin_tot][T] -> [cb][chunk][ks][lane][8]
+    std::vector<uint16_t> wp((size_t)(cop / 16) * p.chunks * p.ksteps * 512, 0);
+    for (int cb = 0; cb < cop / 16; ++cb)
+        for (int ch = 0; ch < p.chunks; ++ch)
+            for (int ks = 0; ks < p.ksteps; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int kk = 8 * (lane >> 4) + j, tap = 2 * ks + (kk >> 4), c = ch * 16 + (kk & 15);
+                        const int co = cb * 16 + (lane & 15);
+                        int src = 0, cl = c;
+                        if (c >= cp1) { src = 1; cl = c - cp1; }
+                        const int creal = src ? cin2 : cin;
+                        float v = 0.f;
+                        if (tap < T && co < cout && cl < creal) v = w[((size_t)co * cin_tot + (src ? cin : 0) + cl) * T + tap];
+                        wp[((((size_t)cb * p.chunks + ch) * p.ksteps + ks) * 64 + lane) * 8 + j] = f2h_bits(v);
+                    }
+    std::vector<float> bp(cop, 0.f);
+    if (bias) for (int i = 0; i < cout; ++i) bp[i] = bias[i];
+    const size_t ovox = (size_t)p.Do * p.Ho * p.Wo;
+    DevBuf dw, db, dout, dst;
+    if (!dw.alloc(wp.size() * 2) || !db.alloc(cop * 4) || !dout.alloc((size_t)n * ovox * cop * 2) ||
+        !dst.alloc((size_t)n * FNN_STAT_REPL * cop * 16)) return FNN_E_HIP;
+    (void)hipMemcpy(dw.p, wp.data(), wp.size() * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db.p, bp.data(), cop * 4, hipMemcpyHostToDevice);
+    (void)hipMemset(dst.p, 0, (size_t)n * FNN_STAT_REPL * cop * 16);
+    (void)hipMemset(dout.p, 0, (size_t)n * ovox * cop * 2);
+    p.wpk = dw.as<f16>(); p.bias = db.as<float>(); p.out = dout.as<f16>(); p.stats_out = dst.as<double>();
+    const int rc = launch_conv3d(p, 0);
+    if (rc != 0) return rc == -1 ? FNN_E_UNSUPPORTED : FNN_E_HIP;
+    if (hipDeviceSynchronize() != hipSuccess) return FNN_E_HIP;
+    std::vector<uint16_t> ho((size_t)n * ovox * cop);
+    std::vector<double> hs((size_t)n * FNN_STAT_REPL * cop * 2);
+    (void)hipMemcpy(ho.data(), dout.p, ho.size() * 2, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(hs.data(), dst.p, hs.size() * 8, hipMemcpyDeviceToHost);
+    for (int b = 0; b < n; ++b)
+        for (int co = 0; co < cout; ++co) {
+            for (size_t v = 0; v < ovox; ++v) y[((size_t)b * cout + co) * ovox + v] = h2f_bits(ho[((size_t)b * ovox + v) * cop + co]);
+            if (stats_out) {
+                double a = 0, q = 0;
+                for (int r = 0; r < FNN_STAT_REPL; ++r) {
+                    a += hs[(((size_t)b * FNN_STAT_REPL + r) * cop + co) * 2];
+                    q += hs[(((size_t)b * FNN_STAT_REPL + r) * cop + co) * 2 + 1];
+                }
+                stats_out[((size_t)b * cout + co) * 2] = a;
+                stats_out[((size_t)b * cout + co) * 2 + 1] = q;
+            }
+        }
+    return 0;
+}
+
+int fnn_op_conv_transpose3d(int device, int n, const int dims[3],
+                            const float *x, int cin, const float *gamma1, const float *beta1, float slope1,
+                            const float *w, const float *bias, int cout, const int stride[3], float *y) {
+    if (!x || !w || !y || !dims || !stride || n < 1 || cin < 1 || cout < 1) return FNN_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return FNN_E_HIP;
+    const size_t vox = (size_t)dims[0] * dims[1] * dims[2];
+    SrcHolder s1;
+    if (!make_src(s1, x, n, cin, vox, gamma1, beta1, slope1)) return FNN_E_HIP;
+    const int cp = pad16(cin), cop = pad16(cout);
+    const int taps = stride[0] * stride[1] * stride[2];
+    TconvParams p{};
+    p.src = s1.d; p.N = n; p.Di = dims[0]; p.Hi = dims[1]; p.Wi = dims[2];
+    p.sd = stride[0]; p.sh = stride[1]; p.sw = stride[2];
+    p.Cout = cop; p.nblk = cop / 16; p.ksteps = (cp + 31) / 32;
+    p.eps = 1e-5f; p.inv_count = 1.f / (float)vox;
+    std::vector<uint16_t> wp((size_t)taps * p.nblk * p.ksteps * 512, 0);
+    for (int tap = 0; tap < taps; ++tap)
+        for (int cb = 0; cb < p.nblk; ++cb)
+            for (int ks = 0; ks < p.ksteps; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int ci = ks * 32 + 8 * (lane >> 4) + j, co = cb * 16 + (lane & 15);
+                        float v = 0.f;
+                        if (ci < cin && co < cout) v = w[((size_t)ci * cout + co) * taps + tap];
+                        wp[((((size_t)tap * p.nblk + cb) * p.ksteps + ks) * 64 + lane) * 8 + j] = f2h_bits(v);
+                    }
+    std::vector<float> bp(cop, 0.f);
+    if (bias) for (int i = 0; i < cout; ++i) bp[i] = bias[i];
+    const size_t ovox = vox * taps;
+    DevBuf dw, db, dout;
+    if (!dw.alloc(wp.size() * 2) || !db.alloc(cop * 4) || !dout.alloc((size_t)n * ovox * cop * 2)) return FNN_E_HIP;
+    (void)hipMemcpy(dw.p, wp.data(), wp.size() * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db.p, bp.data(), cop * 4, hipMemcpyHostToDevice);
+    (void)hipMemset(dout.p, 0, (size_t)n * ovox * cop * 2);
+    p.wpk = dw.as<f16>(); p.bias = db.as<float>(); p.out = dout.as<f16>();
+    if (launch_tconv(p, 0) != 0) return FNN_E_HIP;
+    if (hipDeviceSynchronize() != hipSuccess) return FNN_E_HIP;
+    std::vector<uint16_t> ho((size_t)n * ovox * cop);
+    (void)hipMemcpy(ho.data(), dout.p, ho.size() * 2, hipMemcpyDeviceToHost);
+    for (int b = 0; b < n; ++b)
+        for (int co = 0; co < cout; ++co)
+            for (size_t v = 0; v < ovox; ++v) y[((size_t)b * cout + co) * ovox + v] = h2f_bits(ho[((size_t)b * ovox + v) * cop + co]);
+    return 0;
+}
+
+}  // extern "C"

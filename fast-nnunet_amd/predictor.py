@@ -1,0 +1,257 @@
+"""Drop-in ``nnUNetPredictor`` backed by the MI355X HIP engine.
+
+Mirrors the public surface of the reference's
+``nnunetv2.inference.predict_from_raw_data.nnUNetPredictor``
+(distillation/nnunetv2/inference/predict_from_raw_data.py:39-680) for the hot
+path: constructor knobs, ``initialize_from_trained_model_folder``,
+``manual_initialization``, ``predict_sliding_window_return_logits``,
+``predict_logits_from_preprocessed_data`` and the attributes callers read
+(``network``, ``plans_manager``, ``configuration_manager``, ``label_manager``,
+``dataset_json``, ``list_of_parameters``, ``allowed_mirroring_axes``,
+``device``, ``verbose``).  Everything numerical happens in
+``csrc/libfnn_hip.so``; torch is only used for device memory and streams.
+
+There is no CPU path: the predictor raises if the HIP library or a GPU is
+missing.
+"""
+from __future__ import annotations
+
+import itertools
+import os
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import capi
+from .arch import ArchSpec, check_against_plans, spec_from_state_dict, weight_blob
+from .plans import ConfigurationManager, PlansManager, determine_num_input_channels
+from .sliding_window import compute_gaussian, compute_steps_for_sliding_window
+
+
+def _load_json(path):
+    import json
+    with open(path) as f:
+        return json.load(f)
+
+
+class nnUNetPredictor(object):
+    def __init__(self,
+                 tile_step_size: float = 0.5,
+                 use_gaussian: bool = True,
+                 use_mirroring: bool = True,
+                 perform_everything_on_device: bool = True,
+                 device: torch.device = torch.device('cuda'),
+                 verbose: bool = False,
+                 verbose_preprocessing: bool = False,
+                 allow_tqdm: bool = True,
+                 accumulate_in: str = 'fp16',
+                 patches_per_forward: int = 4):
+        """Same knobs as the reference (:40-65) plus two engine choices:
+
+        accumulate_in  'fp16' reproduces the reference's half accumulators and
+                       their rounding per patch visit; 'fp32' is the exact blend.
+        patches_per_forward  how many patches one network forward batches.
+        """
+        self.verbose = verbose
+        self.verbose_preprocessing = verbose_preprocessing
+        self.allow_tqdm = allow_tqdm
+        self.plans_manager, self.configuration_manager, self.list_of_parameters, self.network, self.dataset_json, \
+            self.trainer_name, self.allowed_mirroring_axes, self.label_manager = (None,) * 8
+        self.tile_step_size = tile_step_size
+        self.use_gaussian = use_gaussian
+        self.use_mirroring = use_mirroring
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise RuntimeError('this predictor runs on an AMD GPU through the HIP engine; there is no CPU path '
+                               f'(got device={device}). Use the reference predictor for CPU inference.')
+        self.device = device
+        self.perform_everything_on_device = perform_everything_on_device
+        if accumulate_in not in ('fp16', 'fp32'):
+            raise ValueError("accumulate_in must be 'fp16' or 'fp32'")
+        self.accumulate_in = accumulate_in
+        self.patches_per_forward = int(patches_per_forward)
+        self._engine: Optional[capi.Engine] = None
+        self._spec: Optional[ArchSpec] = None
+        self._active_fold = 0
+
+    # ------------------------------------------------------------------ init
+    def initialize_from_trained_model_folder(self, model_training_output_dir: str,
+                                             use_folds: Union[Tuple[Union[int, str]], None],
+                                             checkpoint_name: str = 'checkpoint_final.pth'):
+        """Model folder -> plans, dataset.json, per-fold weights (:67-129)."""
+        if use_folds is None:
+            use_folds = nnUNetPredictor.auto_detect_available_folds(model_training_output_dir, checkpoint_name)
+        dataset_json = _load_json(os.path.join(model_training_output_dir, 'dataset.json'))
+        plans_manager = PlansManager(_load_json(os.path.join(model_training_output_dir, 'plans.json')))
+        if isinstance(use_folds, (str, int)):
+            use_folds = [use_folds]
+        parameters, trainer_name, configuration_name, mirror_axes, init_args = [], None, None, None, {}
+        for i, f in enumerate(use_folds):
+            f = int(f) if f != 'all' else f
+            checkpoint = torch.load(os.path.join(model_training_output_dir, f'fold_{f}', checkpoint_name),
+                                    map_location=torch.device('cpu'), weights_only=False)
+            if i == 0:
+                trainer_name = checkpoint['trainer_name']
+                init_args = checkpoint.get('init_args', {})
+                configuration_name = init_args['configuration']
+                mirror_axes = checkpoint.get('inference_allowed_mirroring_axes')
+            parameters.append(checkpoint['network_weights'])
+        configuration_manager = plans_manager.get_configuration(configuration_name)
+        self.plans_manager = plans_manager
+        self.configuration_manager = configuration_manager
+        self.list_of_parameters = parameters
+        self.dataset_json = dataset_json
+        self.trainer_name = trainer_name
+        self.allowed_mirroring_axes = mirror_axes
+        self.label_manager = plans_manager.get_label_manager(dataset_json)
+        self.network = None
+        self._reduction = init_args.get('feature_reduction_factor')
+        self._build_engine()
+
+    def manual_initialization(self, network, plans_manager: PlansManager,
+                              configuration_manager: ConfigurationManager, parameters: Optional[List[dict]],
+                              dataset_json: dict, trainer_name: str,
+                              inference_allowed_mirroring_axes: Optional[Tuple[int, ...]]):
+        """In-process initialisation (:131-154).  ``network`` may be the torch module the caller built
+        (its state dict is read when ``parameters`` is None) or None when ``parameters`` are given."""
+        self.plans_manager = plans_manager
+        self.configuration_manager = configuration_manager
+        self.list_of_parameters = parameters
+        self.network = network
+        self.dataset_json = dataset_json
+        self.trainer_name = trainer_name
+        self.allowed_mirroring_axes = inference_allowed_mirroring_axes
+        self.label_manager = plans_manager.get_label_manager(dataset_json)
+        self._reduction = None
+        self._build_engine()
+
+    @staticmethod
+    def auto_detect_available_folds(model_training_output_dir, checkpoint_name):
+        print('use_folds is None, attempting to auto detect available folds')
+        found = []
+        for name in sorted(os.listdir(model_training_output_dir)):
+            full = os.path.join(model_training_output_dir, name)
+            if os.path.isdir(full) and name.startswith('fold_') and name != 'fold_all' \
+                    and os.path.isfile(os.path.join(full, checkpoint_name)):
+                found.append(int(name.split('_')[-1]))
+        print(f'found the following folds: {found}')
+        return found
+
+    def _state_dicts(self) -> List[dict]:
+        if self.list_of_parameters:
+            return list(self.list_of_parameters)
+        if self.network is not None and hasattr(self.network, 'state_dict'):
+            return [self.network.state_dict()]
+        raise RuntimeError('no parameters: pass `parameters` or a network with a state_dict')
+
+    def _build_engine(self):
+        sds = self._state_dicts()
+        patch = tuple(self.configuration_manager.patch_size)
+        if len(patch) != 3:
+            raise NotImplementedError('the HIP engine implements 3-D (3d_fullres / 3d_lowres) configurations')
+        kw = {}
+        try:
+            kw = self.configuration_manager.network_arch_init_kwargs or {}
+        except (KeyError, TypeError):
+            kw = {}
+        eps = float((kw.get('norm_op_kwargs') or {}).get('eps', 1e-5)) if kw else 1e-5
+        spec = spec_from_state_dict(sds[0], patch, eps=eps)
+        if kw and 'n_stages' in kw and 'strides' in kw:
+            check_against_plans(spec, kw, self._reduction)
+        heads = self.label_manager.num_segmentation_heads
+        if heads != spec.num_heads:
+            raise RuntimeError(f'checkpoint has {spec.num_heads} segmentation heads, dataset.json implies {heads}')
+        if self._engine is not None:
+            self._engine.close()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._engine = capi.Engine(spec.to_desc(), device=idx, max_batch=max(1, self.patches_per_forward))
+        for f, sd in enumerate(sds):
+            blob = weight_blob(spec, sd)
+            if blob.size != self._engine.weight_count:
+                raise RuntimeError('internal error: weight blob size mismatch')
+            self._engine.load_weights(f, blob)
+        g = compute_gaussian(patch, sigma_scale=1. / 8, value_scaling_factor=10, device=torch.device('cpu'))
+        self._engine.set_gaussian(g.contiguous().view(torch.int16).numpy().view(np.uint16))
+        self._spec = spec
+        self._n_folds = len(sds)
+        self._active_fold = 0
+
+    # --------------------------------------------------------------- predict
+    def _opts(self) -> capi.Opts:
+        o = capi.Opts()
+        o.tile_step_size = float(self.tile_step_size)
+        o.use_gaussian = int(bool(self.use_gaussian))
+        axes = self.allowed_mirroring_axes if self.use_mirroring else None
+        if axes is not None:
+            assert max(axes) <= 2, 'mirror_axes does not match the dimension of the input!'
+            o.n_mirror_axes = len(axes)
+            for i, a in enumerate(axes):
+                o.mirror_axes[i] = int(a)
+        o.accum = capi.FNN_ACC_FP16_REFERENCE if self.accumulate_in == 'fp16' else capi.FNN_ACC_FP32
+        o.out_dtype = capi.FNN_OUT_F16
+        o.batch = self.patches_per_forward
+        o.stream = torch.cuda.current_stream(self.device).cuda_stream
+        return o
+
+    def _internal_get_sliding_window_slicers(self, image_size: Tuple[int, ...]):
+        """Patch windows in visit order (:506-538, 3-D branch)."""
+        patch = self.configuration_manager.patch_size
+        steps = compute_steps_for_sliding_window(image_size, patch, self.tile_step_size)
+        return [tuple([slice(None), *[slice(s, s + p) for s, p in zip(st, patch)]])
+                for st in itertools.product(*steps)]
+
+    def _check_input(self, input_image):
+        assert isinstance(input_image, torch.Tensor)
+        assert input_image.ndim == 4, 'input_image must be a 4D np.ndarray or torch.Tensor (c, x, y, z)'
+        if self._engine is None:
+            raise RuntimeError('predictor is not initialised')
+
+    @torch.inference_mode()
+    def predict_sliding_window_return_logits(self, input_image: torch.Tensor) -> torch.Tensor:
+        """[C,X,Y,Z] preprocessed image -> fp16 logits [heads,X,Y,Z] (:634-680)."""
+        self._check_input(input_image)
+        with torch.cuda.device(self.device):
+            x = input_image.to(device=self.device, dtype=torch.float32).contiguous()
+            out = torch.empty((self._spec.num_heads, *x.shape[1:]), dtype=torch.half, device=self.device)
+            self._engine.predict_volume(x.data_ptr(), x.shape, self._opts(), out.data_ptr(), fold=self._active_fold)
+        return out if self.perform_everything_on_device else out.cpu()
+
+    @torch.inference_mode()
+    def predict_logits_from_preprocessed_data(self, data: torch.Tensor) -> torch.Tensor:
+        """Mean over the folds; returned on the CPU like the reference (:471-504)."""
+        self._check_input(data)
+        with torch.cuda.device(self.device):
+            x = data.to(device=self.device, dtype=torch.float32).contiguous()
+            out = torch.empty((self._spec.num_heads, *x.shape[1:]), dtype=torch.half, device=self.device)
+            self._engine.predict_volume(x.data_ptr(), x.shape, self._opts(), out.data_ptr(), n_folds=self._n_folds)
+        if self.verbose:
+            print('Prediction done')
+        return out.to('cpu')
+
+    @torch.inference_mode()
+    def predict_segmentation_from_preprocessed_data(self, data: torch.Tensor) -> torch.Tensor:
+        """Label map on the device (argmax of the ensemble logits), skipping the full-logit D2H copy the
+        reference pays at :386 before ``convert_logits_to_segmentation`` (label_handling.py:173-180)."""
+        if self.label_manager.has_regions:
+            raise NotImplementedError('region-based label conversion is not implemented on the device')
+        self._check_input(data)
+        with torch.cuda.device(self.device):
+            x = data.to(device=self.device, dtype=torch.float32).contiguous()
+            out = torch.empty((self._spec.num_heads, *x.shape[1:]), dtype=torch.half, device=self.device)
+            self._engine.predict_volume(x.data_ptr(), x.shape, self._opts(), out.data_ptr(), n_folds=self._n_folds)
+            labels = torch.empty(x.shape[1:], dtype=torch.uint8, device=self.device)
+            self._engine.argmax_labels(out.data_ptr(), capi.FNN_OUT_F16, self._spec.num_heads, labels.numel(),
+                                       labels.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
+        return labels
+
+    @torch.inference_mode()
+    def forward_patches(self, x: torch.Tensor) -> torch.Tensor:
+        """``self.network(x)`` for a batch of patches: [n,C,px,py,pz] -> fp32 logits [n,heads,px,py,pz]."""
+        assert x.ndim == 5 and tuple(x.shape[2:]) == tuple(self._spec.patch)
+        with torch.cuda.device(self.device):
+            xd = x.to(device=self.device, dtype=torch.float32).contiguous()
+            out = torch.empty((x.shape[0], self._spec.num_heads, *x.shape[2:]), dtype=torch.float32, device=self.device)
+            self._engine.forward_patches(xd.data_ptr(), x.shape[0], out.data_ptr(), fold=self._active_fold,
+                                         stream=torch.cuda.current_stream(self.device).cuda_stream)
+        return out

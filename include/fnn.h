@@ -1,0 +1,199 @@
+/*
+ * fnn.h - C ABI of the MI355X-native sliding-window 3D-U-Net inference engine.
+ *
+ * This is the drop-in boundary for the hot path of 77even/Fast-nnUNet.  The
+ * reference has no native plugin interface for this path: the
+ * boundary in the reference is the Python method
+ *   nnUNetPredictor.predict_sliding_window_return_logits
+ *     (distillation/nnunetv2/inference/predict_from_raw_data.py:634-680)
+ * and the functions it drives.  Each entry point below names the reference
+ * code it replaces.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative FNN_E_* code otherwise;
+ *     fnn_last_error() gives the message (thread-local for fnn_create failures,
+ *     per engine afterwards);
+ *   - volumes / logits are channel-first contiguous [C, X, Y, Z], exactly the
+ *     tensors the reference passes; pointers may be device (HIP) or host
+ *     pointers, the engine detects which;
+ *   - the engine never frees or mutates caller memory; outputs are
+ *     caller-allocated;
+ *   - one engine = one GPU; not re-entrant per engine (like the reference's
+ *     predictor, which swaps fold weights in place, :486-489).
+ */
+#ifndef FNN_H
+#define FNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FNN_MAX_STAGES 8
+#define FNN_ABI_VERSION 1
+
+enum {
+    FNN_OK = 0,
+    FNN_E_INVALID = -1,      /* bad argument (maps to AssertionError / ValueError)            */
+    FNN_E_HIP = -2,          /* HIP runtime failure (maps to RuntimeError)                    */
+    FNN_E_INF = -3,          /* 'Encountered inf in predicted array' (:622-625)               */
+    FNN_E_UNSUPPORTED = -4,  /* topology the engine does not implement                        */
+    FNN_E_STATE = -5         /* weights / gaussian not loaded                                 */
+};
+
+enum { FNN_NET_PLAIN = 0, FNN_NET_RESENC = 1 };
+enum { FNN_ACC_FP16_REFERENCE = 0, FNN_ACC_FP32 = 1 };
+enum { FNN_OUT_F16 = 0, FNN_OUT_F32 = 1 };
+
+/* Network topology: what the reference builds from plans.json + checkpoint
+ * (PlainConvUNet / LiteNNUNetStudent: nnUNetDistillationTrainer.py:74-177,
+ *  get_network_from_plans.py:9-43).  Features are already reduced for a student. */
+typedef struct fnn_arch_desc {
+    int32_t kind;                               /* FNN_NET_*                                  */
+    int32_t n_stages;
+    int32_t in_channels;
+    int32_t num_heads;                          /* LabelManager.num_segmentation_heads        */
+    int32_t features[FNN_MAX_STAGES];
+    int32_t kernels[FNN_MAX_STAGES][3];         /* per-axis 1 or 3                            */
+    int32_t strides[FNN_MAX_STAGES][3];         /* per-axis 1 or 2; stage 0 must be 1,1,1     */
+    int32_t n_conv_enc[FNN_MAX_STAGES];         /* convs (plain) / residual blocks (resenc)   */
+    int32_t n_conv_dec[FNN_MAX_STAGES];
+    int32_t patch[3];                           /* ConfigurationManager.patch_size            */
+    float eps;                                  /* InstanceNorm eps (1e-5)                    */
+    float slope;                                /* LeakyReLU negative slope (0.01)            */
+} fnn_arch_desc;
+
+/* Knobs of nnUNetPredictor.__init__ (:40-65) + engine-side choices. */
+typedef struct fnn_opts {
+    float tile_step_size;                       /* 0 < s <= 1                                 */
+    int32_t use_gaussian;
+    int32_t n_mirror_axes;                      /* 0 = no test-time mirroring                 */
+    int32_t mirror_axes[3];                     /* spatial axes 0..2                          */
+    int32_t accum;                              /* FNN_ACC_*                                  */
+    int32_t out_dtype;                          /* FNN_OUT_*                                  */
+    int32_t batch;                              /* patches per forward, <= max_batch          */
+    void *stream;                               /* hipStream_t; NULL = the null stream        */
+} fnn_opts;
+
+typedef struct fnn_engine fnn_engine;
+
+/* ---- lifecycle ----------------------------------------------------------- */
+int fnn_abi_version(void);
+const char *fnn_last_error(const fnn_engine *e);             /* e may be NULL */
+
+/* Replaces network construction in initialize_from_trained_model_folder
+ * (:104-118) / manual_initialization (:131-154). */
+int fnn_create(const fnn_arch_desc *arch, int device, int max_batch, fnn_engine **out);
+void fnn_destroy(fnn_engine *e);
+
+/* Number of float32 values fnn_load_weights expects and the canonical order:
+ * for every encoder stage s, conv i: weight[F,Cin,kd,kh,kw], bias[F], gamma[F],
+ * beta[F]; then for every decoder level d (deepest first): transpconv
+ * weight[Cbelow,F,sd,sh,sw], bias[F]; its convs as above; finally the last
+ * seg layer weight[heads,F0], bias[heads]. */
+int64_t fnn_weight_count(const fnn_engine *e);
+
+/* Replaces network.load_state_dict(params) per fold (:486-489).  `blob` is
+ * host memory in the order above.  Folds are kept resident on the device. */
+int fnn_load_weights(fnn_engine *e, int fold, const float *blob, int64_t count);
+
+/* The fp16 importance map of compute_gaussian (sliding_window_prediction.py:10-27),
+ * patch[0]*patch[1]*patch[2] IEEE-half bit patterns, computed by the host
+ * mirror with scipy exactly as the reference does. */
+int fnn_set_gaussian(fnn_engine *e, const uint16_t *half_bits, int64_t count);
+
+/* ---- the hot path -------------------------------------------------------- */
+/* Replaces predict_sliding_window_return_logits (:634-680) for fold `fold`:
+ * pad -> slicers -> per patch network (+mirroring) -> weighted accumulate ->
+ * normalise -> un-pad.  vol: float32 [C,X,Y,Z]; out: [heads,X,Y,Z] of
+ * opts->out_dtype.  FNN_E_INF if the normalised logits contain inf. */
+int fnn_predict_volume(fnn_engine *e, int fold, const float *vol, const int64_t shape[4],
+                       const fnn_opts *opts, void *out_logits);
+
+/* Replaces predict_logits_from_preprocessed_data (:471-504): mean over the
+ * loaded folds [0, n_folds) - summed on the device instead of the reference's
+ * per-fold device->host hop (:494-497). */
+int fnn_predict_volume_ensemble(fnn_engine *e, int n_folds, const float *vol, const int64_t shape[4],
+                                const fnn_opts *opts, void *out_logits);
+
+/* One forward of the network on `n` patches (the `self.network(x)` call at
+ * :545): x float32 [n,C,px,py,pz] -> logits float32 [n,heads,px,py,pz].
+ * Used by parity tests and by callers that bring their own tiling. */
+int fnn_forward_patches(fnn_engine *e, int fold, const float *x, int n, float *logits, void *stream);
+
+/* Multi-GPU building blocks (not in the reference, whose only
+ * inference parallelism is case-level -num_parts/-part_id, :918-925).
+ * fnn_accumulate_patches runs patches [patch_begin, patch_end) of the x-major
+ * patch list and ADDS sum(w*logit) / sum(w) into caller-owned fp32 DEVICE
+ * buffers that cover the padded-volume x-range [x0, x1):
+ *   acc [heads][x1-x0][Y][Z], wsum [x1-x0][Y][Z]  (caller zeroes them).
+ * fnn_normalize_slab divides, un-pads and writes rows [x0,x1) of the output
+ * (out points at the full [heads][X][Y][Z] tensor of opts->out_dtype). */
+int fnn_accumulate_patches(fnn_engine *e, int fold, const float *vol, const int64_t shape[4],
+                           const fnn_opts *opts, int64_t patch_begin, int64_t patch_end,
+                           int64_t x0, int64_t x1, float *acc, float *wsum);
+int fnn_normalize_slab(fnn_engine *e, const float *acc, const float *wsum, const int64_t shape[4],
+                       const fnn_opts *opts, int64_t x0, int64_t x1, int64_t out_x0, int64_t out_x1,
+                       void *out_logits);
+
+/* LabelManager.convert_logits_to_segmentation for plain labels
+ * (label_handling.py:173-180): argmax over heads, first maximum wins.
+ * logits [heads, n_vox] f16/f32 -> labels uint8 (heads <= 256). */
+int fnn_argmax_labels(fnn_engine *e, const void *logits, int dtype, int heads, int64_t n_vox,
+                      uint8_t *labels, void *stream);
+
+/* ---- host-side integer logic (no GPU needed) ------------------------------ */
+/* compute_steps_for_sliding_window (sliding_window_prediction.py:30-54) for one
+ * axis; returns the number of steps written (<= cap) or a negative error. */
+int fnn_compute_steps(int64_t image_size, int64_t patch_size, double step, int64_t *steps, int cap);
+
+/* Padded shape, low-side pad, number of patches and (optionally) the patch
+ * origins [n][3] in the reference's visit order - x slowest, z fastest - for a
+ * volume (pad_nd_image use at :657-659 and the slicer loop :525-537). */
+int fnn_plan_volume(const int32_t patch[3], const int64_t shape_sp[3], double step, int64_t padded[3],
+                    int64_t pad_lo[3], int64_t *n_patches, int32_t *origins, int64_t origins_cap);
+
+/* ---- timing / introspection ----------------------------------------------- */
+/* Per-kernel-family device time of the last fnn_predict_volume call, measured
+ * with HIP events on the launch stream when profiling is enabled. */
+typedef struct fnn_profile {
+    double total_ms;
+    double conv_ms, stem_ms, tconv_ms, head_ms, finalize_ms;
+    int64_t conv_launches;
+    double conv_flops;                           /* algorithmic 2*MACs of the timed convs     */
+    int64_t n_patches;
+} fnn_profile;
+int fnn_set_profiling(fnn_engine *e, int enabled);
+int fnn_get_profile(const fnn_engine *e, fnn_profile *out);
+
+/* Algorithmic work of one patch forward: 2*MACs of convs, transposed convs and
+ * the seg head; ideal fp16 activation bytes (each activation written once and
+ * read once).  SURVEY.md 8d. */
+int fnn_patch_work(const fnn_engine *e, double *flops, double *act_bytes);
+
+/* ---- single-op entry points (parity tests call the kernels through these) -- */
+/* Host float32 NCDHW in / out; the library converts to its device layout
+ * (fp16, channels-last), runs the HIP kernel, converts back.
+ * Input transform fused into the kernel's load path: when gammaK != NULL the
+ * input K is treated as a RAW conv output: InstanceNorm3d(eps=1e-5, affine)
+ * with these gamma/beta is applied (statistics of the fp16-rounded input,
+ * computed by the wrapper the way a producer kernel's epilogue would), then
+ * LeakyReLU(slopeK).  gammaK == NULL = identity.  A second input (x2 != NULL)
+ * is the concat-free replacement of torch.cat((x, x2), 1).
+ * stats_out (may be NULL): per (n, cout) sum and sum of squares of the
+ * fp16-rounded outputs, doubles [n][cout][2]. */
+int fnn_op_conv3d(int device, int n, const int dims[3],
+                  const float *x, int cin, const float *gamma1, const float *beta1, float slope1,
+                  const float *x2, int cin2, const float *gamma2, const float *beta2, float slope2,
+                  const float *w, const float *bias, int cout, const int k[3], const int stride[3],
+                  float *y, double *stats_out);
+int fnn_op_conv_transpose3d(int device, int n, const int dims[3],
+                            const float *x, int cin, const float *gamma1, const float *beta1, float slope1,
+                            const float *w, const float *bias, int cout, const int stride[3], float *y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FNN_H */

@@ -1,0 +1,145 @@
+"""Per-kernel parity on a real MI355X: every HIP kernel is called through the C ABI
+(fnn_op_*) and compared with torch's own CPU fp32 ops on the same fp16-rounded
+operands.  Tolerances: the kernels compute fp16 x fp16 products exactly and
+accumulate in fp32, the only other error is the final fp16 store, so
+|err| <= 2^-10 * |ref| + small absolute slack."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _h(a):
+    """round to fp16 like the kernel's operands"""
+    return torch.as_tensor(a).half().float()
+
+
+def _check(y, ref, what):
+    ref = ref.numpy()
+    err = np.abs(y - ref)
+    tol = 2e-3 * np.abs(ref) + 2e-3 * max(1.0, float(np.abs(ref).max())) * 0.5
+    assert (err <= tol).all(), f'{what}: max err {err.max():.4g} (ref max {np.abs(ref).max():.4g})'
+
+
+CONV_CASES = [
+    # n, cin, cout, dims, k, stride
+    (1, 16, 16, (8, 16, 16), (3, 3, 3), (1, 1, 1)),
+    (2, 32, 16, (8, 8, 16), (3, 3, 3), (1, 1, 1)),
+    (1, 16, 32, (8, 16, 16), (3, 3, 3), (2, 2, 2)),
+    (1, 16, 16, (6, 12, 20), (1, 3, 3), (1, 1, 1)),
+    (1, 16, 32, (8, 12, 12), (1, 3, 3), (1, 2, 2)),
+    (2, 32, 48, (10, 6, 6), (3, 3, 3), (2, 1, 1)),
+    (1, 64, 64, (4, 4, 4), (3, 3, 3), (1, 1, 1)),
+    (1, 160, 160, (5, 3, 3), (3, 3, 3), (1, 1, 1)),
+    (1, 8, 24, (7, 9, 11), (3, 3, 3), (1, 1, 1)),          # channel padding (8 -> 16, 24 -> 32), ragged tiles
+    (1, 21, 10, (5, 9, 8), (3, 3, 3), (1, 1, 1)),          # odd channel counts (r = 3, 6 students)
+    (1, 16, 16, (4, 8, 8), (1, 1, 1), (1, 1, 1)),
+    (3, 48, 80, (4, 6, 6), (3, 1, 3), (1, 1, 1)),
+    (1, 320, 160, (4, 4, 4), (3, 3, 3), (1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize('n,cin,cout,dims,k,stride', CONV_CASES)
+def test_conv3d_identity_input(n, cin, cout, dims, k, stride):
+    from fast_nnunet_amd import capi
+    g = torch.Generator().manual_seed(hash((n, cin, cout, dims, k)) % 2 ** 31)
+    x = _h(torch.randn(n, cin, *dims, generator=g))
+    w = _h(torch.randn(cout, cin, *k, generator=g) / (cin * k[0] * k[1] * k[2]) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    y, stats = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), k, stride, want_stats=True)
+    ref = F.conv3d(x, w, b, stride, [(i - 1) // 2 for i in k])
+    _check(y, ref, 'conv3d')
+    # epilogue statistics = sums over the fp16-rounded outputs
+    y64 = y.astype(np.float64)
+    assert np.allclose(stats[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    assert np.allclose(stats[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+
+
+@pytest.mark.parametrize('n,cin,cout,dims,k,stride', CONV_CASES[:6])
+def test_conv3d_with_fused_instancenorm_lrelu_on_load(n, cin, cout, dims, k, stride):
+    from fast_nnunet_amd import capi
+    g = torch.Generator().manual_seed(7 + cin + cout)
+    x = _h(torch.randn(n, cin, *dims, generator=g) * 3 + 1.5)
+    gamma = torch.rand(cin, generator=g) + 0.5
+    beta = torch.randn(cin, generator=g) * 0.1
+    w = _h(torch.randn(cout, cin, *k, generator=g) / (cin * k[0] * k[1] * k[2]) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    y = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), k, stride, gamma=gamma.numpy(), beta=beta.numpy(), slope=0.01)
+    xn = F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01)
+    ref = F.conv3d(xn, w, b, stride, [(i - 1) // 2 for i in k])
+    # the kernel rounds the normalised activation to fp16 before the MFMA
+    ref16 = F.conv3d(_h(xn), w, b, stride, [(i - 1) // 2 for i in k])
+    err = np.abs(y - ref16.numpy())
+    assert err.max() <= 6e-3 * max(1.0, float(ref.abs().max())), err.max()
+
+
+def test_conv3d_two_sources_replaces_concat():
+    from fast_nnunet_amd import capi
+    g = torch.Generator().manual_seed(3)
+    n, c1, c2, cout, dims = 2, 16, 16, 16, (8, 8, 16)
+    up = _h(torch.randn(n, c1, *dims, generator=g))                 # transposed-conv output: identity on load
+    skip = _h(torch.randn(n, c2, *dims, generator=g) * 2 - 1)       # raw conv output: norm + lrelu on load
+    gamma, beta = torch.rand(c2, generator=g) + 0.5, torch.randn(c2, generator=g) * 0.1
+    w = _h(torch.randn(cout, c1 + c2, 3, 3, 3, generator=g) / 30)
+    b = torch.randn(cout, generator=g)
+    y = capi.op_conv3d(up.numpy(), w.numpy(), b.numpy(), (3, 3, 3), (1, 1, 1),
+                       x2=skip.numpy(), gamma2=gamma.numpy(), beta2=beta.numpy(), slope2=0.01)
+    cat = torch.cat((up, _h(F.leaky_relu(F.instance_norm(skip, weight=gamma, bias=beta, eps=1e-5), 0.01))), 1)
+    ref = F.conv3d(cat, w, b, 1, 1)
+    assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_conv3d_two_sources_with_padded_channels():
+    from fast_nnunet_amd import capi
+    g = torch.Generator().manual_seed(4)
+    n, c1, c2, cout, dims = 1, 8, 8, 8, (4, 8, 8)
+    a = _h(torch.randn(n, c1, *dims, generator=g))
+    bsrc = _h(torch.randn(n, c2, *dims, generator=g))
+    w = _h(torch.randn(cout, c1 + c2, 3, 3, 3, generator=g) / 20)
+    y = capi.op_conv3d(a.numpy(), w.numpy(), None, (3, 3, 3), (1, 1, 1), x2=bsrc.numpy())
+    ref = F.conv3d(torch.cat((a, bsrc), 1), w, None, 1, 1)
+    _check(y, ref, 'conv3d 2-src padded')
+
+
+TCONV_CASES = [
+    (1, 32, 16, (4, 8, 8), (2, 2, 2)),
+    (2, 160, 160, (5, 3, 3), (2, 1, 1)),
+    (1, 64, 32, (4, 6, 6), (1, 2, 2)),
+    (1, 16, 8, (3, 5, 7), (2, 2, 2)),
+    (1, 80, 64, (2, 4, 4), (2, 2, 2)),
+    (1, 21, 10, (3, 4, 5), (2, 2, 2)),
+]
+
+
+@pytest.mark.parametrize('n,cin,cout,dims,stride', TCONV_CASES)
+def test_conv_transpose3d(n, cin, cout, dims, stride):
+    from fast_nnunet_amd import capi
+    g = torch.Generator().manual_seed(11 + cin)
+    x = _h(torch.randn(n, cin, *dims, generator=g) * 2 + 0.5)
+    gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+    w = _h(torch.randn(cin, cout, *stride, generator=g) / cin ** 0.5)
+    b = torch.randn(cout, generator=g)
+    y = capi.op_conv_transpose3d(x.numpy(), w.numpy(), b.numpy(), stride, gamma=gamma.numpy(), beta=beta.numpy(),
+                                 slope=0.01)
+    xn = _h(F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01))
+    ref = F.conv_transpose3d(xn, w, b, stride)
+    assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
+    y2 = capi.op_conv_transpose3d(x.numpy(), w.numpy(), b.numpy(), stride)
+    _check(y2, F.conv_transpose3d(x, w, b, stride), 'tconv identity')
+
+
+def test_mfma_operand_map_with_asymmetric_integer_data():
+    """A = I style check with exact integers: catches transposed / permuted fragment maps."""
+    from fast_nnunet_amd import capi
+    cin = cout = 16
+    x = torch.zeros(1, cin, 4, 8, 8)
+    for c in range(cin):
+        x[0, c] = (torch.arange(4 * 8 * 8).reshape(4, 8, 8) % 7) + c          # small ints, channel-dependent
+    w = torch.zeros(cout, cin, 3, 3, 3)
+    for co in range(cout):
+        w[co, (co * 5 + 3) % cin, co % 3, (co // 3) % 3, (co + 1) % 3] = 1.0   # one tap, asymmetric permutation
+    y = capi.op_conv3d(x.numpy(), w.numpy(), None, (3, 3, 3), (1, 1, 1))
+    ref = F.conv3d(x, w, None, 1, 1)
+    assert np.array_equal(y, ref.numpy())

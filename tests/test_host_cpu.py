@@ -1,0 +1,164 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports
+every declared symbol, its integer logic matches the reference's golden vectors,
+the plans / checkpoint readers agree with the reference, and the engine refuses to
+run without a GPU (no silent fallback)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from golden_cases import DATASET_JSONS, PLANS_NEW, PLANS_OLD, toy_unet_spec
+from oracle import sliding_window as osw
+from oracle.unet import synthetic_state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def capi():
+    from fast_nnunet_amd import capi as c
+    c.load_library()
+    return c
+
+
+def test_library_exports_every_symbol_in_header(capi):
+    header = open(os.path.join(ROOT, 'include', 'fnn.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    declared = set(re.findall(r'\b(fnn_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 18
+    lib = capi.load_library()
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/fnn.h but not exported'
+    assert declared == set(capi.EXPORTS)
+    assert lib.fnn_abi_version() == 1
+
+
+def test_compute_steps_matches_reference_golden(capi, golden_dir):
+    from fast_nnunet_amd.sliding_window import compute_steps_for_sliding_window
+    for c in json.load(open(os.path.join(golden_dir, 'steps.json'))):
+        assert compute_steps_for_sliding_window(c['image'], c['patch'], c['step']) == c['steps'], c
+
+
+def test_compute_steps_rejects_bad_arguments(capi):
+    with pytest.raises(AssertionError):
+        capi.compute_steps(10, 16, 0.5)          # image smaller than patch
+    with pytest.raises(AssertionError):
+        capi.compute_steps(32, 16, 0.0)
+    with pytest.raises(AssertionError):
+        capi.compute_steps(32, 16, 1.5)
+
+
+@pytest.mark.parametrize('shape,patch,step', [((40, 36, 44), (16, 16, 16), 0.5), ((11, 30, 9), (16, 16, 16), 0.5),
+                                              ((512, 512, 512), (160, 96, 96), 0.5), ((33, 47, 21), (20, 28, 20), 0.3),
+                                              ((16, 16, 16), (16, 16, 16), 1.0)])
+def test_plan_volume_matches_oracle_slicers(capi, shape, patch, step):
+    padded, lo, origins = capi.plan_volume(patch, shape, step)
+    pads, undo = osw.pad_to_patch(shape, patch)
+    assert lo == [p[0] for p in pads]
+    assert padded == [s + p[0] + p[1] for s, p in zip(shape, pads)]
+    sl = osw.patch_slicers(padded, patch, step)
+    assert origins.shape[0] == len(sl)
+    assert origins.tolist() == [[s[1].start, s[2].start, s[3].start] for s in sl]
+
+
+def test_patch_counts_of_the_benchmark_configs(capi):
+    # 343 (128^3), 216 (160^3), 600 (160x96x96) patches on a 512^3 volume
+    for patch, n in (((128,) * 3, 343), ((160,) * 3, 216), ((160, 96, 96), 600)):
+        assert capi.plan_volume(patch, (512,) * 3, 0.5)[2].shape[0] == n
+
+
+def test_gaussian_matches_reference_golden(golden_dir):
+    from fast_nnunet_amd.sliding_window import compute_gaussian
+    z = np.load(os.path.join(golden_dir, 'gaussian.npz'))
+    for key in z.files:
+        patch = tuple(int(i) for i in key.split('_')[1:])
+        g = compute_gaussian(patch, sigma_scale=1. / 8, value_scaling_factor=10, device=torch.device('cpu'))
+        assert np.array_equal(g.view(torch.int16).numpy().view(np.uint16), z[key])
+
+
+def test_engine_fails_loudly_without_gpu(capi):
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    from fast_nnunet_amd.arch import spec_from_state_dict
+    spec = spec_from_state_dict(synthetic_state_dict(toy_unet_spec(1, 3)), (16, 16, 32))
+    with pytest.raises(RuntimeError, match='no HIP device|no CPU fallback'):
+        capi.Engine(spec.to_desc(), 0, 2)
+    from fast_nnunet_amd import nnUNetPredictor
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        nnUNetPredictor(device=torch.device('cpu'))
+
+
+def test_spec_from_state_dict_roundtrip_and_aliases():
+    from fast_nnunet_amd.arch import spec_from_state_dict, weight_blob
+    ospec = toy_unet_spec(2, 4)
+    sd = synthetic_state_dict(ospec, 5)
+    # add what real checkpoints carry: wrapper prefixes and aliased duplicates
+    noisy = {}
+    for k, v in sd.items():
+        noisy['module._orig_mod.' + k] = v
+        if '.conv.' in k:
+            noisy['module._orig_mod.' + k.replace('.conv.', '.all_modules.0.')] = v
+        if k.startswith('encoder.'):
+            noisy['module._orig_mod.decoder.' + k] = v
+    spec = spec_from_state_dict(noisy, (16, 16, 32))
+    assert spec.features == ospec.features and spec.in_channels == 2 and spec.num_heads == 4
+    assert [tuple(k) for k in spec.kernels] == [tuple(k) for k in ospec.kernels]
+    assert [tuple(s) for s in spec.strides] == [tuple(s) for s in ospec.strides]
+    assert spec.n_conv_enc == ospec.n_conv_enc and spec.n_conv_dec == ospec.n_conv_dec
+    a, b = weight_blob(spec, noisy), weight_blob(spec, sd)
+    assert np.array_equal(a, b)
+    n_params = sum(v.numel() for k, v in sd.items() if 'seg_layers.0' not in k)
+    assert a.size == n_params
+
+
+def test_resenc_checkpoints_are_refused_clearly():
+    from fast_nnunet_amd.arch import spec_from_state_dict
+    from oracle.topology import UNetSpec
+    spec = UNetSpec('resenc', 1, 2, [8, 16], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [1, 2], [1])
+    with pytest.raises(NotImplementedError):
+        spec_from_state_dict(synthetic_state_dict(spec), (16, 16, 16))
+
+
+def test_plans_reader_matches_reference(golden_dir):
+    import copy
+    import warnings
+    from fast_nnunet_amd.plans import PlansManager, determine_num_input_channels
+    expected = json.load(open(os.path.join(golden_dir, 'plans_expected.json')))
+    for tag, plans in (('new', PLANS_NEW), ('old', PLANS_OLD)):
+        pm = PlansManager(copy.deepcopy(plans))
+        assert set(pm.available_configurations) == set(expected[tag])
+        for cfg, exp in expected[tag].items():
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                cm = pm.get_configuration(cfg)
+            assert list(cm.patch_size) == exp['patch_size']
+            assert cm.network_arch_class_name == exp['network_class_name']
+            assert json.loads(json.dumps(cm.network_arch_init_kwargs)) == exp['arch_kwargs']
+            assert json.loads(json.dumps(cm.pool_op_kernel_sizes)) == exp['pool_op_kernel_sizes']
+            assert cm.previous_stage_name == exp['previous_stage']
+            for name, dj in DATASET_JSONS.items():
+                assert pm.get_label_manager(dj).num_segmentation_heads == exp[f'heads__{name}']
+                assert determine_num_input_channels(pm, cm, dj) == exp[f'cin__{name}']
+
+
+def test_plans_errors():
+    from fast_nnunet_amd.plans import PlansManager, LabelManager
+    pm = PlansManager({'configurations': {'a': {'inherits_from': 'b'}, 'b': {'inherits_from': 'a'}}})
+    with pytest.raises(RuntimeError):
+        pm.get_configuration('a')
+    with pytest.raises(RuntimeError):
+        pm.get_configuration('zzz')
+    with pytest.raises(RuntimeError):
+        LabelManager({'a': 1}, None)
+
+
+def test_student_reduction_rule():
+    from fast_nnunet_amd.arch import spec_from_plans
+    kw = PLANS_NEW['configurations']['3d_fullres']['architecture']['arch_kwargs']
+    assert spec_from_plans('PlainConvUNet', kw, 1, 61, (160, 96, 96), reduction=2).features == [16, 32, 64, 128, 160, 160]
+    assert spec_from_plans('PlainConvUNet', kw, 1, 61, (160, 96, 96), reduction=8).features == [8, 8, 16, 32, 40, 40]
+    assert spec_from_plans('PlainConvUNet', kw, 1, 61, (160, 96, 96), reduction=1).features == [32, 64, 128, 256, 320, 320]
