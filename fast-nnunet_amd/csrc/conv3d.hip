@@ -121,35 +121,61 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
         const int c_loc = c_glob - (s ? p.src[0].C : 0) + cg * 8;
         const f16 *sp = p.src[s].ptr;
         const int sC = p.src[s].C;
-        const float slope = p.src[s].slope;
+        const f16 slope_h = (f16)p.src[s].slope;
         float sc[8], sh[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float2 v = sSS[c_glob + cg * 8 + j];
             sc[j] = v.x; sh[j] = v.y;
         }
-        // stage the halo tile of this chunk: global -> normalise + LeakyReLU -> fp16 -> LDS
-        for (int idx = tid; idx < IVOX * 2; idx += 256) {
-            const int v = idx >> 1;
-            const int off = sOff[v];
-            f16x8 o;
-            if (off >= 0) {
-                const f16x8 x = *(const f16x8 *)(sp + (size_t)off * sC + c_loc);
+        // stage the halo tile of this chunk: global -> normalise + LeakyReLU -> fp16 -> LDS.
+        // Loads are issued in batches of 8 before any of them is consumed (one round trip per batch).
+        for (int base = tid; base < IVOX * 2; base += 256 * 8) {
+            int off[8];
+            f16x8 x[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (f16)leaky((float)x[j] * sc[j] + sh[j], slope);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256;
+                off[u] = idx < IVOX * 2 ? sOff[idx >> 1] : -2;
             }
-            *(f16x8 *)(sA + v * 32 + cg * 16) = o;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)       // always a valid address; padding voxels are zeroed below
+                x[u] = *(const f16x8 *)(sp + (size_t)(off[u] >= 0 ? off[u] : 0) * sC + c_loc);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (off[u] == -2) continue;
+                f16x8 o;
+                if (off[u] >= 0) {
+                    // fp32 fma, one rounding to fp16 (v_fma_mixlo/hi_f16), then LeakyReLU as packed-half
+                    // max(y, slope*y) - valid for 0 <= slope <= 1 (slope 1 = identity input)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)x[u][j], sc[j], sh[j]);
+                    o = __builtin_elementwise_max(o, o * slope_h);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
+                }
+                *(f16x8 *)(sA + ((base + u * 256) >> 1) * 32 + cg * 16) = o;
+            }
         }
-        // stage the weight fragments of this chunk
+        // stage the weight fragments of this chunk (same batching)
         {
             const int per_nb = p.ksteps * 64;                       // uint4 per cout block
-            for (int idx = tid; idx < NB * per_nb; idx += 256) {
-                const int nb = idx / per_nb, r = idx - nb * per_nb;
-                const uint4 *g = (const uint4 *)(p.wpk + ((size_t)((cb0 + nb) * p.chunks + ch) * p.ksteps) * 512);
-                ((uint4 *)sB)[idx] = g[r];
+            const int total = NB * per_nb;
+            for (int base = tid; base < total; base += 256 * 8) {
+                uint4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256;
+                    const int idc = idx < total ? idx : 0;
+                    const int nb = idc / per_nb, r = idc - nb * per_nb;
+                    v[u] = ((const uint4 *)(p.wpk + ((size_t)((cb0 + nb) * p.chunks + ch) * p.ksteps) * 512))[r];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256;
+                    if (idx < total) ((uint4 *)sB)[idx] = v[u];
+                }
             }
         }
         __syncthreads();

@@ -46,6 +46,8 @@ struct FoldWeights {
 };
 
 inline int pad16(int c) { return (c + 15) / 16 * 16; }
+// z pitch of the volume accumulators: rows start 16-byte aligned for the vectorised read-modify-write
+inline long long zpitch(long long z) { return (z + 7) / 8 * 8; }
 
 }  // namespace
 
@@ -540,7 +542,7 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
                 HeadParams h = make_head(e, fold, b);
                 const int *oo = &vp.origins[(p0 + b) * 3];
                 h.gauss = o.use_gaussian ? e->gauss : nullptr;
-                h.acc = acc; h.wsum = wsum; h.AX = x1 - x0; h.Y = vp.padded[1]; h.Z = vp.padded[2];
+                h.acc = acc; h.wsum = wsum; h.AX = x1 - x0; h.Y = vp.padded[1]; h.Z = zpitch(vp.padded[2]);
                 h.ox = oo[0] - (int)x0; h.oy = oo[1]; h.oz = oo[2];
                 if (!tta && (h.ox < 0 || h.ox + a.patch[0] > x1 - x0)) return fail(e, FNN_E_INVALID, "patch %lld lies outside the accumulator x-range", (long long)(p0 + b));
                 h.flip_d = flip[0]; h.flip_h = flip[1]; h.flip_w = flip[2];
@@ -558,7 +560,7 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
                 q.n_div = (int)combos.size() + 1; q.inv_n = 1.f / (float)q.n_div;
                 q.PD = a.patch[0]; q.PH = a.patch[1]; q.PW = a.patch[2]; q.heads = a.num_heads;
                 q.gauss = o.use_gaussian ? e->gauss : nullptr;
-                q.acc = acc; q.wsum = wsum; q.AX = x1 - x0; q.Y = vp.padded[1]; q.Z = vp.padded[2];
+                q.acc = acc; q.wsum = wsum; q.AX = x1 - x0; q.Y = vp.padded[1]; q.Z = zpitch(vp.padded[2]);
                 q.ox = oo[0] - (int)x0; q.oy = oo[1]; q.oz = oo[2];
                 q.acc_fp32 = acc_fp32;
                 Scope sc(e, st, FAM_HEAD, 0);
@@ -612,14 +614,14 @@ int predict_one_fold(fnn_engine *e, int fold, const float *vol_dev, const int64_
     const fnn_arch_desc &a = e->arch;
     const int acc_fp32 = o.accum == FNN_ACC_FP32;
     const size_t esz = acc_fp32 ? 4 : 2;
-    const size_t nvox = (size_t)vp.padded[0] * vp.padded[1] * vp.padded[2];
+    const size_t nvox = (size_t)vp.padded[0] * vp.padded[1] * zpitch(vp.padded[2]);
     if (int rc = ensure(e, &e->acc, &e->acc_bytes, nvox * a.num_heads * esz)) return rc;
     if (int rc = ensure(e, &e->wsum, &e->wsum_bytes, nvox * esz)) return rc;
     HIPCHK(e, hipMemsetAsync(e->acc, 0, nvox * a.num_heads * esz, st));
     HIPCHK(e, hipMemsetAsync(e->wsum, 0, nvox * esz, st));
     if (int rc = run_patches(e, fold, vol_dev, vp, o, 0, vp.n_patches, 0, vp.padded[0], e->acc, e->wsum, acc_fp32, st)) return rc;
     FinalizeParams f{};
-    f.acc = e->acc; f.wsum = e->wsum; f.AX = vp.padded[0]; f.Y = vp.padded[1]; f.Z = vp.padded[2];
+    f.acc = e->acc; f.wsum = e->wsum; f.AX = vp.padded[0]; f.Y = vp.padded[1]; f.Z = zpitch(vp.padded[2]);
     f.lo_x = (int)vp.lo[0]; f.lo_y = (int)vp.lo[1]; f.lo_z = (int)vp.lo[2];
     f.OX = shape[1]; f.OY = shape[2]; f.OZ = shape[3];
     f.heads = a.num_heads; f.acc_fp32 = acc_fp32; f.out_fp32 = o.out_dtype == FNN_OUT_F32;
@@ -811,12 +813,12 @@ int fnn_normalize_slab(fnn_engine *e, const float *acc, const float *wsum, const
     const size_t osz = opts->out_dtype == FNN_OUT_F32 ? 4 : 2;
     // finalize writes a [heads][OX][OY][OZ] block; to address rows of the full tensor we run it per head
     HIPCHK(e, hipMemsetAsync(e->inf_flag, 0, sizeof(int), st));
-    const size_t plane_in = (size_t)(x1 - x0) * vp.padded[1] * vp.padded[2];
+    const size_t plane_in = (size_t)(x1 - x0) * vp.padded[1] * zpitch(vp.padded[2]);
     const size_t plane_out = (size_t)shape[1] * shape[2] * shape[3];
     for (int h = 0; h < e->arch.num_heads; ++h) {
         FinalizeParams f{};
         f.acc = acc + (size_t)h * plane_in; f.wsum = wsum;
-        f.AX = x1 - x0; f.Y = vp.padded[1]; f.Z = vp.padded[2];
+        f.AX = x1 - x0; f.Y = vp.padded[1]; f.Z = zpitch(vp.padded[2]);
         f.lo_x = (int)(out_x0 + vp.lo[0] - x0); f.lo_y = (int)vp.lo[1]; f.lo_z = (int)vp.lo[2];
         f.OX = out_x1 - out_x0; f.OY = shape[2]; f.OZ = shape[3];
         f.heads = 1; f.acc_fp32 = 1; f.out_fp32 = opts->out_dtype == FNN_OUT_F32; f.mode = 0;

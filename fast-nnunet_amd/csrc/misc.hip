@@ -6,6 +6,7 @@
 //   finalize_kernel     acc / weight-sum, inf check, un-pad (K8)
 //   argmax_kernel       logits -> labels (K10)
 #include "fnn_device.h"
+#include <cstdlib>
 
 static __device__ __forceinline__ void load_scale_shift(const SrcDesc &s, int n, float inv_count, float eps,
                                                         float2 *sSS, int tid, int nthreads) {
@@ -136,11 +137,12 @@ int launch_tconv(const TconvParams &p, hipStream_t st) {
 //   n   (fp16)[sl] += gaussian          -> fp16 + fp16
 // fp16 subnormals must survive (5.96e-8 weights): no flush-to-zero is used.
 static __device__ __forceinline__ void acc_add(void *acc, size_t idx, float v, int fp32) {
+    // __fadd_rn: never contracted with the producing multiply (the reference rounds the product first)
     if (fp32) {
-        ((float *)acc)[idx] += v;
+        ((float *)acc)[idx] = __fadd_rn(((float *)acc)[idx], v);
     } else {
         f16 *a = (f16 *)acc;
-        a[idx] = (f16)((float)a[idx] + v);
+        a[idx] = (f16)__fadd_rn((float)a[idx], v);
     }
 }
 
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) void seg_head_kernel(const HeadParams p) {
                 const int head = hb0 * 16 + hl;
                 const float val = sT[hl * 65 + lane] + p.bias[head];
                 if (p.mode == 0) {
-                    acc_add(p.acc, (size_t)head * plane + aidx, val * g, p.acc_fp32);
+                    acc_add(p.acc, (size_t)head * plane + aidx, __fmul_rn(val, g), p.acc_fp32);
                 } else {
                     float *pb = p.patch_buf + (size_t)head * P + pv;
                     *pb = (p.mode == 1) ? val : (*pb + val);
@@ -232,14 +234,156 @@ __global__ __launch_bounds__(256) void seg_head_kernel(const HeadParams p) {
     }
 }
 
+// ----------------------------------------------------------------------------
+// fused seg head + accumulate (mode 0), vectorised read-modify-write
+// ----------------------------------------------------------------------------
+// The accumulators have a z pitch that is a multiple of 8 and the patch rows
+// are walked in accumulator-aligned groups of 8 voxels: a row of PW voxels that
+// starts at z = oz becomes GP = ceil(((oz & 7) + PW) / 8) groups, elements
+// outside the patch contribute exactly 0.  One wave = 8 groups (64 padded
+// voxels); after the MFMA the [head][voxel] tile is transposed through LDS so
+// that every lane owns (one head, one group): a 16-byte (fp16) or 2 x 16-byte
+// (fp32) read-modify-write, 8 heads x 128 contiguous bytes per wave instruction.
+#define HEAD_HBP 2                       // head blocks (of 16) per pass
+#define HEAD_LDT 68                      // LDS row stride in floats (64 + pad, keeps 16-B alignment)
+__global__ __launch_bounds__(256) void seg_head_acc_kernel(const HeadParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float2 *sSS = (float2 *)smem;
+    float *sT = (float *)(smem + ((p.src.C * 8 + 255) & ~255)) + wave * (HEAD_HBP * 16 * HEAD_LDT);
+    const int P = p.PD * p.PH * p.PW;
+    const int zoff = p.oz & 7;
+    const int RW = ((zoff + p.PW + 7) >> 3) << 3;         // padded row length
+    const int PV = p.PD * p.PH * RW;
+
+    load_scale_shift(p.src, p.b, p.inv_count, p.eps, sSS, tid, 256);
+    __syncthreads();
+
+    const int v0 = (blockIdx.x * 4 + wave) * 64;
+    if (v0 >= PV) return;
+    const int r = lane & 15, q = lane >> 4;
+
+    // MFMA operand voxels of this lane (4 column blocks)
+    size_t src_vox[4];
+    bool src_ok[4];
+#pragma unroll
+    for (int vb = 0; vb < 4; ++vb) {
+        const int v = v0 + vb * 16 + r;
+        const int wz = v % RW, hh = (v / RW) % p.PH, dd = v / (RW * p.PH);
+        const int w = wz - zoff;
+        src_ok[vb] = v < PV && w >= 0 && w < p.PW;
+        src_vox[vb] = (size_t)p.b * P + ((size_t)dd * p.PH + hh) * p.PW + w;
+    }
+    // read-modify-write role of this lane: group gl of the tile, head sub-index hs
+    const int gl = lane & 7, hs = lane >> 3;
+    const int vg = v0 + 8 * gl;
+    const bool g_ok = vg < PV;
+    const int wz0 = vg % RW, gh = (vg / RW) % p.PH, gd = vg / (RW * p.PH);
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int w = wz0 + e - zoff;
+        const bool ok = g_ok && w >= 0 && w < p.PW;
+        g[e] = ok ? (p.gauss ? (float)p.gauss[((size_t)gd * p.PH + gh) * p.PW + w] : 1.f) : 0.f;
+    }
+    const size_t aidx = ((size_t)(p.ox + gd) * p.Y + (p.oy + gh)) * p.Z + (p.oz - zoff) + wz0;   // multiple of 8
+    const size_t plane = (size_t)p.AX * p.Y * p.Z;
+
+    for (int hb0 = 0; hb0 < p.hblocks; hb0 += HEAD_HBP) {
+        f32x4 acc[HEAD_HBP][4];
+#pragma unroll
+        for (int a = 0; a < HEAD_HBP; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < p.ksteps; ++ks) {
+            f16x8 xf[4];
+#pragma unroll
+            for (int vb = 0; vb < 4; ++vb) xf[vb] = load_act_frag(p.src, src_vox[vb], src_ok[vb], ks * 32 + q * 8, sSS);
+#pragma unroll
+            for (int hb = 0; hb < HEAD_HBP; ++hb) {
+                if (hb0 + hb < p.hblocks) {
+                    const f16x8 wf = *(const f16x8 *)(p.wpk + (((size_t)(hb0 + hb) * p.ksteps + ks) * 64 + lane) * 8);
+#pragma unroll
+                    for (int vb = 0; vb < 4; ++vb)
+                        acc[hb][vb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[vb], acc[hb][vb], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int hb = 0; hb < HEAD_HBP; ++hb)
+#pragma unroll
+            for (int vb = 0; vb < 4; ++vb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sT[(hb * 16 + q * 4 + j) * HEAD_LDT + vb * 16 + r] = acc[hb][vb][j];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        if (g_ok) {
+#pragma unroll
+            for (int i = 0; i < HEAD_HBP * 2; ++i) {
+                const int hl = 8 * i + hs;
+                const int head = hb0 * 16 + hl;
+                if (head < p.heads) {
+                    const float bias = p.bias[head];
+                    const f32x4 t0 = *(const f32x4 *)(sT + hl * HEAD_LDT + 8 * gl);
+                    const f32x4 t1 = *(const f32x4 *)(sT + hl * HEAD_LDT + 8 * gl + 4);
+                    float c[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { c[e] = __fmul_rn(t0[e] + bias, g[e]); c[4 + e] = __fmul_rn(t1[e] + bias, g[4 + e]); }
+                    if (p.acc_fp32) {
+                        f32x4 *ap = (f32x4 *)((float *)p.acc + (size_t)head * plane + aidx);
+                        f32x4 a0 = ap[0], a1 = ap[1];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {          // elements outside the patch keep their bits (-0 stays -0)
+                            a0[e] = g[e] != 0.f ? __fadd_rn(a0[e], c[e]) : a0[e];
+                            a1[e] = g[4 + e] != 0.f ? __fadd_rn(a1[e], c[4 + e]) : a1[e];
+                        }
+                        ap[0] = a0; ap[1] = a1;
+                    } else {
+                        f16x8 *ap = (f16x8 *)((f16 *)p.acc + (size_t)head * plane + aidx);
+                        f16x8 a = *ap;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a[e] = g[e] != 0.f ? (f16)__fadd_rn((float)a[e], c[e]) : a[e];
+                        *ap = a;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (g_ok && hs == 0) {
+        if (p.acc_fp32) {
+            f32x4 *wp = (f32x4 *)((float *)p.wsum + aidx);
+            f32x4 a0 = wp[0], a1 = wp[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a0[e] += g[e]; a1[e] += g[4 + e]; }
+            wp[0] = a0; wp[1] = a1;
+        } else {
+            f16x8 *wp = (f16x8 *)((f16 *)p.wsum + aidx);
+            f16x8 a = *wp;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = (f16)((float)a[e] + g[e]);
+            *wp = a;
+        }
+    }
+}
+
 int launch_head(const HeadParams &p, hipStream_t st) {
     const int P = p.PD * p.PH * p.PW;
-    const size_t lds = (size_t)((p.src.C * 8 + 255) & ~255) + (size_t)4 * 64 * 65 * 4;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)seg_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)seg_head_acc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    static const bool force_scalar = getenv("FNN_HEAD_SCALAR") != nullptr;      // debugging aid
+    if (!force_scalar && p.mode == 0 && (p.Z & 7) == 0 && p.oz >= 0) {
+        const int RW = (((p.oz & 7) + p.PW + 7) >> 3) << 3;
+        const long long PV = (long long)p.PD * p.PH * RW;
+        const size_t lds = (size_t)((p.src.C * 8 + 255) & ~255) + (size_t)4 * HEAD_HBP * 16 * HEAD_LDT * 4;
+        hipLaunchKernelGGL(seg_head_acc_kernel, dim3((unsigned)((PV + 255) / 256)), dim3(256), lds, st, p);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+    const size_t lds = (size_t)((p.src.C * 8 + 255) & ~255) + (size_t)4 * 64 * 65 * 4;
     dim3 grid((P + 255) / 256);
     hipLaunchKernelGGL(seg_head_kernel, grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -260,7 +404,7 @@ __global__ __launch_bounds__(256) void patch_acc_kernel(const PatchAccParams p) 
     const float div = (float)p.n_div;
     for (int head = 0; head < p.heads; ++head) {
         const float val = p.patch_buf[(size_t)head * P + v] / div;
-        acc_add(p.acc, (size_t)head * plane + aidx, val * g, p.acc_fp32);
+        acc_add(p.acc, (size_t)head * plane + aidx, __fmul_rn(val, g), p.acc_fp32);
     }
     if (p.acc_fp32) ((float *)p.wsum)[aidx] += g;
     else { f16 *wsp = (f16 *)p.wsum; wsp[aidx] = (f16)((float)wsp[aidx] + g); }

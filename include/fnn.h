@@ -128,7 +128,9 @@ int fnn_forward_patches(fnn_engine *e, int fold, const float *x, int n, float *l
  * fnn_accumulate_patches runs patches [patch_begin, patch_end) of the x-major
  * patch list and ADDS sum(w*logit) / sum(w) into caller-owned fp32 DEVICE
  * buffers that cover the padded-volume x-range [x0, x1):
- *   acc [heads][x1-x0][Y][Z], wsum [x1-x0][Y][Z]  (caller zeroes them).
+ *   acc [heads][x1-x0][Y][Zp], wsum [x1-x0][Y][Zp]  (caller zeroes them), where
+ *   Y, Z are the padded volume sizes and Zp = Z rounded up to a multiple of 8
+ *   (rows start 16-byte aligned for the vectorised read-modify-write).
  * fnn_normalize_slab divides, un-pads and writes rows [x0,x1) of the output
  * (out points at the full [heads][X][Y][Z] tensor of opts->out_dtype). */
 int fnn_accumulate_patches(fnn_engine *e, int fold, const float *vol, const int64_t shape[4],
