@@ -15,6 +15,7 @@
 // dynamic_network_architectures' ConvDropoutNormReLU, which the reference
 // instantiates at nnUNetDistillationTrainer.py:141-173.
 #include "fnn_device.h"
+#include <cstdlib>
 
 // ----------------------------------------------------------------------------
 // generic MFMA conv
@@ -77,23 +78,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
         for (int c = tid; c < cin_total; c += 256) {
             const int s = (c < p.src[0].C) ? 0 : 1;
             const int cl = c - (s ? p.src[0].C : 0);
-            float sc = 1.f, sh = 0.f;
-            if (p.src[s].stats) {
-                const double *st = p.src[s].stats + ((size_t)n * FNN_STAT_REPL * p.src[s].C + cl) * 2;
-                double s1 = 0, s2 = 0;
-#pragma unroll
-                for (int r = 0; r < FNN_STAT_REPL; ++r) {
-                    s1 += st[(size_t)r * p.src[s].C * 2];
-                    s2 += st[(size_t)r * p.src[s].C * 2 + 1];
-                }
-                const double mean = s1 * (double)p.inv_count;
-                double var = s2 * (double)p.inv_count - mean * mean;
-                var = var > 0 ? var : 0;
-                const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-                sc = p.src[s].gamma[cl] * rstd;
-                sh = p.src[s].beta[cl] - (float)mean * sc;
-            }
-            sSS[c] = make_float2(sc, sh);
+            sSS[c] = p.src[s].ss ? p.src[s].ss[(size_t)n * p.src[s].C + cl] : make_float2(1.f, 0.f);
         }
     }
 
@@ -265,6 +250,270 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
     }
 }
 
+// ----------------------------------------------------------------------------
+// pipelined MFMA conv (stride 1): the hot kernel
+// ----------------------------------------------------------------------------
+// Same GEMM view as conv3d_mfma_kernel, restructured around what rocprof showed
+// on the first version (latency-bound staging, weights re-staged through LDS):
+//   * activations: halo tile of a 16-channel chunk in LDS, DOUBLE BUFFERED; the
+//     global loads of chunk c+1 are issued before the MFMAs of chunk c and
+//     normalised + written to the other buffer afterwards (one barrier per chunk);
+//   * weights: never touch LDS - each wave streams its 1-KiB fragments straight
+//     from L2/L1 into registers, two k-steps ahead (every workgroup of a layer
+//     reads the same <= 2.8 MB, so they stay cache resident);
+//   * MB = 4 or 8 column blocks per wave (tile 4x8x8 or 8x8x8 voxels): thin
+//     layers get twice the work per staged halo voxel and per weight fragment;
+//   * workgroup ids are remapped so that every XCD (private L2) walks a
+//     contiguous range of tiles and neighbouring halos hit the same L2.
+template <int NB, int MB>
+__global__ __launch_bounds__(256) void conv3d_pipe_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int TD = MB;                                 // 4 waves x (MB / 4) depth slices
+    constexpr int PF = 8;                                  // halo elements (16 B) prefetched per thread
+
+    // XCD-aware, bijective remap (blocks b and b + 8 share an XCD)
+    int t;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
+    const int tw = t % p.tiles_w; t /= p.tiles_w;
+    const int th = t % p.tiles_h; t /= p.tiles_h;
+    const int td = t % p.tiles_d;
+    const int n = t / p.tiles_d;
+    const int cb0 = blockIdx.y * NB;
+
+    const int od0 = td * TD, oh0 = th * FNN_TILE_H, ow0 = tw * FNN_TILE_W;
+    const int ID = TD - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
+    const int IVOX = ID * IH * IW;
+    const int T = p.kd * p.kh * p.kw;
+    const int cin_total = p.chunks * 16;
+    const int abytes = (IVOX * 32 + 1023) & ~1023;
+
+    char *sA0 = smem;
+    int *sOff = (int *)(smem + 2 * abytes);
+    float2 *sSS = (float2 *)(sOff + ((IVOX + 3) & ~3));
+    int *sTap = (int *)(sSS + cin_total);
+
+    {
+        const int id0 = od0 - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
+        for (int v = tid; v < IVOX; v += 256) {
+            const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
+            const int gd = id0 + zd, gh = ih0 + zh, gw = iw0 + zw;
+            const bool ok = gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 && gw < p.Wi;
+            sOff[v] = ok ? ((n * p.Di + gd) * p.Hi + gh) * p.Wi + gw : -1;
+        }
+        if (tid < 2 * p.ksteps) {
+            int off = 0;
+            if (tid < T) {
+                const int a = tid / (p.kh * p.kw), b = (tid / p.kw) % p.kh, c = tid % p.kw;
+                off = ((a * IH + b) * IW + c) * 32;
+            }
+            sTap[tid] = off;
+        }
+        for (int c = tid; c < cin_total; c += 256) {
+            const int s = (c < p.src[0].C) ? 0 : 1;
+            const int cl = c - (s ? p.src[0].C : 0);
+            sSS[c] = p.src[s].ss ? p.src[s].ss[(size_t)n * p.src[s].C + cl] : make_float2(1.f, 0.f);
+        }
+    }
+
+    int base[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int r = lane & 15;
+        const int od_l = wave + 4 * (mb >> 2), oh_l = 2 * (mb & 3) + (r >> 3), ow_l = r & 7;
+        base[mb] = ((od_l * IH + oh_l) * IW + ow_l) * 32 + ((lane >> 4) & 1) * 16;
+    }
+
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // weight stream: fragment of global k-step ts (= chunk * ksteps + ks) of cout block nb
+    const int TS = p.chunks * p.ksteps;
+    const f16 *wbase[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) wbase[nb] = p.wpk + (size_t)(cb0 + nb) * TS * 512 + lane * 8;
+    f16x8 w0[NB], w1[NB], w2[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        w0[nb] = *(const f16x8 *)(wbase[nb]);
+        w1[nb] = *(const f16x8 *)(wbase[nb] + (size_t)(TS > 1 ? 1 : 0) * 512);
+    }
+
+    __syncthreads();
+
+    const int cg = tid & 1;
+    int offv[PF];                                           // halo voxel index of this thread's elements
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int idx = tid + u * 256;
+        offv[u] = idx < IVOX * 2 ? sOff[idx >> 1] : -2;
+    }
+    f16x8 xr[PF];
+
+    auto issue = [&](int ch) {
+        const int c_glob = ch * 16;
+        const int s = (c_glob < p.src[0].C) ? 0 : 1;
+        const f16 *sp = p.src[s].ptr + (c_glob - (s ? p.src[0].C : 0) + cg * 8);
+        const int sC = p.src[s].C;
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (u * 256 < IVOX * 2)                        // workgroup-uniform: skip rounds past the tile
+                xr[u] = *(const f16x8 *)(sp + (size_t)(offv[u] >= 0 ? offv[u] : 0) * sC);
+    };
+    auto commit = [&](int ch, char *dst) {
+        const int c_glob = ch * 16;
+        const int s = (c_glob < p.src[0].C) ? 0 : 1;
+        const f16 slope_h = (f16)p.src[s].slope;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float2 v = sSS[c_glob + cg * 8 + j];
+            sc[j] = v.x; sh[j] = v.y;
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (u * 256 >= IVOX * 2 || offv[u] == -2) continue;
+            f16x8 o;
+            if (offv[u] >= 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)xr[u][j], sc[j], sh[j]);
+                o = __builtin_elementwise_max(o, o * slope_h);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
+            }
+            *(f16x8 *)(dst + ((tid + u * 256) >> 1) * 32 + cg * 16) = o;
+        }
+    };
+
+    issue(0);
+    commit(0, sA0);
+    __syncthreads();
+
+    int ts = 0;
+    for (int ch = 0; ch < p.chunks; ++ch) {
+        const char *sA = sA0 + (ch & 1) * abytes;
+        const bool more = ch + 1 < p.chunks;
+        if (more) issue(ch + 1);
+        for (int ks = 0; ks < p.ksteps; ++ks, ++ts) {
+            const int tn = ts + 2 < TS ? ts + 2 : TS - 1;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) w2[nb] = *(const f16x8 *)(wbase[nb] + (size_t)tn * 512);
+            const int toff = sTap[2 * ks + (lane >> 5)];
+            f16x8 xf[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) xf[mb] = *(const f16x8 *)(sA + base[mb] + toff);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nb], xf[mb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) { w0[nb] = w1[nb]; w1[nb] = w2[nb]; }
+        }
+        if (more) commit(ch + 1, sA0 + ((ch + 1) & 1) * abytes);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, fp16 store, statistics
+    const int q = lane >> 4, r = lane & 15;
+    float s1[NB][4], s2[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[nb][j] = 0.f; s2[nb][j] = 0.f; }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int od = od0 + wave + 4 * (mb >> 2);
+        const int oh = oh0 + 2 * (mb & 3) + (r >> 3), ow = ow0 + (r & 7);
+        const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
+        const size_t vox = ((size_t)(n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int co = (cb0 + nb) * 16 + q * 4;
+            const float4 bv = *(const float4 *)(p.bias + co);
+            f16x4 o;
+            o[0] = (f16)(acc[mb][nb][0] + bv.x);
+            o[1] = (f16)(acc[mb][nb][1] + bv.y);
+            o[2] = (f16)(acc[mb][nb][2] + bv.z);
+            o[3] = (f16)(acc[mb][nb][3] + bv.w);
+            if (ok) {
+                *(f16x4 *)(p.out + vox * p.Cout + co) = o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = (float)o[j];
+                    s1[nb][j] += v; s2[nb][j] += v * v;
+                }
+            }
+        }
+    }
+    if (p.stats_out) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+                    s1[nb][j] += __shfl_xor(s1[nb][j], m, 64);
+                    s2[nb][j] += __shfl_xor(s2[nb][j], m, 64);
+                }
+            }
+        float *sRed = (float *)smem;
+        if (r == 0) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = nb * 16 + q * 4 + j;
+                    sRed[(wave * NB * 16 + c) * 2] = s1[nb][j];
+                    sRed[(wave * NB * 16 + c) * 2 + 1] = s2[nb][j];
+                }
+        }
+        __syncthreads();
+        if (tid < NB * 16 * 2) {
+            const int c = tid >> 1, which = tid & 1;
+            double v = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += (double)sRed[(w * NB * 16 + c) * 2 + which];
+            double *dst = p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout
+                                         + cb0 * 16 + c) * 2 + which;
+            unsafeAtomicAdd(dst, v);
+        }
+    }
+}
+
+static size_t pipe_lds_bytes(const ConvParams &p, int mb) {
+    const int ID = mb - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
+    const int IVOX = ID * IH * IW;
+    size_t b = 2 * (size_t)((IVOX * 32 + 1023) & ~1023);
+    b += (size_t)((IVOX + 3) & ~3) * 4 + (size_t)p.chunks * 16 * 8 + 2 * p.ksteps * 4 + 64;
+    return b < 4096 ? 4096 : b;
+}
+
+template <int NB, int MB>
+static int launch_pipe(ConvParams p, hipStream_t st) {
+    p.tile_d = MB;
+    p.tiles_d = (p.Do + MB - 1) / MB;
+    p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
+    p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
+    const size_t lds = pipe_lds_bytes(p, MB);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)conv3d_pipe_kernel<NB, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
+    hipLaunchKernelGGL((conv3d_pipe_kernel<NB, MB>), grid, dim3(256), lds, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 size_t conv3d_lds_bytes(const ConvParams &p, int nb) {
     const int ID = (FNN_TILE_D - 1) * p.sd + p.kd;
     const int IH = (FNN_TILE_H - 1) * p.sh + p.kh;
@@ -296,8 +545,21 @@ static int launch_conv_nb(const ConvParams &p, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-int launch_conv3d(const ConvParams &p, hipStream_t st) {
+int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
+    ConvParams p = p_in;
+    p.tile_d = FNN_TILE_D;
+    p.tiles_d = (p.Do + FNN_TILE_D - 1) / FNN_TILE_D;
+    p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
+    p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
     const int nb = conv3d_pick_nb(p.Cout / 16);
+    static const bool force_v1 = getenv("FNN_CONV_V1") != nullptr;          // debugging / A-B aid
+    if (!force_v1 && p.sd == 1 && p.sh == 1 && p.sw == 1) {
+        // 8 column blocks per wave when the accumulators stay small and the volume is deep enough
+        const bool deep = p.Do >= 8;
+        if (nb == 1) return deep ? launch_pipe<1, 8>(p, st) : launch_pipe<1, 4>(p, st);
+        if (nb == 2) return deep ? launch_pipe<2, 8>(p, st) : launch_pipe<2, 4>(p, st);
+        return launch_pipe<4, 4>(p, st);
+    }
     if (nb == 4) {
         if (conv3d_lds_bytes(p, 4) <= 160 * 1024) return launch_conv_nb<4>(p, st);
         return launch_conv_nb<2>(p, st);

@@ -33,6 +33,7 @@ struct Layer {
     size_t w_off = 0;                 // halves, packed weights (STEM: floats in fparam)
     size_t bias_off = 0, gamma_off = 0, beta_off = 0;   // floats
     size_t stats_off = 0;             // doubles
+    size_t ss_off = 0;                // float2 (scale, shift) per channel
     size_t out_off = 0;               // halves, activation arena (for batch = 1)
     int64_t blob_w = 0, blob_b = 0, blob_g = 0, blob_beta = 0;
     int chunks = 0, ksteps = 0;
@@ -62,10 +63,11 @@ struct fnn_engine {
     size_t head_w_off = 0, head_bias_off = 0;
     int64_t blob_head_w = 0, blob_head_b = 0;
     int64_t blob_count = 0;
-    size_t wpk_halves = 0, fparam_floats = 0, stats_doubles = 0, act_halves = 0;
+    size_t wpk_halves = 0, fparam_floats = 0, stats_doubles = 0, act_halves = 0, ss_count = 0;
     std::vector<FoldWeights> folds;
     f16 *act = nullptr;
     double *stats = nullptr;
+    float2 *ss = nullptr;
     f16 *gauss = nullptr;
     int *inf_flag = nullptr;
     int *origins = nullptr; size_t origins_cap = 0;
@@ -210,7 +212,7 @@ int build_plan(fnn_engine *e) {
     e->blob_count = blob;
 
     // device offsets
-    size_t wpk = 0, fp = 0, st = 0, act = 0;
+    size_t wpk = 0, fp = 0, st = 0, act = 0, ssn = 0;
     double flops = 0, bytes = 0;
     for (Layer &L : e->layers) {
         const size_t ovox = (size_t)L.out_dims[0] * L.out_dims[1] * L.out_dims[2];
@@ -230,6 +232,7 @@ int build_plan(fnn_engine *e) {
         L.bias_off = fp; fp += L.cout_pad;
         if (L.has_norm) { L.gamma_off = fp; fp += L.cout_pad; L.beta_off = fp; fp += L.cout_pad; }
         L.stats_off = st; if (L.has_norm) st += (size_t)FNN_STAT_REPL * L.cout_pad * 2;
+        L.ss_off = ssn; if (L.has_norm) ssn += L.cout_pad;
         L.out_off = act; act += ovox * L.cout_pad;
         flops += L.flops;
         bytes += 2.0 * ovox * L.cout_real * 2.0;            // written once + read once, fp16
@@ -247,7 +250,7 @@ int build_plan(fnn_engine *e) {
         bytes += (double)L.out_dims[0] * L.out_dims[1] * L.out_dims[2] * L.cout_real * 2.0;
     }
     e->patch_act_bytes = bytes;
-    e->wpk_halves = wpk; e->fparam_floats = fp; e->stats_doubles = st; e->act_halves = act;
+    e->wpk_halves = wpk; e->fparam_floats = fp; e->stats_doubles = st; e->act_halves = act; e->ss_count = ssn;
     return 0;
 }
 
@@ -355,13 +358,12 @@ SrcDesc make_src(fnn_engine *e, const FoldWeights &fw, int layer, int nb) {
     s.ptr = e->act + L.out_off * e->max_batch;
     s.C = L.cout_pad;
     if (L.has_norm) {
-        s.stats = e->stats + L.stats_off * e->max_batch;
-        s.gamma = fw.fparam + L.gamma_off;
-        s.beta = fw.fparam + L.beta_off;
+        s.ss = e->ss + L.ss_off * e->max_batch;
         s.slope = e->arch.slope;
     } else {
-        s.stats = nullptr; s.gamma = nullptr; s.beta = nullptr; s.slope = 1.f;
+        s.ss = nullptr; s.slope = 1.f;
     }
+    (void)fw;
     (void)nb;
     return s;
 }
@@ -408,7 +410,7 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
             p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
             p.chunks = L.chunks; p.ksteps = L.ksteps;
-            p.eps = e->arch.eps; p.inv_count = 1.f / ((float)p.Di * p.Hi * p.Wi);
+            p.tile_d = FNN_TILE_D;
             Scope sc(e, st, FAM_CONV, L.flops * nb);
             rc = launch_conv3d(p, st);
         } else {
@@ -418,11 +420,17 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.sd = L.s[0]; p.sh = L.s[1]; p.sw = L.s[2];
             p.Cout = L.cout_pad; p.wpk = fw.wpk + L.w_off; p.bias = fw.fparam + L.bias_off;
             p.out = out; p.ksteps = L.ksteps; p.nblk = L.cout_pad / 16;
-            p.eps = e->arch.eps; p.inv_count = 1.f / ((float)p.Di * p.Hi * p.Wi);
             Scope sc(e, st, FAM_TCONV, L.flops * nb);
             rc = launch_tconv(p, st);
         }
         if (rc != 0) return fail(e, rc == -1 ? FNN_E_UNSUPPORTED : FNN_E_HIP, "kernel launch failed at layer %zu (rc=%d)", li, rc);
+        if (L.has_norm) {
+            StatsFinalizeParams q{};
+            q.stats = stats_out; q.gamma = fw.fparam + L.gamma_off; q.beta = fw.fparam + L.beta_off;
+            q.ss = e->ss + L.ss_off * e->max_batch; q.C = L.cout_pad;
+            q.inv_count = 1.f / ((float)L.out_dims[0] * L.out_dims[1] * L.out_dims[2]); q.eps = e->arch.eps;
+            if (launch_stats_finalize(q, nb, st) != 0) return fail(e, FNN_E_HIP, "stats finalize launch failed");
+        }
     }
     return 0;
 }
@@ -435,7 +443,6 @@ HeadParams make_head(fnn_engine *e, int fold, int b) {
     h.b = b; h.PD = a.patch[0]; h.PH = a.patch[1]; h.PW = a.patch[2];
     h.heads = a.num_heads; h.hblocks = e->hblocks; h.ksteps = e->head_ksteps;
     h.wpk = fw.wpk + e->head_w_off; h.bias = fw.fparam + e->head_bias_off;
-    h.eps = a.eps; h.inv_count = 1.f / ((float)a.patch[0] * a.patch[1] * a.patch[2]);
     return h;
 }
 
@@ -703,6 +710,7 @@ int fnn_create(const fnn_arch_desc *arch, int device, int max_batch, fnn_engine 
     if ((r = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", r);
     if ((r = hipMalloc((void **)&e->act, e->act_halves * max_batch * sizeof(f16))) != hipSuccess) return bail("hipMalloc(activations)", r);
     if ((r = hipMalloc((void **)&e->stats, e->stats_doubles * max_batch * sizeof(double))) != hipSuccess) return bail("hipMalloc(stats)", r);
+    if ((r = hipMalloc((void **)&e->ss, (e->ss_count * max_batch + 1) * sizeof(float2))) != hipSuccess) return bail("hipMalloc(scale/shift)", r);
     if ((r = hipMalloc((void **)&e->inf_flag, sizeof(int))) != hipSuccess) return bail("hipMalloc(flag)", r);
     *out = e;
     return 0;
@@ -712,7 +720,7 @@ void fnn_destroy(fnn_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     for (auto &f : e->folds) { if (f.wpk) (void)hipFree(f.wpk); if (f.fparam) (void)hipFree(f.fparam); }
-    void *ptrs[] = {e->act, e->stats, e->gauss, e->inf_flag, e->origins, e->acc, e->wsum, e->vol_tmp, e->vol_pad, e->out_tmp, e->patch_buf};
+    void *ptrs[] = {e->act, e->stats, e->ss, e->gauss, e->inf_flag, e->origins, e->acc, e->wsum, e->vol_tmp, e->vol_pad, e->out_tmp, e->patch_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ev : e->evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     delete e;

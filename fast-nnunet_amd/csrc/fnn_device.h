@@ -32,9 +32,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct SrcDesc {
     const f16 *ptr;              // [N][D][H][W][C]
     int C;                       // padded channel count (multiple of 16)
-    const double *stats;         // [N][REPL][C][2] (sum, sum of squares) or nullptr = identity
-    const float *gamma;          // [C]
-    const float *beta;           // [C]
+    const float2 *ss;            // [N][C] (scale, shift) of the producer's InstanceNorm, written by
+                                 // stats_finalize_kernel; nullptr = identity
     float slope;                 // LeakyReLU slope applied after the affine (1.0 = none)
 };
 
@@ -50,10 +49,9 @@ struct ConvParams {
     f16 *out;                    // [N][Do][Ho][Wo][Cout]
     double *stats_out;           // [N][REPL][Cout][2] or nullptr
     int tiles_d, tiles_h, tiles_w;
+    int tile_d;                  // output tile depth: 4, or 8 for the pipelined kernel with 8 column blocks per wave
     int chunks;                  // 16-channel chunks over all sources
     int ksteps;                  // MFMA k-steps per chunk = ceil(taps / 2)
-    float eps;
-    float inv_count;             // 1 / (Di*Hi*Wi)
 };
 
 struct StemParams {
@@ -83,7 +81,6 @@ struct TconvParams {
     f16 *out;                    // [N][Di*sd][Hi*sh][Wi*sw][Cout]
     int ksteps;                  // ceil(Cin / 32)
     int nblk;                    // Cout / 16
-    float eps, inv_count;
 };
 
 struct HeadParams {
@@ -104,7 +101,6 @@ struct HeadParams {
     int mode;                    // 0 fused accumulate, 1 patch buffer '=', 2 patch buffer '+='
     float *patch_buf;            // [heads][PD*PH*PW] fp32 (modes 1, 2)
     int acc_fp32;
-    float eps, inv_count;
 };
 
 struct PatchAccParams {          // patch buffer -> volume accumulators (mirroring path)
@@ -134,7 +130,16 @@ struct FinalizeParams {
 
 static __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
 
+struct StatsFinalizeParams {
+    const double *stats;         // [N][REPL][C][2]
+    const float *gamma, *beta;   // [C]
+    float2 *ss;                  // [N][C]
+    int C;
+    float inv_count, eps;
+};
+
 // launchers (implemented in the .hip files)
+int launch_stats_finalize(const StatsFinalizeParams &p, int N, hipStream_t st);
 int launch_conv3d(const ConvParams &p, hipStream_t st);
 size_t conv3d_lds_bytes(const ConvParams &p, int nb);
 int conv3d_pick_nb(int nblk);

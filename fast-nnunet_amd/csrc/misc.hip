@@ -8,27 +8,35 @@
 #include "fnn_device.h"
 #include <cstdlib>
 
-static __device__ __forceinline__ void load_scale_shift(const SrcDesc &s, int n, float inv_count, float eps,
-                                                        float2 *sSS, int tid, int nthreads) {
-    for (int c = tid; c < s.C; c += nthreads) {
-        float sc = 1.f, sh = 0.f;
-        if (s.stats) {
-            const double *st = s.stats + ((size_t)n * FNN_STAT_REPL * s.C + c) * 2;
-            double s1 = 0, s2 = 0;
+static __device__ __forceinline__ void load_scale_shift(const SrcDesc &s, int n, float2 *sSS, int tid, int nthreads) {
+    for (int c = tid; c < s.C; c += nthreads) sSS[c] = s.ss ? s.ss[(size_t)n * s.C + c] : make_float2(1.f, 0.f);
+}
+
+// InstanceNorm statistics -> per (n, channel) (scale, shift):  y = x * scale + shift
+//   mean = sum / count, var = sumsq / count - mean^2 (biased, like torch), scale = gamma / sqrt(var + eps)
+// One thread per (n, channel); the 8 replicas were filled by the producer's epilogue atomics.
+__global__ void stats_finalize_kernel(const StatsFinalizeParams p) {
+    const int c = threadIdx.x + blockIdx.y * blockDim.x, n = blockIdx.x;
+    if (c >= p.C) return;
+    const double *st = p.stats + ((size_t)n * FNN_STAT_REPL * p.C + c) * 2;
+    double s1 = 0, s2 = 0;
 #pragma unroll
-            for (int r = 0; r < FNN_STAT_REPL; ++r) {
-                s1 += st[(size_t)r * s.C * 2];
-                s2 += st[(size_t)r * s.C * 2 + 1];
-            }
-            const double mean = s1 * (double)inv_count;
-            double var = s2 * (double)inv_count - mean * mean;
-            var = var > 0 ? var : 0;
-            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-            sc = s.gamma[c] * rstd;
-            sh = s.beta[c] - (float)mean * sc;
-        }
-        sSS[c] = make_float2(sc, sh);
+    for (int r = 0; r < FNN_STAT_REPL; ++r) {
+        s1 += st[(size_t)r * p.C * 2];
+        s2 += st[(size_t)r * p.C * 2 + 1];
     }
+    const double mean = s1 * (double)p.inv_count;
+    double var = s2 * (double)p.inv_count - mean * mean;
+    var = var > 0 ? var : 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+    const float sc = p.gamma[c] * rstd;
+    p.ss[(size_t)n * p.C + c] = make_float2(sc, p.beta[c] - (float)mean * sc);
+}
+
+int launch_stats_finalize(const StatsFinalizeParams &p, int N, hipStream_t st) {
+    const int bs = p.C < 256 ? ((p.C + 63) / 64) * 64 : 256;
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(N, (p.C + bs - 1) / bs), dim3(bs), 0, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 // Activation fragment (MFMA B operand) of 16 voxels x 32 channels, read from a
@@ -68,7 +76,7 @@ __global__ __launch_bounds__(256) void tconv_mfma_kernel(const TconvParams p) {
     const int tap = blockIdx.y / groups;
     const int cb0 = (blockIdx.y - tap * groups) * NBT;
 
-    load_scale_shift(p.src, n, p.inv_count, p.eps, sSS, tid, 256);
+    load_scale_shift(p.src, n, sSS, tid, 256);
     __syncthreads();
 
     f32x4 acc[4][NBT];
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(256) void seg_head_kernel(const HeadParams p) {
     float *sT = (float *)(smem + ((p.src.C * 8 + 255) & ~255)) + wave * (64 * 65);   // [64 heads][64(+1) voxels]
     const int P = p.PD * p.PH * p.PW;
 
-    load_scale_shift(p.src, p.b, p.inv_count, p.eps, sSS, tid, 256);
+    load_scale_shift(p.src, p.b, sSS, tid, 256);
     __syncthreads();
 
     const int v0 = (blockIdx.x * 4 + wave) * 64;
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(256) void seg_head_acc_kernel(const HeadParams p) {
     const int RW = ((zoff + p.PW + 7) >> 3) << 3;         // padded row length
     const int PV = p.PD * p.PH * RW;
 
-    load_scale_shift(p.src, p.b, p.inv_count, p.eps, sSS, tid, 256);
+    load_scale_shift(p.src, p.b, sSS, tid, 256);
     __syncthreads();
 
     const int v0 = (blockIdx.x * 4 + wave) * 64;

@@ -49,7 +49,7 @@ void to_ndhwc(const float *x, int n, int c, int cp, size_t vox, std::vector<uint
 }
 
 struct SrcHolder {
-    DevBuf act, stats, gamma, beta;
+    DevBuf act, stats, gamma, beta, ss;
     SrcDesc d{};
 };
 
@@ -68,7 +68,13 @@ bool make_src(SrcHolder &h, const float *x, int n, int c, size_t vox, const floa
         (void)hipMemcpy(h.stats.p, st.data(), st.size() * 8, hipMemcpyHostToDevice);
         (void)hipMemcpy(h.gamma.p, g.data(), cp * 4, hipMemcpyHostToDevice);
         (void)hipMemcpy(h.beta.p, b.data(), cp * 4, hipMemcpyHostToDevice);
-        h.d.stats = h.stats.as<double>(); h.d.gamma = h.gamma.as<float>(); h.d.beta = h.beta.as<float>();
+        // what the engine does between producer and consumer: statistics -> (scale, shift)
+        if (!h.ss.alloc((size_t)n * cp * 8)) return false;
+        StatsFinalizeParams q{};
+        q.stats = h.stats.as<double>(); q.gamma = h.gamma.as<float>(); q.beta = h.beta.as<float>();
+        q.ss = h.ss.as<float2>(); q.C = cp; q.inv_count = 1.f / (float)vox; q.eps = 1e-5f;
+        if (launch_stats_finalize(q, n, 0) != 0) return false;
+        h.d.ss = h.ss.as<float2>();
         h.d.slope = slope;
     }
     return true;
@@ -102,7 +108,7 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
     p.Cout = cop; p.chunks = (cp1 + cp2) / 16; p.ksteps = (T + 1) / 2;
     p.tiles_d = (p.Do + FNN_TILE_D - 1) / FNN_TILE_D; p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
     p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
-    p.eps = 1e-5f; p.inv_count = 1.f / (float)vox;
+    p.tile_d = FNN_TILE_D;
     // pack weights [cout][cin_tot][T] -> [cb][chunk][ks][lane][8]
     std::vector<uint16_t> wp((size_t)(cop / 16) * p.chunks * p.ksteps * 512, 0);
     for (int cb = 0; cb < cop / 16; ++cb)
@@ -167,7 +173,6 @@ int fnn_op_conv_transpose3d(int device, int n, const int dims[3],
     p.src = s1.d; p.N = n; p.Di = dims[0]; p.Hi = dims[1]; p.Wi = dims[2];
     p.sd = stride[0]; p.sh = stride[1]; p.sw = stride[2];
     p.Cout = cop; p.nblk = cop / 16; p.ksteps = (cp + 31) / 32;
-    p.eps = 1e-5f; p.inv_count = 1.f / (float)vox;
     std::vector<uint16_t> wp((size_t)taps * p.nblk * p.ksteps * 512, 0);
     for (int tap = 0; tap < taps; ++tap)
         for (int cb = 0; cb < p.nblk; ++cb)
