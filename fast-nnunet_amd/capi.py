@@ -46,8 +46,8 @@ class Profile(C.Structure):
 
 
 EXPORTS = ['fnn_abi_version', 'fnn_last_error', 'fnn_create', 'fnn_destroy', 'fnn_weight_count', 'fnn_load_weights',
-           'fnn_set_gaussian', 'fnn_predict_volume', 'fnn_predict_volume_ensemble', 'fnn_accumulate_patches',
-           'fnn_normalize_slab', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_compute_steps', 'fnn_plan_volume',
+           'fnn_set_gaussian', 'fnn_predict_volume', 'fnn_predict_volume_ensemble', 'fnn_predict_labels',
+           'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_compute_steps', 'fnn_plan_volume',
            'fnn_set_profiling', 'fnn_get_profile', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d']
 
 _lib = None
@@ -80,8 +80,12 @@ def load_library() -> C.CDLL:
     lib.fnn_set_gaussian.argtypes = [vp, vp, i64]
     lib.fnn_predict_volume.argtypes = [vp, i32, vp, C.POINTER(i64), C.POINTER(Opts), vp]
     lib.fnn_predict_volume_ensemble.argtypes = [vp, i32, vp, C.POINTER(i64), C.POINTER(Opts), vp]
-    lib.fnn_accumulate_patches.argtypes = [vp, i32, vp, C.POINTER(i64), C.POINTER(Opts), i64, i64, i64, i64, vp, vp]
-    lib.fnn_normalize_slab.argtypes = [vp, vp, vp, C.POINTER(i64), C.POINTER(Opts), i64, i64, i64, i64, vp]
+    lib.fnn_predict_labels.argtypes = [vp, i32, vp, C.POINTER(i64), C.POINTER(Opts), vp]
+    lib.fnn_accumulator_channels.argtypes = [vp]
+    lib.fnn_accumulator_channels.restype = i64
+    P64 = C.POINTER(i64)
+    lib.fnn_accumulate_patches.argtypes = [vp, i32, vp, P64, C.POINTER(Opts), P64, i64, P64, P64, vp]
+    lib.fnn_normalize_box.argtypes = [vp, vp, P64, C.POINTER(Opts), P64, P64, P64, P64, vp]
     lib.fnn_forward_patches.argtypes = [vp, i32, vp, i32, vp, vp]
     lib.fnn_argmax_labels.argtypes = [vp, vp, i32, i32, i64, vp, vp]
     lib.fnn_compute_steps.argtypes = [i64, i64, C.c_double, C.POINTER(i64), i32]
@@ -236,15 +240,27 @@ class Engine:
             rc = self.lib.fnn_predict_volume(self.handle, fold, vol_ptr, shp, C.byref(opts), out_ptr)
         check(rc, self.lib, self.handle)
 
-    def accumulate_patches(self, vol_ptr, shape, opts, pb, pe, x0, x1, acc_ptr, wsum_ptr, fold=0):
+    def predict_labels(self, vol_ptr: int, shape, opts: Opts, labels_ptr: int, n_folds: int = 1):
         shp = (C.c_int64 * 4)(*[int(i) for i in shape])
-        check(self.lib.fnn_accumulate_patches(self.handle, fold, vol_ptr, shp, C.byref(opts), pb, pe, x0, x1,
-                                              acc_ptr, wsum_ptr), self.lib, self.handle)
+        check(self.lib.fnn_predict_labels(self.handle, n_folds, vol_ptr, shp, C.byref(opts), labels_ptr),
+              self.lib, self.handle)
 
-    def normalize_slab(self, acc_ptr, wsum_ptr, shape, opts, x0, x1, out_x0, out_x1, out_ptr):
+    @property
+    def accumulator_channels(self) -> int:
+        return int(self.lib.fnn_accumulator_channels(self.handle))
+
+    def accumulate_patches(self, vol_ptr, shape, opts, patch_ids, box_lo, box_hi, acc_ptr, fold=0):
         shp = (C.c_int64 * 4)(*[int(i) for i in shape])
-        check(self.lib.fnn_normalize_slab(self.handle, acc_ptr, wsum_ptr, shp, C.byref(opts), x0, x1, out_x0, out_x1,
-                                          out_ptr), self.lib, self.handle)
+        ids = (C.c_int64 * max(1, len(patch_ids)))(*[int(i) for i in patch_ids])
+        lo, hi = (C.c_int64 * 3)(*[int(i) for i in box_lo]), (C.c_int64 * 3)(*[int(i) for i in box_hi])
+        check(self.lib.fnn_accumulate_patches(self.handle, fold, vol_ptr, shp, C.byref(opts), ids, len(patch_ids),
+                                              lo, hi, acc_ptr), self.lib, self.handle)
+
+    def normalize_box(self, acc_ptr, shape, opts, box_lo, box_hi, out_lo, out_hi, out_ptr):
+        shp = (C.c_int64 * 4)(*[int(i) for i in shape])
+        a = [(C.c_int64 * 3)(*[int(i) for i in v]) for v in (box_lo, box_hi, out_lo, out_hi)]
+        check(self.lib.fnn_normalize_box(self.handle, acc_ptr, shp, C.byref(opts), a[0], a[1], a[2], a[3], out_ptr),
+              self.lib, self.handle)
 
     def forward_patches(self, x_ptr: int, n: int, out_ptr: int, fold: int = 0, stream: int = 0):
         check(self.lib.fnn_forward_patches(self.handle, fold, x_ptr, n, out_ptr, stream), self.lib, self.handle)

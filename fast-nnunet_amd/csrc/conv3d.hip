@@ -514,6 +514,292 @@ static int launch_pipe(ConvParams p, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// ----------------------------------------------------------------------------
+// persistent MFMA conv (stride 1) for layers with many tiles
+// ----------------------------------------------------------------------------
+// The thin full-resolution layers do only a few hundred MFMA cycles per tile, so
+// a one-tile-per-workgroup kernel is bound by its own latency chain (table
+// set-up, one global round trip for the halo, weight fetch, epilogue).  Here a
+// workgroup owns a contiguous range of tiles and pipelines ACROSS tiles:
+//   * all weight fragments of its cout group are loaded into LDS once;
+//   * work item = (tile, 16-channel chunk); the halo loads (and the scale/shift
+//     of the producer's InstanceNorm) of item i+1 are in flight while item i
+//     runs on the matrix cores; one barrier per item;
+//   * InstanceNorm statistics are kept in registers across the tiles of one
+//     batch item and flushed with one set of atomics per workgroup.
+template <int NB, int MB>
+__global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams p, const int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int TD = MB;
+    constexpr int PF = 8;
+
+    const int ID = TD - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
+    const int IVOX = ID * IH * IW;
+    const int T = p.kd * p.kh * p.kw;
+    const int TS = p.chunks * p.ksteps;
+    const int abytes = (IVOX * 32 + 1023) & ~1023;
+    const int cb0 = blockIdx.y * NB;
+
+    char *sA0 = smem;
+    char *sW = smem + 2 * abytes;                                    // [NB][TS][64 lanes][16 B]
+    int *sTap = (int *)(sW + NB * TS * 1024);
+    double *sRed = (double *)(sTap + 32);                             // [4 waves][NB*16][2]
+
+    // contiguous tile range of this workgroup; consecutive ranges share an XCD
+    int t_begin, t_end;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        const int g = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+        t_begin = (int)((long long)total_tiles * g / nwg);
+        t_end = (int)((long long)total_tiles * (g + 1) / nwg);
+    }
+    if (t_begin >= t_end) return;
+
+    // ---- one-time set-up: weights -> LDS, tap offsets, this thread's halo coordinates
+    for (int idx = tid; idx < NB * TS * 64; idx += 256) {
+        const int nb = idx / (TS * 64), r = idx - nb * (TS * 64);
+        ((uint4 *)sW)[idx] = ((const uint4 *)(p.wpk + (size_t)(cb0 + nb) * TS * 512))[r];
+    }
+    if (tid < 2 * p.ksteps) {
+        int off = 0;
+        if (tid < T) {
+            const int a = tid / (p.kh * p.kw), b = (tid / p.kw) % p.kh, c = tid % p.kw;
+            off = ((a * IH + b) * IW + c) * 32;
+        }
+        sTap[tid] = off;
+    }
+    const int cg = tid & 1;
+    int rel[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int idx = tid + u * 256;
+        const int v = idx >> 1;
+        rel[u] = idx < IVOX * 2 ? ((v / (IW * IH)) << 16) | (((v / IW) % IH) << 8) | (v % IW) : -1;
+    }
+    int base[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int r = lane & 15;
+        const int od_l = wave + 4 * (mb >> 2), oh_l = 2 * (mb & 3) + (r >> 3), ow_l = r & 7;
+        base[mb] = ((od_l * IH + oh_l) * IW + ow_l) * 32 + ((lane >> 4) & 1) * 16;
+    }
+
+    f32x4 acc[MB][NB];
+    // statistics: fp32 only WITHIN one tile (same grouping as the one-tile-per-workgroup kernels), double
+    // across tiles - sums of fp16-valued numbers in double are exact, so the result does not depend on
+    // how tiles are distributed over workgroups
+    double s1[NB][4], s2[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[nb][j] = 0.0; s2[nb][j] = 0.0; }
+
+    int offv[PF];
+    f16x8 xr[PF];
+    float4 ssr[4];                                                    // 8 x (scale, shift) of the next item
+    float slope_next = 1.f;
+
+    auto tile_coords = [&](int t, int &n, int &od0, int &oh0, int &ow0) {
+        const int tw = t % p.tiles_w; t /= p.tiles_w;
+        const int th = t % p.tiles_h; t /= p.tiles_h;
+        const int td = t % p.tiles_d;
+        n = t / p.tiles_d;
+        od0 = td * TD; oh0 = th * FNN_TILE_H; ow0 = tw * FNN_TILE_W;
+    };
+    auto set_offsets = [&](int n, int od0, int oh0, int ow0) {
+        const int id0 = od0 - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int gd = id0 + (rel[u] >> 16), gh = ih0 + ((rel[u] >> 8) & 255), gw = iw0 + (rel[u] & 255);
+            const bool ok = rel[u] >= 0 && gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 && gw < p.Wi;
+            offv[u] = ok ? ((n * p.Di + gd) * p.Hi + gh) * p.Wi + gw : -1;
+        }
+    };
+    auto issue = [&](int n, int ch) {
+        const int c_glob = ch * 16;
+        const int s = (c_glob < p.src[0].C) ? 0 : 1;
+        const int c_loc = c_glob - (s ? p.src[0].C : 0) + cg * 8;
+        const f16 *sp = p.src[s].ptr + c_loc;
+        const int sC = p.src[s].C;
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (u * 256 < IVOX * 2) xr[u] = *(const f16x8 *)(sp + (size_t)(offv[u] >= 0 ? offv[u] : 0) * sC);
+        slope_next = p.src[s].slope;
+        if (p.src[s].ss) {
+            const float4 *q = (const float4 *)(p.src[s].ss + (size_t)n * sC + c_loc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ssr[j] = q[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ssr[j] = make_float4(1.f, 0.f, 1.f, 0.f);
+        }
+    };
+    auto commit = [&](char *dst) {
+        const f16 slope_h = (f16)slope_next;
+        const float sc[8] = {ssr[0].x, ssr[0].z, ssr[1].x, ssr[1].z, ssr[2].x, ssr[2].z, ssr[3].x, ssr[3].z};
+        const float sh[8] = {ssr[0].y, ssr[0].w, ssr[1].y, ssr[1].w, ssr[2].y, ssr[2].w, ssr[3].y, ssr[3].w};
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (u * 256 >= IVOX * 2 || rel[u] < 0) continue;
+            f16x8 o;
+            if (offv[u] >= 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)xr[u][j], sc[j], sh[j]);
+                o = __builtin_elementwise_max(o, o * slope_h);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
+            }
+            *(f16x8 *)(dst + ((tid + u * 256) >> 1) * 32 + cg * 16) = o;
+        }
+    };
+    auto flush_stats = [&](int n) {
+        if (!p.stats_out) return;
+        const int q = lane >> 4, r = lane & 15;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+                    s1[nb][j] += __shfl_xor(s1[nb][j], m, 64);
+                    s2[nb][j] += __shfl_xor(s2[nb][j], m, 64);
+                }
+                if (r == 0) {
+                    const int c = nb * 16 + q * 4 + j;
+                    sRed[(wave * NB * 16 + c) * 2] = s1[nb][j];
+                    sRed[(wave * NB * 16 + c) * 2 + 1] = s2[nb][j];
+                }
+                s1[nb][j] = 0.0; s2[nb][j] = 0.0;
+            }
+        __syncthreads();
+        if (tid < NB * 16 * 2) {
+            const int c = tid >> 1, which = tid & 1;
+            double v = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += sRed[(w * NB * 16 + c) * 2 + which];
+            unsafeAtomicAdd(p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout
+                                           + cb0 * 16 + c) * 2 + which, v);
+        }
+        __syncthreads();
+    };
+
+    int n_cur, od0, oh0, ow0;
+    tile_coords(t_begin, n_cur, od0, oh0, ow0);
+    set_offsets(n_cur, od0, oh0, ow0);
+    issue(n_cur, 0);
+    commit(sA0);
+    __syncthreads();
+
+    int buf = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int n_next = n_cur, nod0 = od0, noh0 = oh0, now0 = ow0;
+        for (int ch = 0; ch < p.chunks; ++ch) {
+            // prefetch the next work item
+            const bool last_chunk = ch + 1 == p.chunks;
+            const bool more = !last_chunk || t + 1 < t_end;
+            if (more) {
+                if (last_chunk) {
+                    tile_coords(t + 1, n_next, nod0, noh0, now0);
+                    set_offsets(n_next, nod0, noh0, now0);
+                    issue(n_next, 0);
+                } else {
+                    issue(n_cur, ch + 1);
+                }
+            }
+            const char *sA = sA0 + buf * abytes;
+            for (int ks = 0; ks < p.ksteps; ++ks) {
+                const int toff = sTap[2 * ks + (lane >> 5)];
+                f16x8 xf[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) xf[mb] = *(const f16x8 *)(sA + base[mb] + toff);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const f16x8 wf = *(const f16x8 *)(sW + ((size_t)(nb * TS + ch * p.ksteps + ks) * 64 + lane) * 16);
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[mb], acc[mb][nb], 0, 0, 0);
+                }
+            }
+            if (last_chunk) {
+                // epilogue of this tile: bias, fp16 store, statistics
+                const int q = lane >> 4, r = lane & 15;
+                float t1[NB][4], t2[NB][4];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int od = od0 + wave + 4 * (mb >> 2);
+                    const int oh = oh0 + 2 * (mb & 3) + (r >> 3), ow = ow0 + (r & 7);
+                    const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
+                    const size_t vox = ((size_t)(n_cur * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int co = (cb0 + nb) * 16 + q * 4;
+                        const float4 bv = *(const float4 *)(p.bias + co);
+                        f16x4 o;
+                        o[0] = (f16)(acc[mb][nb][0] + bv.x);
+                        o[1] = (f16)(acc[mb][nb][1] + bv.y);
+                        o[2] = (f16)(acc[mb][nb][2] + bv.z);
+                        o[3] = (f16)(acc[mb][nb][3] + bv.w);
+                        if (ok) {
+                            *(f16x4 *)(p.out + vox * p.Cout + co) = o;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float v = (float)o[j];
+                                t1[nb][j] += v; t2[nb][j] += v * v;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s1[nb][j] += (double)t1[nb][j]; s2[nb][j] += (double)t2[nb][j]; }
+            }
+            if (more) commit(sA0 + (buf ^ 1) * abytes);
+            __syncthreads();
+            buf ^= 1;
+        }
+        if (n_next != n_cur || t + 1 == t_end) flush_stats(n_cur);
+        n_cur = n_next; od0 = nod0; oh0 = noh0; ow0 = now0;
+    }
+}
+
+static size_t persist_lds_bytes(const ConvParams &p, int nb, int mb) {
+    const int ID = mb - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
+    const int IVOX = ID * IH * IW;
+    return 2 * (size_t)((IVOX * 32 + 1023) & ~1023) + (size_t)nb * p.chunks * p.ksteps * 1024 + 128 + (size_t)4 * nb * 16 * 2 * 8;
+}
+
+template <int NB, int MB>
+static int launch_persist(ConvParams p, int wgs_per_cu, hipStream_t st) {
+    p.tile_d = MB;
+    p.tiles_d = (p.Do + MB - 1) / MB;
+    p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
+    p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
+    const int total = p.N * p.tiles_d * p.tiles_h * p.tiles_w;
+    const size_t lds = persist_lds_bytes(p, NB, MB);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)conv3d_persist_kernel<NB, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    int gx = 256 * wgs_per_cu;
+    if (gx > total) gx = total;
+    dim3 grid(gx, (p.Cout / 16) / NB);
+    hipLaunchKernelGGL((conv3d_persist_kernel<NB, MB>), grid, dim3(256), lds, st, p, total);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 size_t conv3d_lds_bytes(const ConvParams &p, int nb) {
     const int ID = (FNN_TILE_D - 1) * p.sd + p.kd;
     const int IH = (FNN_TILE_H - 1) * p.sh + p.kh;
@@ -551,13 +837,44 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
     p.tiles_d = (p.Do + FNN_TILE_D - 1) / FNN_TILE_D;
     p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
     p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
-    const int nb = conv3d_pick_nb(p.Cout / 16);
+    int nb = conv3d_pick_nb(p.Cout / 16);
     static const bool force_v1 = getenv("FNN_CONV_V1") != nullptr;          // debugging / A-B aid
     if (!force_v1 && p.sd == 1 && p.sh == 1 && p.sw == 1) {
-        // 8 column blocks per wave when the accumulators stay small and the volume is deep enough
-        const bool deep = p.Do >= 8;
-        if (nb == 1) return deep ? launch_pipe<1, 8>(p, st) : launch_pipe<1, 4>(p, st);
-        if (nb == 2) return deep ? launch_pipe<2, 8>(p, st) : launch_pipe<2, 4>(p, st);
+        // (cout blocks per workgroup, column blocks per wave): prefer the most work per staged byte,
+        // but small feature maps need workgroups first - the deep layers are latency bound otherwise
+        const int nblk = p.Cout / 16;
+        // decisions use the engine's planned batch, not this call's, so that a layer always runs the same
+        // variant (bit-reproducible statistics whatever the number of patches in the batch)
+        const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;
+        const int cand[5][2] = {{4, 4}, {2, 8}, {2, 4}, {1, 8}, {1, 4}};
+        int pick = -1, best = -1;
+        long long best_wgs = -1;
+        for (int i = 0; i < 5; ++i) {
+            const int cnb = cand[i][0], cmb = cand[i][1];
+            if (nblk % cnb) continue;
+            if (cmb == 8 && p.Do < 8) continue;
+            const long long wgs = (long long)plan_n * ((p.Do + cmb - 1) / cmb) * p.tiles_h * p.tiles_w * (nblk / cnb);
+            if (pick < 0 && wgs >= 768) pick = i;
+            if (wgs > best_wgs) { best_wgs = wgs; best = i; }
+        }
+        if (pick < 0) pick = best;
+        nb = cand[pick][0];
+        const int mbsel = cand[pick][1];
+        static const bool no_persist = getenv("FNN_CONV_NO_PERSIST") != nullptr;
+        if (!no_persist && nb <= 2) {
+            // persistent variant: many tiles per workgroup and all weights of the cout group fit in LDS
+            for (int mb = mbsel; mb >= 4; mb -= 4) {
+                const long long tiles = (long long)plan_n * ((p.Do + mb - 1) / mb) * p.tiles_h * p.tiles_w;
+                const size_t lds = persist_lds_bytes(p, nb, mb);
+                const int per_cu = (int)((160 * 1024) / lds);
+                if (per_cu < 2 || tiles < 256LL * 2 * 4) continue;
+                const int wpc = per_cu > 3 ? 3 : per_cu;
+                if (nb == 1) return mb == 8 ? launch_persist<1, 8>(p, wpc, st) : launch_persist<1, 4>(p, wpc, st);
+                return mb == 8 ? launch_persist<2, 8>(p, wpc, st) : launch_persist<2, 4>(p, wpc, st);
+            }
+        }
+        if (nb == 1) return mbsel == 8 ? launch_pipe<1, 8>(p, st) : launch_pipe<1, 4>(p, st);
+        if (nb == 2) return mbsel == 8 ? launch_pipe<2, 8>(p, st) : launch_pipe<2, 4>(p, st);
         return launch_pipe<4, 4>(p, st);
     }
     if (nb == 4) {

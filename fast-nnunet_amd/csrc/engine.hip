@@ -72,7 +72,6 @@ struct fnn_engine {
     int *inf_flag = nullptr;
     int *origins = nullptr; size_t origins_cap = 0;
     void *acc = nullptr; size_t acc_bytes = 0;
-    void *wsum = nullptr; size_t wsum_bytes = 0;
     float *vol_tmp = nullptr; size_t vol_tmp_bytes = 0;
     float *vol_pad = nullptr; size_t vol_pad_bytes = 0;
     void *out_tmp = nullptr; size_t out_tmp_bytes = 0;
@@ -398,7 +397,7 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.n_src = L.n_src;
             for (int i = 0; i < L.n_src; ++i) p.src[i] = make_src(e, fw, L.src_layer[i], nb);
             if (L.n_src == 1) { p.src[1] = p.src[0]; p.src[1].C = 0; }
-            p.N = nb; p.Di = L.in_dims[0]; p.Hi = L.in_dims[1]; p.Wi = L.in_dims[2];
+            p.N = nb; p.plan_N = e->max_batch; p.Di = L.in_dims[0]; p.Hi = L.in_dims[1]; p.Wi = L.in_dims[2];
             p.Do = L.out_dims[0]; p.Ho = L.out_dims[1]; p.Wo = L.out_dims[2];
             p.Cout = L.cout_pad;
             p.kd = L.k[0]; p.kh = L.k[1]; p.kw = L.k[2];
@@ -523,9 +522,15 @@ int check_ready(fnn_engine *e, int fold, const fnn_opts *o) {
     return 0;
 }
 
-// Runs patches [pb, pe) and accumulates into (acc, wsum) covering x in [x0, x1).
-int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp, const fnn_opts &o, int64_t pb,
-                int64_t pe, int64_t x0, int64_t x1, void *acc, void *wsum, int acc_fp32, hipStream_t st) {
+struct Box { int64_t lo[3], hi[3]; };
+
+inline int acc_hp(const fnn_arch_desc &a) { return (a.num_heads + 1 + 7) / 8 * 8; }
+
+// Runs the listed patches and accumulates into `acc`, which covers `box` of the padded volume
+// ([bx][by][bz][HP], channels-last, channel num_heads = weight sum).
+int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp, const fnn_opts &o,
+                const std::vector<int64_t> &ids, const int *ids_origins_dev, const Box &box, void *acc, int acc_fp32,
+                hipStream_t st) {
     const fnn_arch_desc &a = e->arch;
     const long long vdim[3] = {(long long)vp.padded[0], (long long)vp.padded[1], (long long)vp.padded[2]};
     int B = o.batch > 0 ? o.batch : e->max_batch;
@@ -538,20 +543,27 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
         if (int rc = ensure(e, &pbuf, &e->patch_buf_bytes, (size_t)B * a.num_heads * P * sizeof(float))) return rc;
         e->patch_buf = (float *)pbuf;
     }
-    for (int64_t p0 = pb; p0 < pe; p0 += B) {
-        const int nb = (int)((pe - p0 < B) ? pe - p0 : B);
-        const int *org = e->origins + p0 * 3;
+    const int64_t np = (int64_t)ids.size();
+    for (int64_t i = 0; i < np; ++i) {
+        const int *oo = &vp.origins[ids[i] * 3];
+        for (int d = 0; d < 3; ++d)
+            if (oo[d] < box.lo[d] || oo[d] + a.patch[d] > box.hi[d])
+                return fail(e, FNN_E_INVALID, "patch %lld lies outside the accumulator box", (long long)ids[i]);
+    }
+    for (int64_t p0 = 0; p0 < np; p0 += B) {
+        const int nb = (int)((np - p0 < B) ? np - p0 : B);
+        const int *org = ids_origins_dev + p0 * 3;
         for (size_t ci = 0; ci <= (tta ? combos.size() : 0); ++ci) {
             int flip[3] = {0, 0, 0};
             if (ci > 0) for (int ax : combos[ci - 1]) flip[ax] = 1;
             if (int rc = forward_batch(e, fold, vol_dev, 0, vdim, org, nb, flip, st)) return rc;
             for (int b = 0; b < nb; ++b) {
                 HeadParams h = make_head(e, fold, b);
-                const int *oo = &vp.origins[(p0 + b) * 3];
+                const int *oo = &vp.origins[ids[p0 + b] * 3];
                 h.gauss = o.use_gaussian ? e->gauss : nullptr;
-                h.acc = acc; h.wsum = wsum; h.AX = x1 - x0; h.Y = vp.padded[1]; h.Z = zpitch(vp.padded[2]);
-                h.ox = oo[0] - (int)x0; h.oy = oo[1]; h.oz = oo[2];
-                if (!tta && (h.ox < 0 || h.ox + a.patch[0] > x1 - x0)) return fail(e, FNN_E_INVALID, "patch %lld lies outside the accumulator x-range", (long long)(p0 + b));
+                h.acc = acc; h.AX = box.hi[0] - box.lo[0]; h.Y = box.hi[1] - box.lo[1]; h.Z = box.hi[2] - box.lo[2];
+                h.HP = acc_hp(a);
+                h.ox = oo[0] - (int)box.lo[0]; h.oy = oo[1] - (int)box.lo[1]; h.oz = oo[2] - (int)box.lo[2];
                 h.flip_d = flip[0]; h.flip_h = flip[1]; h.flip_w = flip[2];
                 h.acc_fp32 = acc_fp32;
                 if (tta) { h.mode = ci == 0 ? 1 : 2; h.patch_buf = e->patch_buf + (size_t)b * a.num_heads * P; }
@@ -561,14 +573,15 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
         }
         if (tta) {
             for (int b = 0; b < nb; ++b) {
-                const int *oo = &vp.origins[(p0 + b) * 3];
+                const int *oo = &vp.origins[ids[p0 + b] * 3];
                 PatchAccParams q{};
                 q.patch_buf = e->patch_buf + (size_t)b * a.num_heads * P;
-                q.n_div = (int)combos.size() + 1; q.inv_n = 1.f / (float)q.n_div;
+                q.n_div = (int)combos.size() + 1;
                 q.PD = a.patch[0]; q.PH = a.patch[1]; q.PW = a.patch[2]; q.heads = a.num_heads;
                 q.gauss = o.use_gaussian ? e->gauss : nullptr;
-                q.acc = acc; q.wsum = wsum; q.AX = x1 - x0; q.Y = vp.padded[1]; q.Z = zpitch(vp.padded[2]);
-                q.ox = oo[0] - (int)x0; q.oy = oo[1]; q.oz = oo[2];
+                q.acc = acc; q.AX = box.hi[0] - box.lo[0]; q.Y = box.hi[1] - box.lo[1]; q.Z = box.hi[2] - box.lo[2];
+                q.HP = acc_hp(a);
+                q.ox = oo[0] - (int)box.lo[0]; q.oy = oo[1] - (int)box.lo[1]; q.oz = oo[2] - (int)box.lo[2];
                 q.acc_fp32 = acc_fp32;
                 Scope sc(e, st, FAM_HEAD, 0);
                 if (launch_patch_acc(q, st) != 0) return fail(e, FNN_E_HIP, "patch accumulate launch failed");
@@ -606,43 +619,58 @@ int stage_volume(fnn_engine *e, const float *vol, const int64_t shape[4], const 
     return 0;
 }
 
-int upload_origins(fnn_engine *e, const VolPlan &vp, hipStream_t st) {
-    const size_t need = vp.origins.size() * sizeof(int);
+// Origins of the listed patches -> device (the stem conv reads them).
+int upload_origins(fnn_engine *e, const VolPlan &vp, const std::vector<int64_t> &ids, hipStream_t st) {
+    std::vector<int> host(ids.size() * 3);
+    for (size_t i = 0; i < ids.size(); ++i)
+        for (int d = 0; d < 3; ++d) host[i * 3 + d] = vp.origins[ids[i] * 3 + d];
+    const size_t need = host.size() * sizeof(int) + 64;
     void *t = e->origins;
     if (int rc = ensure(e, &t, &e->origins_cap, need)) return rc;
     e->origins = (int *)t;
-    HIPCHK(e, hipMemcpyAsync(e->origins, vp.origins.data(), need, hipMemcpyHostToDevice, st));
-    HIPCHK(e, hipStreamSynchronize(st));       // vp.origins is a host temporary
+    HIPCHK(e, hipMemcpyAsync(e->origins, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipStreamSynchronize(st));       // `host` is a temporary
     return 0;
 }
 
-int predict_one_fold(fnn_engine *e, int fold, const float *vol_dev, const int64_t shape[4], const VolPlan &vp,
-                     const fnn_opts &o, void *out_dev, int ensemble_mode, hipStream_t st) {
+FinalizeParams make_finalize(fnn_engine *e, const void *acc, const Box &box, const int64_t out_lo[3],
+                             const int64_t out_hi[3], const VolPlan &vp, const int64_t shape[4], const fnn_opts &o,
+                             int acc_fp32, int mode, void *out) {
+    // out_lo / out_hi: box of the UN-PADDED volume that is written
+    FinalizeParams f{};
+    f.acc = acc;
+    f.AX = box.hi[0] - box.lo[0]; f.Y = box.hi[1] - box.lo[1]; f.Z = box.hi[2] - box.lo[2];
+    f.HP = acc_hp(e->arch);
+    f.lo_x = (int)(out_lo[0] + vp.lo[0] - box.lo[0]); f.lo_y = (int)(out_lo[1] + vp.lo[1] - box.lo[1]);
+    f.lo_z = (int)(out_lo[2] + vp.lo[2] - box.lo[2]);
+    f.OX = out_hi[0] - out_lo[0]; f.OY = out_hi[1] - out_lo[1]; f.OZ = out_hi[2] - out_lo[2];
+    f.out_X = shape[1]; f.out_Y = shape[2]; f.out_Z = shape[3];
+    f.out_x = out_lo[0]; f.out_y = out_lo[1]; f.out_z = out_lo[2];
+    f.heads = e->arch.num_heads; f.acc_fp32 = acc_fp32; f.out_fp32 = o.out_dtype == FNN_OUT_F32;
+    f.mode = mode; f.out = out; f.inf_flag = e->inf_flag;
+    return f;
+}
+
+int accumulate_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp, const fnn_opts &o,
+                            Box &box, hipStream_t st) {
     const fnn_arch_desc &a = e->arch;
     const int acc_fp32 = o.accum == FNN_ACC_FP32;
     const size_t esz = acc_fp32 ? 4 : 2;
-    const size_t nvox = (size_t)vp.padded[0] * vp.padded[1] * zpitch(vp.padded[2]);
-    if (int rc = ensure(e, &e->acc, &e->acc_bytes, nvox * a.num_heads * esz)) return rc;
-    if (int rc = ensure(e, &e->wsum, &e->wsum_bytes, nvox * esz)) return rc;
-    HIPCHK(e, hipMemsetAsync(e->acc, 0, nvox * a.num_heads * esz, st));
-    HIPCHK(e, hipMemsetAsync(e->wsum, 0, nvox * esz, st));
-    if (int rc = run_patches(e, fold, vol_dev, vp, o, 0, vp.n_patches, 0, vp.padded[0], e->acc, e->wsum, acc_fp32, st)) return rc;
-    FinalizeParams f{};
-    f.acc = e->acc; f.wsum = e->wsum; f.AX = vp.padded[0]; f.Y = vp.padded[1]; f.Z = zpitch(vp.padded[2]);
-    f.lo_x = (int)vp.lo[0]; f.lo_y = (int)vp.lo[1]; f.lo_z = (int)vp.lo[2];
-    f.OX = shape[1]; f.OY = shape[2]; f.OZ = shape[3];
-    f.heads = a.num_heads; f.acc_fp32 = acc_fp32; f.out_fp32 = o.out_dtype == FNN_OUT_F32;
-    f.mode = ensemble_mode; f.out = out_dev; f.inf_flag = e->inf_flag;
-    Scope sc(e, st, FAM_FINAL, 0);
-    if (launch_finalize(f, st) != 0) return fail(e, FNN_E_HIP, "finalize launch failed");
-    return 0;
+    const size_t nvox = (size_t)vp.padded[0] * vp.padded[1] * vp.padded[2];
+    const size_t bytes = nvox * acc_hp(a) * esz;
+    if (int rc = ensure(e, &e->acc, &e->acc_bytes, bytes)) return rc;
+    HIPCHK(e, hipMemsetAsync(e->acc, 0, bytes, st));
+    for (int d = 0; d < 3; ++d) { box.lo[d] = 0; box.hi[d] = vp.padded[d]; }
+    std::vector<int64_t> ids(vp.n_patches);
+    for (int64_t i = 0; i < vp.n_patches; ++i) ids[i] = i;
+    return run_patches(e, fold, vol_dev, vp, o, ids, e->origins, box, e->acc, acc_fp32, st);
 }
 
 int predict_impl(fnn_engine *e, int fold0, int n_folds, const float *vol, const int64_t shape[4], const fnn_opts *o,
-                 void *out) {
+                 void *out, uint8_t *labels) {
     for (int f = fold0; f < fold0 + n_folds; ++f)
         if (int rc = check_ready(e, f, o)) return rc;
-    if (!vol || !out || !shape) return fail(e, FNN_E_INVALID, "NULL argument");
+    if (!vol || (!out && !labels) || !shape) return fail(e, FNN_E_INVALID, "NULL argument");
     const fnn_arch_desc &a = e->arch;
     if (shape[0] != a.in_channels) return fail(e, FNN_E_INVALID, "input has %lld channels, the network expects %d", (long long)shape[0], a.in_channels);
     HIPCHK(e, hipSetDevice(e->device));
@@ -651,26 +679,56 @@ int predict_impl(fnn_engine *e, int fold0, int n_folds, const float *vol, const 
     if (plan_volume(a, shape + 1, o->tile_step_size, vp) != 0) return fail(e, FNN_E_INVALID, "invalid volume shape / step size");
     const float *vol_dev = nullptr;
     if (int rc = stage_volume(e, vol, shape, vp, st, &vol_dev)) return rc;
-    if (int rc = upload_origins(e, vp, st)) return rc;
-    const size_t nout = (size_t)a.num_heads * shape[1] * shape[2] * shape[3];
+    {
+        std::vector<int64_t> all(vp.n_patches);
+        for (int64_t i = 0; i < vp.n_patches; ++i) all[i] = i;
+        if (int rc = upload_origins(e, vp, all, st)) return rc;
+    }
+    const size_t nvox_out = (size_t)shape[1] * shape[2] * shape[3];
+    const size_t nout = (size_t)a.num_heads * nvox_out;
     const size_t osz = o->out_dtype == FNN_OUT_F32 ? 4 : 2;
+    const bool want_logits = out != nullptr;
+    const bool labels_direct = labels && !want_logits && n_folds == 1;     // argmax straight from the accumulators
     void *out_dev = out;
-    const bool out_on_dev = is_device_ptr(out);
-    if (!out_on_dev) {
+    const bool out_on_dev = out && is_device_ptr(out);
+    if (!labels_direct && !out_on_dev) {
         if (int rc = ensure(e, &e->out_tmp, &e->out_tmp_bytes, nout * osz)) return rc;
         out_dev = e->out_tmp;
     }
+    uint8_t *lab_dev = labels;
+    const bool lab_on_dev = labels && is_device_ptr(labels);
+    void *lab_tmp = nullptr;
+    if (labels && !lab_on_dev) { HIPCHK(e, hipMalloc(&lab_tmp, nvox_out)); lab_dev = (uint8_t *)lab_tmp; }
     HIPCHK(e, hipMemsetAsync(e->inf_flag, 0, sizeof(int), st));
     e->ev_used = 0;
-    for (int f = 0; f < n_folds; ++f)
-        if (int rc = predict_one_fold(e, fold0 + f, vol_dev, shape, vp, *o, out_dev, f > 0 ? 1 : 0, st)) return rc;
-    if (n_folds > 1)
+    const int acc_fp32 = o->accum == FNN_ACC_FP32;
+    const int64_t zero3[3] = {0, 0, 0}, full3[3] = {shape[1], shape[2], shape[3]};
+    int rc = 0;
+    for (int f = 0; f < n_folds && rc == 0; ++f) {
+        Box box;
+        rc = accumulate_whole_volume(e, fold0 + f, vol_dev, vp, *o, box, st);
+        if (rc) break;
+        FinalizeParams fp = make_finalize(e, e->acc, box, zero3, full3, vp, shape, *o, acc_fp32, f > 0 ? 1 : 0, out_dev);
+        Scope sc(e, st, FAM_FINAL, 0);
+        if (labels_direct) { if (launch_labels_from_acc(fp, lab_dev, st) != 0) rc = fail(e, FNN_E_HIP, "labels launch failed"); }
+        else if (launch_finalize(fp, st) != 0) rc = fail(e, FNN_E_HIP, "finalize launch failed");
+    }
+    if (rc == 0 && !labels_direct && n_folds > 1)
         if (launch_scale_output(out_dev, o->out_dtype == FNN_OUT_F32, (long long)nout, n_folds, e->inf_flag, st) != 0)
-            return fail(e, FNN_E_HIP, "scale launch failed");
+            rc = fail(e, FNN_E_HIP, "scale launch failed");
+    if (rc == 0 && labels && !labels_direct)
+        if (launch_argmax(out_dev, o->out_dtype == FNN_OUT_F32, a.num_heads, (long long)nvox_out, lab_dev, st) != 0)
+            rc = fail(e, FNN_E_HIP, "argmax launch failed");
     int flag = 0;
-    HIPCHK(e, hipMemcpyAsync(&flag, e->inf_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (!out_on_dev) HIPCHK(e, hipMemcpyAsync(out, out_dev, nout * osz, hipMemcpyDeviceToHost, st));
-    HIPCHK(e, hipStreamSynchronize(st));
+    if (rc == 0) {
+        hipError_t r1 = hipMemcpyAsync(&flag, e->inf_flag, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (r1 == hipSuccess && want_logits && !out_on_dev) r1 = hipMemcpyAsync(out, out_dev, nout * osz, hipMemcpyDeviceToHost, st);
+        if (r1 == hipSuccess && labels && !lab_on_dev) r1 = hipMemcpyAsync(labels, lab_dev, nvox_out, hipMemcpyDeviceToHost, st);
+        if (r1 == hipSuccess) r1 = hipStreamSynchronize(st);
+        if (r1 != hipSuccess) rc = fail(e, FNN_E_HIP, "copy back failed: %s", hipGetErrorString(r1));
+    }
+    if (lab_tmp) (void)hipFree(lab_tmp);
+    if (rc) return rc;
     if (e->profiling) collect_profile(e, vp.n_patches * n_folds);
     if (flag)
         return fail(e, FNN_E_INF, "Encountered inf in predicted array. Aborting... If this problem persists, reduce "
@@ -720,7 +778,7 @@ void fnn_destroy(fnn_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     for (auto &f : e->folds) { if (f.wpk) (void)hipFree(f.wpk); if (f.fparam) (void)hipFree(f.fparam); }
-    void *ptrs[] = {e->act, e->stats, e->ss, e->gauss, e->inf_flag, e->origins, e->acc, e->wsum, e->vol_tmp, e->vol_pad, e->out_tmp, e->patch_buf};
+    void *ptrs[] = {e->act, e->stats, e->ss, e->gauss, e->inf_flag, e->origins, e->acc, e->vol_tmp, e->vol_pad, e->out_tmp, e->patch_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ev : e->evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     delete e;
@@ -778,62 +836,71 @@ int fnn_set_gaussian(fnn_engine *e, const uint16_t *half_bits, int64_t count) {
 
 int fnn_predict_volume(fnn_engine *e, int fold, const float *vol, const int64_t shape[4], const fnn_opts *opts, void *out) {
     if (!e) return FNN_E_INVALID;
-    return predict_impl(e, fold, 1, vol, shape, opts, out);
+    return predict_impl(e, fold, 1, vol, shape, opts, out, nullptr);
 }
 
 int fnn_predict_volume_ensemble(fnn_engine *e, int n_folds, const float *vol, const int64_t shape[4], const fnn_opts *opts, void *out) {
     if (!e) return FNN_E_INVALID;
     if (n_folds < 1) return fail(e, FNN_E_INVALID, "n_folds must be >= 1");
-    return predict_impl(e, 0, n_folds, vol, shape, opts, out);
+    return predict_impl(e, 0, n_folds, vol, shape, opts, out, nullptr);
 }
 
+int fnn_predict_labels(fnn_engine *e, int n_folds, const float *vol, const int64_t shape[4], const fnn_opts *opts, uint8_t *labels) {
+    if (!e) return FNN_E_INVALID;
+    if (n_folds < 1) return fail(e, FNN_E_INVALID, "n_folds must be >= 1");
+    if (!labels) return fail(e, FNN_E_INVALID, "NULL labels");
+    return predict_impl(e, 0, n_folds, vol, shape, opts, nullptr, labels);
+}
+
+int64_t fnn_accumulator_channels(const fnn_engine *e) { return e ? acc_hp(e->arch) : -1; }
+
 int fnn_accumulate_patches(fnn_engine *e, int fold, const float *vol, const int64_t shape[4], const fnn_opts *opts,
-                           int64_t patch_begin, int64_t patch_end, int64_t x0, int64_t x1, float *acc, float *wsum) {
+                           const int64_t *patch_ids, int64_t n_ids, const int64_t box_lo[3], const int64_t box_hi[3],
+                           float *acc) {
     if (int rc = check_ready(e, fold, opts)) return rc;
-    if (!vol || !acc || !wsum) return fail(e, FNN_E_INVALID, "NULL argument");
-    if (!is_device_ptr(acc) || !is_device_ptr(wsum)) return fail(e, FNN_E_INVALID, "accumulators must be device memory");
+    if (!vol || !acc || !box_lo || !box_hi || (n_ids > 0 && !patch_ids)) return fail(e, FNN_E_INVALID, "NULL argument");
+    if (!is_device_ptr(acc)) return fail(e, FNN_E_INVALID, "accumulators must be device memory");
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)opts->stream;
     VolPlan vp;
     if (plan_volume(e->arch, shape + 1, opts->tile_step_size, vp) != 0) return fail(e, FNN_E_INVALID, "invalid volume shape / step size");
-    if (patch_begin < 0 || patch_end > vp.n_patches || patch_begin > patch_end) return fail(e, FNN_E_INVALID, "patch range out of bounds");
-    if (x0 < 0 || x1 > vp.padded[0] || x0 >= x1) return fail(e, FNN_E_INVALID, "x-range out of bounds");
+    Box box;
+    for (int d = 0; d < 3; ++d) {
+        box.lo[d] = box_lo[d]; box.hi[d] = box_hi[d];
+        if (box.lo[d] < 0 || box.hi[d] > vp.padded[d] || box.lo[d] >= box.hi[d]) return fail(e, FNN_E_INVALID, "box out of bounds");
+    }
+    std::vector<int64_t> ids(patch_ids, patch_ids + n_ids);
+    for (int64_t id : ids) if (id < 0 || id >= vp.n_patches) return fail(e, FNN_E_INVALID, "patch id out of range");
+    if (ids.empty()) return 0;
     const float *vol_dev = nullptr;
     if (int rc = stage_volume(e, vol, shape, vp, st, &vol_dev)) return rc;
-    if (int rc = upload_origins(e, vp, st)) return rc;
+    if (int rc = upload_origins(e, vp, ids, st)) return rc;
     e->ev_used = 0;
-    if (int rc = run_patches(e, fold, vol_dev, vp, *opts, patch_begin, patch_end, x0, x1, acc, wsum, 1, st)) return rc;
-    if (e->profiling) { HIPCHK(e, hipStreamSynchronize(st)); collect_profile(e, patch_end - patch_begin); }
+    if (int rc = run_patches(e, fold, vol_dev, vp, *opts, ids, e->origins, box, acc, 1, st)) return rc;
+    if (e->profiling) { HIPCHK(e, hipStreamSynchronize(st)); collect_profile(e, n_ids); }
     return 0;
 }
 
-int fnn_normalize_slab(fnn_engine *e, const float *acc, const float *wsum, const int64_t shape[4], const fnn_opts *opts,
-                       int64_t x0, int64_t x1, int64_t out_x0, int64_t out_x1, void *out) {
+int fnn_normalize_box(fnn_engine *e, const float *acc, const int64_t shape[4], const fnn_opts *opts,
+                      const int64_t box_lo[3], const int64_t box_hi[3], const int64_t out_lo[3], const int64_t out_hi[3],
+                      void *out) {
     if (!e || !opts) return FNN_E_INVALID;
-    if (!acc || !wsum || !out) return fail(e, FNN_E_INVALID, "NULL argument");
+    if (!acc || !out || !box_lo || !box_hi || !out_lo || !out_hi) return fail(e, FNN_E_INVALID, "NULL argument");
+    if (!is_device_ptr(acc) || !is_device_ptr(out)) return fail(e, FNN_E_INVALID, "fnn_normalize_box needs device pointers");
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)opts->stream;
     VolPlan vp;
     if (plan_volume(e->arch, shape + 1, opts->tile_step_size, vp) != 0) return fail(e, FNN_E_INVALID, "invalid volume shape / step size");
-    // output rows [out_x0, out_x1) (un-padded coordinates) must lie inside the slab
-    if (out_x0 < 0 || out_x1 > shape[1] || out_x0 >= out_x1) return fail(e, FNN_E_INVALID, "output x-range out of bounds");
-    if (out_x0 + vp.lo[0] < x0 || out_x1 + vp.lo[0] > x1) return fail(e, FNN_E_INVALID, "output rows are not covered by the slab");
-    const size_t osz = opts->out_dtype == FNN_OUT_F32 ? 4 : 2;
-    // finalize writes a [heads][OX][OY][OZ] block; to address rows of the full tensor we run it per head
-    HIPCHK(e, hipMemsetAsync(e->inf_flag, 0, sizeof(int), st));
-    const size_t plane_in = (size_t)(x1 - x0) * vp.padded[1] * zpitch(vp.padded[2]);
-    const size_t plane_out = (size_t)shape[1] * shape[2] * shape[3];
-    for (int h = 0; h < e->arch.num_heads; ++h) {
-        FinalizeParams f{};
-        f.acc = acc + (size_t)h * plane_in; f.wsum = wsum;
-        f.AX = x1 - x0; f.Y = vp.padded[1]; f.Z = zpitch(vp.padded[2]);
-        f.lo_x = (int)(out_x0 + vp.lo[0] - x0); f.lo_y = (int)vp.lo[1]; f.lo_z = (int)vp.lo[2];
-        f.OX = out_x1 - out_x0; f.OY = shape[2]; f.OZ = shape[3];
-        f.heads = 1; f.acc_fp32 = 1; f.out_fp32 = opts->out_dtype == FNN_OUT_F32; f.mode = 0;
-        f.out = (char *)out + ((size_t)h * plane_out + (size_t)out_x0 * shape[2] * shape[3]) * osz;
-        f.inf_flag = e->inf_flag;
-        if (launch_finalize(f, st) != 0) return fail(e, FNN_E_HIP, "finalize launch failed");
+    Box box;
+    for (int d = 0; d < 3; ++d) {
+        box.lo[d] = box_lo[d]; box.hi[d] = box_hi[d];
+        if (out_lo[d] < 0 || out_hi[d] > shape[1 + d] || out_lo[d] >= out_hi[d]) return fail(e, FNN_E_INVALID, "output box out of bounds");
+        if (out_lo[d] + vp.lo[d] < box.lo[d] || out_hi[d] + vp.lo[d] > box.hi[d])
+            return fail(e, FNN_E_INVALID, "output box is not covered by the accumulator box");
     }
+    HIPCHK(e, hipMemsetAsync(e->inf_flag, 0, sizeof(int), st));
+    FinalizeParams f = make_finalize(e, acc, box, out_lo, out_hi, vp, shape, *opts, 1, 0, out);
+    if (launch_finalize(f, st) != 0) return fail(e, FNN_E_HIP, "finalize launch failed");
     int flag = 0;
     HIPCHK(e, hipMemcpyAsync(&flag, e->inf_flag, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));

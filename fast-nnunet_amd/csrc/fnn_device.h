@@ -41,6 +41,7 @@ struct ConvParams {
     SrcDesc src[2];
     int n_src;
     int N, Di, Hi, Wi;           // input spatial size (both sources)
+    int plan_N;                  // batch size the engine was planned for (kernel-variant choice); 0 = N
     int Do, Ho, Wo;              // output spatial size
     int Cout;                    // padded
     int kd, kh, kw, sd, sh, sw, pd, ph, pw;
@@ -93,10 +94,10 @@ struct HeadParams {
     const f16 *wpk;              // [hblock][kstep][64][8]
     const float *bias;           // [hblocks*16]
     const f16 *gauss;            // [PD][PH][PW] or nullptr (= weight 1)
-    void *acc;                   // [heads][AX][Y][Z] fp16 or fp32, AX = x1 - x0
-    void *wsum;                  // [AX][Y][Z]
+    void *acc;                   // [AX][Y][Z][HP] fp16 or fp32, channel `heads` = weight sum
     long long AX, Y, Z;
-    int ox, oy, oz;              // patch origin relative to the accumulator
+    int HP;                      // round_up(heads + 1, 8)
+    int ox, oy, oz;              // patch origin relative to the accumulator box
     int flip_d, flip_h, flip_w;
     int mode;                    // 0 fused accumulate, 1 patch buffer '=', 2 patch buffer '+='
     float *patch_buf;            // [heads][PD*PH*PW] fp32 (modes 1, 2)
@@ -105,26 +106,29 @@ struct HeadParams {
 
 struct PatchAccParams {          // patch buffer -> volume accumulators (mirroring path)
     const float *patch_buf;      // [heads][P]
-    float inv_n;                 // 1 / (number of mirrored evaluations)
-    int n_div;                   // the integer divisor (reference divides, not multiplies)
+    int n_div;                   // number of mirrored evaluations (the reference divides)
     int PD, PH, PW, heads;
     const f16 *gauss;
-    void *acc; void *wsum;
+    void *acc;
     long long AX, Y, Z;
+    int HP;
     int ox, oy, oz;
     int acc_fp32;
 };
 
 struct FinalizeParams {
-    const void *acc; const void *wsum;
-    long long AX, Y, Z;          // accumulator (padded) size
-    int lo_x, lo_y, lo_z;        // un-pad offsets
-    long long OX, OY, OZ;        // output size
+    const void *acc;             // [AX][Y][Z][HP]
+    long long AX, Y, Z;
+    int HP;
+    int lo_x, lo_y, lo_z;        // first voxel of the box inside the accumulator
+    long long OX, OY, OZ;        // box size
+    long long out_X, out_Y, out_Z;   // full output size
+    long long out_x, out_y, out_z;   // where the box goes in the output
     int heads;
     int acc_fp32;
     int out_fp32;
     int mode;                    // 0 write, 1 add to existing output (fold ensembling)
-    void *out;                   // [heads][OX][OY][OZ]
+    void *out;                   // [heads][out_X][out_Y][out_Z]
     int *inf_flag;
 };
 
@@ -148,6 +152,7 @@ int launch_tconv(const TconvParams &p, hipStream_t st);
 int launch_head(const HeadParams &p, hipStream_t st);
 int launch_patch_acc(const PatchAccParams &p, hipStream_t st);
 int launch_finalize(const FinalizeParams &p, hipStream_t st);
+int launch_labels_from_acc(const FinalizeParams &p, uint8_t *labels, hipStream_t st);
 int launch_scale_output(void *out, int out_fp32, long long n, int divisor, int *inf_flag, hipStream_t st);
 int launch_argmax(const void *logits, int fp32, int heads, long long nvox, uint8_t *labels, hipStream_t st);
 int launch_pad_volume(const float *src, float *dst, int C, const long long s[3], const long long d[3],

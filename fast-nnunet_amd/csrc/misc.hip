@@ -137,29 +137,41 @@ int launch_tconv(const TconvParams &p, hipStream_t st) {
 }
 
 // ----------------------------------------------------------------------------
-// accumulate one weighted logit into the volume accumulators
+// volume accumulators
 // ----------------------------------------------------------------------------
+// Layout: acc[AX][Y][Z][HP], channels-last, fp16 (reference rounding) or fp32;
+//   channel h < heads      sum over patches of  gaussian * logit_h
+//   channel heads          sum of the gaussian weights (the reference's n_predictions)
+//   HP = round_up(heads + 1, 8) so that 4 consecutive channels are an aligned 8 / 16 bytes.
+// One voxel's channels are one or two contiguous 128-byte lines: a patch touches ~5x fewer pages
+// than with a [heads][X][Y][Z] layout, the MFMA result (4 consecutive heads of one voxel per lane)
+// is added straight from registers, and divide / argmax read one line per voxel.
+//
 // Reference rounding (predict_from_raw_data.py:611-614):
-//   pred (fp32) *= gaussian (fp16)      -> fp32 product
+//   pred (fp32) *= gaussian (fp16)      -> fp32 product           (__fmul_rn: never fused)
 //   acc (fp16)[sl] += pred              -> fp32 add, ONE round-to-nearest-even to fp16
 //   n   (fp16)[sl] += gaussian          -> fp16 + fp16
 // fp16 subnormals must survive (5.96e-8 weights): no flush-to-zero is used.
-static __device__ __forceinline__ void acc_add(void *acc, size_t idx, float v, int fp32) {
-    // __fadd_rn: never contracted with the producing multiply (the reference rounds the product first)
-    if (fp32) {
-        ((float *)acc)[idx] = __fadd_rn(((float *)acc)[idx], v);
+template <bool ACC32>
+static __device__ __forceinline__ void acc_add4(void *acc, size_t elem, const float c[4], unsigned mask) {
+    if (ACC32) {
+        f32x4 *ap = (f32x4 *)((float *)acc + elem);
+        f32x4 a = *ap;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = (mask >> j) & 1 ? __fadd_rn(a[j], c[j]) : a[j];
+        *ap = a;
     } else {
-        f16 *a = (f16 *)acc;
-        a[idx] = (f16)__fadd_rn((float)a[idx], v);
+        f16x4 *ap = (f16x4 *)((f16 *)acc + elem);
+        f16x4 a = *ap;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = (mask >> j) & 1 ? (f16)__fadd_rn((float)a[j], c[j]) : a[j];
+        *ap = a;
     }
 }
 
 // ----------------------------------------------------------------------------
-// seg head: D[head, voxel] = Wseg[head, c] * act[c, voxel]  (+ bias), then
-//   mode 0: acc[head, origin + voxel] += D * gauss[voxel]; wsum += gauss
-//   mode 1/2: patch_buf[head, unflip(voxel)] (=, +=) D        (mirroring path)
-// One wave = 64 consecutive patch voxels; the MFMA result is transposed through
-// LDS so that the read-modify-write of every head is a contiguous run.
+// seg head for the mirroring path / raw patch logits:
+//   D[head, voxel] = Wseg[head, c] * act[c, voxel] + bias -> patch_buf[head][unflip(voxel)] (=, +=)
 // ----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void seg_head_kernel(const HeadParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -174,8 +186,6 @@ __global__ __launch_bounds__(256) void seg_head_kernel(const HeadParams p) {
     const int v0 = (blockIdx.x * 4 + wave) * 64;
     if (v0 >= P) return;
     const int r = lane & 15, q = lane >> 4;
-
-    // this lane's voxel for the read-back / RMW phase
     const int v = v0 + lane;
     const bool vok = v < P;
     int w = v % p.PW, h = (v / p.PW) % p.PH, d = v / (p.PW * p.PH);
@@ -183,10 +193,6 @@ __global__ __launch_bounds__(256) void seg_head_kernel(const HeadParams p) {
     if (p.flip_h) h = p.PH - 1 - h;
     if (p.flip_w) w = p.PW - 1 - w;
     const int pv = (d * p.PH + h) * p.PW + w;                 // voxel index in patch space
-    float g = 1.f;
-    if (vok && p.gauss && p.mode == 0) g = (float)p.gauss[pv];
-    const size_t aidx = ((size_t)(p.ox + d) * p.Y + (p.oy + h)) * p.Z + (p.oz + w);
-    const size_t plane = (size_t)p.AX * p.Y * p.Z;
 
     for (int hb0 = 0; hb0 < p.hblocks; hb0 += 4) {
         const int nhb = min(4, p.hblocks - hb0);
@@ -212,7 +218,6 @@ __global__ __launch_bounds__(256) void seg_head_kernel(const HeadParams p) {
                 }
             }
         }
-        // transpose through LDS: sT[head_local][voxel_local]
 #pragma unroll
         for (int hb = 0; hb < 4; ++hb)
 #pragma unroll
@@ -226,151 +231,90 @@ __global__ __launch_bounds__(256) void seg_head_kernel(const HeadParams p) {
             for (int hl = 0; hl < nh; ++hl) {
                 const int head = hb0 * 16 + hl;
                 const float val = sT[hl * 65 + lane] + p.bias[head];
-                if (p.mode == 0) {
-                    acc_add(p.acc, (size_t)head * plane + aidx, __fmul_rn(val, g), p.acc_fp32);
-                } else {
-                    float *pb = p.patch_buf + (size_t)head * P + pv;
-                    *pb = (p.mode == 1) ? val : (*pb + val);
-                }
+                float *pb = p.patch_buf + (size_t)head * P + pv;
+                *pb = (p.mode == 1) ? val : (*pb + val);
             }
         }
         __builtin_amdgcn_wave_barrier();
-    }
-    if (vok && p.mode == 0) {
-        if (p.acc_fp32) ((float *)p.wsum)[aidx] += g;
-        else { f16 *wsp = (f16 *)p.wsum; wsp[aidx] = (f16)((float)wsp[aidx] + g); }
     }
 }
 
 // ----------------------------------------------------------------------------
-// fused seg head + accumulate (mode 0), vectorised read-modify-write
+// fused seg head + Gaussian weighting + accumulate (no mirroring): the K6 + K7 kernel
 // ----------------------------------------------------------------------------
-// The accumulators have a z pitch that is a multiple of 8 and the patch rows
-// are walked in accumulator-aligned groups of 8 voxels: a row of PW voxels that
-// starts at z = oz becomes GP = ceil(((oz & 7) + PW) / 8) groups, elements
-// outside the patch contribute exactly 0.  One wave = 8 groups (64 padded
-// voxels); after the MFMA the [head][voxel] tile is transposed through LDS so
-// that every lane owns (one head, one group): a 16-byte (fp16) or 2 x 16-byte
-// (fp32) read-modify-write, 8 heads x 128 contiguous bytes per wave instruction.
-#define HEAD_HBP 2                       // head blocks (of 16) per pass
-#define HEAD_LDT 68                      // LDS row stride in floats (64 + pad, keeps 16-B alignment)
+// One wave = 64 consecutive patch voxels (4 MFMA column blocks).  For every block of 16 heads the
+// MFMA leaves 4 consecutive heads of one voxel in each lane; they are weighted and added to the
+// channels-last accumulator directly from registers (8-byte fp16 / 16-byte fp32 read-modify-write).
+template <bool ACC32>
 __global__ __launch_bounds__(256) void seg_head_acc_kernel(const HeadParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float2 *sSS = (float2 *)smem;
-    float *sT = (float *)(smem + ((p.src.C * 8 + 255) & ~255)) + wave * (HEAD_HBP * 16 * HEAD_LDT);
     const int P = p.PD * p.PH * p.PW;
-    const int zoff = p.oz & 7;
-    const int RW = ((zoff + p.PW + 7) >> 3) << 3;         // padded row length
-    const int PV = p.PD * p.PH * RW;
-
     load_scale_shift(p.src, p.b, sSS, tid, 256);
     __syncthreads();
 
     const int v0 = (blockIdx.x * 4 + wave) * 64;
-    if (v0 >= PV) return;
+    if (v0 >= P) return;
     const int r = lane & 15, q = lane >> 4;
 
-    // MFMA operand voxels of this lane (4 column blocks)
-    size_t src_vox[4];
-    bool src_ok[4];
+    size_t aelem[4];                       // accumulator element index of this lane's voxel, per column block
+    float g[4];
+    bool ok[4];
 #pragma unroll
     for (int vb = 0; vb < 4; ++vb) {
         const int v = v0 + vb * 16 + r;
-        const int wz = v % RW, hh = (v / RW) % p.PH, dd = v / (RW * p.PH);
-        const int w = wz - zoff;
-        src_ok[vb] = v < PV && w >= 0 && w < p.PW;
-        src_vox[vb] = (size_t)p.b * P + ((size_t)dd * p.PH + hh) * p.PW + w;
+        ok[vb] = v < P;
+        const int vv = ok[vb] ? v : 0;
+        const int w = vv % p.PW, h = (vv / p.PW) % p.PH, d = vv / (p.PW * p.PH);
+        g[vb] = p.gauss ? (float)p.gauss[vv] : 1.f;
+        aelem[vb] = (((size_t)(p.ox + d) * p.Y + (p.oy + h)) * p.Z + (p.oz + w)) * p.HP;
     }
-    // read-modify-write role of this lane: group gl of the tile, head sub-index hs
-    const int gl = lane & 7, hs = lane >> 3;
-    const int vg = v0 + 8 * gl;
-    const bool g_ok = vg < PV;
-    const int wz0 = vg % RW, gh = (vg / RW) % p.PH, gd = vg / (RW * p.PH);
-    float g[8];
+    const bool one_kstep = p.ksteps == 1;
+    f16x8 xf0[4];
+    if (one_kstep) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int w = wz0 + e - zoff;
-        const bool ok = g_ok && w >= 0 && w < p.PW;
-        g[e] = ok ? (p.gauss ? (float)p.gauss[((size_t)gd * p.PH + gh) * p.PW + w] : 1.f) : 0.f;
+        for (int vb = 0; vb < 4; ++vb) xf0[vb] = load_act_frag(p.src, (size_t)p.b * P + v0 + vb * 16 + r, ok[vb], q * 8, sSS);
     }
-    const size_t aidx = ((size_t)(p.ox + gd) * p.Y + (p.oy + gh)) * p.Z + (p.oz - zoff) + wz0;   // multiple of 8
-    const size_t plane = (size_t)p.AX * p.Y * p.Z;
-
-    for (int hb0 = 0; hb0 < p.hblocks; hb0 += HEAD_HBP) {
-        f32x4 acc[HEAD_HBP][4];
+    const int hb_w = p.heads >> 4, q_w = (p.heads >> 2) & 3, j_w = p.heads & 3;     // where the weight-sum channel lives
+    const int hb_total = (p.HP + 15) >> 4;
+    for (int hb = 0; hb < hb_total; ++hb) {
+        const int ch0 = hb * 16 + q * 4;                    // first of this lane's 4 channels
+        if (ch0 >= p.HP) continue;
+        f32x4 acc[4];
 #pragma unroll
-        for (int a = 0; a < HEAD_HBP; ++a)
+        for (int vb = 0; vb < 4; ++vb) acc[vb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (hb < p.hblocks) {
+            for (int ks = 0; ks < p.ksteps; ++ks) {
+                const f16x8 wf = *(const f16x8 *)(p.wpk + (((size_t)hb * p.ksteps + ks) * 64 + lane) * 8);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < p.ksteps; ++ks) {
-            f16x8 xf[4];
-#pragma unroll
-            for (int vb = 0; vb < 4; ++vb) xf[vb] = load_act_frag(p.src, src_vox[vb], src_ok[vb], ks * 32 + q * 8, sSS);
-#pragma unroll
-            for (int hb = 0; hb < HEAD_HBP; ++hb) {
-                if (hb0 + hb < p.hblocks) {
-                    const f16x8 wf = *(const f16x8 *)(p.wpk + (((size_t)(hb0 + hb) * p.ksteps + ks) * 64 + lane) * 8);
-#pragma unroll
-                    for (int vb = 0; vb < 4; ++vb)
-                        acc[hb][vb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[vb], acc[hb][vb], 0, 0, 0);
+                for (int vb = 0; vb < 4; ++vb) {
+                    const f16x8 xf = one_kstep ? xf0[vb]
+                                               : load_act_frag(p.src, (size_t)p.b * P + v0 + vb * 16 + r, ok[vb], ks * 32 + q * 8, sSS);
+                    acc[vb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf, acc[vb], 0, 0, 0);
                 }
             }
         }
+        float bias[4];
+        unsigned mask = 0;
 #pragma unroll
-        for (int hb = 0; hb < HEAD_HBP; ++hb)
-#pragma unroll
-            for (int vb = 0; vb < 4; ++vb)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) sT[(hb * 16 + q * 4 + j) * HEAD_LDT + vb * 16 + r] = acc[hb][vb][j];
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-        if (g_ok) {
-#pragma unroll
-            for (int i = 0; i < HEAD_HBP * 2; ++i) {
-                const int hl = 8 * i + hs;
-                const int head = hb0 * 16 + hl;
-                if (head < p.heads) {
-                    const float bias = p.bias[head];
-                    const f32x4 t0 = *(const f32x4 *)(sT + hl * HEAD_LDT + 8 * gl);
-                    const f32x4 t1 = *(const f32x4 *)(sT + hl * HEAD_LDT + 8 * gl + 4);
-                    float c[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { c[e] = __fmul_rn(t0[e] + bias, g[e]); c[4 + e] = __fmul_rn(t1[e] + bias, g[4 + e]); }
-                    if (p.acc_fp32) {
-                        f32x4 *ap = (f32x4 *)((float *)p.acc + (size_t)head * plane + aidx);
-                        f32x4 a0 = ap[0], a1 = ap[1];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {          // elements outside the patch keep their bits (-0 stays -0)
-                            a0[e] = g[e] != 0.f ? __fadd_rn(a0[e], c[e]) : a0[e];
-                            a1[e] = g[4 + e] != 0.f ? __fadd_rn(a1[e], c[4 + e]) : a1[e];
-                        }
-                        ap[0] = a0; ap[1] = a1;
-                    } else {
-                        f16x8 *ap = (f16x8 *)((f16 *)p.acc + (size_t)head * plane + aidx);
-                        f16x8 a = *ap;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) a[e] = g[e] != 0.f ? (f16)__fadd_rn((float)a[e], c[e]) : a[e];
-                        *ap = a;
-                    }
-                }
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int ch = ch0 + j;
+            bias[j] = ch < p.heads ? p.bias[ch] : 0.f;
+            if (ch <= p.heads) mask |= 1u << j;              // logits and the weight-sum channel; padding untouched
         }
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (g_ok && hs == 0) {
-        if (p.acc_fp32) {
-            f32x4 *wp = (f32x4 *)((float *)p.wsum + aidx);
-            f32x4 a0 = wp[0], a1 = wp[1];
+        const bool has_w = hb == hb_w && q == q_w;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { a0[e] += g[e]; a1[e] += g[4 + e]; }
-            wp[0] = a0; wp[1] = a1;
-        } else {
-            f16x8 *wp = (f16x8 *)((f16 *)p.wsum + aidx);
-            f16x8 a = *wp;
+        for (int vb = 0; vb < 4; ++vb) {
+            if (!ok[vb]) continue;
+            float c[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] = (f16)((float)a[e] + g[e]);
-            *wp = a;
+            for (int j = 0; j < 4; ++j) c[j] = __fmul_rn(acc[vb][j] + bias[j], g[vb]);
+            if (has_w) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c[j] = j == j_w ? g[vb] : c[j];
+            }
+            acc_add4<ACC32>(p.acc, aelem[vb] + ch0, c, mask);
         }
     }
 }
@@ -380,19 +324,16 @@ int launch_head(const HeadParams &p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)seg_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)seg_head_acc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    static const bool force_scalar = getenv("FNN_HEAD_SCALAR") != nullptr;      // debugging aid
-    if (!force_scalar && p.mode == 0 && (p.Z & 7) == 0 && p.oz >= 0) {
-        const int RW = (((p.oz & 7) + p.PW + 7) >> 3) << 3;
-        const long long PV = (long long)p.PD * p.PH * RW;
-        const size_t lds = (size_t)((p.src.C * 8 + 255) & ~255) + (size_t)4 * HEAD_HBP * 16 * HEAD_LDT * 4;
-        hipLaunchKernelGGL(seg_head_acc_kernel, dim3((unsigned)((PV + 255) / 256)), dim3(256), lds, st, p);
+    dim3 grid((P + 255) / 256);
+    if (p.mode == 0) {
+        const size_t lds = (size_t)((p.src.C * 8 + 255) & ~255);
+        if (p.acc_fp32) hipLaunchKernelGGL(seg_head_acc_kernel<true>, grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL(seg_head_acc_kernel<false>, grid, dim3(256), lds, st, p);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     const size_t lds = (size_t)((p.src.C * 8 + 255) & ~255) + (size_t)4 * 64 * 65 * 4;
-    dim3 grid((P + 255) / 256);
     hipLaunchKernelGGL(seg_head_kernel, grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -400,66 +341,121 @@ int launch_head(const HeadParams &p, hipStream_t st) {
 // ----------------------------------------------------------------------------
 // mirrored evaluations: mean of the patch buffer -> accumulators
 // (predict_from_raw_data.py:556 `prediction /= n`, then :611-614)
+// One thread = one voxel x 4 channels.
 // ----------------------------------------------------------------------------
+template <bool ACC32>
 __global__ __launch_bounds__(256) void patch_acc_kernel(const PatchAccParams p) {
     const int P = p.PD * p.PH * p.PW;
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= P) return;
     const int w = v % p.PW, h = (v / p.PW) % p.PH, d = v / (p.PW * p.PH);
     const float g = p.gauss ? (float)p.gauss[v] : 1.f;
-    const size_t aidx = ((size_t)(p.ox + d) * p.Y + (p.oy + h)) * p.Z + (p.oz + w);
-    const size_t plane = (size_t)p.AX * p.Y * p.Z;
+    const size_t aelem = (((size_t)(p.ox + d) * p.Y + (p.oy + h)) * p.Z + (p.oz + w)) * p.HP;
     const float div = (float)p.n_div;
-    for (int head = 0; head < p.heads; ++head) {
-        const float val = p.patch_buf[(size_t)head * P + v] / div;
-        acc_add(p.acc, (size_t)head * plane + aidx, __fmul_rn(val, g), p.acc_fp32);
+    for (int ch0 = 0; ch0 <= p.heads; ch0 += 4) {
+        float c[4];
+        unsigned mask = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = ch0 + j;
+            c[j] = 0.f;
+            if (ch < p.heads) { c[j] = __fmul_rn(__fdiv_rn(p.patch_buf[(size_t)ch * P + v], div), g); mask |= 1u << j; }
+            else if (ch == p.heads) { c[j] = g; mask |= 1u << j; }
+        }
+        acc_add4<ACC32>(p.acc, aelem + ch0, c, mask);
     }
-    if (p.acc_fp32) ((float *)p.wsum)[aidx] += g;
-    else { f16 *wsp = (f16 *)p.wsum; wsp[aidx] = (f16)((float)wsp[aidx] + g); }
 }
 
 int launch_patch_acc(const PatchAccParams &p, hipStream_t st) {
     const int P = p.PD * p.PH * p.PW;
-    hipLaunchKernelGGL(patch_acc_kernel, dim3((P + 255) / 256), dim3(256), 0, st, p);
+    if (p.acc_fp32) hipLaunchKernelGGL(patch_acc_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(patch_acc_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 // ----------------------------------------------------------------------------
-// normalise + un-pad (+ fold ensembling)
-// (predict_from_raw_data.py:620-625, :679, :494-500)
+// normalise + un-pad (+ fold ensembling): channels-last accumulators -> planar logits
+// (predict_from_raw_data.py:620-625, :679, :494-500).  One thread = one output voxel.
 // ----------------------------------------------------------------------------
+template <bool ACC32>
 __global__ __launch_bounds__(256) void finalize_kernel(const FinalizeParams p) {
-    const long long nout = p.OX * p.OY * p.OZ;
+    const long long nbox = p.OX * p.OY * p.OZ;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nout) return;
+    if (i >= nbox) return;
     const long long z = i % p.OZ, y = (i / p.OZ) % p.OY, x = i / (p.OZ * p.OY);
-    const size_t aidx = ((size_t)(x + p.lo_x) * p.Y + (y + p.lo_y)) * p.Z + (z + p.lo_z);
-    const size_t plane = (size_t)p.AX * p.Y * p.Z;
-    const float wsum = p.acc_fp32 ? ((const float *)p.wsum)[aidx] : (float)((const f16 *)p.wsum)[aidx];
+    const size_t aelem = (((size_t)(x + p.lo_x) * p.Y + (y + p.lo_y)) * p.Z + (z + p.lo_z)) * p.HP;
+    const size_t oidx0 = ((size_t)(x + p.out_x) * p.out_Y + (y + p.out_y)) * p.out_Z + (z + p.out_z);
+    const size_t oplane = (size_t)p.out_X * p.out_Y * p.out_Z;
+    const float wsum = ACC32 ? ((const float *)p.acc)[aelem + p.heads] : (float)((const f16 *)p.acc)[aelem + p.heads];
     bool bad = false;
-    for (int head = 0; head < p.heads; ++head) {
-        const float a = p.acc_fp32 ? ((const float *)p.acc)[(size_t)head * plane + aidx]
-                                   : (float)((const f16 *)p.acc)[(size_t)head * plane + aidx];
-        const float qf = a / wsum;
-        const size_t oidx = (size_t)head * nout + i;
-        if (p.out_fp32) {
-            float *o = (float *)p.out;
-            const float r = p.acc_fp32 ? qf : (float)(f16)qf;      // reference-rounding mode rounds to half first
-            o[oidx] = p.mode ? o[oidx] + r : r;
-            bad |= isinf(o[oidx]);
+    for (int ch0 = 0; ch0 < p.heads; ch0 += 4) {
+        float a[4];
+        if (ACC32) {
+            const f32x4 t = *(const f32x4 *)((const float *)p.acc + aelem + ch0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = t[j];
         } else {
-            f16 *o = (f16 *)p.out;
-            const f16 r = (f16)qf;
-            bad |= isinf((float)r);
-            o[oidx] = p.mode ? (f16)((float)o[oidx] + (float)r) : r;
+            const f16x4 t = *(const f16x4 *)((const f16 *)p.acc + aelem + ch0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = (float)t[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int head = ch0 + j;
+            if (head >= p.heads) break;
+            const float qf = __fdiv_rn(a[j], wsum);
+            const size_t oidx = (size_t)head * oplane + oidx0;
+            if (p.out_fp32) {
+                float *o = (float *)p.out;
+                const float rr = ACC32 ? qf : (float)(f16)qf;       // reference-rounding mode rounds to half first
+                o[oidx] = p.mode ? o[oidx] + rr : rr;
+                bad |= isinf(o[oidx]);
+            } else {
+                f16 *o = (f16 *)p.out;
+                const f16 rr = (f16)qf;
+                bad |= isinf((float)rr);
+                o[oidx] = p.mode ? (f16)((float)o[oidx] + (float)rr) : rr;
+            }
         }
     }
     if (bad) atomicOr(p.inf_flag, 1);
 }
 
 int launch_finalize(const FinalizeParams &p, hipStream_t st) {
-    const long long nout = p.OX * p.OY * p.OZ;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, p);
+    const long long n = p.OX * p.OY * p.OZ;
+    if (p.acc_fp32) hipLaunchKernelGGL(finalize_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(finalize_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// Label map straight from the accumulators: argmax_h(acc_h / wsum) with the reference's rounding
+// (divide, round to fp16, first maximum wins) without materialising the logits.
+template <bool ACC32>
+__global__ __launch_bounds__(256) void labels_from_acc_kernel(const FinalizeParams p, uint8_t *labels) {
+    const long long nbox = p.OX * p.OY * p.OZ;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nbox) return;
+    const long long z = i % p.OZ, y = (i / p.OZ) % p.OY, x = i / (p.OZ * p.OY);
+    const size_t aelem = (((size_t)(x + p.lo_x) * p.Y + (y + p.lo_y)) * p.Z + (z + p.lo_z)) * p.HP;
+    const size_t oidx0 = ((size_t)(x + p.out_x) * p.out_Y + (y + p.out_y)) * p.out_Z + (z + p.out_z);
+    const float wsum = ACC32 ? ((const float *)p.acc)[aelem + p.heads] : (float)((const f16 *)p.acc)[aelem + p.heads];
+    float best = 0.f;
+    int arg = 0;
+    bool bad = false;
+    for (int h = 0; h < p.heads; ++h) {
+        const float a = ACC32 ? ((const float *)p.acc)[aelem + h] : (float)((const f16 *)p.acc)[aelem + h];
+        const float v = (float)(f16)__fdiv_rn(a, wsum);
+        bad |= isinf(v);
+        if (h == 0 || v > best) { best = v; arg = h; }
+    }
+    labels[oidx0] = (uint8_t)arg;
+    if (bad) atomicOr(p.inf_flag, 1);
+}
+
+int launch_labels_from_acc(const FinalizeParams &p, uint8_t *labels, hipStream_t st) {
+    const long long n = p.OX * p.OY * p.OZ;
+    if (p.acc_fp32) hipLaunchKernelGGL(labels_from_acc_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, labels);
+    else hipLaunchKernelGGL(labels_from_acc_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, labels);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -231,18 +231,18 @@ class nnUNetPredictor(object):
 
     @torch.inference_mode()
     def predict_segmentation_from_preprocessed_data(self, data: torch.Tensor) -> torch.Tensor:
-        """Label map on the device (argmax of the ensemble logits), skipping the full-logit D2H copy the
-        reference pays at :386 before ``convert_logits_to_segmentation`` (label_handling.py:173-180)."""
+        """Label map on the device, skipping the full-logit D2H copy the reference pays at :386 before
+        ``convert_logits_to_segmentation`` (label_handling.py:173-180).  With one fold the argmax is taken
+        straight from the accumulators; the logits are never written."""
         if self.label_manager.has_regions:
             raise NotImplementedError('region-based label conversion is not implemented on the device')
+        if self._spec.num_heads > 256:
+            raise NotImplementedError('uint8 label maps need <= 256 classes')
         self._check_input(data)
         with torch.cuda.device(self.device):
             x = data.to(device=self.device, dtype=torch.float32).contiguous()
-            out = torch.empty((self._spec.num_heads, *x.shape[1:]), dtype=torch.half, device=self.device)
-            self._engine.predict_volume(x.data_ptr(), x.shape, self._opts(), out.data_ptr(), n_folds=self._n_folds)
             labels = torch.empty(x.shape[1:], dtype=torch.uint8, device=self.device)
-            self._engine.argmax_labels(out.data_ptr(), capi.FNN_OUT_F16, self._spec.num_heads, labels.numel(),
-                                       labels.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
+            self._engine.predict_labels(x.data_ptr(), x.shape, self._opts(), labels.data_ptr(), n_folds=self._n_folds)
         return labels
 
     @torch.inference_mode()

@@ -123,22 +123,32 @@ int fnn_predict_volume_ensemble(fnn_engine *e, int n_folds, const float *vol, co
  * Used by parity tests and by callers that bring their own tiling. */
 int fnn_forward_patches(fnn_engine *e, int fold, const float *x, int n, float *logits, void *stream);
 
+/* Label map without materialising the logits: for one fold the argmax is taken
+ * straight from the accumulators (divide, round to fp16, first maximum wins -
+ * exactly what convert_logits_to_segmentation would see); for several folds the
+ * ensemble logits are formed first.  Replaces the reference's full-logit D2H
+ * copy + numpy argmax (:386, label_handling.py:173-180).  labels: uint8 [X,Y,Z]. */
+int fnn_predict_labels(fnn_engine *e, int n_folds, const float *vol, const int64_t shape[4],
+                       const fnn_opts *opts, uint8_t *labels);
+
 /* Multi-GPU building blocks (not in the reference, whose only
  * inference parallelism is case-level -num_parts/-part_id, :918-925).
- * fnn_accumulate_patches runs patches [patch_begin, patch_end) of the x-major
- * patch list and ADDS sum(w*logit) / sum(w) into caller-owned fp32 DEVICE
- * buffers that cover the padded-volume x-range [x0, x1):
- *   acc [heads][x1-x0][Y][Zp], wsum [x1-x0][Y][Zp]  (caller zeroes them), where
- *   Y, Z are the padded volume sizes and Zp = Z rounded up to a multiple of 8
- *   (rows start 16-byte aligned for the vectorised read-modify-write).
- * fnn_normalize_slab divides, un-pads and writes rows [x0,x1) of the output
- * (out points at the full [heads][X][Y][Z] tensor of opts->out_dtype). */
+ * Accumulators are channels-last fp32 DEVICE buffers that cover a box of the
+ * PADDED volume:  acc[bx][by][bz][HP],  HP = fnn_accumulator_channels(e)
+ * (= num_heads + 1 rounded up to 8); channel h < num_heads holds sum(w * logit_h),
+ * channel num_heads holds sum(w).  The caller zeroes them, exchanges / adds the
+ * overlap regions between ranks, then normalises the part it owns.
+ * fnn_accumulate_patches runs the listed patches (indices into the x-major patch
+ * list of fnn_plan_volume; each must lie inside the box) and ADDS into acc.
+ * fnn_normalize_box divides, un-pads and writes the un-padded box
+ * [out_lo, out_hi) into `out`, the full [heads][X][Y][Z] tensor of opts->out_dtype. */
+int64_t fnn_accumulator_channels(const fnn_engine *e);
 int fnn_accumulate_patches(fnn_engine *e, int fold, const float *vol, const int64_t shape[4],
-                           const fnn_opts *opts, int64_t patch_begin, int64_t patch_end,
-                           int64_t x0, int64_t x1, float *acc, float *wsum);
-int fnn_normalize_slab(fnn_engine *e, const float *acc, const float *wsum, const int64_t shape[4],
-                       const fnn_opts *opts, int64_t x0, int64_t x1, int64_t out_x0, int64_t out_x1,
-                       void *out_logits);
+                           const fnn_opts *opts, const int64_t *patch_ids, int64_t n_ids,
+                           const int64_t box_lo[3], const int64_t box_hi[3], float *acc);
+int fnn_normalize_box(fnn_engine *e, const float *acc, const int64_t shape[4], const fnn_opts *opts,
+                      const int64_t box_lo[3], const int64_t box_hi[3],
+                      const int64_t out_lo[3], const int64_t out_hi[3], void *out_logits);
 
 /* LabelManager.convert_logits_to_segmentation for plain labels
  * (label_handling.py:173-180): argmax over heads, first maximum wins.
