@@ -188,17 +188,20 @@ def main():
     ap.add_argument('--accum', default='fp16', choices=['fp16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--force-sharded', action='store_true', help='run the multi-GPU code path even with one rank')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    distributed = world > 1
+    distributed = world > 1 or args.force_sharded
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29544')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X; the engine has no CPU path')
     device = torch.device('cuda', local_rank)

@@ -242,14 +242,19 @@ __global__ __launch_bounds__(256) void seg_head_kernel(const HeadParams p) {
 // ----------------------------------------------------------------------------
 // fused seg head + Gaussian weighting + accumulate (no mirroring): the K6 + K7 kernel
 // ----------------------------------------------------------------------------
-// One wave = 64 consecutive patch voxels (4 MFMA column blocks).  For every block of 16 heads the
-// MFMA leaves 4 consecutive heads of one voxel in each lane; they are weighted and added to the
-// channels-last accumulator directly from registers (8-byte fp16 / 16-byte fp32 read-modify-write).
+// One wave = 64 consecutive patch voxels, processed as two rounds of 32.  Per round the MFMA result
+// (4 consecutive heads of one voxel per lane) is transposed through LDS so that 8 lanes own the 8
+// channel groups of ONE voxel: every wave instruction of the read-modify-write then covers 8 whole
+// accumulator lines (rocprof showed 1.75x write amplification when lanes wrote 32-byte pieces of a
+// line straight from the MFMA registers).  The 4 accumulator loads of a round are issued before its
+// MFMAs, so a round costs one global round trip.
+#define HEAD_LD 68                        // LDS row stride in floats (64 channels + pad, 16-B aligned rows)
 template <bool ACC32>
 __global__ __launch_bounds__(256) void seg_head_acc_kernel(const HeadParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float2 *sSS = (float2 *)smem;
+    float *sT = (float *)(smem + ((p.src.C * 8 + 255) & ~255)) + wave * (32 * HEAD_LD);      // [32 voxels][64 ch]
     const int P = p.PD * p.PH * p.PW;
     load_scale_shift(p.src, p.b, sSS, tid, 256);
     __syncthreads();
@@ -257,66 +262,112 @@ __global__ __launch_bounds__(256) void seg_head_acc_kernel(const HeadParams p) {
     const int v0 = (blockIdx.x * 4 + wave) * 64;
     if (v0 >= P) return;
     const int r = lane & 15, q = lane >> 4;
-
-    size_t aelem[4];                       // accumulator element index of this lane's voxel, per column block
-    float g[4];
-    bool ok[4];
-#pragma unroll
-    for (int vb = 0; vb < 4; ++vb) {
-        const int v = v0 + vb * 16 + r;
-        ok[vb] = v < P;
-        const int vv = ok[vb] ? v : 0;
-        const int w = vv % p.PW, h = (vv / p.PW) % p.PH, d = vv / (p.PW * p.PH);
-        g[vb] = p.gauss ? (float)p.gauss[vv] : 1.f;
-        aelem[vb] = (((size_t)(p.ox + d) * p.Y + (p.oy + h)) * p.Z + (p.oz + w)) * p.HP;
-    }
+    const int grp = lane & 7, vsub = lane >> 3;              // read-modify-write role: channel group, voxel in round
+    const int hb_w = p.heads >> 4, q_w = (p.heads >> 2) & 3, j_w = p.heads & 3;     // weight-sum channel position
+    const int cgroups = p.HP >> 3;                           // 8-channel groups per 64-channel block
     const bool one_kstep = p.ksteps == 1;
-    f16x8 xf0[4];
-    if (one_kstep) {
+
+    for (int cb0 = 0; cb0 < p.HP; cb0 += 64) {               // 64 accumulator channels at a time
+        const int hb_first = cb0 >> 4;
+#pragma unroll 1
+        for (int rd = 0; rd < 2; ++rd) {
+            // this lane's 4 voxels of the round and their accumulator lines
+            const int vb_base = rd * 2;
+            size_t aelem[4];
+            float g[4];
+            bool ok[4];
+            f16x8 a16[4];
+            f32x4 a32[4][2];
+            const bool grp_ok = cb0 + grp * 8 < p.HP;
 #pragma unroll
-        for (int vb = 0; vb < 4; ++vb) xf0[vb] = load_act_frag(p.src, (size_t)p.b * P + v0 + vb * 16 + r, ok[vb], q * 8, sSS);
-    }
-    const int hb_w = p.heads >> 4, q_w = (p.heads >> 2) & 3, j_w = p.heads & 3;     // where the weight-sum channel lives
-    const int hb_total = (p.HP + 15) >> 4;
-    for (int hb = 0; hb < hb_total; ++hb) {
-        const int ch0 = hb * 16 + q * 4;                    // first of this lane's 4 channels
-        if (ch0 >= p.HP) continue;
-        f32x4 acc[4];
-#pragma unroll
-        for (int vb = 0; vb < 4; ++vb) acc[vb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (hb < p.hblocks) {
-            for (int ks = 0; ks < p.ksteps; ++ks) {
-                const f16x8 wf = *(const f16x8 *)(p.wpk + (((size_t)hb * p.ksteps + ks) * 64 + lane) * 8);
-#pragma unroll
-                for (int vb = 0; vb < 4; ++vb) {
-                    const f16x8 xf = one_kstep ? xf0[vb]
-                                               : load_act_frag(p.src, (size_t)p.b * P + v0 + vb * 16 + r, ok[vb], ks * 32 + q * 8, sSS);
-                    acc[vb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf, acc[vb], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                const int v = v0 + rd * 32 + 8 * i + vsub;
+                ok[i] = v < P && grp_ok;
+                const int vv = v < P ? v : 0;
+                const int w = vv % p.PW, h = (vv / p.PW) % p.PH, d = vv / (p.PW * p.PH);
+                aelem[i] = (((size_t)(p.ox + d) * p.Y + (p.oy + h)) * p.Z + (p.oz + w)) * p.HP + cb0 + grp * 8;
+                g[i] = p.gauss ? (float)p.gauss[vv] : 1.f;
+                if (ok[i]) {
+                    if (ACC32) { a32[i][0] = *(const f32x4 *)((const float *)p.acc + aelem[i]); a32[i][1] = *(const f32x4 *)((const float *)p.acc + aelem[i] + 4); }
+                    else a16[i] = *(const f16x8 *)((const f16 *)p.acc + aelem[i]);
                 }
             }
-        }
-        float bias[4];
-        unsigned mask = 0;
+            // MFMA: [heads of this 64-channel block] x [32 voxels]
+            f32x4 acc[4][2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ch = ch0 + j;
-            bias[j] = ch < p.heads ? p.bias[ch] : 0.f;
-            if (ch <= p.heads) mask |= 1u << j;              // logits and the weight-sum channel; padding untouched
-        }
-        const bool has_w = hb == hb_w && q == q_w;
+            for (int hb = 0; hb < 4; ++hb)
 #pragma unroll
-        for (int vb = 0; vb < 4; ++vb) {
-            if (!ok[vb]) continue;
-            float c[4];
+                for (int vb = 0; vb < 2; ++vb) acc[hb][vb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < p.ksteps; ++ks) {
+                f16x8 xf[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) c[j] = __fmul_rn(acc[vb][j] + bias[j], g[vb]);
-            if (has_w) {
+                for (int vb = 0; vb < 2; ++vb) {
+                    const int v = v0 + (vb_base + vb) * 16 + r;
+                    xf[vb] = load_act_frag(p.src, (size_t)p.b * P + v, v < P, ks * 32 + q * 8, sSS);
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) c[j] = j == j_w ? g[vb] : c[j];
+                for (int hb = 0; hb < 4; ++hb) {
+                    if (hb_first + hb < p.hblocks) {
+                        const f16x8 wf = *(const f16x8 *)(p.wpk + (((size_t)(hb_first + hb) * p.ksteps + ks) * 64 + lane) * 8);
+#pragma unroll
+                        for (int vb = 0; vb < 2; ++vb)
+                            acc[hb][vb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[vb], acc[hb][vb], 0, 0, 0);
+                    }
+                }
             }
-            acc_add4<ACC32>(p.acc, aelem[vb] + ch0, c, mask);
+            (void)one_kstep;
+            // logits (+ bias) -> LDS, [voxel][channel]; the weight-sum channel gets 1 so that it accumulates g
+#pragma unroll
+            for (int hb = 0; hb < 4; ++hb) {
+                const int ch0 = (hb_first + hb) * 16 + q * 4;
+                f32x4 bv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = ch0 + j < p.heads ? p.bias[ch0 + j] : 0.f;
+                const bool has_w = hb_first + hb == hb_w && q == q_w;
+#pragma unroll
+                for (int vb = 0; vb < 2; ++vb) {
+                    f32x4 t = acc[hb][vb] + bv;
+                    if (has_w) t[j_w] = 1.f;
+                    *(f32x4 *)(sT + (vb * 16 + r) * HEAD_LD + hb * 16 + q * 4) = t;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            // read-modify-write: 8 lanes x 16 B (fp16) cover one voxel's 64 channels
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!ok[i]) continue;
+                const f32x4 t0 = *(const f32x4 *)(sT + (8 * i + vsub) * HEAD_LD + grp * 8);
+                const f32x4 t1 = *(const f32x4 *)(sT + (8 * i + vsub) * HEAD_LD + grp * 8 + 4);
+                float c[8];
+                unsigned mask = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = cb0 + grp * 8 + e;
+                    const float t = e < 4 ? t0[e] : t1[e - 4];
+                    c[e] = ch == p.heads ? g[i] : __fmul_rn(t, g[i]);
+                    if (ch <= p.heads) mask |= 1u << e;           // padding channels keep their bits
+                }
+                if (ACC32) {
+                    f32x4 b0 = a32[i][0], b1 = a32[i][1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        b0[e] = (mask >> e) & 1 ? __fadd_rn(b0[e], c[e]) : b0[e];
+                        b1[e] = (mask >> (4 + e)) & 1 ? __fadd_rn(b1[e], c[4 + e]) : b1[e];
+                    }
+                    *(f32x4 *)((float *)p.acc + aelem[i]) = b0;
+                    *(f32x4 *)((float *)p.acc + aelem[i] + 4) = b1;
+                } else {
+                    f16x8 b = a16[i];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) b[e] = (mask >> e) & 1 ? (f16)__fadd_rn((float)b[e], c[e]) : b[e];
+                    *(f16x8 *)((f16 *)p.acc + aelem[i]) = b;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
+    (void)cgroups;
 }
 
 int launch_head(const HeadParams &p, hipStream_t st) {
@@ -328,7 +379,7 @@ int launch_head(const HeadParams &p, hipStream_t st) {
     }
     dim3 grid((P + 255) / 256);
     if (p.mode == 0) {
-        const size_t lds = (size_t)((p.src.C * 8 + 255) & ~255);
+        const size_t lds = (size_t)((p.src.C * 8 + 255) & ~255) + (size_t)4 * 32 * HEAD_LD * 4;
         if (p.acc_fp32) hipLaunchKernelGGL(seg_head_acc_kernel<true>, grid, dim3(256), lds, st, p);
         else hipLaunchKernelGGL(seg_head_acc_kernel<false>, grid, dim3(256), lds, st, p);
         return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -1,0 +1,201 @@
+"""Patches of ONE volume sharded over the GPUs of a node.
+
+Not in the reference: its only inference parallelism is case-level
+(``-num_parts/-part_id``, predict_from_raw_data.py:918-925).  Here the patch grid
+of a volume (x-major list of ``compute_steps_for_sliding_window`` positions) is
+cut into a 3-D grid of rank blocks.  Every rank
+
+1. runs its own patches into an fp32 accumulator that covers only the bounding
+   box of those patches (channels-last ``[bx, by, bz, HP]``, channel ``heads`` is
+   the weight sum - so logits and weights travel together);
+2. exchanges ONLY the overlap regions with the ranks whose boxes intersect its
+   own: each voxel of the padded volume has exactly one owner, and every other
+   rank that touched it sends its partial sums to the owner (point-to-point over
+   RCCL/xGMI, ``batch_isend_irecv``).  A full-buffer all-reduce would move
+   ~57 GB per GPU for 61 classes on 512^3; the halos are a few GB;
+3. normalises and writes the box it owns.
+
+The geometry (`Decomposition`) is pure integer logic and is unit-tested on CPU
+with the gloo backend against the single-process result.
+"""
+from __future__ import annotations
+
+import itertools
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+Box = Tuple[Tuple[int, int, int], Tuple[int, int, int]]          # (lo, hi) in padded-volume coordinates
+
+
+def _split(n: int, parts: int) -> List[Tuple[int, int]]:
+    """`n` items into `parts` contiguous, balanced ranges."""
+    return [(n * i // parts, n * (i + 1) // parts) for i in range(parts)]
+
+
+def rank_grid(world: int, counts: Sequence[int]) -> Tuple[int, int, int]:
+    """Factorisation (gx, gy, gz) of at most `world` ranks over the patch grid `counts`: fewest patches on
+    the busiest rank first, then the smallest total halo surface."""
+    best, best_key = (1, 1, 1), None
+    for gx in range(1, world + 1):
+        for gy in range(1, world // gx + 1):
+            gz = world // (gx * gy)
+            g = (gx, gy, gz)
+            if gx * gy * gz > world or any(gi > c for gi, c in zip(g, counts)):
+                continue
+            busiest = int(np.prod([-(-c // gi) for c, gi in zip(counts, g)]))
+            cuts = sum(gi - 1 for gi in g)
+            key = (busiest, -(gx * gy * gz), cuts)
+            if best_key is None or key < best_key:
+                best, best_key = g, key
+    return best
+
+
+def _intersect(a: Box, b: Box) -> Optional[Box]:
+    lo = tuple(max(a[0][d], b[0][d]) for d in range(3))
+    hi = tuple(min(a[1][d], b[1][d]) for d in range(3))
+    return (lo, hi) if all(h > l for l, h in zip(lo, hi)) else None
+
+
+@dataclass
+class Decomposition:
+    world: int
+    grid: Tuple[int, int, int]
+    patch_ids: List[List[int]]              # per rank
+    boxes: List[Optional[Box]]              # accumulator box per rank (None = idle rank)
+    owned: List[Optional[Box]]              # disjoint boxes that tile the padded volume
+
+    @staticmethod
+    def build(patch: Sequence[int], padded: Sequence[int], steps: Sequence[Sequence[int]], world: int) -> 'Decomposition':
+        counts = [len(s) for s in steps]
+        grid = rank_grid(world, counts)
+        ranges = [_split(counts[d], grid[d]) for d in range(3)]
+        # per axis: accumulator interval and ownership cut points of every block
+        acc_iv, own_iv = [], []
+        for d in range(3):
+            iv = [(steps[d][b], steps[d][e - 1] + patch[d]) for b, e in ranges[d]]
+            cuts = [0]
+            for a in range(len(iv) - 1):
+                lo_next, hi_cur = iv[a + 1][0], iv[a][1]
+                cuts.append((lo_next + hi_cur) // 2 if hi_cur > lo_next else hi_cur)
+            cuts.append(padded[d])
+            acc_iv.append(iv)
+            own_iv.append([(cuts[a], cuts[a + 1]) for a in range(len(iv))])
+        patch_ids, boxes, owned = [], [], []
+        ny, nz = counts[1], counts[2]
+        for r in range(world):
+            if r >= grid[0] * grid[1] * grid[2]:
+                patch_ids.append([]); boxes.append(None); owned.append(None)
+                continue
+            rz, ry, rx = r % grid[2], (r // grid[2]) % grid[1], r // (grid[2] * grid[1])
+            blk = (rx, ry, rz)
+            ids = [(ix * ny + iy) * nz + iz
+                   for ix in range(*ranges[0][rx]) for iy in range(*ranges[1][ry]) for iz in range(*ranges[2][rz])]
+            patch_ids.append(ids)
+            boxes.append((tuple(acc_iv[d][blk[d]][0] for d in range(3)), tuple(acc_iv[d][blk[d]][1] for d in range(3))))
+            owned.append((tuple(own_iv[d][blk[d]][0] for d in range(3)), tuple(own_iv[d][blk[d]][1] for d in range(3))))
+        return Decomposition(world, grid, patch_ids, boxes, owned)
+
+    def transfers(self, rank: int):
+        """-> (sends, recvs): lists of (peer, region) with region in padded coordinates.
+        A rank sends what it accumulated inside another rank's owned box."""
+        sends, recvs = [], []
+        if self.boxes[rank] is None:
+            return sends, recvs
+        for peer in range(self.world):
+            if peer == rank or self.boxes[peer] is None:
+                continue
+            out = _intersect(self.boxes[rank], self.owned[peer])
+            if out is not None:
+                sends.append((peer, out))
+            inc = _intersect(self.boxes[peer], self.owned[rank])
+            if inc is not None:
+                recvs.append((peer, inc))
+        return sends, recvs
+
+    def halo_voxels(self, rank: int) -> int:
+        return sum(int(np.prod([h - l for l, h in zip(*reg)])) for _, reg in self.transfers(rank)[0])
+
+
+def _view(acc: torch.Tensor, box: Box, region: Box) -> torch.Tensor:
+    sl = tuple(slice(region[0][d] - box[0][d], region[1][d] - box[0][d]) for d in range(3))
+    return acc[sl]
+
+
+def exchange_halos(acc: torch.Tensor, dec: Decomposition, rank: int, group=None) -> None:
+    """Adds the other ranks' contributions to the part of `acc` this rank owns.  `acc` is
+    [bx, by, bz, HP] over ``dec.boxes[rank]``."""
+    sends, recvs = dec.transfers(rank)
+    if not sends and not recvs:
+        return
+    box = dec.boxes[rank]
+    ops, landing = [], []
+    for peer, region in sends:
+        buf = _view(acc, box, region).contiguous()
+        ops.append(dist.P2POp(dist.isend, buf, dist.get_global_rank(group, peer) if group is not None else peer, group))
+        landing.append(None)
+    for peer, region in recvs:
+        shape = tuple(region[1][d] - region[0][d] for d in range(3)) + (acc.shape[3],)
+        buf = torch.empty(shape, dtype=acc.dtype, device=acc.device)
+        ops.append(dist.P2POp(dist.irecv, buf, dist.get_global_rank(group, peer) if group is not None else peer, group))
+        landing.append((region, buf))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    # fixed (peer-rank) order -> the fp32 sums are reproducible run to run
+    for item in landing:
+        if item is not None:
+            region, buf = item
+            _view(acc, box, region).add_(buf)
+
+
+def unpadded(box: Box, pad_lo: Sequence[int], shape_sp: Sequence[int]) -> Optional[Box]:
+    lo = tuple(max(0, box[0][d] - pad_lo[d]) for d in range(3))
+    hi = tuple(min(shape_sp[d], box[1][d] - pad_lo[d]) for d in range(3))
+    return (lo, hi) if all(h > l for l, h in zip(lo, hi)) else None
+
+
+class ShardedPredictor:
+    """``predict_sliding_window_return_logits`` of one volume over all ranks of `group`.
+
+    Every rank passes the same (replicated) preprocessed volume.  Returns ``(logits, owned_box)``: a full-size
+    fp16 tensor in which this rank has written the box it owns (un-padded coordinates, ``None`` if idle).
+    """
+
+    def __init__(self, predictor, group=None):
+        self.p = predictor
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    @torch.inference_mode()
+    def predict_sliding_window_return_logits(self, input_image: torch.Tensor, out: Optional[torch.Tensor] = None):
+        from . import capi
+        p = self.p
+        p._check_input(input_image)
+        eng = p._engine
+        patch = p._spec.patch
+        with torch.cuda.device(p.device):
+            x = input_image.to(device=p.device, dtype=torch.float32).contiguous()
+            padded, pad_lo, origins = capi.plan_volume(patch, x.shape[1:], p.tile_step_size)
+            steps = [sorted(set(int(v) for v in origins[:, d])) for d in range(3)]
+            dec = Decomposition.build(patch, padded, steps, self.world)
+            opts = p._opts()
+            opts.accum = capi.FNN_ACC_FP32
+            if out is None:
+                out = torch.empty((p._spec.num_heads, *x.shape[1:]), dtype=torch.half, device=p.device)
+            box = dec.boxes[self.rank]
+            if box is None:
+                exchange_halos(torch.empty(0), dec, self.rank, self.group)
+                return out, None
+            dims = tuple(box[1][d] - box[0][d] for d in range(3))
+            acc = torch.zeros((*dims, eng.accumulator_channels), dtype=torch.float32, device=p.device)
+            eng.accumulate_patches(x.data_ptr(), x.shape, opts, dec.patch_ids[self.rank], box[0], box[1], acc.data_ptr(),
+                                   fold=p._active_fold)
+            exchange_halos(acc, dec, self.rank, self.group)
+            own = unpadded(dec.owned[self.rank], pad_lo, x.shape[1:])
+            if own is not None:
+                eng.normalize_box(acc.data_ptr(), x.shape, opts, box[0], box[1], own[0], own[1], out.data_ptr())
+        return out, own

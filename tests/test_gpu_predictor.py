@@ -256,3 +256,63 @@ def test_idempotence_and_linearity_of_the_blend_at_full_patch_size():
     assert torch.equal(a, b)
     want = bias.half().float()[:, None, None, None].expand_as(a)
     assert (a.float().cpu() - want).abs().max() <= 2e-3
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_sharded_boxes_through_c_abi_match_single_gpu(world):
+    """The multi-GPU building blocks (fnn_accumulate_patches / fnn_normalize_box) driven for `world` virtual
+    ranks on one GPU, with the halo exchange done locally: must reproduce the single-engine fp32 result."""
+    from fast_nnunet_amd import capi
+    from fast_nnunet_amd.dist import Decomposition, _view, unpadded
+    spec, patch = SPECS['toy3']
+    sd = synthetic_state_dict(spec, 21)
+    p = _predictor(spec, patch, [sd], accumulate_in='fp32')
+    image = torch.randn(1, 37, 30, 70, generator=torch.Generator().manual_seed(6))
+    want = p.predict_sliding_window_return_logits(image)
+    x = image.cuda().float().contiguous()
+    padded, pad_lo, origins = capi.plan_volume(patch, x.shape[1:], 0.5)
+    steps = [sorted(set(int(v) for v in origins[:, d])) for d in range(3)]
+    dec = Decomposition.build(patch, padded, steps, world)
+    opts = p._opts()
+    opts.accum = capi.FNN_ACC_FP32
+    hp = p._engine.accumulator_channels
+    accs = []
+    for r in range(world):
+        box = dec.boxes[r]
+        dims = tuple(box[1][d] - box[0][d] for d in range(3))
+        acc = torch.zeros((*dims, hp), dtype=torch.float32, device='cuda')
+        p._engine.accumulate_patches(x.data_ptr(), x.shape, opts, dec.patch_ids[r], box[0], box[1], acc.data_ptr())
+        accs.append(acc)
+    torch.cuda.synchronize()
+    for r in range(world):                       # local stand-in for exchange_halos
+        for peer, region in dec.transfers(r)[1]:
+            _view(accs[r], dec.boxes[r], region).add_(_view(accs[peer], dec.boxes[peer], region))
+    got = torch.zeros_like(want)
+    for r in range(world):
+        own = unpadded(dec.owned[r], pad_lo, x.shape[1:])
+        p._engine.normalize_box(accs[r].data_ptr(), x.shape, opts, dec.boxes[r][0], dec.boxes[r][1], own[0], own[1],
+                                got.data_ptr())
+    torch.cuda.synchronize()
+    # fp32 partial sums are added in a different order than on one GPU: equal up to the final fp16 store
+    diff = (got.float() - want.float()).abs().max()
+    assert diff <= 2e-3 * float(want.float().abs().max()), diff
+    assert (got.argmax(0) != want.argmax(0)).float().mean() < 1e-4
+
+
+def test_sharded_predictor_single_rank_process_group():
+    """ShardedPredictor end to end with a one-rank process group on the GPU."""
+    import torch.distributed as dist
+    from fast_nnunet_amd.dist import ShardedPredictor
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        spec, patch = SPECS['toy3']
+        p = _predictor(spec, patch, [synthetic_state_dict(spec, 22)], accumulate_in='fp32')
+        image = torch.randn(1, 20, 40, 33, generator=torch.Generator().manual_seed(7))
+        want = p.predict_sliding_window_return_logits(image)
+        got, own = ShardedPredictor(p).predict_sliding_window_return_logits(image)
+        assert own == ((0, 0, 0), (20, 40, 33))
+        assert torch.equal(got, want)
+    finally:
+        dist.destroy_process_group()
