@@ -184,7 +184,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='bone_turbo_r2', choices=list(WORKLOADS))
     ap.add_argument('--volume', type=int, default=512)
-    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--accum', default='fp16', choices=['fp16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
