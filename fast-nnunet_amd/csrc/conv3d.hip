@@ -250,6 +250,89 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
     }
 }
 
+static int lds_pitch(int IW) { return (IW & 7) ? ((IW + 3) & ~7) + 4 : IW; }
+
+// ----------------------------------------------------------------------------
+// shared pieces of the stride-1 MFMA conv kernels
+// ----------------------------------------------------------------------------
+// Sum over the 16 lanes of a DPP row = the 16 voxels of one MFMA column block (4 VALU ops, no LDS).
+static __device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, true));  // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, true));  // row_ror:1
+    return v;
+}
+
+// small-integer division by a workgroup-uniform divisor (0 <= v < 2^16): float reciprocal + correction
+static __device__ __forceinline__ int small_div(int v, int d, float rcp) {
+    int q = (int)((float)v * rcp);
+    q -= (q * d > v);
+    q += ((q + 1) * d <= v);
+    return q;
+}
+
+// Epilogue of one output tile: bias, round to fp16, channels-last store (4 consecutive channels per
+// lane), and this lane's partial sums of the rounded values (fp32 within the tile).
+template <int NB, int MB>
+static __device__ __forceinline__ void tile_epilogue(const ConvParams &p, const f32x4 (&acc)[MB][NB], const float4 (&bv)[NB],
+                                                     int n, int od0, int oh0, int ow0, int cb0, int wave, int lane,
+                                                     float (&t1)[NB][4], float (&t2)[NB][4]) {
+    const int q = lane >> 4, r = lane & 15;
+    f16 *outn = p.out + (size_t)n * p.Do * p.Ho * p.Wo * p.Cout + cb0 * 16 + q * 4;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int od = od0 + wave + 4 * (mb >> 2);
+        const int oh = oh0 + 2 * (mb & 3) + (r >> 3), ow = ow0 + (r & 7);
+        const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
+        const unsigned voff = (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            f16x4 o;
+            o[0] = (f16)(acc[mb][nb][0] + bv[nb].x);
+            o[1] = (f16)(acc[mb][nb][1] + bv[nb].y);
+            o[2] = (f16)(acc[mb][nb][2] + bv[nb].z);
+            o[3] = (f16)(acc[mb][nb][3] + bv[nb].w);
+            if (ok) {
+                *(f16x4 *)(outn + voff + nb * 16) = o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = (float)o[j];
+                    t1[nb][j] += v;
+                    t2[nb][j] = fmaf(v, v, t2[nb][j]);
+                }
+            }
+        }
+    }
+}
+
+// Workgroup reduction of the statistics and the double atomics into replica (blockIdx.x & 7).
+// `sRed` = 4 * NB * 32 floats of LDS that nobody else uses between the two barriers.
+template <int NB>
+static __device__ __forceinline__ void stats_to_global(const ConvParams &p, float (&t1)[NB][4], float (&t2)[NB][4], float *sRed,
+                                                       int n, int cb0, int wave, int lane, int tid) {
+    const int q = lane >> 4, r = lane & 15;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = row16_sum(t1[nb][j]), b = row16_sum(t2[nb][j]);
+            if (r == 0) {
+                const int c = nb * 16 + q * 4 + j;
+                sRed[(wave * NB * 16 + c) * 2] = a;
+                sRed[(wave * NB * 16 + c) * 2 + 1] = b;
+            }
+        }
+    __syncthreads();
+    if (tid < NB * 16 * 2) {
+        const int c = tid >> 1, which = tid & 1;
+        double v = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += (double)sRed[(w * NB * 16 + c) * 2 + which];
+        unsafeAtomicAdd(p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout + cb0 * 16 + c) * 2 + which, v);
+    }
+}
+
 // ----------------------------------------------------------------------------
 // pipelined MFMA conv (stride 1): the hot kernel
 // ----------------------------------------------------------------------------
@@ -290,28 +373,27 @@ __global__ __launch_bounds__(256) void conv3d_pipe_kernel(const ConvParams p) {
     const int IVOX = ID * IH * IW;
     const int T = p.kd * p.kh * p.kw;
     const int cin_total = p.chunks * 16;
-    const int abytes = (IVOX * 32 + 1023) & ~1023;
+    // LDS image of the halo tile: row pitch PWp voxels, and the two 16-byte channel halves of a voxel are
+    // swapped on odd rows (swz) - with PWp = 4 (mod 8) every ds_read_b128 of an MFMA operand is then
+    // bank-conflict free (the dense 10-voxel pitch was 2-way conflicted on every read)
+    const int swz = (IW & 7) != 0;
+    const int PWp = swz ? ((IW + 3) & ~7) + 4 : IW;
+    const int abytes = (ID * IH * PWp * 32 + 1023) & ~1023;
 
     char *sA0 = smem;
-    int *sOff = (int *)(smem + 2 * abytes);
-    float2 *sSS = (float2 *)(sOff + ((IVOX + 3) & ~3));
+    float2 *sSS = (float2 *)(smem + 2 * abytes);
     int *sTap = (int *)(sSS + cin_total);
 
     {
-        const int id0 = od0 - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
-        for (int v = tid; v < IVOX; v += 256) {
-            const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
-            const int gd = id0 + zd, gh = ih0 + zh, gw = iw0 + zw;
-            const bool ok = gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 && gw < p.Wi;
-            sOff[v] = ok ? ((n * p.Di + gd) * p.Hi + gh) * p.Wi + gw : -1;
-        }
         if (tid < 2 * p.ksteps) {
-            int off = 0;
+            int off = 0, par = 0;
             if (tid < T) {
                 const int a = tid / (p.kh * p.kw), b = (tid / p.kw) % p.kh, c = tid % p.kw;
-                off = ((a * IH + b) * IW + c) * 32;
+                off = ((a * IH + b) * PWp + c) * 32;
+                par = swz & b & 1;
             }
-            sTap[tid] = off;
+            sTap[tid * 2] = off + 16 * par;                  // column for lanes with kgp = 0
+            sTap[tid * 2 + 1] = off + 16 * (1 - par);        // kgp = 1
         }
         for (int c = tid; c < cin_total; c += 256) {
             const int s = (c < p.src[0].C) ? 0 : 1;
@@ -325,14 +407,18 @@ __global__ __launch_bounds__(256) void conv3d_pipe_kernel(const ConvParams p) {
     for (int mb = 0; mb < MB; ++mb) {
         const int r = lane & 15;
         const int od_l = wave + 4 * (mb >> 2), oh_l = 2 * (mb & 3) + (r >> 3), ow_l = r & 7;
-        base[mb] = ((od_l * IH + oh_l) * IW + ow_l) * 32 + ((lane >> 4) & 1) * 16;
+        base[mb] = ((od_l * IH + oh_l) * PWp + ow_l) * 32;
     }
+    const int kgp = ((lane >> 4) & 1) ^ (swz & ((lane & 15) >> 3));     // channel half after the row swizzle
 
     f32x4 acc[MB][NB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 bv[NB];                                           // bias of this lane's 4 channels per cout block
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const float4 *)(p.bias + (cb0 + nb) * 16 + (lane >> 4) * 4);
 
     // weight stream: fragment of global k-step ts (= chunk * ksteps + ks) of cout block nb
     const int TS = p.chunks * p.ksteps;
@@ -349,11 +435,20 @@ __global__ __launch_bounds__(256) void conv3d_pipe_kernel(const ConvParams p) {
     __syncthreads();
 
     const int cg = tid & 1;
-    int offv[PF];                                           // halo voxel index of this thread's elements
+    int offv[PF];                                           // global voxel index of this thread's halo elements
+    int ldso[PF];                                           // and where they go in the LDS image
+    {
+        const int id0 = od0 - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        const int idx = tid + u * 256;
-        offv[u] = idx < IVOX * 2 ? sOff[idx >> 1] : -2;
+        for (int u = 0; u < PF; ++u) {
+            const int idx = tid + u * 256;
+            const int v = idx >> 1;
+            const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
+            const int gd = id0 + zd, gh = ih0 + zh, gw = iw0 + zw;
+            const bool ok = gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 && gw < p.Wi;
+            offv[u] = idx < IVOX * 2 ? (ok ? ((n * p.Di + gd) * p.Hi + gh) * p.Wi + gw : -1) : -2;
+            ldso[u] = ((zd * IH + zh) * PWp + zw) * 32 + ((cg ^ (swz & zh & 1)) * 16);
+        }
     }
     f16x8 xr[PF];
 
@@ -389,7 +484,7 @@ __global__ __launch_bounds__(256) void conv3d_pipe_kernel(const ConvParams p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
             }
-            *(f16x8 *)(dst + ((tid + u * 256) >> 1) * 32 + cg * 16) = o;
+            *(f16x8 *)(dst + ldso[u]) = o;
         }
     };
 
@@ -406,7 +501,7 @@ __global__ __launch_bounds__(256) void conv3d_pipe_kernel(const ConvParams p) {
             const int tn = ts + 2 < TS ? ts + 2 : TS - 1;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) w2[nb] = *(const f16x8 *)(wbase[nb] + (size_t)tn * 512);
-            const int toff = sTap[2 * ks + (lane >> 5)];
+            const int toff = sTap[(2 * ks + (lane >> 5)) * 2 + kgp];
             f16x8 xf[MB];
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) xf[mb] = *(const f16x8 *)(sA + base[mb] + toff);
@@ -423,77 +518,253 @@ __global__ __launch_bounds__(256) void conv3d_pipe_kernel(const ConvParams p) {
     }
 
     // ---- epilogue: bias, fp16 store, statistics
-    const int q = lane >> 4, r = lane & 15;
-    float s1[NB][4], s2[NB][4];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { s1[nb][j] = 0.f; s2[nb][j] = 0.f; }
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        const int od = od0 + wave + 4 * (mb >> 2);
-        const int oh = oh0 + 2 * (mb & 3) + (r >> 3), ow = ow0 + (r & 7);
-        const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
-        const size_t vox = ((size_t)(n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int co = (cb0 + nb) * 16 + q * 4;
-            const float4 bv = *(const float4 *)(p.bias + co);
-            f16x4 o;
-            o[0] = (f16)(acc[mb][nb][0] + bv.x);
-            o[1] = (f16)(acc[mb][nb][1] + bv.y);
-            o[2] = (f16)(acc[mb][nb][2] + bv.z);
-            o[3] = (f16)(acc[mb][nb][3] + bv.w);
-            if (ok) {
-                *(f16x4 *)(p.out + vox * p.Cout + co) = o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = (float)o[j];
-                    s1[nb][j] += v; s2[nb][j] += v * v;
-                }
-            }
-        }
-    }
-    if (p.stats_out) {
+    {
+        float t1[NB][4], t2[NB][4];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) {
-                    s1[nb][j] += __shfl_xor(s1[nb][j], m, 64);
-                    s2[nb][j] += __shfl_xor(s2[nb][j], m, 64);
-                }
+            for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
+        tile_epilogue<NB, MB>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
+        if (p.stats_out) stats_to_global<NB>(p, t1, t2, (float *)smem, n, cb0, wave, lane, tid);
+    }
+}
+
+
+// ----------------------------------------------------------------------------
+// pipelined MFMA conv, weights through LDS per chunk (stride 1)
+// ----------------------------------------------------------------------------
+// Variant of conv3d_pipe_kernel without any global load inside the k-loop: vmcnt is an in-order
+// counter, so a weight fragment requested after the halo prefetch could not be consumed before the
+// whole prefetch had landed, and every chunk stalled on it.  Here the prefetch of chunk c+1 covers the
+// halo elements AND the chunk's weight fragments (registers), the k-loop reads both from LDS, and the
+// LDS image (single buffered: 2 workgroups per CU even for 8x8x8 tiles) is rewritten between two
+// barriers after the MFMAs of chunk c.
+template <int NB, int MB>
+__global__ __launch_bounds__(256, 2) void conv3d_lds_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    FNN_STAMP_DECL
+    FNN_STAMP();                                             // 0: entry
+    constexpr int TD = MB;                                 // 4 waves x (MB / 4) depth slices
+    constexpr int PF = 8;                                  // halo elements (16 B) prefetched per thread
+
+    // XCD-aware, bijective remap (blocks b and b + 8 share an XCD)
+    int t;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
+    const int tw = t % p.tiles_w; t /= p.tiles_w;
+    const int th = t % p.tiles_h; t /= p.tiles_h;
+    const int td = t % p.tiles_d;
+    const int n = t / p.tiles_d;
+    const int cb0 = blockIdx.y * NB;
+
+    const int od0 = td * TD, oh0 = th * FNN_TILE_H, ow0 = tw * FNN_TILE_W;
+    const int ID = TD - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
+    const int IVOX = ID * IH * IW;
+    const int T = p.kd * p.kh * p.kw;
+    // LDS image of the halo tile: row pitch PWp voxels, and the two 16-byte channel halves of a voxel are
+    // swapped on odd rows (swz) - with PWp = 4 (mod 8) every ds_read_b128 of an MFMA operand is then
+    // bank-conflict free (the dense 10-voxel pitch was 2-way conflicted on every read)
+    const int swz = (IW & 7) != 0;
+    const int PWp = swz ? ((IW + 3) & ~7) + 4 : IW;
+    const int abytes = (ID * IH * PWp * 32 + 1023) & ~1023;
+
+    constexpr int WPF = (NB * 14 * 64 + 255) / 256;          // weight uint4 per thread per chunk (<= 14 k-steps)
+    char *sA0 = smem;
+    char *sW = smem + abytes;                                // [NB][ksteps][64 lanes][16 B] of the current chunk
+    int *sTap = (int *)(sW + NB * p.ksteps * 1024);
+
+    {
+        if (tid < 2 * p.ksteps) {
+            int off = 0, par = 0;
+            if (tid < T) {
+                const int a = tid / (p.kh * p.kw), b = (tid / p.kw) % p.kh, c = tid % p.kw;
+                off = ((a * IH + b) * PWp + c) * 32;
+                par = swz & b & 1;
             }
-        float *sRed = (float *)smem;
-        if (r == 0) {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c = nb * 16 + q * 4 + j;
-                    sRed[(wave * NB * 16 + c) * 2] = s1[nb][j];
-                    sRed[(wave * NB * 16 + c) * 2 + 1] = s2[nb][j];
-                }
-        }
-        __syncthreads();
-        if (tid < NB * 16 * 2) {
-            const int c = tid >> 1, which = tid & 1;
-            double v = 0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) v += (double)sRed[(w * NB * 16 + c) * 2 + which];
-            double *dst = p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout
-                                         + cb0 * 16 + c) * 2 + which;
-            unsafeAtomicAdd(dst, v);
+            sTap[tid * 2] = off + 16 * par;                  // column for lanes with kgp = 0
+            sTap[tid * 2 + 1] = off + 16 * (1 - par);        // kgp = 1
         }
     }
+
+    int base[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int r = lane & 15;
+        const int od_l = wave + 4 * (mb >> 2), oh_l = 2 * (mb & 3) + (r >> 3), ow_l = r & 7;
+        base[mb] = ((od_l * IH + oh_l) * PWp + ow_l) * 32;
+    }
+    const int kgp = ((lane >> 4) & 1) ^ (swz & ((lane & 15) >> 3));     // channel half after the row swizzle
+
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 bv[NB];                                           // bias of this lane's 4 channels per cout block
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const float4 *)(p.bias + (cb0 + nb) * 16 + (lane >> 4) * 4);
+
+    const int per_nb = p.ksteps * 64;                        // 16-byte fragments-lanes per cout block per chunk
+    const int wtotal = NB * per_nb;
+    f16x8 wr[WPF];                                           // native vector type: stays in registers
+    int wofs[WPF];                                           // this thread's weight elements (16-B units), chunk 0
+#pragma unroll
+    for (int u = 0; u < WPF; ++u) {
+        const int idx = tid + u * 256;
+        const int idc = idx < wtotal ? idx : wtotal - 1;
+        const int nb = idc / per_nb, r = idc - nb * per_nb;
+        wofs[u] = (cb0 + nb) * p.chunks * per_nb + r;
+    }
+    float4 ssr[4];                                           // 8 x (scale, shift) for the chunk being prefetched
+    float slope_next = 1.f;
+    __syncthreads();
+
+    const int cg = tid & 1;
+    int offv[PF];                                           // global voxel index of this thread's halo elements
+    int ldso[PF];                                           // and where they go in the LDS image
+    {
+        const int id0 = od0 - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
+        const float rcp_iw = 1.0f / (float)IW, rcp_ih = 1.0f / (float)IH;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int idx = tid + u * 256;
+            const int v = idx >> 1;
+            const int row = small_div(v, IW, rcp_iw), zw = v - row * IW;
+            const int zd = small_div(row, IH, rcp_ih), zh = row - zd * IH;
+            const int gd = id0 + zd, gh = ih0 + zh, gw = iw0 + zw;
+            const bool ok = gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 && gw < p.Wi;
+            offv[u] = idx < IVOX * 2 ? (ok ? ((n * p.Di + gd) * p.Hi + gh) * p.Wi + gw : -1) : -2;
+            ldso[u] = ((zd * IH + zh) * PWp + zw) * 32 + ((cg ^ (swz & zh & 1)) * 16);
+        }
+    }
+    f16x8 xr[PF];
+
+    auto issue = [&](int ch) {
+        const int c_glob = ch * 16;
+        const int s = (c_glob < p.src[0].C) ? 0 : 1;
+        const f16 *sp = p.src[s].ptr + (c_glob - (s ? p.src[0].C : 0) + cg * 8);
+        const int sC = p.src[s].C;
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (u * 256 < IVOX * 2)                        // workgroup-uniform: skip rounds past the tile
+                xr[u] = *(const f16x8 *)(sp + (size_t)(offv[u] >= 0 ? offv[u] : 0) * sC);
+#pragma unroll
+        for (int u = 0; u < WPF; ++u) wr[u] = ((const f16x8 *)p.wpk)[wofs[u] + ch * per_nb];
+        slope_next = p.src[s].slope;
+        if (p.src[s].ss) {
+            const float4 *q4 = (const float4 *)(p.src[s].ss + (size_t)n * sC + (c_glob - (s ? p.src[0].C : 0)) + cg * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ssr[j] = q4[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ssr[j] = make_float4(1.f, 0.f, 1.f, 0.f);
+        }
+    };
+    auto commit = [&](int ch, char *dst) {
+        (void)ch;
+        const f16 slope_h = (f16)slope_next;
+        const float sc[8] = {ssr[0].x, ssr[0].z, ssr[1].x, ssr[1].z, ssr[2].x, ssr[2].z, ssr[3].x, ssr[3].z};
+        const float sh[8] = {ssr[0].y, ssr[0].w, ssr[1].y, ssr[1].w, ssr[2].y, ssr[2].w, ssr[3].y, ssr[3].w};
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (u * 256 >= IVOX * 2 || offv[u] == -2) continue;
+            f16x8 o;
+            if (offv[u] >= 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)xr[u][j], sc[j], sh[j]);
+                o = __builtin_elementwise_max(o, o * slope_h);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
+            }
+            *(f16x8 *)(dst + ldso[u]) = o;
+        }
+#pragma unroll
+        for (int u = 0; u < WPF; ++u) {
+            const int idx = tid + u * 256;
+            if (idx < wtotal) ((f16x8 *)sW)[idx] = wr[u];
+        }
+    };
+
+    FNN_STAMP();                                             // 1: tables done
+    issue(0);
+    FNN_STAMP();                                             // 2: first loads issued
+    commit(0, sA0);
+    __syncthreads();
+    FNN_STAMP();                                             // 3: first chunk staged
+
+    for (int ch = 0; ch < p.chunks; ++ch) {
+        const bool more = ch + 1 < p.chunks;
+        if (more) issue(ch + 1);                             // global loads stay in flight during the MFMAs
+        for (int ks = 0; ks < p.ksteps; ++ks) {
+            const int toff = sTap[(2 * ks + (lane >> 5)) * 2 + kgp];
+            f16x8 xf[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) xf[mb] = *(const f16x8 *)(sA0 + base[mb] + toff);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const f16x8 wf = *(const f16x8 *)(sW + ((nb * p.ksteps + ks) * 64 + lane) * 16);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[mb], acc[mb][nb], 0, 0, 0);
+            }
+        }
+        FNN_STAMP();                                         // k-loop done
+        if (more) {
+            __syncthreads();                                 // every wave is done reading this chunk
+            commit(ch + 1, sA0);
+        }
+        __syncthreads();
+        FNN_STAMP();                                         // next chunk staged
+    }
+
+    // ---- epilogue: bias, fp16 store, statistics
+    {
+        float t1[NB][4], t2[NB][4];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
+        tile_epilogue<NB, MB>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
+        if (p.stats_out) stats_to_global<NB>(p, t1, t2, (float *)smem, n, cb0, wave, lane, tid);
+    }
+    FNN_STAMP();                                             // epilogue done
+    FNN_STAMP_FLUSH(p.dbg);
+}
+
+static size_t ldsk_lds_bytes(const ConvParams &p, int nb, int mb) {
+    const int ID = mb - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
+    size_t b = (size_t)((ID * IH * lds_pitch(IW) * 32 + 1023) & ~1023) + (size_t)nb * p.ksteps * 1024;
+    b += 4 * p.ksteps * 4 + 64;
+    const size_t red = (size_t)4 * nb * 16 * 2 * 4;
+    return b > red ? b : red;
+}
+
+template <int NB, int MB>
+static int launch_ldsk(ConvParams p, hipStream_t st) {
+    p.tile_d = MB;
+    p.tiles_d = (p.Do + MB - 1) / MB;
+    p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
+    p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
+    const size_t lds = ldsk_lds_bytes(p, NB, MB);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)conv3d_lds_kernel<NB, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
+    hipLaunchKernelGGL((conv3d_lds_kernel<NB, MB>), grid, dim3(256), lds, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 static size_t pipe_lds_bytes(const ConvParams &p, int mb) {
     const int ID = mb - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
-    const int IVOX = ID * IH * IW;
-    size_t b = 2 * (size_t)((IVOX * 32 + 1023) & ~1023);
-    b += (size_t)((IVOX + 3) & ~3) * 4 + (size_t)p.chunks * 16 * 8 + 2 * p.ksteps * 4 + 64;
+    size_t b = 2 * (size_t)((ID * IH * lds_pitch(IW) * 32 + 1023) & ~1023);
+    b += (size_t)p.chunks * 16 * 8 + 4 * p.ksteps * 4 + 64;
     return b < 4096 ? 4096 : b;
 }
 
@@ -538,13 +809,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
     const int IVOX = ID * IH * IW;
     const int T = p.kd * p.kh * p.kw;
     const int TS = p.chunks * p.ksteps;
-    const int abytes = (IVOX * 32 + 1023) & ~1023;
+    const int swz = (IW & 7) != 0;                                    // LDS image: see conv3d_pipe_kernel
+    const int PWp = swz ? ((IW + 3) & ~7) + 4 : IW;
+    const int abytes = (ID * IH * PWp * 32 + 1023) & ~1023;
     const int cb0 = blockIdx.y * NB;
 
     char *sA0 = smem;
     char *sW = smem + 2 * abytes;                                    // [NB][TS][64 lanes][16 B]
     int *sTap = (int *)(sW + NB * TS * 1024);
-    double *sRed = (double *)(sTap + 32);                             // [4 waves][NB*16][2]
+    double *sRed = (double *)(sTap + 64);                             // [4 waves][NB*16][2]
 
     // contiguous tile range of this workgroup; consecutive ranges share an XCD
     int t_begin, t_end;
@@ -563,28 +836,33 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
         ((uint4 *)sW)[idx] = ((const uint4 *)(p.wpk + (size_t)(cb0 + nb) * TS * 512))[r];
     }
     if (tid < 2 * p.ksteps) {
-        int off = 0;
+        int off = 0, par = 0;
         if (tid < T) {
             const int a = tid / (p.kh * p.kw), b = (tid / p.kw) % p.kh, c = tid % p.kw;
-            off = ((a * IH + b) * IW + c) * 32;
+            off = ((a * IH + b) * PWp + c) * 32;
+            par = swz & b & 1;
         }
-        sTap[tid] = off;
+        sTap[tid * 2] = off + 16 * par;
+        sTap[tid * 2 + 1] = off + 16 * (1 - par);
     }
     const int cg = tid & 1;
-    int rel[PF];
+    int rel[PF], ldso[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const int idx = tid + u * 256;
         const int v = idx >> 1;
-        rel[u] = idx < IVOX * 2 ? ((v / (IW * IH)) << 16) | (((v / IW) % IH) << 8) | (v % IW) : -1;
+        const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
+        rel[u] = idx < IVOX * 2 ? (zd << 16) | (zh << 8) | zw : -1;
+        ldso[u] = ((zd * IH + zh) * PWp + zw) * 32 + ((cg ^ (swz & zh & 1)) * 16);
     }
     int base[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int r = lane & 15;
         const int od_l = wave + 4 * (mb >> 2), oh_l = 2 * (mb & 3) + (r >> 3), ow_l = r & 7;
-        base[mb] = ((od_l * IH + oh_l) * IW + ow_l) * 32 + ((lane >> 4) & 1) * 16;
+        base[mb] = ((od_l * IH + oh_l) * PWp + ow_l) * 32;
     }
+    const int kgp = ((lane >> 4) & 1) ^ (swz & ((lane & 15) >> 3));
 
     f32x4 acc[MB][NB];
     // statistics: fp32 only WITHIN one tile (same grouping as the one-tile-per-workgroup kernels), double
@@ -595,6 +873,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s1[nb][j] = 0.0; s2[nb][j] = 0.0; }
+
+    float4 bv[NB];                                                    // bias of this lane's 4 channels per cout block
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const float4 *)(p.bias + (cb0 + nb) * 16 + (lane >> 4) * 4);
 
     int offv[PF];
     f16x8 xr[PF];
@@ -652,7 +934,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
             }
-            *(f16x8 *)(dst + ((tid + u * 256) >> 1) * 32 + cg * 16) = o;
+            *(f16x8 *)(dst + ldso[u]) = o;
         }
     };
     auto flush_stats = [&](int n) {
@@ -715,7 +997,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
             }
             const char *sA = sA0 + buf * abytes;
             for (int ks = 0; ks < p.ksteps; ++ks) {
-                const int toff = sTap[2 * ks + (lane >> 5)];
+                const int toff = sTap[(2 * ks + (lane >> 5)) * 2 + kgp];
                 f16x8 xf[MB];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) xf[mb] = *(const f16x8 *)(sA + base[mb] + toff);
@@ -728,38 +1010,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
                 }
             }
             if (last_chunk) {
-                // epilogue of this tile: bias, fp16 store, statistics
-                const int q = lane >> 4, r = lane & 15;
+                // epilogue of this tile: bias, fp16 store, statistics (fp32 within the tile, double across tiles)
                 float t1[NB][4], t2[NB][4];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const int od = od0 + wave + 4 * (mb >> 2);
-                    const int oh = oh0 + 2 * (mb & 3) + (r >> 3), ow = ow0 + (r & 7);
-                    const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
-                    const size_t vox = ((size_t)(n_cur * p.Do + od) * p.Ho + oh) * p.Wo + ow;
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        const int co = (cb0 + nb) * 16 + q * 4;
-                        const float4 bv = *(const float4 *)(p.bias + co);
-                        f16x4 o;
-                        o[0] = (f16)(acc[mb][nb][0] + bv.x);
-                        o[1] = (f16)(acc[mb][nb][1] + bv.y);
-                        o[2] = (f16)(acc[mb][nb][2] + bv.z);
-                        o[3] = (f16)(acc[mb][nb][3] + bv.w);
-                        if (ok) {
-                            *(f16x4 *)(p.out + vox * p.Cout + co) = o;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float v = (float)o[j];
-                                t1[nb][j] += v; t2[nb][j] += v * v;
-                            }
-                        }
-                    }
-                }
+                tile_epilogue<NB, MB>(p, acc, bv, n_cur, od0, oh0, ow0, cb0, wave, lane, t1, t2);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -776,8 +1033,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
 
 static size_t persist_lds_bytes(const ConvParams &p, int nb, int mb) {
     const int ID = mb - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
-    const int IVOX = ID * IH * IW;
-    return 2 * (size_t)((IVOX * 32 + 1023) & ~1023) + (size_t)nb * p.chunks * p.ksteps * 1024 + 128 + (size_t)4 * nb * 16 * 2 * 8;
+    return 2 * (size_t)((ID * IH * lds_pitch(IW) * 32 + 1023) & ~1023) + (size_t)nb * p.chunks * p.ksteps * 1024 + 256 +
+           (size_t)4 * nb * 16 * 2 * 8;
 }
 
 template <int NB, int MB>
@@ -872,6 +1129,11 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
                 if (nb == 1) return mb == 8 ? launch_persist<1, 8>(p, wpc, st) : launch_persist<1, 4>(p, wpc, st);
                 return mb == 8 ? launch_persist<2, 8>(p, wpc, st) : launch_persist<2, 4>(p, wpc, st);
             }
+        }
+        static const bool stream_w = getenv("FNN_CONV_STREAMW") != nullptr;   // A-B aid: weights streamed from L2
+        if (!stream_w && p.ksteps <= 14) {
+            if (nb == 1) return mbsel == 8 ? launch_ldsk<1, 8>(p, st) : launch_ldsk<1, 4>(p, st);
+            if (nb == 2) return mbsel == 8 ? launch_ldsk<2, 8>(p, st) : launch_ldsk<2, 4>(p, st);
         }
         if (nb == 1) return mbsel == 8 ? launch_pipe<1, 8>(p, st) : launch_pipe<1, 4>(p, st);
         if (nb == 2) return mbsel == 8 ? launch_pipe<2, 8>(p, st) : launch_pipe<2, 4>(p, st);

@@ -51,6 +51,7 @@ struct ConvParams {
     double *stats_out;           // [N][REPL][Cout][2] or nullptr
     int tiles_d, tiles_h, tiles_w;
     int tile_d;                  // output tile depth: 4, or 8 for the pipelined kernel with 8 column blocks per wave
+    unsigned long long *dbg;     // diagnostic builds only (-DFNN_STAMPS): per-workgroup s_memtime stamps
     int chunks;                  // 16-channel chunks over all sources
     int ksteps;                  // MFMA k-steps per chunk = ceil(taps / 2)
 };
@@ -131,6 +132,16 @@ struct FinalizeParams {
     void *out;                   // [heads][out_X][out_Y][out_Z]
     int *inf_flag;
 };
+
+#ifdef FNN_STAMPS
+#define FNN_STAMP_DECL unsigned long long _st[12]; int _si = 0;
+#define FNN_STAMP() do { if (_si < 12) { __builtin_amdgcn_sched_barrier(0); _st[_si++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define FNN_STAMP_FLUSH(dbg) do { if ((dbg) && threadIdx.x == 0) { for (int _i = 0; _i < 12; ++_i) (dbg)[(size_t)blockIdx.x * 12 + _i] = _i < _si ? _st[_i] : 0ull; } } while (0)
+#else
+#define FNN_STAMP_DECL
+#define FNN_STAMP() do {} while (0)
+#define FNN_STAMP_FLUSH(dbg) do {} while (0)
+#endif
 
 static __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
 

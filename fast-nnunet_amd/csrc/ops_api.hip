@@ -8,6 +8,7 @@
 #include "fnn_device.h"
 #include "../../include/fnn.h"
 
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -136,9 +137,38 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
     (void)hipMemset(dst.p, 0, (size_t)n * FNN_STAT_REPL * cop * 16);
     (void)hipMemset(dout.p, 0, (size_t)n * ovox * cop * 2);
     p.wpk = dw.as<f16>(); p.bias = db.as<float>(); p.out = dout.as<f16>(); p.stats_out = dst.as<double>();
+#ifdef FNN_STAMPS
+    DevBuf ddbg;
+    const size_t dbg_n = (size_t)1 << 20;
+    if (!ddbg.alloc(dbg_n * 8)) return FNN_E_HIP;
+    (void)hipMemset(ddbg.p, 0, dbg_n * 8);
+    p.dbg = ddbg.as<unsigned long long>();
+    (void)launch_conv3d(p, 0);                      // warm-up
+    (void)hipDeviceSynchronize();
+    (void)hipMemset(dst.p, 0, (size_t)n * FNN_STAT_REPL * cop * 16);
+#endif
     const int rc = launch_conv3d(p, 0);
     if (rc != 0) return rc == -1 ? FNN_E_UNSUPPORTED : FNN_E_HIP;
     if (hipDeviceSynchronize() != hipSuccess) return FNN_E_HIP;
+#ifdef FNN_STAMPS
+    {
+        std::vector<unsigned long long> h(dbg_n);
+        (void)hipMemcpy(h.data(), ddbg.p, dbg_n * 8, hipMemcpyDeviceToHost);
+        double sum[12] = {0}; long cnt = 0;
+        unsigned long long tmin = ~0ull, tmax = 0;
+        for (size_t w = 0; w * 12 + 11 < dbg_n; ++w) {
+            if (h[w * 12] == 0) continue;
+            ++cnt;
+            int last = 0;
+            for (int i = 1; i < 12; ++i) if (h[w * 12 + i]) { sum[i] += (double)(h[w * 12 + i] - h[w * 12 + i - 1]); last = i; }
+            if (h[w * 12] < tmin) tmin = h[w * 12];
+            if (h[w * 12 + last] > tmax) tmax = h[w * 12 + last];
+        }
+        fprintf(stderr, "[stamps] %ld workgroups, kernel span %.0f ticks; mean ticks per segment:", cnt, (double)(tmax - tmin));
+        for (int i = 1; i < 12; ++i) fprintf(stderr, " %d:%.0f", i, cnt ? sum[i] / cnt : 0.0);
+        fprintf(stderr, "\n");
+    }
+#endif
     std::vector<uint16_t> ho((size_t)n * ovox * cop);
     std::vector<double> hs((size_t)n * FNN_STAT_REPL * cop * 2);
     (void)hipMemcpy(ho.data(), dout.p, ho.size() * 2, hipMemcpyDeviceToHost);
