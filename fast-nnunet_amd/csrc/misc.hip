@@ -43,18 +43,20 @@ int launch_stats_finalize(const StatsFinalizeParams &p, int N, hipStream_t st) {
 // channels-last tensor with the producer's norm + LeakyReLU applied.
 static __device__ __forceinline__ f16x8 load_act_frag(const SrcDesc &s, size_t vox, bool vox_ok, int c0,
                                                       const float2 *sSS) {
+    // unconditional load from a clamped (always valid) address, zeroed afterwards: a per-lane branch around
+    // the load makes hipcc wait for it immediately and serialises the loads of a k-step
+    const bool live = vox_ok && c0 < s.C;
+    const int cc = c0 < s.C ? c0 : 0;
+    const f16x8 x = *(const f16x8 *)(s.ptr + (vox_ok ? vox : 0) * s.C + cc);
     f16x8 o;
-    if (vox_ok && c0 < s.C) {
-        const f16x8 x = *(const f16x8 *)(s.ptr + vox * s.C + c0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float2 ss = sSS[c0 + j];
-            o[j] = (f16)leaky((float)x[j] * ss.x + ss.y, s.slope);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
+    for (int j = 0; j < 8; ++j) {
+        const float2 ss = sSS[cc + j];
+        o[j] = (f16)fmaf((float)x[j], ss.x, ss.y);
     }
+    o = __builtin_elementwise_max(o, o * (f16)s.slope);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = live ? o[j] : (f16)0.f;
     return o;
 }
 
@@ -263,35 +265,46 @@ __global__ __launch_bounds__(256) void seg_head_acc_kernel(const HeadParams p) {
     if (v0 >= P) return;
     const int r = lane & 15, q = lane >> 4;
     const int grp = lane & 7, vsub = lane >> 3;              // read-modify-write role: channel group, voxel in round
-    const int hb_w = p.heads >> 4, q_w = (p.heads >> 2) & 3, j_w = p.heads & 3;     // weight-sum channel position
-    const int cgroups = p.HP >> 3;                           // 8-channel groups per 64-channel block
-    const bool one_kstep = p.ksteps == 1;
 
+    // All global loads of a round are issued unconditionally (clamped addresses) and back to back, so a
+    // round costs ONE memory round trip; predicates are applied to the values afterwards.  (With per-lane
+    // `if`s around the loads hipcc serialised them behind s_waitcnt vmcnt(0): ~12 round trips per round.)
     for (int cb0 = 0; cb0 < p.HP; cb0 += 64) {               // 64 accumulator channels at a time
         const int hb_first = cb0 >> 4;
+        const int grp_c = cb0 + grp * 8 < p.HP ? grp : 0;     // clamp: lanes past HP re-read group 0 and write nothing
+        const bool grp_ok = cb0 + grp * 8 < p.HP;
+        // bias of this lane's 4 channels per head block (the bias array is zero padded to hblocks * 16)
+        f32x4 bv[4];
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb) {
+            const int hbc = hb_first + hb < p.hblocks ? hb_first + hb : p.hblocks - 1;
+            bv[hb] = *(const f32x4 *)(p.bias + hbc * 16 + q * 4);
+        }
 #pragma unroll 1
         for (int rd = 0; rd < 2; ++rd) {
-            // this lane's 4 voxels of the round and their accumulator lines
-            const int vb_base = rd * 2;
             size_t aelem[4];
             float g[4];
             bool ok[4];
             f16x8 a16[4];
             f32x4 a32[4][2];
-            const bool grp_ok = cb0 + grp * 8 < p.HP;
+            f16 graw[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int v = v0 + rd * 32 + 8 * i + vsub;
                 ok[i] = v < P && grp_ok;
-                const int vv = v < P ? v : 0;
+                const int vv = v < P ? v : P - 1;
                 const int w = vv % p.PW, h = (vv / p.PW) % p.PH, d = vv / (p.PW * p.PH);
-                aelem[i] = (((size_t)(p.ox + d) * p.Y + (p.oy + h)) * p.Z + (p.oz + w)) * p.HP + cb0 + grp * 8;
-                g[i] = p.gauss ? (float)p.gauss[vv] : 1.f;
-                if (ok[i]) {
-                    if (ACC32) { a32[i][0] = *(const f32x4 *)((const float *)p.acc + aelem[i]); a32[i][1] = *(const f32x4 *)((const float *)p.acc + aelem[i] + 4); }
-                    else a16[i] = *(const f16x8 *)((const f16 *)p.acc + aelem[i]);
-                }
+                aelem[i] = (((size_t)(p.ox + d) * p.Y + (p.oy + h)) * p.Z + (p.oz + w)) * p.HP + cb0 + grp_c * 8;
+                graw[i] = p.gauss ? p.gauss[vv] : (f16)1.f;
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (ACC32) { a32[i][0] = *(const f32x4 *)((const float *)p.acc + aelem[i]); a32[i][1] = *(const f32x4 *)((const float *)p.acc + aelem[i] + 4); }
+                else a16[i] = *(const f16x8 *)((const f16 *)p.acc + aelem[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = (float)graw[i];
+
             // MFMA: [heads of this 64-channel block] x [32 voxels]
             f32x4 acc[4][2];
 #pragma unroll
@@ -299,54 +312,46 @@ __global__ __launch_bounds__(256) void seg_head_acc_kernel(const HeadParams p) {
 #pragma unroll
                 for (int vb = 0; vb < 2; ++vb) acc[hb][vb] = (f32x4){0.f, 0.f, 0.f, 0.f};
             for (int ks = 0; ks < p.ksteps; ++ks) {
-                f16x8 xf[2];
-#pragma unroll
-                for (int vb = 0; vb < 2; ++vb) {
-                    const int v = v0 + (vb_base + vb) * 16 + r;
-                    xf[vb] = load_act_frag(p.src, (size_t)p.b * P + v, v < P, ks * 32 + q * 8, sSS);
-                }
+                f16x8 xf[2], wf[4];
 #pragma unroll
                 for (int hb = 0; hb < 4; ++hb) {
-                    if (hb_first + hb < p.hblocks) {
-                        const f16x8 wf = *(const f16x8 *)(p.wpk + (((size_t)(hb_first + hb) * p.ksteps + ks) * 64 + lane) * 8);
-#pragma unroll
-                        for (int vb = 0; vb < 2; ++vb)
-                            acc[hb][vb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[vb], acc[hb][vb], 0, 0, 0);
-                    }
+                    const int hbc = hb_first + hb < p.hblocks ? hb_first + hb : p.hblocks - 1;
+                    wf[hb] = *(const f16x8 *)(p.wpk + (((size_t)hbc * p.ksteps + ks) * 64 + lane) * 8);
                 }
-            }
-            (void)one_kstep;
-            // logits (+ bias) -> LDS, [voxel][channel]; the weight-sum channel gets 1 so that it accumulates g
-#pragma unroll
-            for (int hb = 0; hb < 4; ++hb) {
-                const int ch0 = (hb_first + hb) * 16 + q * 4;
-                f32x4 bv;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bv[j] = ch0 + j < p.heads ? p.bias[ch0 + j] : 0.f;
-                const bool has_w = hb_first + hb == hb_w && q == q_w;
 #pragma unroll
                 for (int vb = 0; vb < 2; ++vb) {
-                    f32x4 t = acc[hb][vb] + bv;
-                    if (has_w) t[j_w] = 1.f;
+                    const int v = v0 + (rd * 2 + vb) * 16 + r;
+                    xf[vb] = load_act_frag(p.src, (size_t)p.b * P + (v < P ? v : P - 1), true, ks * 32 + q * 8, sSS);
+                }
+#pragma unroll
+                for (int hb = 0; hb < 4; ++hb)
+#pragma unroll
+                    for (int vb = 0; vb < 2; ++vb)
+                        acc[hb][vb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[hb], xf[vb], acc[hb][vb], 0, 0, 0);
+            }
+            // logits (+ bias) -> LDS, [voxel][channel]
+#pragma unroll
+            for (int hb = 0; hb < 4; ++hb)
+#pragma unroll
+                for (int vb = 0; vb < 2; ++vb) {
+                    const f32x4 t = hb_first + hb < p.hblocks ? acc[hb][vb] + bv[hb] : (f32x4){0.f, 0.f, 0.f, 0.f};
                     *(f32x4 *)(sT + (vb * 16 + r) * HEAD_LD + hb * 16 + q * 4) = t;
                 }
-            }
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
             // read-modify-write: 8 lanes x 16 B (fp16) cover one voxel's 64 channels
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (!ok[i]) continue;
-                const f32x4 t0 = *(const f32x4 *)(sT + (8 * i + vsub) * HEAD_LD + grp * 8);
-                const f32x4 t1 = *(const f32x4 *)(sT + (8 * i + vsub) * HEAD_LD + grp * 8 + 4);
+                const f32x4 t0 = *(const f32x4 *)(sT + (8 * i + vsub) * HEAD_LD + grp_c * 8);
+                const f32x4 t1 = *(const f32x4 *)(sT + (8 * i + vsub) * HEAD_LD + grp_c * 8 + 4);
                 float c[8];
                 unsigned mask = 0;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const int ch = cb0 + grp * 8 + e;
+                    const int ch = cb0 + grp_c * 8 + e;
                     const float t = e < 4 ? t0[e] : t1[e - 4];
-                    c[e] = ch == p.heads ? g[i] : __fmul_rn(t, g[i]);
-                    if (ch <= p.heads) mask |= 1u << e;           // padding channels keep their bits
+                    c[e] = ch == p.heads ? g[i] : __fmul_rn(t, g[i]);      // channel `heads` accumulates the weight
+                    if (ch <= p.heads) mask |= 1u << e;                      // padding channels keep their bits
                 }
                 if (ACC32) {
                     f32x4 b0 = a32[i][0], b1 = a32[i][1];
@@ -355,19 +360,20 @@ __global__ __launch_bounds__(256) void seg_head_acc_kernel(const HeadParams p) {
                         b0[e] = (mask >> e) & 1 ? __fadd_rn(b0[e], c[e]) : b0[e];
                         b1[e] = (mask >> (4 + e)) & 1 ? __fadd_rn(b1[e], c[4 + e]) : b1[e];
                     }
-                    *(f32x4 *)((float *)p.acc + aelem[i]) = b0;
-                    *(f32x4 *)((float *)p.acc + aelem[i] + 4) = b1;
+                    if (ok[i]) {
+                        *(f32x4 *)((float *)p.acc + aelem[i]) = b0;
+                        *(f32x4 *)((float *)p.acc + aelem[i] + 4) = b1;
+                    }
                 } else {
-                    f16x8 b = a16[i];
+                    f16x8 bq = a16[i];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) b[e] = (mask >> e) & 1 ? (f16)__fadd_rn((float)b[e], c[e]) : b[e];
-                    *(f16x8 *)((f16 *)p.acc + aelem[i]) = b;
+                    for (int e = 0; e < 8; ++e) bq[e] = (mask >> e) & 1 ? (f16)__fadd_rn((float)bq[e], c[e]) : bq[e];
+                    if (ok[i]) *(f16x8 *)((f16 *)p.acc + aelem[i]) = bq;
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
-    (void)cgroups;
 }
 
 int launch_head(const HeadParams &p, hipStream_t st) {
