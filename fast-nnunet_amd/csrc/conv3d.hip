@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
         for (int c = tid; c < cin_total; c += 256) {
             const int s = (c < p.src[0].C) ? 0 : 1;
             const int cl = c - (s ? p.src[0].C : 0);
-            sSS[c] = p.src[s].ss ? p.src[s].ss[(size_t)n * p.src[s].C + cl] : make_float2(1.f, 0.f);
+            sSS[c] = p.src[s].ss ? make_float2(p.src[s].ss[(size_t)(2 * n) * p.src[s].C + cl], p.src[s].ss[(size_t)(2 * n + 1) * p.src[s].C + cl])
+                                 : make_float2(1.f, 0.f);
         }
     }
 
@@ -398,7 +399,8 @@ __global__ __launch_bounds__(256) void conv3d_pipe_kernel(const ConvParams p) {
         for (int c = tid; c < cin_total; c += 256) {
             const int s = (c < p.src[0].C) ? 0 : 1;
             const int cl = c - (s ? p.src[0].C : 0);
-            sSS[c] = p.src[s].ss ? p.src[s].ss[(size_t)n * p.src[s].C + cl] : make_float2(1.f, 0.f);
+            sSS[c] = p.src[s].ss ? make_float2(p.src[s].ss[(size_t)(2 * n) * p.src[s].C + cl], p.src[s].ss[(size_t)(2 * n + 1) * p.src[s].C + cl])
+                                 : make_float2(1.f, 0.f);
         }
     }
 
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_lds_kernel(const ConvParams p) 
         const int nb = idc / per_nb, r = idc - nb * per_nb;
         wofs[u] = (cb0 + nb) * p.chunks * per_nb + r;
     }
-    float4 ssr[4];                                           // 8 x (scale, shift) for the chunk being prefetched
+    float4 scr[2], shr[2];                                   // 8 scales, 8 shifts of the chunk being prefetched
     float slope_next = 1.f;
     __syncthreads();
 
@@ -649,26 +651,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_lds_kernel(const ConvParams p) 
         const f16 *sp = p.src[s].ptr + (c_glob - (s ? p.src[0].C : 0) + cg * 8);
         const int sC = p.src[s].C;
 #pragma unroll
-        for (int u = 0; u < PF; ++u)
-            if (u * 256 < IVOX * 2)                        // workgroup-uniform: skip rounds past the tile
-                xr[u] = *(const f16x8 *)(sp + (size_t)(offv[u] >= 0 ? offv[u] : 0) * sC);
+        for (int u = 0; u < PF; ++u)                        // unconditional: branches around loads make hipcc drain vmcnt
+            xr[u] = *(const f16x8 *)(sp + (size_t)(offv[u] >= 0 ? offv[u] : 0) * sC);
 #pragma unroll
         for (int u = 0; u < WPF; ++u) wr[u] = ((const f16x8 *)p.wpk)[wofs[u] + ch * per_nb];
         slope_next = p.src[s].slope;
         if (p.src[s].ss) {
-            const float4 *q4 = (const float4 *)(p.src[s].ss + (size_t)n * sC + (c_glob - (s ? p.src[0].C : 0)) + cg * 8);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ssr[j] = q4[j];
+            const float *q4 = p.src[s].ss + (size_t)(2 * n) * sC + (c_glob - (s ? p.src[0].C : 0)) + cg * 8;
+            scr[0] = *(const float4 *)q4; scr[1] = *(const float4 *)(q4 + 4);
+            shr[0] = *(const float4 *)(q4 + sC); shr[1] = *(const float4 *)(q4 + sC + 4);
         } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ssr[j] = make_float4(1.f, 0.f, 1.f, 0.f);
+            scr[0] = scr[1] = make_float4(1.f, 1.f, 1.f, 1.f);
+            shr[0] = shr[1] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto commit = [&](int ch, char *dst) {
         (void)ch;
         const f16 slope_h = (f16)slope_next;
-        const float sc[8] = {ssr[0].x, ssr[0].z, ssr[1].x, ssr[1].z, ssr[2].x, ssr[2].z, ssr[3].x, ssr[3].z};
-        const float sh[8] = {ssr[0].y, ssr[0].w, ssr[1].y, ssr[1].w, ssr[2].y, ssr[2].w, ssr[3].y, ssr[3].w};
+        const float sc[8] = {scr[0].x, scr[0].y, scr[0].z, scr[0].w, scr[1].x, scr[1].y, scr[1].z, scr[1].w};
+        const float sh[8] = {shr[0].x, shr[0].y, shr[0].z, shr[0].w, shr[1].x, shr[1].y, shr[1].z, shr[1].w};
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             if (u * 256 >= IVOX * 2 || offv[u] == -2) continue;
@@ -697,9 +698,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_lds_kernel(const ConvParams p) 
     __syncthreads();
     FNN_STAMP();                                             // 3: first chunk staged
 
-    for (int ch = 0; ch < p.chunks; ++ch) {
-        const bool more = ch + 1 < p.chunks;
-        if (more) issue(ch + 1);                             // global loads stay in flight during the MFMAs
+    auto kloop = [&]() {
         for (int ks = 0; ks < p.ksteps; ++ks) {
             const int toff = sTap[(2 * ks + (lane >> 5)) * 2 + kgp];
             f16x8 xf[MB];
@@ -713,14 +712,23 @@ __global__ __launch_bounds__(256, 2) void conv3d_lds_kernel(const ConvParams p) 
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[mb], acc[mb][nb], 0, 0, 0);
             }
         }
+    };
+    // All but the last chunk prefetch their successor.  The last chunk is peeled off so that the wait for
+    // the prefetch sits on an unconditional path: with `if (more)` around issue/commit, hipcc's waitcnt
+    // pass had to assume loads of the previous iteration were still pending and drained vmcnt to 0 in the
+    // middle of issue() - the "prefetch" then cost two exposed round trips per chunk.
+    for (int ch = 0; ch + 1 < p.chunks; ++ch) {
+        issue(ch + 1);                                       // global loads stay in flight during the MFMAs
+        kloop();
         FNN_STAMP();                                         // k-loop done
-        if (more) {
-            __syncthreads();                                 // every wave is done reading this chunk
-            commit(ch + 1, sA0);
-        }
+        __syncthreads();                                     // every wave is done reading this chunk
+        commit(ch + 1, sA0);
         __syncthreads();
         FNN_STAMP();                                         // next chunk staged
     }
+    kloop();
+    FNN_STAMP();
+    __syncthreads();
 
     // ---- epilogue: bias, fp16 store, statistics
     {
@@ -880,7 +888,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
 
     int offv[PF];
     f16x8 xr[PF];
-    float4 ssr[4];                                                    // 8 x (scale, shift) of the next item
+    float4 scr[2], shr[2];                                            // 8 scales, 8 shifts of the next item
     float slope_next = 1.f;
 
     auto tile_coords = [&](int t, int &n, int &od0, int &oh0, int &ow0) {
@@ -906,22 +914,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
         const f16 *sp = p.src[s].ptr + c_loc;
         const int sC = p.src[s].C;
 #pragma unroll
-        for (int u = 0; u < PF; ++u)
-            if (u * 256 < IVOX * 2) xr[u] = *(const f16x8 *)(sp + (size_t)(offv[u] >= 0 ? offv[u] : 0) * sC);
+        for (int u = 0; u < PF; ++u)                        // unconditional: branches around loads make hipcc drain vmcnt
+            xr[u] = *(const f16x8 *)(sp + (size_t)(offv[u] >= 0 ? offv[u] : 0) * sC);
         slope_next = p.src[s].slope;
         if (p.src[s].ss) {
-            const float4 *q = (const float4 *)(p.src[s].ss + (size_t)n * sC + c_loc);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ssr[j] = q[j];
+            const float *q4 = p.src[s].ss + (size_t)(2 * n) * sC + c_loc;
+            scr[0] = *(const float4 *)q4; scr[1] = *(const float4 *)(q4 + 4);
+            shr[0] = *(const float4 *)(q4 + sC); shr[1] = *(const float4 *)(q4 + sC + 4);
         } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ssr[j] = make_float4(1.f, 0.f, 1.f, 0.f);
+            scr[0] = scr[1] = make_float4(1.f, 1.f, 1.f, 1.f);
+            shr[0] = shr[1] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto commit = [&](char *dst) {
         const f16 slope_h = (f16)slope_next;
-        const float sc[8] = {ssr[0].x, ssr[0].z, ssr[1].x, ssr[1].z, ssr[2].x, ssr[2].z, ssr[3].x, ssr[3].z};
-        const float sh[8] = {ssr[0].y, ssr[0].w, ssr[1].y, ssr[1].w, ssr[2].y, ssr[2].w, ssr[3].y, ssr[3].w};
+        const float sc[8] = {scr[0].x, scr[0].y, scr[0].z, scr[0].w, scr[1].x, scr[1].y, scr[1].z, scr[1].w};
+        const float sh[8] = {shr[0].x, shr[0].y, shr[0].z, shr[0].w, shr[1].x, shr[1].y, shr[1].z, shr[1].w};
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             if (u * 256 >= IVOX * 2 || rel[u] < 0) continue;
@@ -983,17 +991,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
             for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
         int n_next = n_cur, nod0 = od0, noh0 = oh0, now0 = ow0;
         for (int ch = 0; ch < p.chunks; ++ch) {
-            // prefetch the next work item
+            // prefetch the next work item.  The very last item prefetches itself again (a few redundant, cached
+            // loads) so that issue / commit sit on an unconditional path: hipcc's waitcnt pass is then exact
             const bool last_chunk = ch + 1 == p.chunks;
-            const bool more = !last_chunk || t + 1 < t_end;
-            if (more) {
-                if (last_chunk) {
-                    tile_coords(t + 1, n_next, nod0, noh0, now0);
-                    set_offsets(n_next, nod0, noh0, now0);
-                    issue(n_next, 0);
-                } else {
-                    issue(n_cur, ch + 1);
-                }
+            if (last_chunk) {
+                tile_coords(t + 1 < t_end ? t + 1 : t, n_next, nod0, noh0, now0);
+                set_offsets(n_next, nod0, noh0, now0);
+                issue(n_next, 0);
+            } else {
+                issue(n_cur, ch + 1);
             }
             const char *sA = sA0 + buf * abytes;
             for (int ks = 0; ks < p.ksteps; ++ks) {
@@ -1022,7 +1028,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { s1[nb][j] += (double)t1[nb][j]; s2[nb][j] += (double)t2[nb][j]; }
             }
-            if (more) commit(sA0 + (buf ^ 1) * abytes);
+            commit(sA0 + (buf ^ 1) * abytes);
             __syncthreads();
             buf ^= 1;
         }
@@ -1134,6 +1140,7 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
         if (!stream_w && p.ksteps <= 14) {
             if (nb == 1) return mbsel == 8 ? launch_ldsk<1, 8>(p, st) : launch_ldsk<1, 4>(p, st);
             if (nb == 2) return mbsel == 8 ? launch_ldsk<2, 8>(p, st) : launch_ldsk<2, 4>(p, st);
+            return launch_ldsk<4, 4>(p, st);
         }
         if (nb == 1) return mbsel == 8 ? launch_pipe<1, 8>(p, st) : launch_pipe<1, 4>(p, st);
         if (nb == 2) return mbsel == 8 ? launch_pipe<2, 8>(p, st) : launch_pipe<2, 4>(p, st);

@@ -67,7 +67,7 @@ struct fnn_engine {
     std::vector<FoldWeights> folds;
     f16 *act = nullptr;
     double *stats = nullptr;
-    float2 *ss = nullptr;
+    float *ss = nullptr;                    // [layer][max_batch][2][C]
     f16 *gauss = nullptr;
     int *inf_flag = nullptr;
     int *origins = nullptr; size_t origins_cap = 0;
@@ -357,7 +357,7 @@ SrcDesc make_src(fnn_engine *e, const FoldWeights &fw, int layer, int nb) {
     s.ptr = e->act + L.out_off * e->max_batch;
     s.C = L.cout_pad;
     if (L.has_norm) {
-        s.ss = e->ss + L.ss_off * e->max_batch;
+        s.ss = e->ss + L.ss_off * e->max_batch * 2;
         s.slope = e->arch.slope;
     } else {
         s.ss = nullptr; s.slope = 1.f;
@@ -426,7 +426,7 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
         if (L.has_norm) {
             StatsFinalizeParams q{};
             q.stats = stats_out; q.gamma = fw.fparam + L.gamma_off; q.beta = fw.fparam + L.beta_off;
-            q.ss = e->ss + L.ss_off * e->max_batch; q.C = L.cout_pad;
+            q.ss = e->ss + L.ss_off * e->max_batch * 2; q.C = L.cout_pad;
             q.inv_count = 1.f / ((float)L.out_dims[0] * L.out_dims[1] * L.out_dims[2]); q.eps = e->arch.eps;
             if (launch_stats_finalize(q, nb, st) != 0) return fail(e, FNN_E_HIP, "stats finalize launch failed");
         }
@@ -768,7 +768,7 @@ int fnn_create(const fnn_arch_desc *arch, int device, int max_batch, fnn_engine 
     if ((r = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", r);
     if ((r = hipMalloc((void **)&e->act, e->act_halves * max_batch * sizeof(f16))) != hipSuccess) return bail("hipMalloc(activations)", r);
     if ((r = hipMalloc((void **)&e->stats, e->stats_doubles * max_batch * sizeof(double))) != hipSuccess) return bail("hipMalloc(stats)", r);
-    if ((r = hipMalloc((void **)&e->ss, (e->ss_count * max_batch + 1) * sizeof(float2))) != hipSuccess) return bail("hipMalloc(scale/shift)", r);
+    if ((r = hipMalloc((void **)&e->ss, (e->ss_count * max_batch * 2 + 4) * sizeof(float))) != hipSuccess) return bail("hipMalloc(scale/shift)", r);
     if ((r = hipMalloc((void **)&e->inf_flag, sizeof(int))) != hipSuccess) return bail("hipMalloc(flag)", r);
     *out = e;
     return 0;

@@ -32,8 +32,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct SrcDesc {
     const f16 *ptr;              // [N][D][H][W][C]
     int C;                       // padded channel count (multiple of 16)
-    const float2 *ss;            // [N][C] (scale, shift) of the producer's InstanceNorm, written by
-                                 // stats_finalize_kernel; nullptr = identity
+    const float *ss;             // [N][2][C]: scale row then shift row of the producer's InstanceNorm, written
+                                 // by stats_finalize_kernel; nullptr = identity
     float slope;                 // LeakyReLU slope applied after the affine (1.0 = none)
 };
 
@@ -148,7 +148,7 @@ static __device__ __forceinline__ float leaky(float x, float slope) { return x >
 struct StatsFinalizeParams {
     const double *stats;         // [N][REPL][C][2]
     const float *gamma, *beta;   // [C]
-    float2 *ss;                  // [N][C]
+    float *ss;                   // [N][2][C]
     int C;
     float inv_count, eps;
 };

@@ -9,7 +9,8 @@
 #include <cstdlib>
 
 static __device__ __forceinline__ void load_scale_shift(const SrcDesc &s, int n, float2 *sSS, int tid, int nthreads) {
-    for (int c = tid; c < s.C; c += nthreads) sSS[c] = s.ss ? s.ss[(size_t)n * s.C + c] : make_float2(1.f, 0.f);
+    for (int c = tid; c < s.C; c += nthreads)
+        sSS[c] = s.ss ? make_float2(s.ss[(size_t)(2 * n) * s.C + c], s.ss[(size_t)(2 * n + 1) * s.C + c]) : make_float2(1.f, 0.f);
 }
 
 // InstanceNorm statistics -> per (n, channel) (scale, shift):  y = x * scale + shift
@@ -30,7 +31,8 @@ __global__ void stats_finalize_kernel(const StatsFinalizeParams p) {
     var = var > 0 ? var : 0;
     const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
     const float sc = p.gamma[c] * rstd;
-    p.ss[(size_t)n * p.C + c] = make_float2(sc, p.beta[c] - (float)mean * sc);
+    p.ss[(size_t)(2 * n) * p.C + c] = sc;
+    p.ss[(size_t)(2 * n + 1) * p.C + c] = p.beta[c] - (float)mean * sc;
 }
 
 int launch_stats_finalize(const StatsFinalizeParams &p, int N, hipStream_t st) {

@@ -73,9 +73,9 @@ bool make_src(SrcHolder &h, const float *x, int n, int c, size_t vox, const floa
         if (!h.ss.alloc((size_t)n * cp * 8)) return false;
         StatsFinalizeParams q{};
         q.stats = h.stats.as<double>(); q.gamma = h.gamma.as<float>(); q.beta = h.beta.as<float>();
-        q.ss = h.ss.as<float2>(); q.C = cp; q.inv_count = 1.f / (float)vox; q.eps = 1e-5f;
+        q.ss = h.ss.as<float>(); q.C = cp; q.inv_count = 1.f / (float)vox; q.eps = 1e-5f;
         if (launch_stats_finalize(q, n, 0) != 0) return false;
-        h.d.ss = h.ss.as<float2>();
+        h.d.ss = h.ss.as<float>();
         h.d.slope = slope;
     }
     return true;
