@@ -806,7 +806,7 @@ static int launch_pipe(ConvParams p, hipStream_t st) {
 //     runs on the matrix cores; one barrier per item;
 //   * InstanceNorm statistics are kept in registers across the tiles of one
 //     batch item and flushed with one set of atomics per workgroup.
-template <int NB, int MB>
+template <int NB, int MB, bool WRES>
 __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams p, const int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -822,9 +822,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
     const int abytes = (ID * IH * PWp * 32 + 1023) & ~1023;
     const int cb0 = blockIdx.y * NB;
 
+    // WRES: all weight fragments of the cout group stay in LDS, halo tile double buffered (one barrier per
+    // item).  !WRES: the weights of one chunk travel with the halo prefetch, single buffers, two barriers.
+    constexpr int NBUF = WRES ? 2 : 1;
+    constexpr int WPF = WRES ? 1 : (NB * 14 * 64 + 255) / 256;
     char *sA0 = smem;
-    char *sW = smem + 2 * abytes;                                    // [NB][TS][64 lanes][16 B]
-    int *sTap = (int *)(sW + NB * TS * 1024);
+    char *sW = smem + NBUF * abytes;                                 // [NB][TS or ksteps][64 lanes][16 B]
+    int *sTap = (int *)(sW + NB * (WRES ? TS : p.ksteps) * 1024);
     double *sRed = (double *)(sTap + 64);                             // [4 waves][NB*16][2]
 
     // contiguous tile range of this workgroup; consecutive ranges share an XCD
@@ -838,10 +842,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
     }
     if (t_begin >= t_end) return;
 
-    // ---- one-time set-up: weights -> LDS, tap offsets, this thread's halo coordinates
-    for (int idx = tid; idx < NB * TS * 64; idx += 256) {
-        const int nb = idx / (TS * 64), r = idx - nb * (TS * 64);
-        ((uint4 *)sW)[idx] = ((const uint4 *)(p.wpk + (size_t)(cb0 + nb) * TS * 512))[r];
+    // ---- one-time set-up: weights -> LDS (WRES), tap offsets, this thread's halo coordinates
+    if (WRES) {
+        for (int idx = tid; idx < NB * TS * 64; idx += 256) {
+            const int nb = idx / (TS * 64), r = idx - nb * (TS * 64);
+            ((uint4 *)sW)[idx] = ((const uint4 *)(p.wpk + (size_t)(cb0 + nb) * TS * 512))[r];
+        }
+    }
+    const int per_nb = p.ksteps * 64, wtotal = NB * per_nb;
+    f16x8 wr[WPF];
+    int wofs[WPF];
+#pragma unroll
+    for (int u = 0; u < WPF; ++u) {
+        const int idx = tid + u * 256;
+        const int idc = idx < wtotal ? idx : wtotal - 1;
+        const int nb = idc / per_nb, r = idc - nb * per_nb;
+        wofs[u] = (cb0 + nb) * p.chunks * per_nb + r;
     }
     if (tid < 2 * p.ksteps) {
         int off = 0, par = 0;
@@ -854,14 +870,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
         sTap[tid * 2 + 1] = off + 16 * (1 - par);
     }
     const int cg = tid & 1;
-    int rel[PF], ldso[PF];
+    int rel[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const int idx = tid + u * 256;
         const int v = idx >> 1;
         const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
         rel[u] = idx < IVOX * 2 ? (zd << 16) | (zh << 8) | zw : -1;
-        ldso[u] = ((zd * IH + zh) * PWp + zw) * 32 + ((cg ^ (swz & zh & 1)) * 16);
     }
     int base[MB];
 #pragma unroll
@@ -874,13 +889,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
 
     f32x4 acc[MB][NB];
     // statistics: fp32 only WITHIN one tile (same grouping as the one-tile-per-workgroup kernels), double
-    // across tiles - sums of fp16-valued numbers in double are exact, so the result does not depend on
-    // how tiles are distributed over workgroups
-    double s1[NB][4], s2[NB][4];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { s1[nb][j] = 0.0; s2[nb][j] = 0.0; }
+    // across tiles - sums of fp16-valued numbers in double are exact, so the result does not depend on how
+    // tiles are distributed over workgroups.  The double accumulators live in LDS (one slot per wave).
+    for (int i = tid; i < 4 * NB * 16 * 2; i += 256) sRed[i] = 0.0;
 
     float4 bv[NB];                                                    // bias of this lane's 4 channels per cout block
 #pragma unroll
@@ -916,6 +927,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
 #pragma unroll
         for (int u = 0; u < PF; ++u)                        // unconditional: branches around loads make hipcc drain vmcnt
             xr[u] = *(const f16x8 *)(sp + (size_t)(offv[u] >= 0 ? offv[u] : 0) * sC);
+        if (!WRES) {
+#pragma unroll
+            for (int u = 0; u < WPF; ++u) wr[u] = ((const f16x8 *)p.wpk)[wofs[u] + ch * per_nb];
+        }
         slope_next = p.src[s].slope;
         if (p.src[s].ss) {
             const float *q4 = p.src[s].ss + (size_t)(2 * n) * sC + c_loc;
@@ -942,34 +957,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
             }
-            *(f16x8 *)(dst + ldso[u]) = o;
+            const int zd = rel[u] >> 16, zh = (rel[u] >> 8) & 255, zw = rel[u] & 255;
+            *(f16x8 *)(dst + ((zd * IH + zh) * PWp + zw) * 32 + ((cg ^ (swz & zh & 1)) * 16)) = o;
+        }
+        if (!WRES) {
+#pragma unroll
+            for (int u = 0; u < WPF; ++u) {
+                const int idx = tid + u * 256;
+                if (idx < wtotal) ((f16x8 *)sW)[idx] = wr[u];
+            }
         }
     };
     auto flush_stats = [&](int n) {
         if (!p.stats_out) return;
-        const int q = lane >> 4, r = lane & 15;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) {
-                    s1[nb][j] += __shfl_xor(s1[nb][j], m, 64);
-                    s2[nb][j] += __shfl_xor(s2[nb][j], m, 64);
-                }
-                if (r == 0) {
-                    const int c = nb * 16 + q * 4 + j;
-                    sRed[(wave * NB * 16 + c) * 2] = s1[nb][j];
-                    sRed[(wave * NB * 16 + c) * 2 + 1] = s2[nb][j];
-                }
-                s1[nb][j] = 0.0; s2[nb][j] = 0.0;
-            }
         __syncthreads();
         if (tid < NB * 16 * 2) {
             const int c = tid >> 1, which = tid & 1;
             double v = 0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += sRed[(w * NB * 16 + c) * 2 + which];
+            for (int w = 0; w < 4; ++w) { v += sRed[(w * NB * 16 + c) * 2 + which]; sRed[(w * NB * 16 + c) * 2 + which] = 0.0; }
             unsafeAtomicAdd(p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout
                                            + cb0 * 16 + c) * 2 + which, v);
         }
@@ -1001,7 +1007,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
             } else {
                 issue(n_cur, ch + 1);
             }
-            const char *sA = sA0 + buf * abytes;
+            const char *sA = sA0 + (WRES ? buf * abytes : 0);
             for (int ks = 0; ks < p.ksteps; ++ks) {
                 const int toff = sTap[(2 * ks + (lane >> 5)) * 2 + kgp];
                 f16x8 xf[MB];
@@ -1009,7 +1015,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
                 for (int mb = 0; mb < MB; ++mb) xf[mb] = *(const f16x8 *)(sA + base[mb] + toff);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const f16x8 wf = *(const f16x8 *)(sW + ((size_t)(nb * TS + ch * p.ksteps + ks) * 64 + lane) * 16);
+                    const f16x8 wf = *(const f16x8 *)(sW + ((size_t)(WRES ? nb * TS + ch * p.ksteps + ks : nb * p.ksteps + ks) * 64 + lane) * 16);
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb)
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[mb], acc[mb][nb], 0, 0, 0);
@@ -1023,12 +1029,23 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
                 tile_epilogue<NB, MB>(p, acc, bv, n_cur, od0, oh0, ow0, cb0, wave, lane, t1, t2);
+                if (p.stats_out) {
+                    const int q = lane >> 4;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
+                    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { s1[nb][j] += (double)t1[nb][j]; s2[nb][j] += (double)t2[nb][j]; }
+                        for (int j = 0; j < 4; ++j) {
+                            const float sa = row16_sum(t1[nb][j]), sb = row16_sum(t2[nb][j]);
+                            if ((lane & 15) == 0) {                  // one lane per (wave, channel): no atomics needed
+                                double *slot = sRed + (wave * NB * 16 + nb * 16 + q * 4 + j) * 2;
+                                slot[0] += (double)sa;
+                                slot[1] += (double)sb;
+                            }
+                        }
+                }
             }
-            commit(sA0 + (buf ^ 1) * abytes);
+            if (!WRES) __syncthreads();                          // single buffers: everybody is done reading
+            commit(sA0 + (WRES ? (buf ^ 1) * abytes : 0));
             __syncthreads();
             buf ^= 1;
         }
@@ -1037,29 +1054,29 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
     }
 }
 
-static size_t persist_lds_bytes(const ConvParams &p, int nb, int mb) {
+static size_t persist_lds_bytes(const ConvParams &p, int nb, int mb, bool wres) {
     const int ID = mb - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
-    return 2 * (size_t)((ID * IH * lds_pitch(IW) * 32 + 1023) & ~1023) + (size_t)nb * p.chunks * p.ksteps * 1024 + 256 +
-           (size_t)4 * nb * 16 * 2 * 8;
+    const size_t ab = (size_t)((ID * IH * lds_pitch(IW) * 32 + 1023) & ~1023);
+    return (wres ? 2 : 1) * ab + (size_t)nb * (wres ? p.chunks : 1) * p.ksteps * 1024 + 256 + (size_t)4 * nb * 16 * 2 * 8;
 }
 
-template <int NB, int MB>
+template <int NB, int MB, bool WRES>
 static int launch_persist(ConvParams p, int wgs_per_cu, hipStream_t st) {
     p.tile_d = MB;
     p.tiles_d = (p.Do + MB - 1) / MB;
     p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
     p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
     const int total = p.N * p.tiles_d * p.tiles_h * p.tiles_w;
-    const size_t lds = persist_lds_bytes(p, NB, MB);
+    const size_t lds = persist_lds_bytes(p, NB, MB, WRES);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)conv3d_persist_kernel<NB, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv3d_persist_kernel<NB, MB, WRES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     int gx = 256 * wgs_per_cu;
     if (gx > total) gx = total;
     dim3 grid(gx, (p.Cout / 16) / NB);
-    hipLaunchKernelGGL((conv3d_persist_kernel<NB, MB>), grid, dim3(256), lds, st, p, total);
+    hipLaunchKernelGGL((conv3d_persist_kernel<NB, MB, WRES>), grid, dim3(256), lds, st, p, total);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -1124,16 +1141,25 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
         nb = cand[pick][0];
         const int mbsel = cand[pick][1];
         static const bool no_persist = getenv("FNN_CONV_NO_PERSIST") != nullptr;
-        if (!no_persist && nb <= 2) {
-            // persistent variant: many tiles per workgroup and all weights of the cout group fit in LDS
+        static const int persist_max_nb = getenv("FNN_PERSIST_MAX_NB") ? atoi(getenv("FNN_PERSIST_MAX_NB")) : 1;   // A-B aid
+        if (!no_persist && p.ksteps <= 14 && nb <= persist_max_nb) {
+            // persistent variants: a workgroup walks a range of tiles and prefetches across tile boundaries.
+            // Weights resident in LDS when the whole cout group fits next to a double-buffered halo tile with
+            // 2 workgroups per CU, otherwise they travel with the prefetch chunk by chunk.
             for (int mb = mbsel; mb >= 4; mb -= 4) {
                 const long long tiles = (long long)plan_n * ((p.Do + mb - 1) / mb) * p.tiles_h * p.tiles_w;
-                const size_t lds = persist_lds_bytes(p, nb, mb);
-                const int per_cu = (int)((160 * 1024) / lds);
-                if (per_cu < 2 || tiles < 256LL * 2 * 4) continue;
-                const int wpc = per_cu > 3 ? 3 : per_cu;
-                if (nb == 1) return mb == 8 ? launch_persist<1, 8>(p, wpc, st) : launch_persist<1, 4>(p, wpc, st);
-                return mb == 8 ? launch_persist<2, 8>(p, wpc, st) : launch_persist<2, 4>(p, wpc, st);
+                if (tiles < 256LL * 2 * 4) continue;
+                for (int wres = 1; wres >= 0; --wres) {
+                    const size_t lds = persist_lds_bytes(p, nb, mb, wres != 0);
+                    const int per_cu = (int)((160 * 1024) / lds);
+                    if (per_cu < 2) continue;
+                    const int wpc = per_cu > 3 ? 3 : per_cu;
+#define FNN_PERSIST(NBv, MBv) (wres ? launch_persist<NBv, MBv, true>(p, wpc, st) : launch_persist<NBv, MBv, false>(p, wpc, st))
+                    if (nb == 1) return mb == 8 ? FNN_PERSIST(1, 8) : FNN_PERSIST(1, 4);
+                    if (nb == 2) return mb == 8 ? FNN_PERSIST(2, 8) : FNN_PERSIST(2, 4);
+                    if (mb == 4) return FNN_PERSIST(4, 4);
+#undef FNN_PERSIST
+                }
             }
         }
         static const bool stream_w = getenv("FNN_CONV_STREAMW") != nullptr;   // A-B aid: weights streamed from L2
@@ -1157,12 +1183,15 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
 // ----------------------------------------------------------------------------
 // stem conv: fp32 volume window -> raw fp16 + statistics
 // ----------------------------------------------------------------------------
-// One thread = one output voxel x 16 output channels, fp32 FMA.  The conv's
-// zero padding is at the PATCH border (each patch is an independent network
-// input), not at the volume border.
+// fp32 FMA (1..8 input channels: no MFMA shape fits).  Workgroup = 16 x 8 x 8 output voxels x 16 output
+// channels; a thread owns one (h, w) column and walks 4 depth slices, so the statistics' cross-lane
+// reduction is paid once per 4 voxels (it dominated the one-voxel-per-thread version: 192 ds_bpermute per
+// voxel).  The conv's zero padding is at the PATCH border (each patch is an independent network input),
+// not at the volume border; mirroring flips the window read.
+#define STEM_TD 16
 __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int t = blockIdx.x;
     const int tw = t % p.tiles_w; t /= p.tiles_w;
     const int th = t % p.tiles_h; t /= p.tiles_h;
@@ -1171,99 +1200,111 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
     const int cb = blockIdx.y;                       // block of 16 output channels
 
     const int pd = (p.kd - 1) / 2, ph = (p.kh - 1) / 2, pw = (p.kw - 1) / 2;
-    const int ID = FNN_TILE_D - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
+    const int ID = STEM_TD - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
     const int IVOX = ID * IH * IW;
     const int T = p.kd * p.kh * p.kw;
 
     float *sIn = (float *)smem;                      // [C][IVOX]
     float *sW = sIn + ((p.C * IVOX + 3) & ~3);       // [C][T][16]
-    float *sRed = sW + p.C * T * 16;                 // [4][16][2]
+    float *sRed = sW + p.C * T * 16;                 // [16 rows][16][2]
 
     const int ox = p.origins[n * 3 + 0], oy = p.origins[n * 3 + 1], oz = p.origins[n * 3 + 2];
-    const int d0 = td * FNN_TILE_D - pd, h0 = th * FNN_TILE_H - ph, w0 = tw * FNN_TILE_W - pw;
-    for (int idx = tid; idx < p.C * IVOX; idx += 256) {
-        const int c = idx / IVOX, v = idx - c * IVOX;
-        const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
-        int d = d0 + zd, h = h0 + zh, w = w0 + zw;
-        float val = 0.f;
-        if (d >= 0 && d < p.PD && h >= 0 && h < p.PH && w >= 0 && w < p.PW) {
+    const int d0 = td * STEM_TD - pd, h0 = th * FNN_TILE_H - ph, w0 = tw * FNN_TILE_W - pw;
+    const float rcp_iw = 1.0f / (float)IW, rcp_ih = 1.0f / (float)IH;
+    const float *voln = p.vol + (size_t)n * p.vol_batch_stride;
+    for (int c = 0; c < p.C; ++c)
+        for (int v = tid; v < IVOX; v += 256) {
+            const int row = small_div(v, IW, rcp_iw), zw = v - row * IW;
+            const int zd = small_div(row, IH, rcp_ih), zh = row - zd * IH;
+            int d = d0 + zd, h = h0 + zh, w = w0 + zw;
+            const bool ok = d >= 0 && d < p.PD && h >= 0 && h < p.PH && w >= 0 && w < p.PW;
             if (p.flip_d) d = p.PD - 1 - d;
             if (p.flip_h) h = p.PH - 1 - h;
             if (p.flip_w) w = p.PW - 1 - w;
-            val = p.vol[(size_t)n * p.vol_batch_stride + (((size_t)c * p.X + (ox + d)) * p.Y + (oy + h)) * p.Z + (oz + w)];
+            const float val = voln[(((size_t)c * p.X + (ox + (ok ? d : 0))) * p.Y + (oy + (ok ? h : 0))) * p.Z + (oz + (ok ? w : 0))];
+            sIn[c * IVOX + v] = ok ? val : 0.f;
         }
-        sIn[idx] = val;
-    }
-    for (int idx = tid; idx < p.C * T * 16; idx += 256) {
-        const int co = idx & 15, ct = idx >> 4;
-        sW[idx] = p.w[(size_t)ct * p.Cout + cb * 16 + co];
-    }
+    for (int idx = tid; idx < p.C * T * 16; idx += 256) sW[idx] = p.w[(size_t)(idx >> 4) * p.Cout + cb * 16 + (idx & 15)];
+    float bias[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bias[j] = p.bias[cb * 16 + j];
     __syncthreads();
 
-    const int ow_l = tid & 7, oh_l = (tid >> 3) & 7, od_l = tid >> 6;
-    float acc[16];
+    const int ow_l = lane & 7, oh_l = lane >> 3;
+    const int oh = th * FNN_TILE_H + oh_l, ow = tw * FNN_TILE_W + ow_l;
+    float t1[16], t2[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    for (int c = 0; c < p.C; ++c) {
-        for (int a = 0; a < p.kd; ++a)
-            for (int b = 0; b < p.kh; ++b)
-                for (int e = 0; e < p.kw; ++e) {
-                    const float x = sIn[c * IVOX + ((od_l + a) * IH + (oh_l + b)) * IW + (ow_l + e)];
-                    const float4 *wv = (const float4 *)(sW + ((c * T) + (a * p.kh + b) * p.kw + e) * 16);
+    for (int j = 0; j < 16; ++j) { t1[j] = 0.f; t2[j] = 0.f; }
+    for (int dd = 0; dd < 4; ++dd) {
+        const int od_l = wave * 4 + dd;
+        const int od = td * STEM_TD + od_l;
+        float acc[16];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 w4 = wv[g];
-                        acc[4 * g + 0] += x * w4.x; acc[4 * g + 1] += x * w4.y;
-                        acc[4 * g + 2] += x * w4.z; acc[4 * g + 3] += x * w4.w;
+        for (int j = 0; j < 16; ++j) acc[j] = bias[j];
+        for (int c = 0; c < p.C; ++c)
+            for (int a = 0; a < p.kd; ++a)
+                for (int b = 0; b < p.kh; ++b)
+                    for (int e = 0; e < p.kw; ++e) {
+                        const float x = sIn[c * IVOX + ((od_l + a) * IH + (oh_l + b)) * IW + (ow_l + e)];
+                        const float4 *wv = (const float4 *)(sW + ((c * T) + (a * p.kh + b) * p.kw + e) * 16);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 w4 = wv[g];
+                            acc[4 * g + 0] = fmaf(x, w4.x, acc[4 * g + 0]); acc[4 * g + 1] = fmaf(x, w4.y, acc[4 * g + 1]);
+                            acc[4 * g + 2] = fmaf(x, w4.z, acc[4 * g + 2]); acc[4 * g + 3] = fmaf(x, w4.w, acc[4 * g + 3]);
+                        }
                     }
-                }
-    }
-    const int od = td * FNN_TILE_D + od_l, oh = th * FNN_TILE_H + oh_l, ow = tw * FNN_TILE_W + ow_l;
-    const bool ok = od < p.PD && oh < p.PH && ow < p.PW;
-    f16x8 o0, o1;
-    float v1[16], v2[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const f16 hv = (f16)(acc[j] + p.bias[cb * 16 + j]);
-        if (j < 8) o0[j] = hv; else o1[j - 8] = hv;
-        const float f = ok ? (float)hv : 0.f;
-        v1[j] = f; v2[j] = f * f;
-    }
-    if (ok) {
-        f16 *dst = p.out + ((((size_t)n * p.PD + od) * p.PH + oh) * p.PW + ow) * p.Cout + cb * 16;
-        *(f16x8 *)dst = o0;
-        *(f16x8 *)(dst + 8) = o1;
-    }
-    if (p.stats_out) {
-        const int lane = tid & 63, wave = tid >> 6;
+        const bool ok = od < p.PD && oh < p.PH && ow < p.PW;
+        f16x8 o0, o1;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) {
-                v1[j] += __shfl_xor(v1[j], m, 64);
-                v2[j] += __shfl_xor(v2[j], m, 64);
-            }
+            const f16 hv = (f16)acc[j];
+            if (j < 8) o0[j] = hv; else o1[j - 8] = hv;
+            const float f = ok ? (float)hv : 0.f;
+            t1[j] += f;
+            t2[j] = fmaf(f, f, t2[j]);
         }
-        if (lane == 0) {
+        if (ok) {
+            f16 *dst = p.out + ((((size_t)n * p.PD + od) * p.PH + oh) * p.PW + ow) * p.Cout + cb * 16;
+            *(f16x8 *)dst = o0;
+            *(f16x8 *)(dst + 8) = o1;
+        }
+    }
+    if (p.stats_out) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { sRed[(wave * 16 + j) * 2] = v1[j]; sRed[(wave * 16 + j) * 2 + 1] = v2[j]; }
+        for (int j = 0; j < 16; ++j) {
+            const float a = row16_sum(t1[j]), b = row16_sum(t2[j]);
+            if ((lane & 15) == 0) {
+                sRed[((wave * 4 + (lane >> 4)) * 16 + j) * 2] = a;
+                sRed[((wave * 4 + (lane >> 4)) * 16 + j) * 2 + 1] = b;
+            }
         }
         __syncthreads();
         if (tid < 32) {
             const int c = tid >> 1, which = tid & 1;
             double v = 0;
-            for (int w = 0; w < 4; ++w) v += (double)sRed[(w * 16 + c) * 2 + which];
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) v += (double)sRed[(rr * 16 + c) * 2 + which];
             unsafeAtomicAdd(p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout
                                            + cb * 16 + c) * 2 + which, v);
         }
     }
 }
 
-int launch_stem(const StemParams &p, int N, hipStream_t st) {
-    const int ID = FNN_TILE_D - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
+int launch_stem(const StemParams &p_in, int N, hipStream_t st) {
+    StemParams p = p_in;
+    p.tiles_d = (p.PD + STEM_TD - 1) / STEM_TD;
+    p.tiles_h = (p.PH + FNN_TILE_H - 1) / FNN_TILE_H;
+    p.tiles_w = (p.PW + FNN_TILE_W - 1) / FNN_TILE_W;
+    const int ID = STEM_TD - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
     const int IVOX = ID * IH * IW, T = p.kd * p.kh * p.kw;
-    const size_t lds = (size_t)((p.C * IVOX + 3) & ~3) * 4 + (size_t)p.C * T * 16 * 4 + 4 * 16 * 2 * 4;
-    if (lds > 64 * 1024) return -1;
+    const size_t lds = (size_t)((p.C * IVOX + 3) & ~3) * 4 + (size_t)p.C * T * 16 * 4 + 16 * 16 * 2 * 4;
+    if (lds > 160 * 1024) return -1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)stem_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
     dim3 grid(N * p.tiles_d * p.tiles_h * p.tiles_w, p.Cout / 16);
     hipLaunchKernelGGL(stem_conv_kernel, grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -65,9 +65,11 @@ static __device__ __forceinline__ f16x8 load_act_frag(const SrcDesc &s, size_t v
 // ----------------------------------------------------------------------------
 // transposed conv, kernel = stride: one GEMM per kernel tap
 //   D[cout, voxel] = sum_cin W_tap[cout, cin] * X[cin, voxel]
-// grid.x = N * ceil(vox / 256), grid.y = taps * (nblk / NBT); wave = 64 voxels.
+// A wave owns 64 input voxels (4 MFMA column blocks) and produces TG taps x NBT cout blocks for them:
+// the activation fragments are loaded (and normalised) once and reused for every tap of the group.
+// grid.x = N * ceil(vox / 256), grid.y = (taps / TG) * (nblk / NBT).
 // ----------------------------------------------------------------------------
-template <int NBT>
+template <int NBT, int TG>
 __global__ __launch_bounds__(256) void tconv_mfma_kernel(const TconvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *sSS = (float2 *)smem;
@@ -77,53 +79,68 @@ __global__ __launch_bounds__(256) void tconv_mfma_kernel(const TconvParams p) {
     const int n = blockIdx.x / wg_per_n;
     const int v0 = (blockIdx.x - n * wg_per_n) * 256 + wave * 64;
     const int groups = p.nblk / NBT;
-    const int tap = blockIdx.y / groups;
-    const int cb0 = (blockIdx.y - tap * groups) * NBT;
+    const int tap0 = (blockIdx.y / groups) * TG;
+    const int cb0 = (blockIdx.y - (blockIdx.y / groups) * groups) * NBT;
 
     load_scale_shift(p.src, n, sSS, tid, 256);
     __syncthreads();
+    if (v0 >= vox_in) return;
 
-    f32x4 acc[4][NBT];
+    f32x4 acc[4][TG][NBT];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < NBT; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int tg = 0; tg < TG; ++tg)
+#pragma unroll
+            for (int nb = 0; nb < NBT; ++nb) acc[mb][tg][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int r = lane & 15, q = lane >> 4;
     for (int ks = 0; ks < p.ksteps; ++ks) {
+        f16x8 wf[TG][NBT];
+#pragma unroll
+        for (int tg = 0; tg < TG; ++tg)
+#pragma unroll
+            for (int nb = 0; nb < NBT; ++nb)
+                wf[tg][nb] = *(const f16x8 *)(p.wpk + ((((size_t)(tap0 + tg) * p.nblk + cb0 + nb) * p.ksteps + ks) * 64 + lane) * 8);
         f16x8 xf[4];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             const int v = v0 + mb * 16 + r;
-            xf[mb] = load_act_frag(p.src, (size_t)n * vox_in + v, v < vox_in, ks * 32 + q * 8, sSS);
+            xf[mb] = load_act_frag(p.src, (size_t)n * vox_in + (v < vox_in ? v : vox_in - 1), true, ks * 32 + q * 8, sSS);
         }
 #pragma unroll
-        for (int nb = 0; nb < NBT; ++nb) {
-            const f16x8 wf = *(const f16x8 *)(p.wpk + ((((size_t)tap * p.nblk + cb0 + nb) * p.ksteps + ks) * 64 + lane) * 8);
+        for (int tg = 0; tg < TG; ++tg)
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[mb], acc[mb][nb], 0, 0, 0);
-        }
+            for (int nb = 0; nb < NBT; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    acc[mb][tg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tg][nb], xf[mb], acc[mb][tg][nb], 0, 0, 0);
     }
 
-    const int jd = tap / (p.sh * p.sw), jh = (tap / p.sw) % p.sh, jw = tap % p.sw;
     const int Do = p.Di * p.sd, Ho = p.Hi * p.sh, Wo = p.Wi * p.sw;
+    float4 bv[NBT];
+#pragma unroll
+    for (int nb = 0; nb < NBT; ++nb) bv[nb] = *(const float4 *)(p.bias + (cb0 + nb) * 16 + q * 4);
+    f16 *outn = p.out + (size_t)n * Do * Ho * Wo * p.Cout + cb0 * 16 + q * 4;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         const int v = v0 + mb * 16 + r;
         if (v >= vox_in) continue;
         const int iw = v % p.Wi, ih = (v / p.Wi) % p.Hi, id = v / (p.Wi * p.Hi);
-        const size_t ov = (((size_t)n * Do + id * p.sd + jd) * Ho + ih * p.sh + jh) * Wo + iw * p.sw + jw;
 #pragma unroll
-        for (int nb = 0; nb < NBT; ++nb) {
-            const int co = (cb0 + nb) * 16 + q * 4;
-            const float4 bv = *(const float4 *)(p.bias + co);
-            f16x4 o;
-            o[0] = (f16)(acc[mb][nb][0] + bv.x);
-            o[1] = (f16)(acc[mb][nb][1] + bv.y);
-            o[2] = (f16)(acc[mb][nb][2] + bv.z);
-            o[3] = (f16)(acc[mb][nb][3] + bv.w);
-            *(f16x4 *)(p.out + ov * p.Cout + co) = o;
+        for (int tg = 0; tg < TG; ++tg) {
+            const int tap = tap0 + tg;
+            const int jd = tap / (p.sh * p.sw), jh = (tap / p.sw) % p.sh, jw = tap % p.sw;
+            const unsigned ov = (unsigned)((((id * p.sd + jd) * Ho + ih * p.sh + jh) * Wo + iw * p.sw + jw) * p.Cout);
+#pragma unroll
+            for (int nb = 0; nb < NBT; ++nb) {
+                f16x4 o;
+                o[0] = (f16)(acc[mb][tg][nb][0] + bv[nb].x);
+                o[1] = (f16)(acc[mb][tg][nb][1] + bv[nb].y);
+                o[2] = (f16)(acc[mb][tg][nb][2] + bv[nb].z);
+                o[3] = (f16)(acc[mb][tg][nb][3] + bv[nb].w);
+                *(f16x4 *)(outn + ov + nb * 16) = o;
+            }
         }
     }
 }
@@ -132,11 +149,14 @@ int launch_tconv(const TconvParams &p, hipStream_t st) {
     const int vox_in = p.Di * p.Hi * p.Wi;
     const int taps = p.sd * p.sh * p.sw;
     const size_t lds = (size_t)p.src.C * 8;
-    const int nbt = (p.nblk % 4 == 0) ? 4 : (p.nblk % 2 == 0) ? 2 : 1;
-    dim3 grid(p.N * ((vox_in + 255) / 256), taps * (p.nblk / nbt));
-    if (nbt == 4) hipLaunchKernelGGL(tconv_mfma_kernel<4>, grid, dim3(256), lds, st, p);
-    else if (nbt == 2) hipLaunchKernelGGL(tconv_mfma_kernel<2>, grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL(tconv_mfma_kernel<1>, grid, dim3(256), lds, st, p);
+    // accumulators: 4 column blocks x TG taps x NBT cout blocks x 4 registers; keep TG * NBT <= 8
+    const int nbt = (p.nblk % 2 == 0) ? 2 : 1;
+    const int tg = taps >= 4 ? 4 : taps;               // taps is 1, 2, 4 or 8
+    dim3 grid(p.N * ((vox_in + 255) / 256), (taps / tg) * (p.nblk / nbt));
+#define FNN_TCONV(NBTv, TGv) hipLaunchKernelGGL((tconv_mfma_kernel<NBTv, TGv>), grid, dim3(256), lds, st, p)
+    if (nbt == 2) { if (tg == 4) FNN_TCONV(2, 4); else if (tg == 2) FNN_TCONV(2, 2); else FNN_TCONV(2, 1); }
+    else          { if (tg == 4) FNN_TCONV(1, 4); else if (tg == 2) FNN_TCONV(1, 2); else FNN_TCONV(1, 1); }
+#undef FNN_TCONV
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
