@@ -273,6 +273,15 @@ static __device__ __forceinline__ int small_div(int v, int d, float rcp) {
     return q;
 }
 
+// Where a wave's column block `mb` sits in the output tile.  MB = 4 or 8: tile MB x 8 x 8, wave = depth
+// slice (+4), block = two h rows.  MB = 2 (strided convs): tile 2 x 8 x 8, wave = (depth slice, h half).
+template <int MB>
+static __device__ __forceinline__ void mb_coords(int wave, int mb, int r, int &od_l, int &oh_l, int &ow_l) {
+    if (MB == 2) { od_l = wave >> 1; oh_l = 4 * (wave & 1) + 2 * mb + (r >> 3); }
+    else { od_l = wave + 4 * (mb >> 2); oh_l = 2 * (mb & 3) + (r >> 3); }
+    ow_l = r & 7;
+}
+
 // Epilogue of one output tile: bias, round to fp16, channels-last store (4 consecutive channels per
 // lane), and this lane's partial sums of the rounded values (fp32 within the tile).
 template <int NB, int MB>
@@ -283,8 +292,9 @@ static __device__ __forceinline__ void tile_epilogue(const ConvParams &p, const 
     f16 *outn = p.out + (size_t)n * p.Do * p.Ho * p.Wo * p.Cout + cb0 * 16 + q * 4;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-        const int od = od0 + wave + 4 * (mb >> 2);
-        const int oh = oh0 + 2 * (mb & 3) + (r >> 3), ow = ow0 + (r & 7);
+        int od_l, oh_l, ow_l;
+        mb_coords<MB>(wave, mb, r, od_l, oh_l, ow_l);
+        const int od = od0 + od_l, oh = oh0 + oh_l, ow = ow0 + ow_l;
         const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
         const unsigned voff = (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout);
 #pragma unroll
@@ -541,14 +551,13 @@ __global__ __launch_bounds__(256) void conv3d_pipe_kernel(const ConvParams p) {
 // halo elements AND the chunk's weight fragments (registers), the k-loop reads both from LDS, and the
 // LDS image (single buffered: 2 workgroups per CU even for 8x8x8 tiles) is rewritten between two
 // barriers after the MFMAs of chunk c.
-template <int NB, int MB>
+template <int NB, int MB, int PF>
 __global__ __launch_bounds__(256, 2) void conv3d_lds_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     FNN_STAMP_DECL
     FNN_STAMP();                                             // 0: entry
-    constexpr int TD = MB;                                 // 4 waves x (MB / 4) depth slices
-    constexpr int PF = 8;                                  // halo elements (16 B) prefetched per thread
+    constexpr int TD = MB == 2 ? 2 : MB;                   // output tile depth
 
     // XCD-aware, bijective remap (blocks b and b + 8 share an XCD)
     int t;
@@ -564,13 +573,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_lds_kernel(const ConvParams p) 
     const int cb0 = blockIdx.y * NB;
 
     const int od0 = td * TD, oh0 = th * FNN_TILE_H, ow0 = tw * FNN_TILE_W;
-    const int ID = TD - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
+    const int ID = (TD - 1) * p.sd + p.kd, IH = (FNN_TILE_H - 1) * p.sh + p.kh, IW = (FNN_TILE_W - 1) * p.sw + p.kw;
     const int IVOX = ID * IH * IW;
     const int T = p.kd * p.kh * p.kw;
     // LDS image of the halo tile: row pitch PWp voxels, and the two 16-byte channel halves of a voxel are
     // swapped on odd rows (swz) - with PWp = 4 (mod 8) every ds_read_b128 of an MFMA operand is then
     // bank-conflict free (the dense 10-voxel pitch was 2-way conflicted on every read)
-    const int swz = (IW & 7) != 0;
+    const int swz = p.sw == 1 && (IW & 7) != 0;
     const int PWp = swz ? ((IW + 3) & ~7) + 4 : IW;
     const int abytes = (ID * IH * PWp * 32 + 1023) & ~1023;
 
@@ -596,8 +605,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_lds_kernel(const ConvParams p) 
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int r = lane & 15;
-        const int od_l = wave + 4 * (mb >> 2), oh_l = 2 * (mb & 3) + (r >> 3), ow_l = r & 7;
-        base[mb] = ((od_l * IH + oh_l) * PWp + ow_l) * 32;
+        int od_l, oh_l, ow_l;
+        mb_coords<MB>(wave, mb, r, od_l, oh_l, ow_l);
+        base[mb] = ((od_l * p.sd * IH + oh_l * p.sh) * PWp + ow_l * p.sw) * 32;
     }
     const int kgp = ((lane >> 4) & 1) ^ (swz & ((lane & 15) >> 3));     // channel half after the row swizzle
 
@@ -629,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_lds_kernel(const ConvParams p) 
     int offv[PF];                                           // global voxel index of this thread's halo elements
     int ldso[PF];                                           // and where they go in the LDS image
     {
-        const int id0 = od0 - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
+        const int id0 = od0 * p.sd - p.pd, ih0 = oh0 * p.sh - p.ph, iw0 = ow0 * p.sw - p.pw;
         const float rcp_iw = 1.0f / (float)IW, rcp_ih = 1.0f / (float)IH;
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
@@ -745,27 +755,30 @@ __global__ __launch_bounds__(256, 2) void conv3d_lds_kernel(const ConvParams p) 
 }
 
 static size_t ldsk_lds_bytes(const ConvParams &p, int nb, int mb) {
-    const int ID = mb - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
-    size_t b = (size_t)((ID * IH * lds_pitch(IW) * 32 + 1023) & ~1023) + (size_t)nb * p.ksteps * 1024;
+    const int td = mb == 2 ? 2 : mb;
+    const int ID = (td - 1) * p.sd + p.kd, IH = (FNN_TILE_H - 1) * p.sh + p.kh, IW = (FNN_TILE_W - 1) * p.sw + p.kw;
+    const int pitch = p.sw == 1 ? lds_pitch(IW) : IW;
+    size_t b = (size_t)((ID * IH * pitch * 32 + 1023) & ~1023) + (size_t)nb * p.ksteps * 1024;
     b += 4 * p.ksteps * 4 + 64;
     const size_t red = (size_t)4 * nb * 16 * 2 * 4;
     return b > red ? b : red;
 }
 
-template <int NB, int MB>
+template <int NB, int MB, int PF = 8>
 static int launch_ldsk(ConvParams p, hipStream_t st) {
-    p.tile_d = MB;
-    p.tiles_d = (p.Do + MB - 1) / MB;
+    constexpr int TD = MB == 2 ? 2 : MB;
+    p.tile_d = TD;
+    p.tiles_d = (p.Do + TD - 1) / TD;
     p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
     p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
     const size_t lds = ldsk_lds_bytes(p, NB, MB);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)conv3d_lds_kernel<NB, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv3d_lds_kernel<NB, MB, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
-    hipLaunchKernelGGL((conv3d_lds_kernel<NB, MB>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv3d_lds_kernel<NB, MB, PF>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -1171,6 +1184,16 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
         if (nb == 1) return mbsel == 8 ? launch_pipe<1, 8>(p, st) : launch_pipe<1, 4>(p, st);
         if (nb == 2) return mbsel == 8 ? launch_pipe<2, 8>(p, st) : launch_pipe<2, 4>(p, st);
         return launch_pipe<4, 4>(p, st);
+    }
+    static const bool strided_v1 = getenv("FNN_CONV_STRIDED_V1") != nullptr;   // A-B aid
+    if (!force_v1 && !strided_v1 && p.ksteps <= 14) {
+        // strided convs: 2 x 8 x 8 output tile, up to 16 halo elements per thread, <= 2 cout blocks
+        const int nbs = (p.Cout / 16) % 2 == 0 ? 2 : 1;
+        const int ID = (2 - 1) * p.sd + p.kd, IH = (FNN_TILE_H - 1) * p.sh + p.kh, IW = (FNN_TILE_W - 1) * p.sw + p.kw;
+        if (ID * IH * IW * 2 <= 16 * 256 && ldsk_lds_bytes(p, nbs, 2) <= 80 * 1024) {
+            if (ID * IH * IW * 2 <= 8 * 256) return nbs == 2 ? launch_ldsk<2, 2, 8>(p, st) : launch_ldsk<1, 2, 8>(p, st);
+            return nbs == 2 ? launch_ldsk<2, 2, 16>(p, st) : launch_ldsk<1, 2, 16>(p, st);
+        }
     }
     if (nb == 4) {
         if (conv3d_lds_bytes(p, 4) <= 160 * 1024) return launch_conv_nb<4>(p, st);
