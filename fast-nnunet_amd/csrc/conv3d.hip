@@ -587,6 +587,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_lds_kernel(const ConvParams p) 
     char *sA0 = smem;
     char *sW = smem + abytes;                                // [NB][ksteps][64 lanes][16 B] of the current chunk
     int *sTap = (int *)(sW + NB * p.ksteps * 1024);
+    float *sBias = (float *)(sTap + 4 * p.ksteps + 4);        // [NB * 16]: read in the epilogue (no global round trip there)
 
     {
         if (tid < 2 * p.ksteps) {
@@ -599,6 +600,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_lds_kernel(const ConvParams p) 
             sTap[tid * 2] = off + 16 * par;                  // column for lanes with kgp = 0
             sTap[tid * 2 + 1] = off + 16 * (1 - par);        // kgp = 1
         }
+        if (tid >= 64 && tid < 64 + NB * 16) sBias[tid - 64] = p.bias[cb0 * 16 + tid - 64];
     }
 
     int base[MB];
@@ -616,9 +618,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_lds_kernel(const ConvParams p) 
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 bv[NB];                                           // bias of this lane's 4 channels per cout block
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const float4 *)(p.bias + (cb0 + nb) * 16 + (lane >> 4) * 4);
 
     const int per_nb = p.ksteps * 64;                        // 16-byte fragments-lanes per cout block per chunk
     const int wtotal = NB * per_nb;
@@ -628,8 +627,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_lds_kernel(const ConvParams p) 
     for (int u = 0; u < WPF; ++u) {
         const int idx = tid + u * 256;
         const int idc = idx < wtotal ? idx : wtotal - 1;
-        const int nb = idc / per_nb, r = idc - nb * per_nb;
-        wofs[u] = (cb0 + nb) * p.chunks * per_nb + r;
+        const int nb = (idc >= per_nb) + (idc >= 2 * per_nb) + (idc >= 3 * per_nb);      // NB <= 4: no division
+        wofs[u] = (cb0 + nb) * p.chunks * per_nb + idc - nb * per_nb;
     }
     float4 scr[2], shr[2];                                   // 8 scales, 8 shifts of the chunk being prefetched
     float slope_next = 1.f;
@@ -742,6 +741,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_lds_kernel(const ConvParams p) 
 
     // ---- epilogue: bias, fp16 store, statistics
     {
+        float4 bv[NB];                                       // bias of this lane's 4 channels per cout block
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const float4 *)(sBias + nb * 16 + (lane >> 4) * 4);
         float t1[NB][4], t2[NB][4];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -759,7 +761,7 @@ static size_t ldsk_lds_bytes(const ConvParams &p, int nb, int mb) {
     const int ID = (td - 1) * p.sd + p.kd, IH = (FNN_TILE_H - 1) * p.sh + p.kh, IW = (FNN_TILE_W - 1) * p.sw + p.kw;
     const int pitch = p.sw == 1 ? lds_pitch(IW) : IW;
     size_t b = (size_t)((ID * IH * pitch * 32 + 1023) & ~1023) + (size_t)nb * p.ksteps * 1024;
-    b += 4 * p.ksteps * 4 + 64;
+    b += 4 * p.ksteps * 4 + 16 + (size_t)nb * 16 * 4 + 64;
     const size_t red = (size_t)4 * nb * 16 * 2 * 4;
     return b > red ? b : red;
 }
@@ -819,10 +821,11 @@ static int launch_pipe(ConvParams p, hipStream_t st) {
 //     runs on the matrix cores; one barrier per item;
 //   * InstanceNorm statistics are kept in registers across the tiles of one
 //     batch item and flushed with one set of atomics per workgroup.
-template <int NB, int MB, bool WRES>
+template <int NB, int MB, bool WRES, int KS>
 __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams p, const int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    FNN_STAMP_DECL
     constexpr int TD = MB;
     constexpr int PF = 8;
 
@@ -883,13 +886,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
         sTap[tid * 2 + 1] = off + 16 * (1 - par);
     }
     const int cg = tid & 1;
-    int rel[PF];
+    int rel[PF], rvox[PF];                                            // packed halo coords / relative input voxel offset
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const int idx = tid + u * 256;
         const int v = idx >> 1;
         const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
         rel[u] = idx < IVOX * 2 ? (zd << 16) | (zh << 8) | zw : -1;
+        rvox[u] = (zd * p.Hi + zh) * p.Wi + zw;
     }
     int base[MB];
 #pragma unroll
@@ -922,24 +926,38 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
         n = t / p.tiles_d;
         od0 = td * TD; oh0 = th * FNN_TILE_H; ow0 = tw * FNN_TILE_W;
     };
-    auto set_offsets = [&](int n, int od0, int oh0, int ow0) {
+    // consecutive tiles: step the coordinates instead of dividing again (w fastest, then h, d, batch item)
+    auto next_tile = [&](int &n, int &od0, int &oh0, int &ow0) {
+        ow0 += FNN_TILE_W;
+        if (ow0 >= p.tiles_w * FNN_TILE_W) {
+            ow0 = 0; oh0 += FNN_TILE_H;
+            if (oh0 >= p.tiles_h * FNN_TILE_H) {
+                oh0 = 0; od0 += TD;
+                if (od0 >= p.tiles_d * TD) { od0 = 0; ++n; }
+            }
+        }
+    };
+    // offv = voxel index inside batch item n (or -1 for conv padding); the item's base pointer is uniform
+    auto set_offsets = [&](int od0, int oh0, int ow0) {
         const int id0 = od0 - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
+        const int base_vox = (id0 * p.Hi + ih0) * p.Wi + iw0;
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const int gd = id0 + (rel[u] >> 16), gh = ih0 + ((rel[u] >> 8) & 255), gw = iw0 + (rel[u] & 255);
-            const bool ok = rel[u] >= 0 && gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 && gw < p.Wi;
-            offv[u] = ok ? ((n * p.Di + gd) * p.Hi + gh) * p.Wi + gw : -1;
+            const unsigned gd = (unsigned)(id0 + (rel[u] >> 16)), gh = (unsigned)(ih0 + ((rel[u] >> 8) & 255)),
+                           gw = (unsigned)(iw0 + (rel[u] & 255));
+            const bool ok = rel[u] >= 0 && gd < (unsigned)p.Di && gh < (unsigned)p.Hi && gw < (unsigned)p.Wi;
+            offv[u] = ok ? base_vox + rvox[u] : -1;
         }
     };
     auto issue = [&](int n, int ch) {
         const int c_glob = ch * 16;
         const int s = (c_glob < p.src[0].C) ? 0 : 1;
         const int c_loc = c_glob - (s ? p.src[0].C : 0) + cg * 8;
-        const f16 *sp = p.src[s].ptr + c_loc;
         const int sC = p.src[s].C;
+        const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + c_loc);   // uniform base
 #pragma unroll
         for (int u = 0; u < PF; ++u)                        // unconditional: branches around loads make hipcc drain vmcnt
-            xr[u] = *(const f16x8 *)(sp + (size_t)(offv[u] >= 0 ? offv[u] : 0) * sC);
+            xr[u] = *(const f16x8 *)(sp + (unsigned)((offv[u] >= 0 ? offv[u] : 0) * sC * 2));
         if (!WRES) {
 #pragma unroll
             for (int u = 0; u < WPF; ++u) wr[u] = ((const f16x8 *)p.wpk)[wofs[u] + ch * per_nb];
@@ -997,10 +1015,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
 
     int n_cur, od0, oh0, ow0;
     tile_coords(t_begin, n_cur, od0, oh0, ow0);
-    set_offsets(n_cur, od0, oh0, ow0);
+    set_offsets(od0, oh0, ow0);
     issue(n_cur, 0);
     commit(sA0);
     __syncthreads();
+    int toffs[14];                                                    // this lane's tap offset per k-step (KS known);
+    if (KS) {                                                         // read after the barrier that publishes sTap
+#pragma unroll
+        for (int ks = 0; ks < (KS < 14 ? KS : 14); ++ks) toffs[ks] = sTap[(2 * ks + (lane >> 5)) * 2 + kgp];
+    }
 
     int buf = 0;
     for (int t = t_begin; t < t_end; ++t) {
@@ -1012,17 +1035,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
         for (int ch = 0; ch < p.chunks; ++ch) {
             // prefetch the next work item.  The very last item prefetches itself again (a few redundant, cached
             // loads) so that issue / commit sit on an unconditional path: hipcc's waitcnt pass is then exact
+#ifdef FNN_STAMPS
+            const bool stamp_it = t == t_begin + 2 && ch == 0;
+            if (stamp_it) FNN_STAMP();                           // 0: item start
+#endif
             const bool last_chunk = ch + 1 == p.chunks;
             if (last_chunk) {
-                tile_coords(t + 1 < t_end ? t + 1 : t, n_next, nod0, noh0, now0);
-                set_offsets(n_next, nod0, noh0, now0);
+                if (t + 1 < t_end) next_tile(n_next, nod0, noh0, now0);
+                set_offsets(nod0, noh0, now0);
                 issue(n_next, 0);
             } else {
                 issue(n_cur, ch + 1);
             }
+#ifdef FNN_STAMPS
+            if (stamp_it) FNN_STAMP();                           // 1: prefetch issued
+#endif
             const char *sA = sA0 + (WRES ? buf * abytes : 0);
-            for (int ks = 0; ks < p.ksteps; ++ks) {
-                const int toff = sTap[(2 * ks + (lane >> 5)) * 2 + kgp];
+#pragma unroll
+            for (int ks = 0; ks < (KS ? KS : p.ksteps); ++ks) {
+                const int toff = KS ? toffs[ks < 14 ? ks : 0] : sTap[(2 * ks + (lane >> 5)) * 2 + kgp];
                 f16x8 xf[MB];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) xf[mb] = *(const f16x8 *)(sA + base[mb] + toff);
@@ -1034,6 +1065,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[mb], acc[mb][nb], 0, 0, 0);
                 }
             }
+#ifdef FNN_STAMPS
+            if (stamp_it) FNN_STAMP();                           // 2: k-loop done
+#endif
             if (last_chunk) {
                 // epilogue of this tile: bias, fp16 store, statistics (fp32 within the tile, double across tiles)
                 float t1[NB][4], t2[NB][4];
@@ -1057,14 +1091,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
                         }
                 }
             }
+#ifdef FNN_STAMPS
+            if (stamp_it) FNN_STAMP();                           // 3: epilogue done
+#endif
             if (!WRES) __syncthreads();                          // single buffers: everybody is done reading
             commit(sA0 + (WRES ? (buf ^ 1) * abytes : 0));
             __syncthreads();
+#ifdef FNN_STAMPS
+            if (stamp_it) FNN_STAMP();                           // 4: commit + barrier done
+#endif
             buf ^= 1;
         }
         if (n_next != n_cur || t + 1 == t_end) flush_stats(n_cur);
         n_cur = n_next; od0 = nod0; oh0 = noh0; ow0 = now0;
     }
+    FNN_STAMP_FLUSH(p.dbg);
 }
 
 static size_t persist_lds_bytes(const ConvParams &p, int nb, int mb, bool wres) {
@@ -1073,8 +1114,8 @@ static size_t persist_lds_bytes(const ConvParams &p, int nb, int mb, bool wres) 
     return (wres ? 2 : 1) * ab + (size_t)nb * (wres ? p.chunks : 1) * p.ksteps * 1024 + 256 + (size_t)4 * nb * 16 * 2 * 8;
 }
 
-template <int NB, int MB, bool WRES>
-static int launch_persist(ConvParams p, int wgs_per_cu, hipStream_t st) {
+template <int NB, int MB, bool WRES, int KS>
+static int launch_persist_ks(ConvParams p, int wgs_per_cu, hipStream_t st) {
     p.tile_d = MB;
     p.tiles_d = (p.Do + MB - 1) / MB;
     p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
@@ -1083,14 +1124,23 @@ static int launch_persist(ConvParams p, int wgs_per_cu, hipStream_t st) {
     const size_t lds = persist_lds_bytes(p, NB, MB, WRES);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)conv3d_persist_kernel<NB, MB, WRES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv3d_persist_kernel<NB, MB, WRES, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     int gx = 256 * wgs_per_cu;
     if (gx > total) gx = total;
     dim3 grid(gx, (p.Cout / 16) / NB);
-    hipLaunchKernelGGL((conv3d_persist_kernel<NB, MB, WRES>), grid, dim3(256), lds, st, p, total);
+    hipLaunchKernelGGL((conv3d_persist_kernel<NB, MB, WRES, KS>), grid, dim3(256), lds, st, p, total);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int NB, int MB, bool WRES>
+static int launch_persist(const ConvParams &p, int wgs_per_cu, hipStream_t st) {
+    // fully unrolled k-loops for the two common tap counts (9 taps = 5 k-steps, 27 taps = 14); only instantiated
+    // for the thin single-cout-block layers that the persistent kernel is used for
+    if (NB == 1 && p.ksteps == 5) return launch_persist_ks<NB, MB, WRES, (NB == 1 ? 5 : 0)>(p, wgs_per_cu, st);
+    if (NB == 1 && p.ksteps == 14) return launch_persist_ks<NB, MB, WRES, (NB == 1 ? 14 : 0)>(p, wgs_per_cu, st);
+    return launch_persist_ks<NB, MB, WRES, 0>(p, wgs_per_cu, st);
 }
 
 size_t conv3d_lds_bytes(const ConvParams &p, int nb) {
