@@ -274,11 +274,20 @@ def main():
         pr = predictor._engine.profile()
         predictor._engine.set_profiling(False)
         achieved = pr.conv_flops / (pr.conv_ms * 1e-3) / 1e12 if pr.conv_ms > 0 else 0.0
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        if os.path.isfile(tpath) and args.workload == 'bone_turbo_r2' and args.volume == 512 and args.batch == 16:
+            try:                                  # HBM bytes per launch of the same kernel family from separate PMC passes
+                fam = json.load(open(tpath))['families']['conv3d_mfma']
+                traffic, traffic_src = int(fam['bytes_per_launch']), 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, reads x2)'
+            except Exception:
+                pass
         result['roofline'] = {
-            'kernel': 'conv3d_mfma_kernel', 'bound': 'mfma',
+            'kernel': 'conv3d_*_kernel (MFMA conv family: lds / persist / pipe / mfma variants)', 'bound': 'mfma',
             'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
-            'traffic': None,
+            'traffic': traffic, 'traffic_source': traffic_src,
+            'algorithmic_act_bytes_per_patch': int(act_bytes_patch),
             'launches': int(pr.conv_launches),
             'avg_launch_us': round(pr.conv_ms * 1e3 / max(1, pr.conv_launches), 2),
             'flop_per_launch': round(pr.conv_flops / max(1, pr.conv_launches) / 1e9, 3),

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""HBM traffic per kernel family from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+
+    python tools_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json]
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads
+(MI355X_MICROARCH.md, HBM section), so reads are doubled; WRITE_SIZE is exact for 16-byte-per-lane stores and
+uncalibrated for the 8-byte-per-lane channels-last conv stores (stated with the numbers).
+"""
+import collections
+import csv
+import json
+import sys
+
+FAMILIES = {'conv3d_': 'conv3d_mfma', 'stem_conv': 'stem', 'tconv_mfma': 'tconv', 'seg_head': 'seg_head_accumulate',
+            'finalize': 'finalize', 'stats_finalize': 'stats_finalize'}
+
+
+def family(name):
+    for k, v in FAMILIES.items():
+        if name.startswith(k) or name.startswith('void ' + k):
+            return v
+    return 'other'
+
+
+def load(path, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] != counter:
+            continue
+        a = agg[family(r['Kernel_Name'])]
+        a[0] += 1
+        a[1] += float(r['Counter_Value'])
+    return agg
+
+
+fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
+out = {}
+for fam in sorted(set(fetch) | set(write)):
+    n = max(fetch[fam][0], write[fam][0])
+    rd, wr = 2.0 * fetch[fam][1] * 1024, write[fam][1] * 1024
+    out[fam] = {'launches': n, 'read_bytes_per_launch': rd / max(1, n), 'write_bytes_per_launch': wr / max(1, n),
+                'bytes_per_launch': (rd + wr) / max(1, n), 'total_GB': (rd + wr) / 1e9}
+print(json.dumps(out, indent=1))
+if len(sys.argv) > 3:
+    json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), reads x2 per the gfx950 correction; '
+                       'bench.py --steps 1 --warmup 0 on the default workload', 'families': out}, open(sys.argv[3], 'w'), indent=1)
