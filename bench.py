@@ -39,6 +39,7 @@ WORKLOADS = {
     'iso128_r2': ((1.0, 1.0, 1.0), (128, 128, 128), 2, 2),
     'iso128_teacher': ((1.0, 1.0, 1.0), (128, 128, 128), 2, 1),
 }
+# BASELINE configs 4 (teacher, 5 folds) and 5 (ResEnc student, fp8) are parity-test topologies, not bench lines.
 
 
 def plan_topology(spacing, patch, min_edge=4):

@@ -90,30 +90,34 @@ def _count(sd, pattern: str) -> int:
 def spec_from_state_dict(state_dict: Mapping[str, object], patch: Sequence[int], eps: float = 1e-5,
                          slope: float = 0.01) -> ArchSpec:
     sd = canonical_state_dict(state_dict)
-    if any(k.startswith('encoder.stem.') or '.blocks.' in k for k in sd):
-        raise NotImplementedError('ResidualEncoderUNet checkpoints are recognised but the residual-encoder blocks '
-                                  'are not implemented in the HIP engine yet')
+    resenc = any(k.startswith('encoder.stem.') for k in sd)
     n = _count(sd, r'encoder\.stages\.(\d+)\.')
     if n < 2:
-        raise RuntimeError('state dict does not look like a PlainConvUNet (no encoder.stages.*)')
+        raise RuntimeError('state dict does not look like a PlainConvUNet / ResidualEncoderUNet (no encoder.stages.*)')
+    first = (lambda s: f'encoder.stages.{s}.blocks.0.conv1.conv.weight') if resenc else \
+        (lambda s: f'encoder.stages.{s}.0.convs.0.conv.weight')
     feats, kernels, n_enc = [], [], []
     for s in range(n):
-        w = sd[f'encoder.stages.{s}.0.convs.0.conv.weight']
+        w = sd[first(s)]
         if w.ndim != 5:
             raise NotImplementedError('only 3-D (Conv3d) networks are supported')
         feats.append(int(w.shape[0]))
         kernels.append(tuple(int(i) for i in w.shape[2:]))
-        n_enc.append(_count(sd, rf'encoder\.stages\.{s}\.0\.convs\.(\d+)\.'))
+        n_enc.append(_count(sd, rf'encoder\.stages\.{s}\.blocks\.(\d+)\.') if resenc
+                     else _count(sd, rf'encoder\.stages\.{s}\.0\.convs\.(\d+)\.'))
     strides = [(1, 1, 1)] * n
     n_dec = []
     for d in range(n - 1):
         tw = sd[f'decoder.transpconvs.{d}.weight']
         strides[n - 1 - d] = tuple(int(i) for i in tw.shape[2:])
         n_dec.append(_count(sd, rf'decoder\.stages\.{d}\.convs\.(\d+)\.'))
-    in_ch = int(sd['encoder.stages.0.0.convs.0.conv.weight'].shape[1])
+    w0 = sd['encoder.stem.convs.0.conv.weight'] if resenc else sd['encoder.stages.0.0.convs.0.conv.weight']
+    if resenc and (int(w0.shape[0]) != feats[0] or tuple(int(i) for i in w0.shape[2:]) != kernels[0]):
+        raise NotImplementedError('stem with a width / kernel different from stage 0 is not supported')
+    in_ch = int(w0.shape[1])
     heads = int(sd[f'decoder.seg_layers.{n - 2}.weight'].shape[0])
-    return ArchSpec(capi.FNN_NET_PLAIN, in_ch, heads, feats, kernels, strides, n_enc, n_dec,
-                    tuple(int(i) for i in patch), eps, slope)
+    return ArchSpec(capi.FNN_NET_RESENC if resenc else capi.FNN_NET_PLAIN, in_ch, heads, feats, kernels, strides,
+                    n_enc, n_dec, tuple(int(i) for i in patch), eps, slope)
 
 
 def check_against_plans(spec: ArchSpec, arch_kwargs: dict, reduction: Optional[int] = None):
@@ -148,9 +152,25 @@ def weight_blob(spec: ArchSpec, state_dict: Mapping[str, object]) -> np.ndarray:
         parts.append(sd[prefix + '.norm.bias'])
 
     n = spec.n_stages
-    for s in range(n):
-        for i in range(spec.n_conv_enc[s]):
-            conv_block(f'encoder.stages.{s}.0.convs.{i}')
+    if spec.kind == capi.FNN_NET_RESENC:
+        conv_block('encoder.stem.convs.0')
+        cin = spec.features[0]
+        for s in range(n):
+            for b in range(spec.n_conv_enc[s]):
+                pre = f'encoder.stages.{s}.blocks.{b}'
+                conv_block(pre + '.conv1')
+                conv_block(pre + '.conv2')
+                if cin != spec.features[s]:
+                    # skip = Sequential([AvgPool3d if strided], conv1x1 + norm): the projection is the last entry
+                    idx = _count(sd, rf'encoder\.stages\.{s}\.blocks\.{b}\.skip\.(\d+)\.') - 1
+                    parts.append(sd[f'{pre}.skip.{idx}.conv.weight'].reshape(-1))
+                    parts.append(sd[f'{pre}.skip.{idx}.norm.weight'])
+                    parts.append(sd[f'{pre}.skip.{idx}.norm.bias'])
+                cin = spec.features[s]
+    else:
+        for s in range(n):
+            for i in range(spec.n_conv_enc[s]):
+                conv_block(f'encoder.stages.{s}.0.convs.{i}')
     for d in range(n - 1):
         tw = sd[f'decoder.transpconvs.{d}.weight']
         parts.append(tw.reshape(-1))
@@ -166,18 +186,17 @@ def weight_blob(spec: ArchSpec, state_dict: Mapping[str, object]) -> np.ndarray:
 def spec_from_plans(arch_class_name: str, arch_kwargs: dict, in_channels: int, num_heads: int, patch: Sequence[int],
                     reduction: int = 1) -> ArchSpec:
     """Topology from the plans alone (teacher: reduction 1; student: features ``max(f // r, 8)``)."""
-    if 'Residual' in arch_class_name or 'ResEnc' in arch_class_name:
-        raise NotImplementedError('ResidualEncoderUNet is not implemented in the HIP engine yet')
+    resenc = 'Residual' in arch_class_name or 'ResEnc' in arch_class_name
     n = int(arch_kwargs['n_stages'])
     feats = [max(int(f) // reduction, 8) if reduction != 1 else int(f) for f in arch_kwargs['features_per_stage']]
     ks = arch_kwargs['kernel_sizes']
     kernels = [(int(ks),) * 3] * n if isinstance(ks, int) else [
         tuple(int(i) for i in (k[0] if isinstance(k[0], (list, tuple)) else k)) for k in ks]
     strides = [tuple(int(i) for i in s) for s in arch_kwargs['strides']]
-    enc = arch_kwargs['n_conv_per_stage']
+    enc = arch_kwargs['n_blocks_per_stage' if resenc else 'n_conv_per_stage']
     enc = [int(enc)] * n if isinstance(enc, int) else [int(i) for i in enc]
     dec = arch_kwargs['n_conv_per_stage_decoder']
     dec = [int(dec)] * (n - 1) if isinstance(dec, int) else [int(i) for i in dec]
     eps = float((arch_kwargs.get('norm_op_kwargs') or {}).get('eps', 1e-5))
-    return ArchSpec(capi.FNN_NET_PLAIN, in_channels, num_heads, feats, kernels, strides, enc, dec,
-                    tuple(int(i) for i in patch), eps)
+    return ArchSpec(capi.FNN_NET_RESENC if resenc else capi.FNN_NET_PLAIN, in_channels, num_heads, feats, kernels,
+                    strides, enc, dec, tuple(int(i) for i in patch), eps)

@@ -21,14 +21,16 @@ namespace {
 thread_local std::string g_err;
 
 struct Layer {
-    enum Type { STEM, CONV, TCONV } type;
+    enum Type { STEM, CONV, TCONV, POOL, COMBINE } type;
     int n_src = 1;
     int cin_real[2] = {0, 0}, cin_pad[2] = {0, 0};
     int cout_real = 0, cout_pad = 0;
     int k[3] = {1, 1, 1}, s[3] = {1, 1, 1};
     int in_dims[3], out_dims[3];
     int src_layer[2] = {-1, -1};      // producing layer (-1 = the volume)
-    bool has_norm = true;             // a conv's output is normalised by its consumers; a tconv's is not
+    bool has_norm = true;             // a conv's output is normalised by its consumers; a tconv's / pool's / block's is not
+    bool act = true;                  // LeakyReLU after the norm (false: conv2 and the skip projection of a residual block)
+    bool has_bias = true;             // the skip projection of a residual block has no bias
     // offsets
     size_t w_off = 0;                 // halves, packed weights (STEM: floats in fparam)
     size_t bias_off = 0, gamma_off = 0, beta_off = 0;   // floats
@@ -123,7 +125,7 @@ int ensure(fnn_engine *e, void **p, size_t *have, size_t need) {
 // ---------------------------------------------------------------------------
 int build_plan(fnn_engine *e) {
     const fnn_arch_desc &a = e->arch;
-    if (a.kind != FNN_NET_PLAIN) return fail(e, FNN_E_UNSUPPORTED, "only PlainConvUNet topologies are implemented (kind=%d)", a.kind);
+    if (a.kind != FNN_NET_PLAIN && a.kind != FNN_NET_RESENC) return fail(e, FNN_E_UNSUPPORTED, "unknown network kind %d", a.kind);
     if (a.n_stages < 2 || a.n_stages > FNN_MAX_STAGES) return fail(e, FNN_E_INVALID, "n_stages out of range");
     if (a.in_channels < 1 || a.in_channels > 8) return fail(e, FNN_E_UNSUPPORTED, "in_channels must be 1..8");
     if (a.num_heads < 1 || a.num_heads > 256) return fail(e, FNN_E_UNSUPPORTED, "num_heads must be 1..256");
@@ -143,10 +145,11 @@ int build_plan(fnn_engine *e) {
                 return fail(e, FNN_E_INVALID, "patch size %d is not divisible by the pooling of axis %d", a.patch[d], d);
         }
     int64_t blob = 0;
+    bool next_has_bias = true, next_act = true;
     auto add_conv = [&](Layer::Type type, int nsrc, const int cin[2], const int src[2], int cout, const int32_t *k,
                         const int32_t *s, const int *in_d, const int *out_d) {
         Layer L;
-        L.type = type; L.n_src = nsrc;
+        L.type = type; L.n_src = nsrc; L.has_bias = next_has_bias; L.act = next_act;
         int cin_tot = 0;
         for (int i = 0; i < nsrc; ++i) {
             L.cin_real[i] = cin[i]; L.cin_pad[i] = (type == Layer::STEM) ? cin[i] : pad16(cin[i]);
@@ -156,7 +159,7 @@ int build_plan(fnn_engine *e) {
         for (int d = 0; d < 3; ++d) { L.k[d] = k[d]; L.s[d] = s[d]; L.in_dims[d] = in_d[d]; L.out_dims[d] = out_d[d]; }
         const int T = k[0] * k[1] * k[2];
         L.blob_w = blob; blob += (int64_t)cout * cin_tot * T;
-        L.blob_b = blob; blob += cout;
+        L.blob_b = blob; if (L.has_bias) blob += cout;
         L.blob_g = blob; blob += cout;
         L.blob_beta = blob; blob += cout;
         L.flops = 2.0 * cout * cin_tot * T * out_d[0] * out_d[1] * out_d[2];
@@ -166,17 +169,63 @@ int build_plan(fnn_engine *e) {
     const int32_t one[3] = {1, 1, 1};
     int prev = -1, prev_c = a.in_channels;
     int enc_last[FNN_MAX_STAGES];
-    for (int s = 0; s < a.n_stages; ++s) {
-        if (a.n_conv_enc[s] < 1) return fail(e, FNN_E_INVALID, "n_conv_per_stage must be >= 1");
-        for (int i = 0; i < a.n_conv_enc[s]; ++i) {
-            const int cin[2] = {prev_c, 0}, src[2] = {prev, -1};
-            const bool first = (s == 0 && i == 0);
-            const int *in_d = (i == 0 && s > 0) ? dims[s - 1] : dims[s];
-            prev = add_conv(first ? Layer::STEM : Layer::CONV, 1, cin, src, a.features[s], a.kernels[s],
-                            i == 0 ? a.strides[s] : one, in_d, dims[s]);
-            prev_c = a.features[s];
+    auto add_aux = [&](Layer::Type type, int src0, int src1, int channels, const int32_t *st, const int *in_d, const int *out_d) {
+        Layer L;
+        L.type = type; L.n_src = src1 >= 0 ? 2 : 1; L.has_norm = false;
+        L.src_layer[0] = src0; L.src_layer[1] = src1;
+        L.cin_real[0] = channels; L.cin_pad[0] = pad16(channels);
+        L.cout_real = channels; L.cout_pad = pad16(channels);
+        for (int d = 0; d < 3; ++d) { L.s[d] = st[d]; L.in_dims[d] = in_d[d]; L.out_dims[d] = out_d[d]; }
+        e->layers.push_back(L);
+        return (int)e->layers.size() - 1;
+    };
+    if (a.kind == FNN_NET_PLAIN) {
+        for (int s = 0; s < a.n_stages; ++s) {
+            if (a.n_conv_enc[s] < 1) return fail(e, FNN_E_INVALID, "n_conv_per_stage must be >= 1");
+            for (int i = 0; i < a.n_conv_enc[s]; ++i) {
+                const int cin[2] = {prev_c, 0}, src[2] = {prev, -1};
+                const bool first = (s == 0 && i == 0);
+                const int *in_d = (i == 0 && s > 0) ? dims[s - 1] : dims[s];
+                prev = add_conv(first ? Layer::STEM : Layer::CONV, 1, cin, src, a.features[s], a.kernels[s],
+                                i == 0 ? a.strides[s] : one, in_d, dims[s]);
+                prev_c = a.features[s];
+            }
+            enc_last[s] = prev;
         }
-        enc_last[s] = prev;
+    } else {
+        // ResidualEncoderUNet: stem conv, then per stage n_conv_enc[s] BasicBlockD blocks
+        //   y = LeakyReLU(norm(conv2(act(norm(conv1(x))))) + skip(x)),  skip = [AvgPool(stride)] [1x1x1 conv (no bias) + norm]
+        {
+            const int cin[2] = {a.in_channels, 0}, src[2] = {-1, -1};
+            prev = add_conv(Layer::STEM, 1, cin, src, a.features[0], a.kernels[0], one, dims[0], dims[0]);
+            prev_c = a.features[0];
+        }
+        for (int s = 0; s < a.n_stages; ++s) {
+            if (a.n_conv_enc[s] < 1) return fail(e, FNN_E_INVALID, "n_blocks_per_stage must be >= 1");
+            for (int b = 0; b < a.n_conv_enc[s]; ++b) {
+                const int32_t *st = b == 0 ? a.strides[s] : one;
+                const int *in_d = (b == 0 && s > 0) ? dims[s - 1] : dims[s];
+                const bool strided = st[0] != 1 || st[1] != 1 || st[2] != 1;
+                const int F = a.features[s];
+                const int cin1[2] = {prev_c, 0}, src1[2] = {prev, -1};
+                const int c1 = add_conv(Layer::CONV, 1, cin1, src1, F, a.kernels[s], st, in_d, dims[s]);
+                const int cin2[2] = {F, 0}, src2[2] = {c1, -1};
+                next_act = false;
+                const int c2 = add_conv(Layer::CONV, 1, cin2, src2, F, a.kernels[s], one, dims[s], dims[s]);
+                next_act = true;
+                int skip = prev;
+                if (strided) skip = add_aux(Layer::POOL, prev, -1, prev_c, st, in_d, dims[s]);
+                if (prev_c != F) {
+                    const int cinp[2] = {prev_c, 0}, srcp[2] = {skip, -1};
+                    next_has_bias = false; next_act = false;
+                    skip = add_conv(Layer::CONV, 1, cinp, srcp, F, one, one, dims[s], dims[s]);
+                    next_has_bias = true; next_act = true;
+                }
+                prev = add_aux(Layer::COMBINE, c2, skip, F, one, dims[s], dims[s]);
+                prev_c = F;
+            }
+            enc_last[s] = prev;
+        }
     }
     for (int d = 0; d < a.n_stages - 1; ++d) {
         const int lvl = a.n_stages - 2 - d;           // encoder stage whose skip is consumed
@@ -223,7 +272,7 @@ int build_plan(fnn_engine *e) {
             L.chunks = (L.cin_pad[0] + (L.n_src > 1 ? L.cin_pad[1] : 0)) / 16;
             L.ksteps = (T + 1) / 2;
             L.w_off = wpk; wpk += (size_t)(L.cout_pad / 16) * L.chunks * L.ksteps * 512;
-        } else {
+        } else if (L.type == Layer::TCONV) {
             const int taps = L.s[0] * L.s[1] * L.s[2];
             L.ksteps = (L.cin_pad[0] + 31) / 32;
             L.w_off = wpk; wpk += (size_t)taps * (L.cout_pad / 16) * L.ksteps * 512;
@@ -358,7 +407,7 @@ SrcDesc make_src(fnn_engine *e, const FoldWeights &fw, int layer, int nb) {
     s.C = L.cout_pad;
     if (L.has_norm) {
         s.ss = e->ss + L.ss_off * e->max_batch * 2;
-        s.slope = e->arch.slope;
+        s.slope = L.act ? e->arch.slope : 1.f;
     } else {
         s.ss = nullptr; s.slope = 1.f;
     }
@@ -412,6 +461,22 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.tile_d = FNN_TILE_D;
             Scope sc(e, st, FAM_CONV, L.flops * nb);
             rc = launch_conv3d(p, st);
+        } else if (L.type == Layer::POOL) {
+            PoolParams p{};
+            p.src = make_src(e, fw, L.src_layer[0], nb);
+            p.N = nb; p.Di = L.in_dims[0]; p.Hi = L.in_dims[1]; p.Wi = L.in_dims[2];
+            p.sd = L.s[0]; p.sh = L.s[1]; p.sw = L.s[2];
+            p.out = out;
+            Scope sc(e, st, FAM_TCONV, 0);
+            rc = launch_avgpool(p, st);
+        } else if (L.type == Layer::COMBINE) {
+            CombineParams p{};
+            p.a = make_src(e, fw, L.src_layer[0], nb);
+            p.b = make_src(e, fw, L.src_layer[1], nb);
+            p.vox = (long long)L.out_dims[0] * L.out_dims[1] * L.out_dims[2];
+            p.N = nb; p.slope = e->arch.slope; p.out = out;
+            Scope sc(e, st, FAM_TCONV, 0);
+            rc = launch_combine(p, st);
         } else {
             TconvParams p{};
             p.src = make_src(e, fw, L.src_layer[0], nb);
@@ -797,6 +862,7 @@ int fnn_load_weights(fnn_engine *e, int fold, const float *blob, int64_t count) 
     std::vector<uint16_t> wpk(e->wpk_halves, 0);
     std::vector<float> fp(e->fparam_floats, 0.f);
     for (const Layer &L : e->layers) {
+        if (L.type == Layer::POOL || L.type == Layer::COMBINE) continue;
         const float *W = blob + L.blob_w;
         if (L.type == Layer::STEM) {
             const int T = L.k[0] * L.k[1] * L.k[2], C = L.cin_real[0];
@@ -810,7 +876,7 @@ int fnn_load_weights(fnn_engine *e, int fold, const float *blob, int64_t count) 
             pack_tconv(L, W, wpk.data() + L.w_off);
         }
         for (int c = 0; c < L.cout_real; ++c) {
-            fp[L.bias_off + c] = blob[L.blob_b + c];
+            fp[L.bias_off + c] = L.has_bias ? blob[L.blob_b + c] : 0.f;
             if (L.has_norm) { fp[L.gamma_off + c] = blob[L.blob_g + c]; fp[L.beta_off + c] = blob[L.blob_beta + c]; }
         }
     }

@@ -145,6 +145,24 @@ struct FinalizeParams {
 
 static __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
 
+// Residual-encoder blocks (BasicBlockD): skip-path average pooling and the block's closing
+//   y = LeakyReLU( norm2(conv2) + skip )
+struct PoolParams {
+    SrcDesc src;                 // [N][Di][Hi][Wi][C] with its on-load transform
+    int N, Di, Hi, Wi;
+    int sd, sh, sw;              // AvgPool3d(kernel = stride)
+    f16 *out;                    // [N][Di/sd][Hi/sh][Wi/sw][C], final values
+};
+
+struct CombineParams {
+    SrcDesc a;                   // conv2 raw output (+ its InstanceNorm, no activation)
+    SrcDesc b;                   // skip: projection conv raw output (+ norm) or an already final tensor
+    long long vox;               // voxels per batch item
+    int N;
+    float slope;                 // LeakyReLU slope of the block output
+    f16 *out;                    // [N][vox][C], final values
+};
+
 struct StatsFinalizeParams {
     const double *stats;         // [N][REPL][C][2]
     const float *gamma, *beta;   // [C]
@@ -155,6 +173,8 @@ struct StatsFinalizeParams {
 
 // launchers (implemented in the .hip files)
 int launch_stats_finalize(const StatsFinalizeParams &p, int N, hipStream_t st);
+int launch_avgpool(const PoolParams &p, hipStream_t st);
+int launch_combine(const CombineParams &p, hipStream_t st);
 int launch_conv3d(const ConvParams &p, hipStream_t st);
 size_t conv3d_lds_bytes(const ConvParams &p, int nb);
 int conv3d_pick_nb(int nblk);

@@ -63,6 +63,84 @@ static __device__ __forceinline__ f16x8 load_act_frag(const SrcDesc &s, size_t v
 }
 
 // ----------------------------------------------------------------------------
+// residual-encoder helpers (BasicBlockD of dynamic_network_architectures' ResidualEncoderUNet, instantiated
+// by the reference at nnUNetDistillationTrainer.py:248-266): one thread = one voxel x 8 channels
+// ----------------------------------------------------------------------------
+static __device__ __forceinline__ void apply8(const SrcDesc &s, int n, int c0, const f16x8 &x, float (&y)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = (float)x[j];
+        if (s.ss) v = fmaf(v, s.ss[(size_t)(2 * n) * s.C + c0 + j], s.ss[(size_t)(2 * n + 1) * s.C + c0 + j]);
+        y[j] = leaky(v, s.slope);
+    }
+}
+
+// skip path of a strided block: AvgPool3d(stride, stride) of the (transformed) block input
+__global__ __launch_bounds__(256) void avgpool_kernel(const PoolParams p) {
+    const int Do = p.Di / p.sd, Ho = p.Hi / p.sh, Wo = p.Wi / p.sw;
+    const int cg = p.src.C >> 3;
+    const long long total = (long long)p.N * Do * Ho * Wo * cg;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int g = (int)(i % cg);
+    long long v = i / cg;
+    const int ow = (int)(v % Wo); v /= Wo;
+    const int oh = (int)(v % Ho); v /= Ho;
+    const int od = (int)(v % Do);
+    const int n = (int)(v / Do);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int a = 0; a < p.sd; ++a)
+        for (int b = 0; b < p.sh; ++b)
+            for (int c = 0; c < p.sw; ++c) {
+                const size_t vin = (((size_t)n * p.Di + od * p.sd + a) * p.Hi + oh * p.sh + b) * p.Wi + ow * p.sw + c;
+                const f16x8 x = *(const f16x8 *)(p.src.ptr + vin * p.src.C + g * 8);
+                float y[8];
+                apply8(p.src, n, g * 8, x, y);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += y[j];
+            }
+    const float inv = 1.f / (float)(p.sd * p.sh * p.sw);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)(acc[j] * inv);
+    *(f16x8 *)(p.out + ((((size_t)n * Do + od) * Ho + oh) * Wo + ow) * p.src.C + g * 8) = o;
+}
+
+int launch_avgpool(const PoolParams &p, hipStream_t st) {
+    const long long total = (long long)p.N * (p.Di / p.sd) * (p.Hi / p.sh) * (p.Wi / p.sw) * (p.src.C >> 3);
+    hipLaunchKernelGGL(avgpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// y = LeakyReLU(T_a(a) + T_b(b)): the closing add of a residual block, stored as final values
+__global__ __launch_bounds__(256) void combine_kernel(const CombineParams p) {
+    const int cg = p.a.C >> 3;
+    const long long total = (long long)p.N * p.vox * cg;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int g = (int)(i % cg);
+    const long long v = i / cg;
+    const int n = (int)(v / p.vox);
+    const f16x8 xa = *(const f16x8 *)(p.a.ptr + (size_t)v * p.a.C + g * 8);
+    const f16x8 xb = *(const f16x8 *)(p.b.ptr + (size_t)v * p.b.C + g * 8);
+    float ya[8], yb[8];
+    apply8(p.a, n, g * 8, xa, ya);
+    apply8(p.b, n, g * 8, xb, yb);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)leaky(ya[j] + yb[j], p.slope);
+    *(f16x8 *)(p.out + (size_t)v * p.a.C + g * 8) = o;
+}
+
+int launch_combine(const CombineParams &p, hipStream_t st) {
+    const long long total = (long long)p.N * p.vox * (p.a.C >> 3);
+    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ----------------------------------------------------------------------------
 // transposed conv, kernel = stride: one GEMM per kernel tap
 //   D[cout, voxel] = sum_cin W_tap[cout, cin] * X[cin, voxel]
 // A wave owns 64 input voxels (4 MFMA column blocks) and produces TG taps x NBT cout blocks for them:

@@ -88,11 +88,16 @@ const char *fnn_last_error(const fnn_engine *e);             /* e may be NULL */
 int fnn_create(const fnn_arch_desc *arch, int device, int max_batch, fnn_engine **out);
 void fnn_destroy(fnn_engine *e);
 
-/* Number of float32 values fnn_load_weights expects and the canonical order:
- * for every encoder stage s, conv i: weight[F,Cin,kd,kh,kw], bias[F], gamma[F],
+/* Number of float32 values fnn_load_weights expects and the canonical order.
+ * FNN_NET_PLAIN: for every encoder stage s, conv i: weight[F,Cin,kd,kh,kw], bias[F], gamma[F],
  * beta[F]; then for every decoder level d (deepest first): transpconv
  * weight[Cbelow,F,sd,sh,sw], bias[F]; its convs as above; finally the last
- * seg layer weight[heads,F0], bias[heads]. */
+ * seg layer weight[heads,F0], bias[heads].
+ * FNN_NET_RESENC (ResidualEncoderUNet, n_conv_enc = residual blocks per stage): the
+ * stem conv (weight, bias, gamma, beta); then per stage, per block: conv1
+ * (weight, bias, gamma, beta), conv2 (same), and - only when the block changes
+ * the channel count - the 1x1x1 skip projection (weight[F,Cin], gamma, beta; it
+ * has no bias); decoder and seg layer as above. */
 int64_t fnn_weight_count(const fnn_engine *e);
 
 /* Replaces network.load_state_dict(params) per fold (:486-489).  `blob` is

@@ -78,6 +78,11 @@ SPECS = {
     'heads61': (UNetSpec('plain', 1, 61, [16, 32], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2]), (16, 16, 32)),
     'one_conv_per_stage': (UNetSpec('plain', 1, 2, [16, 32, 32], [(3, 3, 3)] * 3, [(1, 1, 1), (2, 2, 2), (2, 2, 2)],
                                     [1, 1, 1], [1, 1]), (16, 16, 16)),
+    # ResidualEncoderUNet: projections with and without pooling, identity skips, strided identity skip
+    'resenc4': (UNetSpec('resenc', 1, 3, [16, 32, 32, 48], [(1, 3, 3), (3, 3, 3), (3, 3, 3), (3, 3, 3)],
+                         [(1, 1, 1), (1, 2, 2), (2, 2, 2), (2, 1, 1)], [1, 3, 2, 2], [1, 1, 1]), (16, 32, 32)),
+    'resenc_2ch_odd': (UNetSpec('resenc', 2, 4, [8, 10, 21], [(3, 3, 3)] * 3, [(1, 1, 1), (2, 2, 2), (2, 2, 2)],
+                                [2, 2, 1], [1, 1]), (16, 16, 16)),
 }
 
 
@@ -316,3 +321,18 @@ def test_sharded_predictor_single_rank_process_group():
         assert torch.equal(got, want)
     finally:
         dist.destroy_process_group()
+
+
+def test_resenc_sliding_window_bit_identical_and_close_to_oracle():
+    spec, patch = SPECS['resenc4']
+    sd = {'network.' + k: v for k, v in synthetic_state_dict(spec, 31).items()}        # student checkpoints carry `network.`
+    p = _predictor(spec, patch, [sd], mirror=[0, 2])
+    image = torch.randn(1, 24, 40, 50, generator=torch.Generator().manual_seed(3))
+    got = p.predict_sliding_window_return_logits(image).cpu()
+    want = osw.sliding_window_logits(lambda x: p.forward_patches(x).cpu(), image, patch, spec.num_heads, mirror_axes=[0, 2])
+    assert torch.equal(got, want)
+    net = build_oracle(spec, synthetic_state_dict(spec, 31))
+    ref = osw.sliding_window_logits(net, image, patch, spec.num_heads, mirror_axes=[0, 2], accum='fp32')
+    inner = (slice(None), slice(3, -3), slice(3, -3), slice(3, -3))
+    mr, rr = _report('resenc4 volume', got.float()[inner], ref[inner])
+    assert mr <= MAX_REL and rr <= RMSE_REL

@@ -115,12 +115,22 @@ def test_spec_from_state_dict_roundtrip_and_aliases():
     assert a.size == n_params
 
 
-def test_resenc_checkpoints_are_refused_clearly():
-    from fast_nnunet_amd.arch import spec_from_state_dict
+def test_resenc_checkpoint_topology_and_blob():
+    """ResidualEncoderUNet students carry a `network.` prefix (nnUNetDistillationTrainer.py:248) and a skip
+    Sequential whose projection index depends on the presence of the AvgPool."""
+    from fast_nnunet_amd import capi
+    from fast_nnunet_amd.arch import spec_from_state_dict, weight_blob
     from oracle.topology import UNetSpec
-    spec = UNetSpec('resenc', 1, 2, [8, 16], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [1, 2], [1])
-    with pytest.raises(NotImplementedError):
-        spec_from_state_dict(synthetic_state_dict(spec), (16, 16, 16))
+    ospec = UNetSpec('resenc', 2, 3, [8, 16, 16, 24], [(1, 3, 3), (3, 3, 3), (3, 3, 3), (3, 3, 3)],
+                     [(1, 1, 1), (1, 2, 2), (2, 2, 2), (2, 1, 1)], [1, 3, 2, 2], [1, 1, 1])
+    sd = {'network.' + k: v for k, v in synthetic_state_dict(ospec, 2).items()}
+    spec = spec_from_state_dict(sd, (16, 16, 16))
+    assert spec.kind == capi.FNN_NET_RESENC
+    assert spec.features == ospec.features and spec.n_conv_enc == ospec.n_conv_enc and spec.n_conv_dec == ospec.n_conv_dec
+    assert [tuple(s) for s in spec.strides] == [tuple(s) for s in ospec.strides]
+    assert [tuple(k) for k in spec.kernels] == [tuple(k) for k in ospec.kernels]
+    n_params = sum(v.numel() for k, v in sd.items() if not any(f'seg_layers.{i}.' in k for i in range(2)))
+    assert weight_blob(spec, sd).size == n_params
 
 
 def test_plans_reader_matches_reference(golden_dir):
