@@ -336,3 +336,69 @@ def test_resenc_sliding_window_bit_identical_and_close_to_oracle():
     inner = (slice(None), slice(3, -3), slice(3, -3), slice(3, -3))
     mr, rr = _report('resenc4 volume', got.float()[inner], ref[inner])
     assert mr <= MAX_REL and rr <= RMSE_REL
+
+
+def test_initialize_from_trained_model_folder_distilled_student(tmp_path):
+    """The reference's model-folder layout (plans.json, dataset.json, fold_k/checkpoint_*.pth with the
+    nnUNetTrainer.save_checkpoint schema, nnUNetTrainer.py:1159-1169) for a DISTILLED student - which the
+    reference's own predictor cannot rebuild: folds auto-detected, weights wrapped the way real
+    checkpoints are, ensemble == oracle."""
+    import json
+    from fast_nnunet_amd import nnUNetPredictor
+    r = 2
+    teacher_feats = [32, 64, 64]
+    kernels = [[3, 3, 3]] * 3
+    strides = [[1, 1, 1], [2, 2, 2], [1, 2, 2]]
+    spec = UNetSpec('plain', 1, 3, [max(f // r, 8) for f in teacher_feats], [tuple(k) for k in kernels],
+                    [tuple(s) for s in strides], [2, 2, 2], [2, 2])
+    patch = (16, 16, 32)
+    plans = {'dataset_name': 'Dataset123_Toy', 'plans_name': 'nnUNetPlans', 'transpose_forward': [0, 1, 2],
+             'transpose_backward': [0, 1, 2], 'label_manager': 'LabelManager',
+             'configurations': {
+                 '3d_fullres': {'patch_size': list(patch), 'spacing': [1.0, 1.0, 1.0], 'batch_size': 2,
+                                'architecture': {'network_class_name': 'dynamic_network_architectures.architectures.unet.PlainConvUNet',
+                                                 'arch_kwargs': {'n_stages': 3, 'features_per_stage': teacher_feats,
+                                                                 'kernel_sizes': kernels, 'strides': strides,
+                                                                 'n_conv_per_stage': [2, 2, 2], 'n_conv_per_stage_decoder': [2, 2],
+                                                                 'conv_bias': True, 'norm_op_kwargs': {'eps': 1e-5, 'affine': True}},
+                                                 '_kw_requires_import': []}},
+                 '3d_fullres_student': {'inherits_from': '3d_fullres'}}}
+    dataset_json = {'labels': {'background': 0, 'liver': 1, 'tumour': 2}, 'channel_names': {'0': 'CT'}, 'file_ending': '.nii.gz'}
+    folder = tmp_path / 'nnUNetDistillationTrainer__nnUNetPlans__3d_fullres_student'
+    folder.mkdir()
+    (folder / 'plans.json').write_text(json.dumps(plans))
+    (folder / 'dataset.json').write_text(json.dumps(dataset_json))
+    sds = []
+    for fold in (0, 1):
+        sd = synthetic_state_dict(spec, 70 + fold)
+        sds.append(sd)
+        wrapped = {}
+        for k, v in sd.items():                               # aliases real checkpoints carry
+            wrapped[k] = v
+            if '.conv.' in k:
+                wrapped[k.replace('.conv.', '.all_modules.0.')] = v
+        (folder / f'fold_{fold}').mkdir()
+        torch.save({'network_weights': wrapped, 'optimizer_state': None, 'current_epoch': 1000,
+                    'init_args': {'configuration': '3d_fullres_student', 'feature_reduction_factor': r, 'fold': fold},
+                    'trainer_name': 'nnUNetDistillationTrainer', 'inference_allowed_mirroring_axes': (0, 1, 2)},
+                   folder / f'fold_{fold}' / 'checkpoint_best.pth')
+    (folder / 'fold_all').mkdir()                             # must be ignored by auto-detection
+    p = nnUNetPredictor(tile_step_size=0.5, use_gaussian=True, use_mirroring=False, device=torch.device('cuda', 0),
+                        allow_tqdm=False, patches_per_forward=2)
+    p.initialize_from_trained_model_folder(str(folder), use_folds=None, checkpoint_name='checkpoint_best.pth')
+    assert p.trainer_name == 'nnUNetDistillationTrainer' and p.allowed_mirroring_axes == (0, 1, 2)
+    assert p.label_manager.num_segmentation_heads == 3 and len(p.list_of_parameters) == 2
+    assert p.configuration_manager.patch_size == list(patch)
+    image = torch.randn(1, 20, 24, 40, generator=torch.Generator().manual_seed(11))
+    got = p.predict_logits_from_preprocessed_data(image).float()
+    nets = [build_oracle(spec, sd) for sd in sds]
+    ref = osw.ensemble_logits(nets, image, patch, 3, accum='fp32')
+    inner = (slice(None), slice(3, -3), slice(3, -3), slice(3, -3))
+    mr, rr = _report('model folder', got[inner], ref[inner])
+    assert mr <= MAX_REL and rr <= RMSE_REL
+    # a wrong reduction factor in init_args is caught against the plans
+    ck = torch.load(folder / 'fold_0' / 'checkpoint_best.pth', weights_only=False)
+    ck['init_args']['feature_reduction_factor'] = 4
+    torch.save(ck, folder / 'fold_0' / 'checkpoint_best.pth')
+    with pytest.raises(RuntimeError, match='do not match'):
+        p.initialize_from_trained_model_folder(str(folder), use_folds=(0,), checkpoint_name='checkpoint_best.pth')
