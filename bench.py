@@ -208,7 +208,7 @@ def main():
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
 
-    accumulate_in = 'fp32' if distributed else args.accum       # halo sums are exchanged in fp32
+    accumulate_in = args.accum                                  # halo sums travel in the accumulator dtype
     predictor, sd, info = build_predictor(args.workload, device, args.batch, accumulate_in)
     vol = synthetic_volume(args.volume, device)
     from fast_nnunet_amd import capi

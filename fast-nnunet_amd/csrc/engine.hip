@@ -922,7 +922,7 @@ int64_t fnn_accumulator_channels(const fnn_engine *e) { return e ? acc_hp(e->arc
 
 int fnn_accumulate_patches(fnn_engine *e, int fold, const float *vol, const int64_t shape[4], const fnn_opts *opts,
                            const int64_t *patch_ids, int64_t n_ids, const int64_t box_lo[3], const int64_t box_hi[3],
-                           float *acc) {
+                           void *acc) {
     if (int rc = check_ready(e, fold, opts)) return rc;
     if (!vol || !acc || !box_lo || !box_hi || (n_ids > 0 && !patch_ids)) return fail(e, FNN_E_INVALID, "NULL argument");
     if (!is_device_ptr(acc)) return fail(e, FNN_E_INVALID, "accumulators must be device memory");
@@ -942,12 +942,12 @@ int fnn_accumulate_patches(fnn_engine *e, int fold, const float *vol, const int6
     if (int rc = stage_volume(e, vol, shape, vp, st, &vol_dev)) return rc;
     if (int rc = upload_origins(e, vp, ids, st)) return rc;
     e->ev_used = 0;
-    if (int rc = run_patches(e, fold, vol_dev, vp, *opts, ids, e->origins, box, acc, 1, st)) return rc;
+    if (int rc = run_patches(e, fold, vol_dev, vp, *opts, ids, e->origins, box, acc, opts->accum == FNN_ACC_FP32, st)) return rc;
     if (e->profiling) { HIPCHK(e, hipStreamSynchronize(st)); collect_profile(e, n_ids); }
     return 0;
 }
 
-int fnn_normalize_box(fnn_engine *e, const float *acc, const int64_t shape[4], const fnn_opts *opts,
+int fnn_normalize_box(fnn_engine *e, const void *acc, const int64_t shape[4], const fnn_opts *opts,
                       const int64_t box_lo[3], const int64_t box_hi[3], const int64_t out_lo[3], const int64_t out_hi[3],
                       void *out) {
     if (!e || !opts) return FNN_E_INVALID;
@@ -965,7 +965,7 @@ int fnn_normalize_box(fnn_engine *e, const float *acc, const int64_t shape[4], c
             return fail(e, FNN_E_INVALID, "output box is not covered by the accumulator box");
     }
     HIPCHK(e, hipMemsetAsync(e->inf_flag, 0, sizeof(int), st));
-    FinalizeParams f = make_finalize(e, acc, box, out_lo, out_hi, vp, shape, *opts, 1, 0, out);
+    FinalizeParams f = make_finalize(e, acc, box, out_lo, out_hi, vp, shape, *opts, opts->accum == FNN_ACC_FP32, 0, out);
     if (launch_finalize(f, st) != 0) return fail(e, FNN_E_HIP, "finalize launch failed");
     int flag = 0;
     HIPCHK(e, hipMemcpyAsync(&flag, e->inf_flag, sizeof(int), hipMemcpyDeviceToHost, st));

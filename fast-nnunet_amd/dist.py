@@ -5,9 +5,9 @@ Not in the reference: its only inference parallelism is case-level
 of a volume (x-major list of ``compute_steps_for_sliding_window`` positions) is
 cut into a 3-D grid of rank blocks.  Every rank
 
-1. runs its own patches into an fp32 accumulator that covers only the bounding
-   box of those patches (channels-last ``[bx, by, bz, HP]``, channel ``heads`` is
-   the weight sum - so logits and weights travel together);
+1. runs its own patches into an accumulator (fp16 like the reference's, or fp32) that
+   covers only the bounding box of those patches (channels-last ``[bx, by, bz, HP]``,
+   channel ``heads`` is the weight sum - so logits and weights travel together);
 2. exchanges ONLY the overlap regions with the ranks whose boxes intersect its
    own: each voxel of the padded volume has exactly one owner, and every other
    rank that touched it sends its partial sums to the owner (point-to-point over
@@ -182,8 +182,8 @@ class ShardedPredictor:
             padded, pad_lo, origins = capi.plan_volume(patch, x.shape[1:], p.tile_step_size)
             steps = [sorted(set(int(v) for v in origins[:, d])) for d in range(3)]
             dec = Decomposition.build(patch, padded, steps, self.world)
-            opts = p._opts()
-            opts.accum = capi.FNN_ACC_FP32
+            opts = p._opts()                                  # accumulator dtype follows predictor.accumulate_in
+            acc_dtype = torch.float32 if p.accumulate_in == 'fp32' else torch.half
             if out is None:
                 out = torch.empty((p._spec.num_heads, *x.shape[1:]), dtype=torch.half, device=p.device)
             box = dec.boxes[self.rank]
@@ -191,7 +191,7 @@ class ShardedPredictor:
                 exchange_halos(torch.empty(0), dec, self.rank, self.group)
                 return out, None
             dims = tuple(box[1][d] - box[0][d] for d in range(3))
-            acc = torch.zeros((*dims, eng.accumulator_channels), dtype=torch.float32, device=p.device)
+            acc = torch.zeros((*dims, eng.accumulator_channels), dtype=acc_dtype, device=p.device)
             eng.accumulate_patches(x.data_ptr(), x.shape, opts, dec.patch_ids[self.rank], box[0], box[1], acc.data_ptr(),
                                    fold=p._active_fold)
             exchange_halos(acc, dec, self.rank, self.group)

@@ -138,7 +138,8 @@ int fnn_predict_labels(fnn_engine *e, int n_folds, const float *vol, const int64
 
 /* Multi-GPU building blocks (not in the reference, whose only
  * inference parallelism is case-level -num_parts/-part_id, :918-925).
- * Accumulators are channels-last fp32 DEVICE buffers that cover a box of the
+ * Accumulators are channels-last DEVICE buffers - fp32 when opts->accum is
+ * FNN_ACC_FP32, fp16 otherwise - that cover a box of the
  * PADDED volume:  acc[bx][by][bz][HP],  HP = fnn_accumulator_channels(e)
  * (= num_heads + 1 rounded up to 8); channel h < num_heads holds sum(w * logit_h),
  * channel num_heads holds sum(w).  The caller zeroes them, exchanges / adds the
@@ -150,8 +151,8 @@ int fnn_predict_labels(fnn_engine *e, int n_folds, const float *vol, const int64
 int64_t fnn_accumulator_channels(const fnn_engine *e);
 int fnn_accumulate_patches(fnn_engine *e, int fold, const float *vol, const int64_t shape[4],
                            const fnn_opts *opts, const int64_t *patch_ids, int64_t n_ids,
-                           const int64_t box_lo[3], const int64_t box_hi[3], float *acc);
-int fnn_normalize_box(fnn_engine *e, const float *acc, const int64_t shape[4], const fnn_opts *opts,
+                           const int64_t box_lo[3], const int64_t box_hi[3], void *acc);
+int fnn_normalize_box(fnn_engine *e, const void *acc, const int64_t shape[4], const fnn_opts *opts,
                       const int64_t box_lo[3], const int64_t box_hi[3],
                       const int64_t out_lo[3], const int64_t out_hi[3], void *out_logits);
 

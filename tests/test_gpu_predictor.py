@@ -263,15 +263,16 @@ def test_idempotence_and_linearity_of_the_blend_at_full_patch_size():
     assert (a.float().cpu() - want).abs().max() <= 2e-3
 
 
+@pytest.mark.parametrize('acc_mode', ['fp32', 'fp16'])
 @pytest.mark.parametrize('world', [2, 4])
-def test_sharded_boxes_through_c_abi_match_single_gpu(world):
+def test_sharded_boxes_through_c_abi_match_single_gpu(world, acc_mode):
     """The multi-GPU building blocks (fnn_accumulate_patches / fnn_normalize_box) driven for `world` virtual
     ranks on one GPU, with the halo exchange done locally: must reproduce the single-engine fp32 result."""
     from fast_nnunet_amd import capi
     from fast_nnunet_amd.dist import Decomposition, _view, unpadded
     spec, patch = SPECS['toy3']
     sd = synthetic_state_dict(spec, 21)
-    p = _predictor(spec, patch, [sd], accumulate_in='fp32')
+    p = _predictor(spec, patch, [sd], accumulate_in=acc_mode)
     image = torch.randn(1, 37, 30, 70, generator=torch.Generator().manual_seed(6))
     want = p.predict_sliding_window_return_logits(image)
     x = image.cuda().float().contiguous()
@@ -279,13 +280,13 @@ def test_sharded_boxes_through_c_abi_match_single_gpu(world):
     steps = [sorted(set(int(v) for v in origins[:, d])) for d in range(3)]
     dec = Decomposition.build(patch, padded, steps, world)
     opts = p._opts()
-    opts.accum = capi.FNN_ACC_FP32
     hp = p._engine.accumulator_channels
+    adt = torch.float32 if acc_mode == 'fp32' else torch.half
     accs = []
     for r in range(world):
         box = dec.boxes[r]
         dims = tuple(box[1][d] - box[0][d] for d in range(3))
-        acc = torch.zeros((*dims, hp), dtype=torch.float32, device='cuda')
+        acc = torch.zeros((*dims, hp), dtype=adt, device='cuda')
         p._engine.accumulate_patches(x.data_ptr(), x.shape, opts, dec.patch_ids[r], box[0], box[1], acc.data_ptr())
         accs.append(acc)
     torch.cuda.synchronize()
@@ -298,10 +299,14 @@ def test_sharded_boxes_through_c_abi_match_single_gpu(world):
         p._engine.normalize_box(accs[r].data_ptr(), x.shape, opts, dec.boxes[r][0], dec.boxes[r][1], own[0], own[1],
                                 got.data_ptr())
     torch.cuda.synchronize()
-    # fp32 partial sums are added in a different order than on one GPU: equal up to the final fp16 store
-    diff = (got.float() - want.float()).abs().max()
-    assert diff <= 2e-3 * float(want.float().abs().max()), diff
-    assert (got.argmax(0) != want.argmax(0)).float().mean() < 1e-4
+    # partial sums are added in a different order than on one GPU: fp32 agrees up to the final fp16 store; fp16
+    # accumulators round differently per visit (same error class as the reference's own fp16 accumulation, whose
+    # +-0.5 quantisation at the 5.96e-8-weight volume border is excluded)
+    m = 3
+    inner = (slice(None), slice(m, -m), slice(m, -m), slice(m, -m))
+    diff = (got.float() - want.float())[inner].abs().max()
+    assert diff <= (2e-3 if acc_mode == 'fp32' else 2e-2) * float(want.float().abs().max()), diff
+    assert (got.argmax(0) != want.argmax(0))[inner[1:]].float().mean() < (1e-4 if acc_mode == 'fp32' else 2e-3)
 
 
 def test_sharded_predictor_single_rank_process_group():
