@@ -15,6 +15,7 @@
 // dynamic_network_architectures' ConvDropoutNormReLU, which the reference
 // instantiates at nnUNetDistillationTrainer.py:141-173.
 #include "fnn_device.h"
+#include "conv_common.h"
 #include <cstdlib>
 
 // ----------------------------------------------------------------------------
@@ -252,97 +253,6 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
 }
 
 static int lds_pitch(int IW) { return (IW & 7) ? ((IW + 3) & ~7) + 4 : IW; }
-
-// ----------------------------------------------------------------------------
-// shared pieces of the stride-1 MFMA conv kernels
-// ----------------------------------------------------------------------------
-// Sum over the 16 lanes of a DPP row = the 16 voxels of one MFMA column block (4 VALU ops, no LDS).
-static __device__ __forceinline__ float row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));  // row_ror:4
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, true));  // row_ror:2
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, true));  // row_ror:1
-    return v;
-}
-
-// small-integer division by a workgroup-uniform divisor (0 <= v < 2^16): float reciprocal + correction
-static __device__ __forceinline__ int small_div(int v, int d, float rcp) {
-    int q = (int)((float)v * rcp);
-    q -= (q * d > v);
-    q += ((q + 1) * d <= v);
-    return q;
-}
-
-// Where a wave's column block `mb` sits in the output tile.  MB = 4 or 8: tile MB x 8 x 8, wave = depth
-// slice (+4), block = two h rows.  MB = 2 (strided convs): tile 2 x 8 x 8, wave = (depth slice, h half).
-template <int MB>
-static __device__ __forceinline__ void mb_coords(int wave, int mb, int r, int &od_l, int &oh_l, int &ow_l) {
-    if (MB == 2) { od_l = wave >> 1; oh_l = 4 * (wave & 1) + 2 * mb + (r >> 3); }
-    else { od_l = wave + 4 * (mb >> 2); oh_l = 2 * (mb & 3) + (r >> 3); }
-    ow_l = r & 7;
-}
-
-// Epilogue of one output tile: bias, round to fp16, channels-last store (4 consecutive channels per
-// lane), and this lane's partial sums of the rounded values (fp32 within the tile).
-template <int NB, int MB>
-static __device__ __forceinline__ void tile_epilogue(const ConvParams &p, const f32x4 (&acc)[MB][NB], const float4 (&bv)[NB],
-                                                     int n, int od0, int oh0, int ow0, int cb0, int wave, int lane,
-                                                     float (&t1)[NB][4], float (&t2)[NB][4]) {
-    const int q = lane >> 4, r = lane & 15;
-    f16 *outn = p.out + (size_t)n * p.Do * p.Ho * p.Wo * p.Cout + cb0 * 16 + q * 4;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        int od_l, oh_l, ow_l;
-        mb_coords<MB>(wave, mb, r, od_l, oh_l, ow_l);
-        const int od = od0 + od_l, oh = oh0 + oh_l, ow = ow0 + ow_l;
-        const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
-        const unsigned voff = (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            f16x4 o;
-            o[0] = (f16)(acc[mb][nb][0] + bv[nb].x);
-            o[1] = (f16)(acc[mb][nb][1] + bv[nb].y);
-            o[2] = (f16)(acc[mb][nb][2] + bv[nb].z);
-            o[3] = (f16)(acc[mb][nb][3] + bv[nb].w);
-            if (ok) {
-                *(f16x4 *)(outn + voff + nb * 16) = o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = (float)o[j];
-                    t1[nb][j] += v;
-                    t2[nb][j] = fmaf(v, v, t2[nb][j]);
-                }
-            }
-        }
-    }
-}
-
-// Workgroup reduction of the statistics and the double atomics into replica (blockIdx.x & 7).
-// `sRed` = 4 * NB * 32 floats of LDS that nobody else uses between the two barriers.
-template <int NB>
-static __device__ __forceinline__ void stats_to_global(const ConvParams &p, float (&t1)[NB][4], float (&t2)[NB][4], float *sRed,
-                                                       int n, int cb0, int wave, int lane, int tid) {
-    const int q = lane >> 4, r = lane & 15;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float a = row16_sum(t1[nb][j]), b = row16_sum(t2[nb][j]);
-            if (r == 0) {
-                const int c = nb * 16 + q * 4 + j;
-                sRed[(wave * NB * 16 + c) * 2] = a;
-                sRed[(wave * NB * 16 + c) * 2 + 1] = b;
-            }
-        }
-    __syncthreads();
-    if (tid < NB * 16 * 2) {
-        const int c = tid >> 1, which = tid & 1;
-        double v = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) v += (double)sRed[(w * NB * 16 + c) * 2 + which];
-        unsafeAtomicAdd(p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout + cb0 * 16 + c) * 2 + which, v);
-    }
-}
 
 // ----------------------------------------------------------------------------
 // pipelined MFMA conv (stride 1): the hot kernel
@@ -1180,6 +1090,7 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
     p.tiles_d = (p.Do + FNN_TILE_D - 1) / FNN_TILE_D;
     p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
     p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
+    if (p.packing == FNN_PACK_ZR) return launch_conv3d_zr(p, st);      // weights are in that kernel's order
     int nb = conv3d_pick_nb(p.Cout / 16);
     static const bool force_v1 = getenv("FNN_CONV_V1") != nullptr;          // debugging / A-B aid
     if (!force_v1 && p.sd == 1 && p.sh == 1 && p.sw == 1) {
@@ -1209,14 +1120,16 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
             // persistent variants: a workgroup walks a range of tiles and prefetches across tile boundaries.
             // Weights resident in LDS when the whole cout group fits next to a double-buffered halo tile with
             // 2 workgroups per CU, otherwise they travel with the prefetch chunk by chunk.
-            for (int mb = mbsel; mb >= 4; mb -= 4) {
+            static const int persist_mb = getenv("FNN_PERSIST_MB") ? atoi(getenv("FNN_PERSIST_MB")) : 8;          // A-B aids
+            static const int persist_wpc = getenv("FNN_PERSIST_WPC") ? atoi(getenv("FNN_PERSIST_WPC")) : 3;
+            for (int mb = mbsel < persist_mb ? mbsel : persist_mb; mb >= 4; mb -= 4) {
                 const long long tiles = (long long)plan_n * ((p.Do + mb - 1) / mb) * p.tiles_h * p.tiles_w;
                 if (tiles < 256LL * 2 * 4) continue;
                 for (int wres = 1; wres >= 0; --wres) {
                     const size_t lds = persist_lds_bytes(p, nb, mb, wres != 0);
                     const int per_cu = (int)((160 * 1024) / lds);
                     if (per_cu < 2) continue;
-                    const int wpc = per_cu > 3 ? 3 : per_cu;
+                    const int wpc = per_cu > persist_wpc ? persist_wpc : per_cu;
 #define FNN_PERSIST(NBv, MBv) (wres ? launch_persist<NBv, MBv, true>(p, wpc, st) : launch_persist<NBv, MBv, false>(p, wpc, st))
                     if (nb == 1) return mb == 8 ? FNN_PERSIST(1, 8) : FNN_PERSIST(1, 4);
                     if (nb == 2) return mb == 8 ? FNN_PERSIST(2, 8) : FNN_PERSIST(2, 4);

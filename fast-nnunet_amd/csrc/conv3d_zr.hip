@@ -1,0 +1,250 @@
+// conv3d_zr.hip - 3x3x3 stride-1 Conv3d with depth-shift operand reuse (gfx950).
+//
+// Same GEMM view and fusions as conv3d_lds_kernel (conv3d.hip): D[cout, voxel] = W[cout, k] X[k, voxel]
+// on v_mfma_f32_16x16x32_f16, halo tile of one 16-channel chunk + that chunk's weight fragments in LDS,
+// producer InstanceNorm + LeakyReLU applied while staging, own statistics in the epilogue.  What changes
+// is who owns which voxels: a wave owns two h rows (16 voxels = one MFMA column block) in EVERY depth
+// slice of the TD x 8 x 8 output tile.  The "B" fragment of halo plane p for an in-plane tap pair is then
+// the operand of depth tap dz for output slice p - dz, for all three dz: it is read from LDS once and
+// feeds 3 MFMAs per cout block.  Per (chunk, tap pair) a wave issues TD + 2 activation reads and 3 NB weight
+// reads for 3 TD NB MFMAs - 0.33 LDS reads per MFMA at NB = 2, TD = 8 instead of 0.63 in the linear-tap
+// kernels, which at 32 output channels were bound by LDS bandwidth, not by the matrix cores.
+// Cost: the 9 in-plane taps pair up into 5 k-steps (one half padded) -> 30 tap slots instead of 28.
+//
+// Replaces the same reference code as conv3d.hip (ConvDropoutNormReLU stacks,
+// nnUNetDistillationTrainer.py:141-173).
+#include "fnn_device.h"
+#include "conv_common.h"
+#include <cstdlib>
+
+int conv3d_ksteps(int packing, int taps) { return packing == FNN_PACK_ZR ? 15 : (taps + 1) / 2; }
+
+int conv3d_kstep_tap(int packing, int ks, int half, int taps) {
+    if (packing == FNN_PACK_ZR) {
+        const int pr = ks / 3, dz = ks % 3, t = 2 * pr + half;
+        return t < 9 ? dz * 9 + t : -1;
+    }
+    const int t = 2 * ks + half;
+    return t < taps ? t : -1;
+}
+
+// (cout blocks per workgroup, tile depth) the ZR kernel would run with, or false when the layer keeps the
+// linear-tap kernels: not 3x3x3 / stride 1, or too few workgroups to fill the chip.
+static bool zr_pick(const ConvParams &p, int &nb, int &td) {
+    static const bool off = getenv("FNN_CONV_NO_ZR") != nullptr;                  // A-B aid
+    static const int max_cout = getenv("FNN_ZR_MAX_COUT") ? atoi(getenv("FNN_ZR_MAX_COUT")) : 1 << 30;
+    static const int min_cout = getenv("FNN_ZR_MIN_COUT") ? atoi(getenv("FNN_ZR_MIN_COUT")) : 0;
+    if (off || p.kd != 3 || p.kh != 3 || p.kw != 3 || p.sd != 1 || p.sh != 1 || p.sw != 1) return false;
+    if (p.Cout > max_cout || p.Cout < min_cout) return false;
+    const int nblk = p.Cout / 16;
+    nb = nblk % 2 == 0 ? 2 : 1;
+    const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;
+    const long long th = (p.Ho + 7) / 8, tw = (p.Wo + 7) / 8;
+    for (td = 8; td >= 4; td -= 4) {
+        if (p.Do < td) continue;
+        if ((long long)plan_n * ((p.Do + td - 1) / td) * th * tw * (nblk / nb) >= 768) return true;
+    }
+    return false;
+}
+
+int conv3d_packing(const ConvParams &p) {
+    int nb, td;
+    return zr_pick(p, nb, td) ? FNN_PACK_ZR : FNN_PACK_LINEAR;
+}
+
+template <int NB, int TD>
+__global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int IH = 10, IW = 10, PW = 12, ID = TD + 2;    // halo tile, row pitch 12 = 4 (mod 8) voxels
+    constexpr int PS = IH * PW * 32;                          // bytes per halo plane
+    constexpr int ABYTES = (ID * PS + 1023) & ~1023;
+    constexpr int KS = 15;
+    constexpr int IELEM = ID * IH * IW * 2;                   // 16-byte halo elements per chunk
+    constexpr int PF = (IELEM + 255) / 256;
+    constexpr int WTOT = NB * KS * 64;                        // 16-byte weight elements per chunk
+    constexpr int WPF = (WTOT + 255) / 256;
+
+    // XCD-aware, bijective remap (blocks b and b + 8 share an XCD)
+    int t;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
+    const int tw = t % p.tiles_w; t /= p.tiles_w;
+    const int th = t % p.tiles_h; t /= p.tiles_h;
+    const int td = t % p.tiles_d;
+    const int n = t / p.tiles_d;
+    const int cb0 = blockIdx.y * NB;
+    const int od0 = td * TD, oh0 = th * 8, ow0 = tw * 8;
+
+    char *sA = smem;                                          // halo image: [ID][IH][PW] voxels x 32 B, halves swapped on odd rows
+    char *sW = smem + ABYTES;                                 // [NB][15][64 lanes][16 B]
+    float *sBias = (float *)(sW + NB * KS * 1024);
+    if (tid < NB * 16) sBias[tid] = p.bias[cb0 * 16 + tid];
+
+    // MFMA "B" operand: lane = (voxel r of the wave's two rows, k-group): k-group bit 1 picks the tap of the pair,
+    // bit 0 the 8-channel half
+    int toff[5];
+    {
+        const int r = lane & 15, hl = lane >> 5, kh = (lane >> 4) & 1;
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const int tp = 2 * pr + hl < 9 ? 2 * pr + hl : 8;   // padded slot: any finite data (its weights are 0)
+            const int row = 2 * wave + (r >> 3) + tp / 3, col = (r & 7) + tp % 3;
+            toff[pr] = (row * PW + col) * 32 + ((kh ^ (row & 1)) * 16);
+        }
+    }
+
+    f32x4 acc[TD][NB];
+#pragma unroll
+    for (int j = 0; j < TD; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[j][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // this thread's share of the prefetch: PF halo elements (voxel, 8-channel half) + WPF weight elements
+    const int cg = tid & 1;
+    int offv[PF];                                             // global voxel index; -1 = zero padding, -2 = no element
+    int ldso[PF];
+    {
+        const int id0 = od0 - 1, ih0 = oh0 - 1, iw0 = ow0 - 1;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int idx = tid + u * 256;
+            const int v = idx >> 1;
+            const int zd = v / (IH * IW), rem = v - zd * (IH * IW), zh = rem / IW, zw = rem - zh * IW;
+            const int gd = id0 + zd, gh = ih0 + zh, gw = iw0 + zw;
+            const bool ok = gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 && gw < p.Wi;
+            offv[u] = idx < IELEM ? (ok ? ((n * p.Di + gd) * p.Hi + gh) * p.Wi + gw : -1) : -2;
+            ldso[u] = zd * PS + (zh * PW + zw) * 32 + ((cg ^ (zh & 1)) * 16);
+        }
+    }
+    int wofs[WPF];
+#pragma unroll
+    for (int u = 0; u < WPF; ++u) {
+        const int idx = tid + u * 256;
+        const int idc = idx < WTOT ? idx : WTOT - 1;
+        const int nb = idc >= KS * 64 ? 1 : 0;                // NB <= 2
+        wofs[u] = (cb0 + nb) * p.chunks * (KS * 64) + idc - nb * (KS * 64);
+    }
+    f16x8 xr[PF], wr[WPF];
+    float4 scr[2], shr[2];
+    float slope_next = 1.f;
+
+    auto issue = [&](int ch) {
+        const int c_glob = ch * 16;
+        const int s = (c_glob < p.src[0].C) ? 0 : 1;
+        const int c_loc = c_glob - (s ? p.src[0].C : 0) + cg * 8;
+        const f16 *sp = p.src[s].ptr + c_loc;
+        const int sC = p.src[s].C;
+#pragma unroll
+        for (int u = 0; u < PF; ++u)                          // unconditional: branches around loads make hipcc drain vmcnt
+            xr[u] = *(const f16x8 *)(sp + (size_t)(offv[u] >= 0 ? offv[u] : 0) * sC);
+#pragma unroll
+        for (int u = 0; u < WPF; ++u) wr[u] = ((const f16x8 *)p.wpk)[wofs[u] + ch * (KS * 64)];
+        slope_next = p.src[s].slope;
+        if (p.src[s].ss) {
+            const float *q4 = p.src[s].ss + (size_t)(2 * n) * sC + c_loc;
+            scr[0] = *(const float4 *)q4; scr[1] = *(const float4 *)(q4 + 4);
+            shr[0] = *(const float4 *)(q4 + sC); shr[1] = *(const float4 *)(q4 + sC + 4);
+        } else {
+            scr[0] = scr[1] = make_float4(1.f, 1.f, 1.f, 1.f);
+            shr[0] = shr[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&]() {
+        const f16 slope_h = (f16)slope_next;
+        const float sc[8] = {scr[0].x, scr[0].y, scr[0].z, scr[0].w, scr[1].x, scr[1].y, scr[1].z, scr[1].w};
+        const float sh[8] = {shr[0].x, shr[0].y, shr[0].z, shr[0].w, shr[1].x, shr[1].y, shr[1].z, shr[1].w};
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if ((u + 1) * 256 > IELEM && offv[u] == -2) continue;
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)xr[u][j], sc[j], sh[j]);
+            o = __builtin_elementwise_max(o, o * slope_h);
+            if (offv[u] < 0) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};      // the conv's zero padding
+            *(f16x8 *)(sA + ldso[u]) = o;
+        }
+#pragma unroll
+        for (int u = 0; u < WPF; ++u) {
+            const int idx = tid + u * 256;
+            if ((u + 1) * 256 <= WTOT || idx < WTOT) ((f16x8 *)sW)[idx] = wr[u];
+        }
+    };
+    auto kloop = [&]() {
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const char *bp = sA + toff[pr];
+            f16x8 xf[ID];
+#pragma unroll
+            for (int pl = 0; pl < ID; ++pl) xf[pl] = *(const f16x8 *)(bp + pl * PS);
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                f16x8 wf[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wf[nb] = *(const f16x8 *)(sW + ((nb * KS + pr * 3 + dz) * 64 + lane) * 16);
+#pragma unroll
+                for (int j = 0; j < TD; ++j)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nb], xf[j + dz], acc[j][nb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);                // keep the next pair's reads from being hoisted: registers
+        }
+    };
+
+    issue(0);
+    commit();
+    __syncthreads();
+    // the last chunk is peeled off so that the wait for the prefetch sits on an unconditional path (see conv3d_lds_kernel)
+    for (int ch = 0; ch + 1 < p.chunks; ++ch) {
+        issue(ch + 1);                                        // global loads stay in flight during the MFMAs
+        kloop();
+        __syncthreads();                                      // every wave is done reading this chunk
+        commit();
+        __syncthreads();
+    }
+    kloop();
+    __syncthreads();
+
+    // ---- epilogue: bias, fp16 store, statistics
+    {
+        float4 bv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const float4 *)(sBias + nb * 16 + (lane >> 4) * 4);
+        float t1[NB][4], t2[NB][4];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
+        tile_epilogue<NB, TD, true>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
+        if (p.stats_out) stats_to_global<NB>(p, t1, t2, (float *)smem, n, cb0, wave, lane, tid);
+    }
+}
+
+template <int NB, int TD>
+static int launch_zr(ConvParams p, hipStream_t st) {
+    p.tile_d = TD;
+    p.tiles_d = (p.Do + TD - 1) / TD;
+    p.tiles_h = (p.Ho + 7) / 8;
+    p.tiles_w = (p.Wo + 7) / 8;
+    const size_t lds = (size_t)(((TD + 2) * 10 * 12 * 32 + 1023) & ~1023) + (size_t)NB * 15 * 1024 + (size_t)NB * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)conv3d_zr_kernel<NB, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
+    hipLaunchKernelGGL((conv3d_zr_kernel<NB, TD>), grid, dim3(256), lds, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// Runs the layer on the ZR kernel; the weights must have been packed as FNN_PACK_ZR (p.packing).
+int launch_conv3d_zr(const ConvParams &p, hipStream_t st) {
+    int nb, td;
+    if (p.packing != FNN_PACK_ZR || p.ksteps != 15 || !zr_pick(p, nb, td)) return -1;
+    if (nb == 2) return td == 8 ? launch_zr<2, 8>(p, st) : launch_zr<2, 4>(p, st);
+    return td == 8 ? launch_zr<1, 8>(p, st) : launch_zr<1, 4>(p, st);
+}

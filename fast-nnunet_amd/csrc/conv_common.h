@@ -1,0 +1,97 @@
+// conv_common.h - pieces shared by the MFMA conv kernels (conv3d.hip, conv3d_zr.hip)
+#pragma once
+#include "fnn_device.h"
+
+// ----------------------------------------------------------------------------
+// shared pieces of the stride-1 MFMA conv kernels
+// ----------------------------------------------------------------------------
+// Sum over the 16 lanes of a DPP row = the 16 voxels of one MFMA column block (4 VALU ops, no LDS).
+static __device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, true));  // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, true));  // row_ror:1
+    return v;
+}
+
+// small-integer division by a workgroup-uniform divisor (0 <= v < 2^16): float reciprocal + correction
+static __device__ __forceinline__ int small_div(int v, int d, float rcp) {
+    int q = (int)((float)v * rcp);
+    q -= (q * d > v);
+    q += ((q + 1) * d <= v);
+    return q;
+}
+
+// Where a wave's column block `mb` sits in the output tile.  MB = 4 or 8: tile MB x 8 x 8, wave = depth
+// slice (+4), block = two h rows.  MB = 2 (strided convs): tile 2 x 8 x 8, wave = (depth slice, h half).
+// ZR (conv3d_zr_kernel): tile MB x 8 x 8, wave = two h rows, block = depth slice.
+template <int MB, bool ZR = false>
+static __device__ __forceinline__ void mb_coords(int wave, int mb, int r, int &od_l, int &oh_l, int &ow_l) {
+    if (ZR) { od_l = mb; oh_l = 2 * wave + (r >> 3); }
+    else if (MB == 2) { od_l = wave >> 1; oh_l = 4 * (wave & 1) + 2 * mb + (r >> 3); }
+    else { od_l = wave + 4 * (mb >> 2); oh_l = 2 * (mb & 3) + (r >> 3); }
+    ow_l = r & 7;
+}
+
+// Epilogue of one output tile: bias, round to fp16, channels-last store (4 consecutive channels per
+// lane), and this lane's partial sums of the rounded values (fp32 within the tile).
+template <int NB, int MB, bool ZR = false>
+static __device__ __forceinline__ void tile_epilogue(const ConvParams &p, const f32x4 (&acc)[MB][NB], const float4 (&bv)[NB],
+                                                     int n, int od0, int oh0, int ow0, int cb0, int wave, int lane,
+                                                     float (&t1)[NB][4], float (&t2)[NB][4]) {
+    const int q = lane >> 4, r = lane & 15;
+    f16 *outn = p.out + (size_t)n * p.Do * p.Ho * p.Wo * p.Cout + cb0 * 16 + q * 4;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        int od_l, oh_l, ow_l;
+        mb_coords<MB, ZR>(wave, mb, r, od_l, oh_l, ow_l);
+        const int od = od0 + od_l, oh = oh0 + oh_l, ow = ow0 + ow_l;
+        const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
+        const unsigned voff = (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            f16x4 o;
+            o[0] = (f16)(acc[mb][nb][0] + bv[nb].x);
+            o[1] = (f16)(acc[mb][nb][1] + bv[nb].y);
+            o[2] = (f16)(acc[mb][nb][2] + bv[nb].z);
+            o[3] = (f16)(acc[mb][nb][3] + bv[nb].w);
+            if (ok) {
+                *(f16x4 *)(outn + voff + nb * 16) = o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = (float)o[j];
+                    t1[nb][j] += v;
+                    t2[nb][j] = fmaf(v, v, t2[nb][j]);
+                }
+            }
+        }
+    }
+}
+
+// Workgroup reduction of the statistics and the double atomics into replica (blockIdx.x & 7).
+// `sRed` = 4 * NB * 32 floats of LDS that nobody else uses between the two barriers.
+template <int NB>
+static __device__ __forceinline__ void stats_to_global(const ConvParams &p, float (&t1)[NB][4], float (&t2)[NB][4], float *sRed,
+                                                       int n, int cb0, int wave, int lane, int tid) {
+    const int q = lane >> 4, r = lane & 15;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = row16_sum(t1[nb][j]), b = row16_sum(t2[nb][j]);
+            if (r == 0) {
+                const int c = nb * 16 + q * 4 + j;
+                sRed[(wave * NB * 16 + c) * 2] = a;
+                sRed[(wave * NB * 16 + c) * 2 + 1] = b;
+            }
+        }
+    __syncthreads();
+    if (tid < NB * 16 * 2) {
+        const int c = tid >> 1, which = tid & 1;
+        double v = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += (double)sRed[(w * NB * 16 + c) * 2 + which];
+        unsafeAtomicAdd(p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout + cb0 * 16 + c) * 2 + which, v);
+    }
+}
+

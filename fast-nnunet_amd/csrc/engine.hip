@@ -38,7 +38,7 @@ struct Layer {
     size_t ss_off = 0;                // float2 (scale, shift) per channel
     size_t out_off = 0;               // halves, activation arena (for batch = 1)
     int64_t blob_w = 0, blob_b = 0, blob_g = 0, blob_beta = 0;
-    int chunks = 0, ksteps = 0;
+    int chunks = 0, ksteps = 0, packing = 0;
     double flops = 0;                 // 2*MACs per patch
 };
 
@@ -270,7 +270,14 @@ int build_plan(fnn_engine *e) {
         } else if (L.type == Layer::CONV) {
             const int T = L.k[0] * L.k[1] * L.k[2];
             L.chunks = (L.cin_pad[0] + (L.n_src > 1 ? L.cin_pad[1] : 0)) / 16;
-            L.ksteps = (T + 1) / 2;
+            {
+                ConvParams q{};                               // the shape facts the launcher's variant choice looks at
+                q.plan_N = e->max_batch; q.N = e->max_batch; q.Cout = L.cout_pad;
+                q.Do = L.out_dims[0]; q.Ho = L.out_dims[1]; q.Wo = L.out_dims[2];
+                q.kd = L.k[0]; q.kh = L.k[1]; q.kw = L.k[2]; q.sd = L.s[0]; q.sh = L.s[1]; q.sw = L.s[2];
+                L.packing = conv3d_packing(q);
+            }
+            L.ksteps = conv3d_ksteps(L.packing, T);
             L.w_off = wpk; wpk += (size_t)(L.cout_pad / 16) * L.chunks * L.ksteps * 512;
         } else if (L.type == Layer::TCONV) {
             const int taps = L.s[0] * L.s[1] * L.s[2];
@@ -317,12 +324,12 @@ void pack_conv(const Layer &L, const float *W, uint16_t *dst) {
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
                         const int k = 8 * (lane >> 4) + j;
-                        const int tap = 2 * ks + (k >> 4), c = ch * 16 + (k & 15);
+                        const int tap = conv3d_kstep_tap(L.packing, ks, k >> 4, T), c = ch * 16 + (k & 15);
                         const int co = cb * 16 + (lane & 15);
                         int src = 0, cl = c;
                         if (c >= L.cin_pad[0]) { src = 1; cl = c - L.cin_pad[0]; }
                         float v = 0.f;
-                        if (tap < T && co < L.cout_real && cl < L.cin_real[src]) {
+                        if (tap >= 0 && co < L.cout_real && cl < L.cin_real[src]) {
                             const int ci = (src ? L.cin_real[0] : 0) + cl;
                             v = W[((size_t)co * cin_tot + ci) * T + tap];
                         }
@@ -457,7 +464,7 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.tiles_d = (p.Do + FNN_TILE_D - 1) / FNN_TILE_D;
             p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
             p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
-            p.chunks = L.chunks; p.ksteps = L.ksteps;
+            p.chunks = L.chunks; p.ksteps = L.ksteps; p.packing = L.packing;
             p.tile_d = FNN_TILE_D;
             Scope sc(e, st, FAM_CONV, L.flops * nb);
             rc = launch_conv3d(p, st);

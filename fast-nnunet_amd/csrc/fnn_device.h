@@ -53,8 +53,16 @@ struct ConvParams {
     int tile_d;                  // output tile depth: 4, or 8 for the pipelined kernel with 8 column blocks per wave
     unsigned long long *dbg;     // diagnostic builds only (-DFNN_STAMPS): per-workgroup s_memtime stamps
     int chunks;                  // 16-channel chunks over all sources
-    int ksteps;                  // MFMA k-steps per chunk = ceil(taps / 2)
+    int ksteps;                  // MFMA k-steps per chunk: conv3d_ksteps(packing, taps)
+    int packing;                 // FNN_PACK_*: which taps share a k-step (fixed per layer when the weights are packed)
 };
+
+// Weight packings of a conv layer.  One k-step (K = 32) always holds 2 taps x 16 input channels;
+//   FNN_PACK_LINEAR : k-step ks = taps (2 ks, 2 ks + 1) in d-major linear order, ceil(T / 2) k-steps;
+//   FNN_PACK_ZR     : 3x3x3 only, 15 k-steps: ks = 3 * pr + dz holds the in-plane taps (2 pr, 2 pr + 1) of depth
+//                     offset dz (in-plane tap 9 = zero padding) - the order conv3d_zr_kernel walks.
+#define FNN_PACK_LINEAR 0
+#define FNN_PACK_ZR 1
 
 struct StemParams {
     const float *vol;            // [C][X][Y][Z] fp32 (the padded volume)
@@ -178,6 +186,11 @@ int launch_combine(const CombineParams &p, hipStream_t st);
 int launch_conv3d(const ConvParams &p, hipStream_t st);
 size_t conv3d_lds_bytes(const ConvParams &p, int nb);
 int conv3d_pick_nb(int nblk);
+// packing the launcher will expect for a layer of this shape (decided from the PLANNED batch size)
+int conv3d_packing(const ConvParams &p);
+int conv3d_ksteps(int packing, int taps);
+int conv3d_kstep_tap(int packing, int ks, int half, int taps);     // linear tap index, or -1 = zero padding
+int launch_conv3d_zr(const ConvParams &p, hipStream_t st);
 int launch_stem(const StemParams &p, int N, hipStream_t st);
 int launch_tconv(const TconvParams &p, hipStream_t st);
 int launch_head(const HeadParams &p, hipStream_t st);

@@ -106,7 +106,8 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
     p.kd = k[0]; p.kh = k[1]; p.kw = k[2]; p.sd = stride[0]; p.sh = stride[1]; p.sw = stride[2];
     p.pd = (k[0] - 1) / 2; p.ph = (k[1] - 1) / 2; p.pw = (k[2] - 1) / 2;
     p.Do = (p.Di + 2 * p.pd - p.kd) / p.sd + 1; p.Ho = (p.Hi + 2 * p.ph - p.kh) / p.sh + 1; p.Wo = (p.Wi + 2 * p.pw - p.kw) / p.sw + 1;
-    p.Cout = cop; p.chunks = (cp1 + cp2) / 16; p.ksteps = (T + 1) / 2;
+    p.Cout = cop; p.chunks = (cp1 + cp2) / 16;
+    p.packing = conv3d_packing(p); p.ksteps = conv3d_ksteps(p.packing, T);
     p.tiles_d = (p.Do + FNN_TILE_D - 1) / FNN_TILE_D; p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
     p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
     p.tile_d = FNN_TILE_D;
@@ -117,13 +118,13 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
             for (int ks = 0; ks < p.ksteps; ++ks)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
-                        const int kk = 8 * (lane >> 4) + j, tap = 2 * ks + (kk >> 4), c = ch * 16 + (kk & 15);
+                        const int kk = 8 * (lane >> 4) + j, tap = conv3d_kstep_tap(p.packing, ks, kk >> 4, T), c = ch * 16 + (kk & 15);
                         const int co = cb * 16 + (lane & 15);
                         int src = 0, cl = c;
                         if (c >= cp1) { src = 1; cl = c - cp1; }
                         const int creal = src ? cin2 : cin;
                         float v = 0.f;
-                        if (tap < T && co < cout && cl < creal) v = w[((size_t)co * cin_tot + (src ? cin : 0) + cl) * T + tap];
+                        if (tap >= 0 && co < cout && cl < creal) v = w[((size_t)co * cin_tot + (src ? cin : 0) + cl) * T + tap];
                         wp[((((size_t)cb * p.chunks + ch) * p.ksteps + ks) * 64 + lane) * 8 + j] = f2h_bits(v);
                     }
     std::vector<float> bp(cop, 0.f);

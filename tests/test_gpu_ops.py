@@ -143,3 +143,65 @@ def test_mfma_operand_map_with_asymmetric_integer_data():
     y = capi.op_conv3d(x.numpy(), w.numpy(), None, (3, 3, 3), (1, 1, 1))
     ref = F.conv3d(x, w, None, 1, 1)
     assert np.array_equal(y, ref.numpy())
+
+
+# ---- conv3d_zr_kernel (depth-shift operand reuse): shapes large enough for the launcher to pick it
+ZR_CASES = [
+    # n, cin, cout, dims                       variant
+    (4, 32, 32, (61, 45, 43)),               # <2, 8>, ragged tiles on every axis
+    (6, 16, 16, (64, 40, 40)),               # <1, 8>
+    (3, 16, 16, (36, 48, 50)),               # <1, 4>
+    (2, 32, 64, (20, 56, 56)),               # <2, 4>, two workgroup columns
+    (5, 40, 24, (33, 41, 47)),               # channel padding on both sides (3 chunks, 2 cout blocks)
+]
+
+
+@pytest.mark.parametrize('n,cin,cout,dims', ZR_CASES)
+def test_conv3d_zr_variants(n, cin, cout, dims):
+    from fast_nnunet_amd import capi
+    g = torch.Generator().manual_seed(11 + cin + cout + dims[0])
+    x = _h(torch.randn(n, cin, *dims, generator=g) * 2 + 0.5)
+    gamma = torch.rand(cin, generator=g) + 0.5
+    beta = torch.randn(cin, generator=g) * 0.1
+    w = _h(torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    y, stats = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), (1, 1, 1), want_stats=True)
+    _check(y, F.conv3d(x, w, b, 1, 1), 'conv3d zr')
+    y64 = y.astype(np.float64)
+    assert np.allclose(stats[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    assert np.allclose(stats[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    y = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), (1, 1, 1), gamma=gamma.numpy(), beta=beta.numpy(),
+                       slope=0.01)
+    xn = _h(F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01))
+    ref = F.conv3d(xn, w, b, 1, 1)
+    assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_conv3d_zr_two_sources():
+    from fast_nnunet_amd import capi
+    g = torch.Generator().manual_seed(5)
+    n, c1, c2, cout, dims = 6, 32, 32, 32, (32, 48, 48)
+    up = _h(torch.randn(n, c1, *dims, generator=g))
+    skip = _h(torch.randn(n, c2, *dims, generator=g) * 2 - 1)
+    gamma, beta = torch.rand(c2, generator=g) + 0.5, torch.randn(c2, generator=g) * 0.1
+    w = _h(torch.randn(cout, c1 + c2, 3, 3, 3, generator=g) / 40)
+    b = torch.randn(cout, generator=g)
+    y = capi.op_conv3d(up.numpy(), w.numpy(), b.numpy(), (3, 3, 3), (1, 1, 1),
+                       x2=skip.numpy(), gamma2=gamma.numpy(), beta2=beta.numpy(), slope2=0.01)
+    cat = torch.cat((up, _h(F.leaky_relu(F.instance_norm(skip, weight=gamma, bias=beta, eps=1e-5), 0.01))), 1)
+    ref = F.conv3d(cat, w, b, 1, 1)
+    assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_conv3d_zr_operand_map_with_exact_integers():
+    """one-hot taps on integer data: any permuted tap pair / depth shift / fragment lane shows up as inequality"""
+    from fast_nnunet_amd import capi
+    n, c, dims = 6, 16, (64, 40, 40)
+    base = (torch.arange(dims[0] * dims[1] * dims[2]).reshape(dims) * 7 % 23).float()
+    x = torch.stack([torch.stack([base + ch + 3 * i for ch in range(c)]) for i in range(n)])
+    w = torch.zeros(c, c, 3, 3, 3)
+    for co in range(c):
+        w[co, (co * 5 + 3) % c, co % 3, (co // 3) % 3, (co + 1) % 3] = 1.0
+        w[co, (co * 3 + 1) % c, (co + 2) % 3, (co + 1) % 3, co % 3] += 2.0
+    y = capi.op_conv3d(x.numpy(), w.numpy(), None, (3, 3, 3), (1, 1, 1))
+    assert np.array_equal(y, F.conv3d(x, w, None, 1, 1).numpy())
