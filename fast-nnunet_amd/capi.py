@@ -17,6 +17,8 @@ FNN_OK, FNN_E_INVALID, FNN_E_HIP, FNN_E_INF, FNN_E_UNSUPPORTED, FNN_E_STATE = 0,
 FNN_NET_PLAIN, FNN_NET_RESENC = 0, 1
 FNN_ACC_FP16_REFERENCE, FNN_ACC_FP32 = 0, 1
 FNN_OUT_F16, FNN_OUT_F32 = 0, 1
+FNN_LABELS_ARGMAX, FNN_LABELS_REGIONS = 0, 1
+FNN_LABEL_U8, FNN_LABEL_U16 = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libfnn_hip.so')
@@ -47,7 +49,7 @@ class Profile(C.Structure):
 
 EXPORTS = ['fnn_abi_version', 'fnn_last_error', 'fnn_create', 'fnn_destroy', 'fnn_weight_count', 'fnn_load_weights',
            'fnn_set_gaussian', 'fnn_predict_volume', 'fnn_predict_volume_ensemble', 'fnn_predict_labels',
-           'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_compute_steps', 'fnn_plan_volume',
+           'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_compute_steps', 'fnn_plan_volume',
            'fnn_set_profiling', 'fnn_get_profile', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d']
 
 _lib = None
@@ -81,6 +83,7 @@ def load_library() -> C.CDLL:
     lib.fnn_predict_volume.argtypes = [vp, i32, vp, C.POINTER(i64), C.POINTER(Opts), vp]
     lib.fnn_predict_volume_ensemble.argtypes = [vp, i32, vp, C.POINTER(i64), C.POINTER(Opts), vp]
     lib.fnn_predict_labels.argtypes = [vp, i32, vp, C.POINTER(i64), C.POINTER(Opts), vp]
+    lib.fnn_set_label_rule.argtypes = [vp, i32, C.POINTER(i32), i32, i32]
     lib.fnn_accumulator_channels.argtypes = [vp]
     lib.fnn_accumulator_channels.restype = i64
     P64 = C.POINTER(i64)
@@ -264,6 +267,16 @@ class Engine:
 
     def forward_patches(self, x_ptr: int, n: int, out_ptr: int, fold: int = 0, stream: int = 0):
         check(self.lib.fnn_forward_patches(self.handle, fold, x_ptr, n, out_ptr, stream), self.lib, self.handle)
+
+    def set_label_rule(self, regions_class_order=None, uint16: bool = False):
+        """``None`` = argmax over heads; a sequence = region-based training (sigmoid > 0.5 painted in that order)."""
+        dt = FNN_LABEL_U16 if uint16 else FNN_LABEL_U8
+        if regions_class_order is None:
+            rc = self.lib.fnn_set_label_rule(self.handle, FNN_LABELS_ARGMAX, None, 0, dt)
+        else:
+            order = (C.c_int32 * len(regions_class_order))(*[int(i) for i in regions_class_order])
+            rc = self.lib.fnn_set_label_rule(self.handle, FNN_LABELS_REGIONS, order, len(regions_class_order), dt)
+        check(rc, self.lib, self.handle)
 
     def argmax_labels(self, logits_ptr, dtype, heads, n_vox, labels_ptr, stream=0):
         check(self.lib.fnn_argmax_labels(self.handle, logits_ptr, dtype, heads, n_vox, labels_ptr, stream),

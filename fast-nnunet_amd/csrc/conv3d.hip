@@ -1000,12 +1000,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
                             }
                         }
                 }
+                // commit() is duplicated on purpose: on this path hipcc can wait for the (older) prefetch loads
+                // alone - vmcnt(number of epilogue stores) - instead of vmcnt(0) after a merge point, which would
+                // expose the store acknowledgement latency once per tile
+                if (!WRES) __syncthreads();                      // single buffers: everybody is done reading
+                commit(sA0 + (WRES ? (buf ^ 1) * abytes : 0));
+            } else {
+                if (!WRES) __syncthreads();
+                commit(sA0 + (WRES ? (buf ^ 1) * abytes : 0));
             }
 #ifdef FNN_STAMPS
-            if (stamp_it) FNN_STAMP();                           // 3: epilogue done
+            if (stamp_it) FNN_STAMP();                           // 3: epilogue + commit done
 #endif
-            if (!WRES) __syncthreads();                          // single buffers: everybody is done reading
-            commit(sA0 + (WRES ? (buf ^ 1) * abytes : 0));
             __syncthreads();
 #ifdef FNN_STAMPS
             if (stamp_it) FNN_STAMP();                           // 4: commit + barrier done

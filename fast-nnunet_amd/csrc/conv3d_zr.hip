@@ -56,6 +56,8 @@ template <int NB, int TD>
 __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    FNN_STAMP_DECL
+    FNN_STAMP();                                              // 0: entry
     constexpr int IH = 10, IW = 10, PW = 12, ID = TD + 2;    // halo tile, row pitch 12 = 4 (mod 8) voxels
     constexpr int PS = IH * PW * 32;                          // bytes per halo plane
     constexpr int ABYTES = (ID * PS + 1023) & ~1023;
@@ -195,18 +197,24 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
         }
     };
 
+    FNN_STAMP();                                              // 1: index tables done
     issue(0);
+    FNN_STAMP();                                              // 2: first loads issued
     commit();
     __syncthreads();
+    FNN_STAMP();                                              // 3: first chunk staged
     // the last chunk is peeled off so that the wait for the prefetch sits on an unconditional path (see conv3d_lds_kernel)
     for (int ch = 0; ch + 1 < p.chunks; ++ch) {
         issue(ch + 1);                                        // global loads stay in flight during the MFMAs
         kloop();
+        FNN_STAMP();                                          // k-loop done
         __syncthreads();                                      // every wave is done reading this chunk
         commit();
         __syncthreads();
+        FNN_STAMP();                                          // next chunk staged
     }
     kloop();
+    FNN_STAMP();
     __syncthreads();
 
     // ---- epilogue: bias, fp16 store, statistics
@@ -222,6 +230,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
         tile_epilogue<NB, TD, true>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
         if (p.stats_out) stats_to_global<NB>(p, t1, t2, (float *)smem, n, cb0, wave, lane, tid);
     }
+    FNN_STAMP();                                              // epilogue done
+    FNN_STAMP_FLUSH(p.dbg);
 }
 
 template <int NB, int TD>
@@ -241,6 +251,9 @@ static int launch_zr(ConvParams p, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// A persistent form of this kernel (tile ranges per workgroup, cross-tile prefetch, like conv3d_persist_kernel) was
+// built and measured: 5-20 % SLOWER on every layer of the benchmark net - <2, 8> does not fit 256 VGPRs next to the
+// prefetch registers, <2, 4> loses the operand reuse - so one tile per workgroup it stays.
 // Runs the layer on the ZR kernel; the weights must have been packed as FNN_PACK_ZR (p.packing).
 int launch_conv3d_zr(const ConvParams &p, hipStream_t st) {
     int nb, td;

@@ -35,19 +35,27 @@ static __device__ __forceinline__ void mb_coords(int wave, int mb, int r, int &o
 
 // Epilogue of one output tile: bias, round to fp16, channels-last store (4 consecutive channels per
 // lane), and this lane's partial sums of the rounded values (fp32 within the tile).
+// Branch-free: voxels outside the tensor get a buffer offset beyond num_records, which the hardware
+// drops.  With `if (ok)` around global stores the number of stores in flight was unknown to hipcc's
+// waitcnt pass, and a persistent kernel that prefetches its next tile across the epilogue had to wait
+// for vmcnt(0) - the store acknowledgements - before it could touch the prefetched data.
+typedef int fnn_i32x2 __attribute__((ext_vector_type(2)));
 template <int NB, int MB, bool ZR = false>
 static __device__ __forceinline__ void tile_epilogue(const ConvParams &p, const f32x4 (&acc)[MB][NB], const float4 (&bv)[NB],
                                                      int n, int od0, int oh0, int ow0, int cb0, int wave, int lane,
                                                      float (&t1)[NB][4], float (&t2)[NB][4]) {
     const int q = lane >> 4, r = lane & 15;
-    f16 *outn = p.out + (size_t)n * p.Do * p.Ho * p.Wo * p.Cout + cb0 * 16 + q * 4;
+    const unsigned item_bytes = (unsigned)p.Do * p.Ho * p.Wo * p.Cout * 2;          // < 2^31 (checked by the launchers)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)n * (item_bytes >> 1), 0,
+                                                                           item_bytes, 0x00020000);
+    const unsigned coff = (unsigned)(cb0 * 16 + q * 4) * 2;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         int od_l, oh_l, ow_l;
         mb_coords<MB, ZR>(wave, mb, r, od_l, oh_l, ow_l);
         const int od = od0 + od_l, oh = oh0 + oh_l, ow = ow0 + ow_l;
         const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
-        const unsigned voff = (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout);
+        const unsigned voff = ok ? (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout) * 2 + coff : 0x80000000u;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             f16x4 o;
@@ -55,14 +63,12 @@ static __device__ __forceinline__ void tile_epilogue(const ConvParams &p, const 
             o[1] = (f16)(acc[mb][nb][1] + bv[nb].y);
             o[2] = (f16)(acc[mb][nb][2] + bv[nb].z);
             o[3] = (f16)(acc[mb][nb][3] + bv[nb].w);
-            if (ok) {
-                *(f16x4 *)(outn + voff + nb * 16) = o;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fnn_i32x2, o), rsrc, voff, nb * 32, 0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = (float)o[j];
-                    t1[nb][j] += v;
-                    t2[nb][j] = fmaf(v, v, t2[nb][j]);
-                }
+            for (int j = 0; j < 4; ++j) {
+                const float v = ok ? (float)o[j] : 0.f;
+                t1[nb][j] += v;
+                t2[nb][j] = fmaf(v, v, t2[nb][j]);
             }
         }
     }

@@ -72,6 +72,9 @@ struct fnn_engine {
     float *ss = nullptr;                    // [layer][max_batch][2][C]
     f16 *gauss = nullptr;
     int *inf_flag = nullptr;
+    // label rule of the label-map entry points (fnn_set_label_rule)
+    int label_mode = FNN_LABELS_ARGMAX, label_u16 = 0;
+    int *label_order = nullptr;             // device: regions_class_order[num_heads]
     int *origins = nullptr; size_t origins_cap = 0;
     void *acc = nullptr; size_t acc_bytes = 0;
     float *vol_tmp = nullptr; size_t vol_tmp_bytes = 0;
@@ -739,7 +742,7 @@ int accumulate_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const
 }
 
 int predict_impl(fnn_engine *e, int fold0, int n_folds, const float *vol, const int64_t shape[4], const fnn_opts *o,
-                 void *out, uint8_t *labels) {
+                 void *out, void *labels) {
     for (int f = fold0; f < fold0 + n_folds; ++f)
         if (int rc = check_ready(e, f, o)) return rc;
     if (!vol || (!out && !labels) || !shape) return fail(e, FNN_E_INVALID, "NULL argument");
@@ -767,10 +770,14 @@ int predict_impl(fnn_engine *e, int fold0, int n_folds, const float *vol, const 
         if (int rc = ensure(e, &e->out_tmp, &e->out_tmp_bytes, nout * osz)) return rc;
         out_dev = e->out_tmp;
     }
-    uint8_t *lab_dev = labels;
+    void *lab_dev = labels;
     const bool lab_on_dev = labels && is_device_ptr(labels);
     void *lab_tmp = nullptr;
-    if (labels && !lab_on_dev) { HIPCHK(e, hipMalloc(&lab_tmp, nvox_out)); lab_dev = (uint8_t *)lab_tmp; }
+    const size_t lab_bytes = nvox_out * (e->label_u16 ? 2 : 1);
+    const int *lab_order = e->label_mode == FNN_LABELS_REGIONS ? e->label_order : nullptr;
+    if (labels && !e->label_u16 && e->label_mode == FNN_LABELS_ARGMAX && a.num_heads > 256)
+        return fail(e, FNN_E_INVALID, "%d classes do not fit uint8 labels: fnn_set_label_rule(..., FNN_LABEL_U16)", a.num_heads);
+    if (labels && !lab_on_dev) { HIPCHK(e, hipMalloc(&lab_tmp, lab_bytes)); lab_dev = lab_tmp; }
     HIPCHK(e, hipMemsetAsync(e->inf_flag, 0, sizeof(int), st));
     e->ev_used = 0;
     const int acc_fp32 = o->accum == FNN_ACC_FP32;
@@ -782,20 +789,20 @@ int predict_impl(fnn_engine *e, int fold0, int n_folds, const float *vol, const 
         if (rc) break;
         FinalizeParams fp = make_finalize(e, e->acc, box, zero3, full3, vp, shape, *o, acc_fp32, f > 0 ? 1 : 0, out_dev);
         Scope sc(e, st, FAM_FINAL, 0);
-        if (labels_direct) { if (launch_labels_from_acc(fp, lab_dev, st) != 0) rc = fail(e, FNN_E_HIP, "labels launch failed"); }
+        if (labels_direct) { if (launch_labels_from_acc(fp, lab_dev, e->label_u16, lab_order, st) != 0) rc = fail(e, FNN_E_HIP, "labels launch failed"); }
         else if (launch_finalize(fp, st) != 0) rc = fail(e, FNN_E_HIP, "finalize launch failed");
     }
     if (rc == 0 && !labels_direct && n_folds > 1)
         if (launch_scale_output(out_dev, o->out_dtype == FNN_OUT_F32, (long long)nout, n_folds, e->inf_flag, st) != 0)
             rc = fail(e, FNN_E_HIP, "scale launch failed");
     if (rc == 0 && labels && !labels_direct)
-        if (launch_argmax(out_dev, o->out_dtype == FNN_OUT_F32, a.num_heads, (long long)nvox_out, lab_dev, st) != 0)
+        if (launch_argmax(out_dev, o->out_dtype == FNN_OUT_F32, a.num_heads, (long long)nvox_out, lab_dev, e->label_u16, lab_order, st) != 0)
             rc = fail(e, FNN_E_HIP, "argmax launch failed");
     int flag = 0;
     if (rc == 0) {
         hipError_t r1 = hipMemcpyAsync(&flag, e->inf_flag, sizeof(int), hipMemcpyDeviceToHost, st);
         if (r1 == hipSuccess && want_logits && !out_on_dev) r1 = hipMemcpyAsync(out, out_dev, nout * osz, hipMemcpyDeviceToHost, st);
-        if (r1 == hipSuccess && labels && !lab_on_dev) r1 = hipMemcpyAsync(labels, lab_dev, nvox_out, hipMemcpyDeviceToHost, st);
+        if (r1 == hipSuccess && labels && !lab_on_dev) r1 = hipMemcpyAsync(labels, lab_dev, lab_bytes, hipMemcpyDeviceToHost, st);
         if (r1 == hipSuccess) r1 = hipStreamSynchronize(st);
         if (r1 != hipSuccess) rc = fail(e, FNN_E_HIP, "copy back failed: %s", hipGetErrorString(r1));
     }
@@ -850,7 +857,7 @@ void fnn_destroy(fnn_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     for (auto &f : e->folds) { if (f.wpk) (void)hipFree(f.wpk); if (f.fparam) (void)hipFree(f.fparam); }
-    void *ptrs[] = {e->act, e->stats, e->ss, e->gauss, e->inf_flag, e->origins, e->acc, e->vol_tmp, e->vol_pad, e->out_tmp, e->patch_buf};
+    void *ptrs[] = {e->label_order, e->act, e->stats, e->ss, e->gauss, e->inf_flag, e->origins, e->acc, e->vol_tmp, e->vol_pad, e->out_tmp, e->patch_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ev : e->evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     delete e;
@@ -918,7 +925,7 @@ int fnn_predict_volume_ensemble(fnn_engine *e, int n_folds, const float *vol, co
     return predict_impl(e, 0, n_folds, vol, shape, opts, out, nullptr);
 }
 
-int fnn_predict_labels(fnn_engine *e, int n_folds, const float *vol, const int64_t shape[4], const fnn_opts *opts, uint8_t *labels) {
+int fnn_predict_labels(fnn_engine *e, int n_folds, const float *vol, const int64_t shape[4], const fnn_opts *opts, void *labels) {
     if (!e) return FNN_E_INVALID;
     if (n_folds < 1) return fail(e, FNN_E_INVALID, "n_folds must be >= 1");
     if (!labels) return fail(e, FNN_E_INVALID, "NULL labels");
@@ -1031,12 +1038,37 @@ int fnn_forward_patches(fnn_engine *e, int fold, const float *x, int n, float *l
     return 0;
 }
 
-int fnn_argmax_labels(fnn_engine *e, const void *logits, int dtype, int heads, int64_t n_vox, uint8_t *labels, void *stream) {
+int fnn_set_label_rule(fnn_engine *e, int mode, const int32_t *regions_class_order, int n_regions, int label_dtype) {
     if (!e) return FNN_E_INVALID;
-    if (!logits || !labels || heads < 1 || heads > 256) return fail(e, FNN_E_INVALID, "bad argument");
+    if ((mode != FNN_LABELS_ARGMAX && mode != FNN_LABELS_REGIONS) || (label_dtype != FNN_LABEL_U8 && label_dtype != FNN_LABEL_U16))
+        return fail(e, FNN_E_INVALID, "unknown label mode / dtype");
+    if (mode == FNN_LABELS_REGIONS) {
+        if (!regions_class_order || n_regions != e->arch.num_heads)
+            return fail(e, FNN_E_INVALID, "regions_class_order needs one entry per segmentation head (%d), got %d", e->arch.num_heads, n_regions);
+        const int limit = label_dtype == FNN_LABEL_U16 ? 65535 : 255;
+        for (int i = 0; i < n_regions; ++i)
+            if (regions_class_order[i] < 0 || regions_class_order[i] > limit)
+                return fail(e, FNN_E_INVALID, "regions_class_order[%d] = %d does not fit the label dtype", i, regions_class_order[i]);
+        HIPCHK(e, hipSetDevice(e->device));
+        if (!e->label_order) HIPCHK(e, hipMalloc((void **)&e->label_order, sizeof(int) * (size_t)e->arch.num_heads));
+        HIPCHK(e, hipMemcpy(e->label_order, regions_class_order, sizeof(int) * (size_t)n_regions, hipMemcpyHostToDevice));
+    }
+    e->label_mode = mode;
+    e->label_u16 = label_dtype == FNN_LABEL_U16;
+    return FNN_OK;
+}
+
+int fnn_argmax_labels(fnn_engine *e, const void *logits, int dtype, int heads, int64_t n_vox, void *labels, void *stream) {
+    if (!e) return FNN_E_INVALID;
+    if (!logits || !labels || heads < 1) return fail(e, FNN_E_INVALID, "bad argument");
+    const bool regions = e->label_mode == FNN_LABELS_REGIONS;
+    if (regions && heads != e->arch.num_heads) return fail(e, FNN_E_INVALID, "the region rule was set for %d heads, got %d", e->arch.num_heads, heads);
+    if (!regions && !e->label_u16 && heads > 256) return fail(e, FNN_E_INVALID, "%d classes do not fit uint8 labels", heads);
     if (!is_device_ptr(logits) || !is_device_ptr(labels)) return fail(e, FNN_E_INVALID, "fnn_argmax_labels needs device pointers");
     HIPCHK(e, hipSetDevice(e->device));
-    if (launch_argmax(logits, dtype == FNN_OUT_F32, heads, n_vox, labels, (hipStream_t)stream) != 0) return fail(e, FNN_E_HIP, "argmax launch failed");
+    if (launch_argmax(logits, dtype == FNN_OUT_F32, heads, n_vox, labels, e->label_u16, regions ? e->label_order : nullptr,
+                      (hipStream_t)stream) != 0)
+        return fail(e, FNN_E_HIP, "argmax launch failed");
     return 0;
 }
 

@@ -196,8 +196,9 @@ int launch_tconv(const TconvParams &p, hipStream_t st);
 int launch_head(const HeadParams &p, hipStream_t st);
 int launch_patch_acc(const PatchAccParams &p, hipStream_t st);
 int launch_finalize(const FinalizeParams &p, hipStream_t st);
-int launch_labels_from_acc(const FinalizeParams &p, uint8_t *labels, hipStream_t st);
+int launch_labels_from_acc(const FinalizeParams &p, void *labels, int label_u16, const int *order, hipStream_t st);
 int launch_scale_output(void *out, int out_fp32, long long n, int divisor, int *inf_flag, hipStream_t st);
-int launch_argmax(const void *logits, int fp32, int heads, long long nvox, uint8_t *labels, hipStream_t st);
+int launch_argmax(const void *logits, int fp32, int heads, long long nvox, void *labels, int label_u16, const int *order,
+                  hipStream_t st);
 int launch_pad_volume(const float *src, float *dst, int C, const long long s[3], const long long d[3],
                       const long long lo[3], hipStream_t st);

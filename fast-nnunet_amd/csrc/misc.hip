@@ -587,8 +587,24 @@ int launch_finalize(const FinalizeParams &p, hipStream_t st) {
 
 // Label map straight from the accumulators: argmax_h(acc_h / wsum) with the reference's rounding
 // (divide, round to fp16, first maximum wins) without materialising the logits.
-template <bool ACC32>
-__global__ __launch_bounds__(256) void labels_from_acc_kernel(const FinalizeParams p, uint8_t *labels) {
+// LabelManager.convert_logits_to_segmentation on one voxel's logits (label_handling.py:163-181):
+//   plain labels: numpy argmax - first maximum wins, the first NaN wins;
+//   regions     : label 0, then for i in order: if sigmoid(float(logit_i)) > 0.5: label = regions_class_order[i].
+// torch's fp32 sigmoid exceeds 0.5 exactly for x > 1.5 * 2^-24 (probed over every fp32 around the threshold and every
+// fp16 value, tests/test_oracle_golden.py) - "logit > 0" would differ for the two smallest positive fp16 values.
+#define FNN_SIGMOID_HALF_THRESHOLD 0x1.8p-24f
+struct LabelPick {
+    float best = 0.f; int arg = 0; bool best_nan = false; int seg = 0;
+    __device__ __forceinline__ void feed(int h, float v, const int *order) {
+        if (order) { if (v > FNN_SIGMOID_HALF_THRESHOLD) seg = order[h]; }
+        else if (h == 0) { best = v; best_nan = v != v; }
+        else if (!best_nan && (v > best || v != v)) { best = v; arg = h; best_nan = v != v; }
+    }
+    __device__ __forceinline__ int result(const int *order) const { return order ? seg : arg; }
+};
+
+template <bool ACC32, typename LT>
+__global__ __launch_bounds__(256) void labels_from_acc_kernel(const FinalizeParams p, LT *labels, const int *order) {
     const long long nbox = p.OX * p.OY * p.OZ;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= nbox) return;
@@ -596,23 +612,28 @@ __global__ __launch_bounds__(256) void labels_from_acc_kernel(const FinalizePara
     const size_t aelem = (((size_t)(x + p.lo_x) * p.Y + (y + p.lo_y)) * p.Z + (z + p.lo_z)) * p.HP;
     const size_t oidx0 = ((size_t)(x + p.out_x) * p.out_Y + (y + p.out_y)) * p.out_Z + (z + p.out_z);
     const float wsum = ACC32 ? ((const float *)p.acc)[aelem + p.heads] : (float)((const f16 *)p.acc)[aelem + p.heads];
-    float best = 0.f;
-    int arg = 0;
+    LabelPick pick;
     bool bad = false;
     for (int h = 0; h < p.heads; ++h) {
         const float a = ACC32 ? ((const float *)p.acc)[aelem + h] : (float)((const f16 *)p.acc)[aelem + h];
         const float v = (float)(f16)__fdiv_rn(a, wsum);
         bad |= isinf(v);
-        if (h == 0 || v > best) { best = v; arg = h; }
+        pick.feed(h, v, order);
     }
-    labels[oidx0] = (uint8_t)arg;
+    labels[oidx0] = (LT)pick.result(order);
     if (bad) atomicOr(p.inf_flag, 1);
 }
 
-int launch_labels_from_acc(const FinalizeParams &p, uint8_t *labels, hipStream_t st) {
+int launch_labels_from_acc(const FinalizeParams &p, void *labels, int label_u16, const int *order, hipStream_t st) {
     const long long n = p.OX * p.OY * p.OZ;
-    if (p.acc_fp32) hipLaunchKernelGGL(labels_from_acc_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, labels);
-    else hipLaunchKernelGGL(labels_from_acc_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, labels);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (p.acc_fp32) {
+        if (label_u16) hipLaunchKernelGGL((labels_from_acc_kernel<true, uint16_t>), grid, dim3(256), 0, st, p, (uint16_t *)labels, order);
+        else hipLaunchKernelGGL((labels_from_acc_kernel<true, uint8_t>), grid, dim3(256), 0, st, p, (uint8_t *)labels, order);
+    } else {
+        if (label_u16) hipLaunchKernelGGL((labels_from_acc_kernel<false, uint16_t>), grid, dim3(256), 0, st, p, (uint16_t *)labels, order);
+        else hipLaunchKernelGGL((labels_from_acc_kernel<false, uint8_t>), grid, dim3(256), 0, st, p, (uint8_t *)labels, order);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -629,25 +650,26 @@ int launch_scale_output(void *out, int out_fp32, long long n, int divisor, int *
 }
 
 // ----------------------------------------------------------------------------
-// argmax over heads, first maximum wins (numpy argmax, label_handling.py:177)
+// logits [heads][n_vox] -> label map (argmax or regions, see LabelPick)
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void argmax_kernel(const void *logits, int fp32, int heads, long long nvox,
-                                                     uint8_t *labels) {
+template <typename LT>
+__global__ __launch_bounds__(256) void argmax_kernel(const void *logits, int fp32, int heads, long long nvox, LT *labels,
+                                                     const int *order) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= nvox) return;
-    float best = fp32 ? ((const float *)logits)[i] : (float)((const f16 *)logits)[i];
-    int arg = 0;
-    bool best_nan = best != best;
-    for (int h = 1; h < heads; ++h) {
+    LabelPick pick;
+    for (int h = 0; h < heads; ++h) {
         const float v = fp32 ? ((const float *)logits)[(size_t)h * nvox + i] : (float)((const f16 *)logits)[(size_t)h * nvox + i];
-        // numpy: the first NaN wins; otherwise strictly greater replaces
-        if (!best_nan && (v > best || v != v)) { best = v; arg = h; best_nan = v != v; }
+        pick.feed(h, v, order);
     }
-    labels[i] = (uint8_t)arg;
+    labels[i] = (LT)pick.result(order);
 }
 
-int launch_argmax(const void *logits, int fp32, int heads, long long nvox, uint8_t *labels, hipStream_t st) {
-    hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, logits, fp32, heads, nvox, labels);
+int launch_argmax(const void *logits, int fp32, int heads, long long nvox, void *labels, int label_u16, const int *order,
+                  hipStream_t st) {
+    const dim3 grid((unsigned)((nvox + 255) / 256));
+    if (label_u16) hipLaunchKernelGGL(argmax_kernel<uint16_t>, grid, dim3(256), 0, st, logits, fp32, heads, nvox, (uint16_t *)labels, order);
+    else hipLaunchKernelGGL(argmax_kernel<uint8_t>, grid, dim3(256), 0, st, logits, fp32, heads, nvox, (uint8_t *)labels, order);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -230,19 +230,52 @@ class nnUNetPredictor(object):
         return out.to('cpu')
 
     @torch.inference_mode()
+    def _label_rule(self):
+        """(regions_class_order or None, uint16?) - LabelManager.convert_logits_to_segmentation
+        (label_handling.py:163-181) and the dtype rule of export_prediction.py:45-46."""
+        lm = self.label_manager
+        order = None
+        if lm.has_regions:
+            assert lm.regions_class_order is not None, \
+                'if region-based training is requested then you need to define regions_class_order!'
+            order = [int(c) for c in lm.regions_class_order]
+        return order, len(lm.foreground_labels) >= 255
+
     def predict_segmentation_from_preprocessed_data(self, data: torch.Tensor) -> torch.Tensor:
         """Label map on the device, skipping the full-logit D2H copy the reference pays at :386 before
-        ``convert_logits_to_segmentation`` (label_handling.py:173-180).  With one fold the argmax is taken
-        straight from the accumulators; the logits are never written."""
-        if self.label_manager.has_regions:
-            raise NotImplementedError('region-based label conversion is not implemented on the device')
-        if self._spec.num_heads > 256:
-            raise NotImplementedError('uint8 label maps need <= 256 classes')
+        ``convert_logits_to_segmentation`` (label_handling.py:144-195): argmax for plain labels, sigmoid > 0.5
+        painted in ``regions_class_order`` for region-based training; uint8, or uint16 (returned as int32 - torch
+        has no uint16 arithmetic) when the dataset has >= 255 foreground labels (export_prediction.py:45-46).
+        With one fold the labels are taken straight from the accumulators; the logits are never written."""
         self._check_input(data)
+        order, u16 = self._label_rule()
         with torch.cuda.device(self.device):
             x = data.to(device=self.device, dtype=torch.float32).contiguous()
-            labels = torch.empty(x.shape[1:], dtype=torch.uint8, device=self.device)
+            self._engine.set_label_rule(order, uint16=u16)
+            labels = torch.empty(x.shape[1:], dtype=torch.int16 if u16 else torch.uint8, device=self.device)
             self._engine.predict_labels(x.data_ptr(), x.shape, self._opts(), labels.data_ptr(), n_folds=self._n_folds)
+            if u16:
+                labels = labels.to(torch.int32) & 0xffff
+        return labels
+
+    def convert_logits_to_segmentation(self, predicted_logits: torch.Tensor) -> torch.Tensor:
+        """``LabelManager.convert_logits_to_segmentation`` (label_handling.py:183-195) on resident logits
+        ``[heads, X, Y, Z]`` (fp16 or fp32, on the device)."""
+        from . import capi
+        assert predicted_logits.ndim == 4 and predicted_logits.shape[0] == self._spec.num_heads
+        order, u16 = self._label_rule()
+        with torch.cuda.device(self.device):
+            lg = predicted_logits.to(self.device)
+            if lg.dtype not in (torch.half, torch.float32):
+                lg = lg.float()
+            lg = lg.contiguous()
+            self._engine.set_label_rule(order, uint16=u16)
+            labels = torch.empty(lg.shape[1:], dtype=torch.int16 if u16 else torch.uint8, device=self.device)
+            self._engine.argmax_labels(lg.data_ptr(), capi.FNN_OUT_F32 if lg.dtype == torch.float32 else capi.FNN_OUT_F16,
+                                       lg.shape[0], lg[0].numel(), labels.data_ptr(),
+                                       torch.cuda.current_stream(self.device).cuda_stream)
+            if u16:
+                labels = labels.to(torch.int32) & 0xffff
         return labels
 
     @torch.inference_mode()

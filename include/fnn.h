@@ -128,13 +128,26 @@ int fnn_predict_volume_ensemble(fnn_engine *e, int n_folds, const float *vol, co
  * Used by parity tests and by callers that bring their own tiling. */
 int fnn_forward_patches(fnn_engine *e, int fold, const float *x, int n, float *logits, void *stream);
 
-/* Label map without materialising the logits: for one fold the argmax is taken
- * straight from the accumulators (divide, round to fp16, first maximum wins -
+/* How the label-map entry points turn logits into labels (engine state, default
+ * ARGMAX / U8) - LabelManager.convert_logits_to_segmentation, label_handling.py:144-195:
+ *   FNN_LABELS_ARGMAX  plain labels: argmax over heads, first maximum wins (:176-180);
+ *   FNN_LABELS_REGIONS region-based training: label = 0, then for i in order
+ *                      `if sigmoid(float(logit_i)) > 0.5: label = regions_class_order[i]`
+ *                      (:163-170; n_regions must equal num_heads).
+ * label_dtype follows export_prediction.py:45-46: uint8 when the dataset has
+ * < 255 foreground labels, else uint16. */
+enum { FNN_LABELS_ARGMAX = 0, FNN_LABELS_REGIONS = 1 };
+enum { FNN_LABEL_U8 = 0, FNN_LABEL_U16 = 1 };
+int fnn_set_label_rule(fnn_engine *e, int mode, const int32_t *regions_class_order, int n_regions, int label_dtype);
+
+/* Label map without materialising the logits: for one fold the labels are taken
+ * straight from the accumulators (divide, round to fp16, then the label rule -
  * exactly what convert_logits_to_segmentation would see); for several folds the
  * ensemble logits are formed first.  Replaces the reference's full-logit D2H
- * copy + numpy argmax (:386, label_handling.py:173-180).  labels: uint8 [X,Y,Z]. */
+ * copy + numpy argmax (:386, label_handling.py:173-180).  labels: uint8 or
+ * uint16 [X,Y,Z] per fnn_set_label_rule. */
 int fnn_predict_labels(fnn_engine *e, int n_folds, const float *vol, const int64_t shape[4],
-                       const fnn_opts *opts, uint8_t *labels);
+                       const fnn_opts *opts, void *labels);
 
 /* Multi-GPU building blocks (not in the reference, whose only
  * inference parallelism is case-level -num_parts/-part_id, :918-925).
@@ -156,11 +169,10 @@ int fnn_normalize_box(fnn_engine *e, const void *acc, const int64_t shape[4], co
                       const int64_t box_lo[3], const int64_t box_hi[3],
                       const int64_t out_lo[3], const int64_t out_hi[3], void *out_logits);
 
-/* LabelManager.convert_logits_to_segmentation for plain labels
- * (label_handling.py:173-180): argmax over heads, first maximum wins.
- * logits [heads, n_vox] f16/f32 -> labels uint8 (heads <= 256). */
+/* LabelManager.convert_logits_to_segmentation on resident logits with the
+ * engine's label rule: logits [heads, n_vox] f16/f32 -> labels uint8/uint16. */
 int fnn_argmax_labels(fnn_engine *e, const void *logits, int dtype, int heads, int64_t n_vox,
-                      uint8_t *labels, void *stream);
+                      void *labels, void *stream);
 
 /* ---- host-side integer logic (no GPU needed) ------------------------------ */
 /* compute_steps_for_sliding_window (sliding_window_prediction.py:30-54) for one

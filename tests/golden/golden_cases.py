@@ -96,6 +96,9 @@ DATASET_JSONS = {
                 'file_ending': '.nii.gz'},
     'regions': {'labels': {'background': 0, 'whole': [1, 2, 3], 'core': [2, 3], 'enh': 3},
                 'regions_class_order': [1, 2, 3], 'channel_names': {'0': 'T1'}, 'file_ending': '.nii.gz'},
+    # >= 255 foreground labels: uint16 label maps (export_prediction.py:45-46); class values above 255
+    'regions_u16': {'labels': {'background': 0, 'whole': list(range(1, 301)), 'core': list(range(100, 301)), 'enh': 300},
+                    'regions_class_order': [1, 100, 300], 'channel_names': {'0': 'T1'}, 'file_ending': '.nii.gz'},
 }
 
 
@@ -174,3 +177,24 @@ def make_case_networks(case):
         nets.append(net.eval())
         params.append(sd)
     return nets, params
+
+
+def label_rule_inputs():
+    """Logits for the label-rule golden vectors (tests/golden/label_rules.npz), rebuilt from fixed seeds."""
+    import numpy as np
+    import torch
+    allh = torch.arange(0, 65536, dtype=torch.int32).to(torch.int16).view(torch.half)          # every fp16 bit pattern
+    g = torch.Generator().manual_seed(123)
+    heads = [allh[torch.randperm(65536, generator=g)] for _ in range(3)]
+    regions_f16 = torch.stack(heads).reshape(3, 64, 32, 32)
+    # fp32 logits on both sides of torch's sigmoid(x) > 0.5 threshold (1.5 * 2^-24), plus ordinary values
+    bits = np.arange(0x33bffff0, 0x33c00010, dtype=np.uint32)
+    near = torch.from_numpy(bits.view(np.float32).copy())
+    body = torch.randn(3, 4096 - near.numel(), generator=g) * 1e-3
+    f32 = torch.cat([torch.stack([near, near.flip(0), -near]), body], 1).reshape(3, 16, 16, 16)
+    # argmax: 5 heads of coarse values (many ties), a few NaNs
+    am = (torch.randint(-3, 4, (5, 16, 16, 16), generator=g).float() * 0.5).half()
+    am[2, 0, 0, :4] = float('nan')
+    am[4, 1, 0, :4] = float('nan')
+    am[0, 2, 0, :4] = float('nan')
+    return {'regions_f16': regions_f16, 'regions_f32': f32, 'argmax_f16': am}

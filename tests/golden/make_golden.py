@@ -160,7 +160,30 @@ def gen_topology():
         json.dump(out, f)
 
 
+def gen_label_rules():
+    """LabelManager.convert_logits_to_segmentation on crafted logits: every fp16 bit pattern in every head (the
+    sigmoid > 0.5 threshold sits between the two smallest positive fp16 values), fp32 logits around that threshold,
+    and the plain argmax with ties / NaNs.  Inputs are rebuilt from seeds by golden_cases.label_rule_inputs()."""
+    from golden_cases import label_rule_inputs
+    arrays = {}
+    inp = label_rule_inputs()
+    lm = LabelManager(DATASET_JSONS['regions']['labels'], DATASET_JSONS['regions']['regions_class_order'])
+    arrays['regions_f16'] = lm.convert_logits_to_segmentation(inp['regions_f16']).numpy().astype(np.int16)
+    arrays['regions_f32'] = lm.convert_logits_to_segmentation(inp['regions_f32']).numpy().astype(np.int16)
+    lm2 = LabelManager(DATASET_JSONS['regions_u16']['labels'], DATASET_JSONS['regions_u16']['regions_class_order'])
+    arrays['regions_u16'] = lm2.convert_logits_to_segmentation(inp['regions_f16']).numpy().astype(np.int16)
+    lm3 = LabelManager({('background' if i == 0 else f'c{i}'): i for i in range(5)}, None)
+    arrays['argmax_f16'] = lm3.convert_logits_to_segmentation(inp['argmax_f16']).numpy().astype(np.int16)
+    np.savez_compressed(os.path.join(HERE, 'label_rules.npz'), **arrays)
+    print('label rules', {k: (v.shape, int(v.max())) for k, v in arrays.items()})
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1:                                   # regenerate single fixtures: labels, plans
+        for what in sys.argv[1:]:
+            {'labels': gen_label_rules, 'plans': gen_plans}[what]()
+        sys.exit(0)
+    gen_label_rules()
     gen_steps()
     gen_gaussian()
     gen_topology()

@@ -45,12 +45,12 @@ def _plans(patch):
 
 
 def _predictor(spec: UNetSpec, patch, state_dicts, mirror=None, step=0.5, gaussian=True, accumulate_in='fp16',
-               batch=3, on_device=True):
+               batch=3, on_device=True, dataset_json=None):
     from fast_nnunet_amd import nnUNetPredictor
     pm = _plans(patch)
     cm = pm.get_configuration('3d_fullres')
-    dj = {'labels': {('background' if i == 0 else f'c{i}'): i for i in range(spec.num_heads)},
-          'channel_names': {str(i): 'CT' for i in range(spec.in_channels)}, 'file_ending': '.nii.gz'}
+    dj = dataset_json or {'labels': {('background' if i == 0 else f'c{i}'): i for i in range(spec.num_heads)},
+                          'channel_names': {str(i): 'CT' for i in range(spec.in_channels)}, 'file_ending': '.nii.gz'}
     p = nnUNetPredictor(tile_step_size=step, use_gaussian=gaussian, use_mirroring=mirror is not None,
                         perform_everything_on_device=on_device, device=torch.device('cuda', 0), verbose=False,
                         allow_tqdm=False, accumulate_in=accumulate_in, patches_per_forward=batch)
@@ -212,6 +212,44 @@ def test_argmax_labels_on_device_match_numpy():
     labels = p.predict_segmentation_from_preprocessed_data(image).cpu().numpy()
     assert np.array_equal(labels, logits.cpu().numpy().argmax(0))
     assert labels.max() > 0
+
+
+def test_label_rules_match_reference_golden(golden_dir):
+    """f-1: LabelManager.convert_logits_to_segmentation on the device - regions (sigmoid > 0.5 in
+    regions_class_order) on every fp16 bit pattern and on fp32 logits around the threshold, uint16 labels for
+    >= 255 foreground labels, argmax with ties and NaNs - bit-exact against vectors made by the reference."""
+    from golden_cases import DATASET_JSONS, label_rule_inputs
+    z = np.load(os.path.join(golden_dir, 'label_rules.npz'))
+    inp = label_rule_inputs()
+    spec, patch = SPECS['toy3']                                         # 3 heads = the 3 regions
+    sd = synthetic_state_dict(spec, 1)
+    p = _predictor(spec, patch, [sd], dataset_json=DATASET_JSONS['regions'])
+    got = p.convert_logits_to_segmentation(inp['regions_f16'].cuda())
+    assert got.dtype == torch.uint8 and np.array_equal(got.cpu().numpy(), z['regions_f16'])
+    got = p.convert_logits_to_segmentation(inp['regions_f32'].cuda())
+    assert np.array_equal(got.cpu().numpy(), z['regions_f32'])
+    p16 = _predictor(spec, patch, [sd], dataset_json=DATASET_JSONS['regions_u16'])
+    got = p16.convert_logits_to_segmentation(inp['regions_f16'].cuda())
+    assert np.array_equal(got.cpu().numpy(), z['regions_u16']) and int(got.max()) == 300
+    spec5, patch5 = SPECS['aniso5']
+    p5 = _predictor(spec5, patch5, [synthetic_state_dict(spec5, 1)])
+    got = p5.convert_logits_to_segmentation(inp['argmax_f16'].cuda())
+    assert np.array_equal(got.cpu().numpy(), z['argmax_f16'])
+
+
+@pytest.mark.parametrize('n_folds', [1, 2])
+def test_region_labels_straight_from_the_accumulators(n_folds):
+    from golden_cases import DATASET_JSONS
+    spec, patch = SPECS['toy3']
+    sds = [synthetic_state_dict(spec, 3 + i) for i in range(n_folds)]
+    for dj_name in ('regions', 'regions_u16'):
+        p = _predictor(spec, patch, sds, dataset_json=DATASET_JSONS[dj_name])
+        image = torch.randn(1, 24, 20, 40, generator=torch.Generator().manual_seed(4))
+        logits = p.predict_logits_from_preprocessed_data(image)
+        want = osw.logits_to_labels(logits.cpu(), DATASET_JSONS[dj_name]['regions_class_order'])
+        got = p.predict_segmentation_from_preprocessed_data(image).cpu()
+        assert torch.equal(got.to(torch.int64), want.to(torch.int64))
+        assert len(torch.unique(got)) >= 3
 
 
 def test_results_on_cpu_when_not_everything_on_device():

@@ -124,3 +124,22 @@ def test_inf_check_raises():
 def test_ndim_assert():
     with pytest.raises(AssertionError):
         osw.sliding_window_logits(lambda x: x, torch.zeros(16, 16, 16), (8, 8, 8), 1)
+
+
+def test_label_rules_match_reference_golden(golden_dir):
+    """LabelManager.convert_logits_to_segmentation on every fp16 bit pattern, on fp32 logits around the
+    sigmoid > 0.5 threshold, with class values above 255, and the plain argmax with ties and NaNs."""
+    from golden_cases import label_rule_inputs
+    z = np.load(os.path.join(golden_dir, 'label_rules.npz'))
+    inp = label_rule_inputs()
+    order = DATASET_JSONS['regions']['regions_class_order']
+    assert np.array_equal(osw.logits_to_labels(inp['regions_f16'], order).numpy(), z['regions_f16'])
+    assert np.array_equal(osw.logits_to_labels(inp['regions_f32'], order).numpy(), z['regions_f32'])
+    order16 = DATASET_JSONS['regions_u16']['regions_class_order']
+    assert np.array_equal(osw.logits_to_labels(inp['regions_f16'], order16).numpy(), z['regions_u16'])
+    assert np.array_equal(osw.logits_to_labels(inp['argmax_f16']).numpy(), z['argmax_f16'])
+    # the closed form the HIP kernels use: sigmoid(float(x)) > 0.5  <=>  x > 1.5 * 2^-24
+    x = inp['regions_f16'].float()
+    assert torch.equal(torch.sigmoid(x) > 0.5, x > 1.5 * 2.0 ** -24)
+    x = inp['regions_f32']
+    assert torch.equal(torch.sigmoid(x) > 0.5, x > 1.5 * 2.0 ** -24)
