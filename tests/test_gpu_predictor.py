@@ -164,6 +164,35 @@ def test_driver_bit_identical_to_oracle_driver_on_engine_logits(case):
     assert same == 1.0
 
 
+@pytest.mark.parametrize('shape,folds,accum', [((24, 40, 64), 1, 'fp16'), ((19, 23, 72), 2, 'fp16'), ((17, 16, 40), 1, 'fp32')])
+def test_driver_with_61_heads_uses_the_tiled_finalize(shape, folds, accum):
+    """61 heads -> 64-channel accumulator rows: the vectorised seg head and the LDS-tiled finalize kernel
+    (aligned and ragged z extents, fold ensembling through the add mode) against the oracle driver."""
+    spec, patch = SPECS['heads61']
+    sds = [synthetic_state_dict(spec, 70 + f) for f in range(folds)]
+    p = _predictor(spec, patch, sds, accumulate_in=accum)
+    image = torch.randn(1, *shape, generator=torch.Generator().manual_seed(13))
+
+    def engine_net(fold):
+        def f(x):
+            p._active_fold = fold
+            return p.forward_patches(x).cpu()
+        return f
+
+    nets = [engine_net(f) for f in range(folds)]
+    if folds > 1:
+        want = osw.ensemble_logits(nets, image, patch, spec.num_heads, accum=accum)
+        got = p.predict_logits_from_preprocessed_data(image).cpu()
+    else:
+        want = osw.sliding_window_logits(nets[0], image, patch, spec.num_heads, accum=accum)
+        p._active_fold = 0
+        got = p.predict_sliding_window_return_logits(image).cpu()
+    if accum == 'fp16':
+        assert (_bits(got) == _bits(want)).all()
+    else:
+        assert (got.float() - want.float()).abs().max() <= 2e-3 * float(want.abs().max()) + 1e-3
+
+
 def test_fp32_accumulators_match_exact_blend():
     spec, patch = SPECS['toy3']
     sd = synthetic_state_dict(spec, 3)
