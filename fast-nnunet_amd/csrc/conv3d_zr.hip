@@ -84,27 +84,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
     char *sA = smem;                                          // halo image: [ID][IH][PW] voxels x 32 B, halves swapped on odd rows
     char *sW = smem + ABYTES;                                 // [NB][15][64 lanes][16 B]
     float *sBias = (float *)(sW + NB * KS * 1024);
-    if (tid < NB * 16) sBias[tid] = p.bias[cb0 * 16 + tid];
 
-    // MFMA "B" operand: lane = (voxel r of the wave's two rows, k-group): k-group bit 1 picks the tap of the pair,
-    // bit 0 the 8-channel half
-    int toff[5];
-    {
-        const int r = lane & 15, hl = lane >> 5, kh = (lane >> 4) & 1;
-#pragma unroll
-        for (int pr = 0; pr < 5; ++pr) {
-            const int tp = 2 * pr + hl < 9 ? 2 * pr + hl : 8;   // padded slot: any finite data (its weights are 0)
-            const int row = 2 * wave + (r >> 3) + tp / 3, col = (r & 7) + tp % 3;
-            toff[pr] = (row * PW + col) * 32 + ((kh ^ (row & 1)) * 16);
-        }
-    }
-
+    int toff[5];                                              // filled in after the first loads have left
     f32x4 acc[TD][NB];
-#pragma unroll
-    for (int j = 0; j < TD; ++j)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[j][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     // this thread's share of the prefetch: PF halo elements (voxel, 8-channel half) + WPF weight elements
     const int cg = tid & 1;
     int offv[PF];                                             // global voxel index; -1 = zero padding, -2 = no element
@@ -137,14 +119,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
     auto issue = [&](int ch) {
         const int c_glob = ch * 16;
         const int s = (c_glob < p.src[0].C) ? 0 : 1;
-        const int c_loc = c_glob - (s ? p.src[0].C : 0) + cg * 8;
-        const f16 *sp = p.src[s].ptr + c_loc;
+        const int c_uni = c_glob - (s ? p.src[0].C : 0);
+        const int c_loc = c_uni + cg * 8;
         const int sC = p.src[s].C;
+        // uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset: one address VGPR per load (tensors < 4 GiB)
+        const char *sp = (const char *)(p.src[s].ptr + c_uni);
 #pragma unroll
         for (int u = 0; u < PF; ++u)                          // unconditional: branches around loads make hipcc drain vmcnt
-            xr[u] = *(const f16x8 *)(sp + (size_t)(offv[u] >= 0 ? offv[u] : 0) * sC);
+            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * sC + cg * 8) * 2));
 #pragma unroll
-        for (int u = 0; u < WPF; ++u) wr[u] = ((const f16x8 *)p.wpk)[wofs[u] + ch * (KS * 64)];
+        for (int u = 0; u < WPF; ++u) wr[u] = *(const f16x8 *)((const char *)p.wpk + (unsigned)((wofs[u] + ch * (KS * 64)) * 16));
         slope_next = p.src[s].slope;
         if (p.src[s].ss) {
             const float *q4 = p.src[s].ss + (size_t)(2 * n) * sC + c_loc;
@@ -197,9 +181,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
         }
     };
 
-    FNN_STAMP();                                              // 1: index tables done
+    FNN_STAMP();                                              // 1: prefetch coordinates done
     issue(0);
+    __builtin_amdgcn_sched_barrier(0);                        // the loads leave first; the rest of the set-up runs under them
     FNN_STAMP();                                              // 2: first loads issued
+    if (tid < NB * 16) sBias[tid] = p.bias[cb0 * 16 + tid];
+    // MFMA "B" operand: lane = (voxel r of the wave's two rows, k-group): k-group bit 1 picks the tap of the pair,
+    // bit 0 the 8-channel half
+    {
+        const int r = lane & 15, hl = lane >> 5, kh = (lane >> 4) & 1;
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const int tp = 2 * pr + hl < 9 ? 2 * pr + hl : 8;   // padded slot: any finite data (its weights are 0)
+            const int row = 2 * wave + (r >> 3) + tp / 3, col = (r & 7) + tp % 3;
+            toff[pr] = (row * PW + col) * 32 + ((kh ^ (row & 1)) * 16);
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < TD; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[j][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
     commit();
     __syncthreads();
     FNN_STAMP();                                              // 3: first chunk staged
