@@ -40,6 +40,7 @@ class ArchSpec:
     patch: Tuple[int, int, int]
     eps: float = 1e-5
     slope: float = 0.01
+    spatial_dims: int = 3                      # 2: `2d` configuration, run as patch (1, py, pz) with kernels (1, k, k)
 
     @property
     def n_stages(self) -> int:
@@ -61,6 +62,7 @@ class ArchSpec:
         for a in range(3):
             d.patch[a] = int(self.patch[a])
         d.eps, d.slope = self.eps, self.slope
+        d.spatial_dims = self.spatial_dims
         return d
 
 
@@ -97,27 +99,32 @@ def spec_from_state_dict(state_dict: Mapping[str, object], patch: Sequence[int],
     first = (lambda s: f'encoder.stages.{s}.blocks.0.conv1.conv.weight') if resenc else \
         (lambda s: f'encoder.stages.{s}.0.convs.0.conv.weight')
     feats, kernels, n_enc = [], [], []
+    nd = sd[first(0)].ndim - 2                                   # Conv3d weights are 5-D, Conv2d (`2d` configurations) 4-D
+    if nd not in (2, 3):
+        raise NotImplementedError('only Conv2d / Conv3d networks are supported')
+    lift = (lambda t: (1, *t)) if nd == 2 else (lambda t: tuple(t))      # 2-D runs as depth-1 3-D
     for s in range(n):
         w = sd[first(s)]
-        if w.ndim != 5:
-            raise NotImplementedError('only 3-D (Conv3d) networks are supported')
         feats.append(int(w.shape[0]))
-        kernels.append(tuple(int(i) for i in w.shape[2:]))
+        kernels.append(lift(tuple(int(i) for i in w.shape[2:])))
         n_enc.append(_count(sd, rf'encoder\.stages\.{s}\.blocks\.(\d+)\.') if resenc
                      else _count(sd, rf'encoder\.stages\.{s}\.0\.convs\.(\d+)\.'))
     strides = [(1, 1, 1)] * n
     n_dec = []
     for d in range(n - 1):
         tw = sd[f'decoder.transpconvs.{d}.weight']
-        strides[n - 1 - d] = tuple(int(i) for i in tw.shape[2:])
+        strides[n - 1 - d] = lift(tuple(int(i) for i in tw.shape[2:]))
         n_dec.append(_count(sd, rf'decoder\.stages\.{d}\.convs\.(\d+)\.'))
+    patch = tuple(int(i) for i in patch)
+    if len(patch) != nd:
+        raise RuntimeError(f'patch_size {patch} does not match the {nd}-D network of the checkpoint')
     w0 = sd['encoder.stem.convs.0.conv.weight'] if resenc else sd['encoder.stages.0.0.convs.0.conv.weight']
-    if resenc and (int(w0.shape[0]) != feats[0] or tuple(int(i) for i in w0.shape[2:]) != kernels[0]):
+    if resenc and (int(w0.shape[0]) != feats[0] or lift(tuple(int(i) for i in w0.shape[2:])) != kernels[0]):
         raise NotImplementedError('stem with a width / kernel different from stage 0 is not supported')
     in_ch = int(w0.shape[1])
     heads = int(sd[f'decoder.seg_layers.{n - 2}.weight'].shape[0])
     return ArchSpec(capi.FNN_NET_RESENC if resenc else capi.FNN_NET_PLAIN, in_ch, heads, feats, kernels, strides,
-                    n_enc, n_dec, tuple(int(i) for i in patch), eps, slope)
+                    n_enc, n_dec, lift(patch), eps, slope, nd)
 
 
 def check_against_plans(spec: ArchSpec, arch_kwargs: dict, reduction: Optional[int] = None):
@@ -125,11 +132,14 @@ def check_against_plans(spec: ArchSpec, arch_kwargs: dict, reduction: Optional[i
     n = int(arch_kwargs['n_stages'])
     if n != spec.n_stages:
         raise RuntimeError(f'checkpoint has {spec.n_stages} stages, plans say {n}')
+    nd = spec.spatial_dims
+    lift = (lambda t: (1, *t)) if nd == 2 else (lambda t: tuple(t))
     ks = arch_kwargs['kernel_sizes']
-    plan_k = [tuple(k) if not isinstance(k, int) else (k,) * 3 for k in (ks if not isinstance(ks, int) else [ks] * n)]
-    if [tuple(k) for k in spec.kernels] != [tuple(int(i) for i in k) for k in plan_k]:
+    plan_k = [tuple(k) if not isinstance(k, int) else (k,) * nd for k in (ks if not isinstance(ks, int) else [ks] * n)]
+    plan_k = [lift(tuple(int(i) for i in k)) for k in plan_k]
+    if [tuple(k) for k in spec.kernels] != plan_k:
         raise RuntimeError(f'kernel sizes differ: checkpoint {spec.kernels} vs plans {plan_k}')
-    plan_s = [tuple(int(i) for i in s) for s in arch_kwargs['strides']]
+    plan_s = [lift(tuple(int(i) for i in (s if not isinstance(s, int) else (s,) * nd))) for s in arch_kwargs['strides']]
     if list(spec.strides) != plan_s:
         raise RuntimeError(f'strides differ: checkpoint {spec.strides} vs plans {plan_s}')
     if reduction is not None:
@@ -189,14 +199,16 @@ def spec_from_plans(arch_class_name: str, arch_kwargs: dict, in_channels: int, n
     resenc = 'Residual' in arch_class_name or 'ResEnc' in arch_class_name
     n = int(arch_kwargs['n_stages'])
     feats = [max(int(f) // reduction, 8) if reduction != 1 else int(f) for f in arch_kwargs['features_per_stage']]
+    nd = len(patch)
+    lift = (lambda t: (1, *t)) if nd == 2 else (lambda t: tuple(t))      # `2d` configurations run as depth-1 3-D
     ks = arch_kwargs['kernel_sizes']
-    kernels = [(int(ks),) * 3] * n if isinstance(ks, int) else [
-        tuple(int(i) for i in (k[0] if isinstance(k[0], (list, tuple)) else k)) for k in ks]
-    strides = [tuple(int(i) for i in s) for s in arch_kwargs['strides']]
+    kernels = [lift((int(ks),) * nd)] * n if isinstance(ks, int) else [
+        lift(tuple(int(i) for i in (k[0] if isinstance(k[0], (list, tuple)) else k))) for k in ks]
+    strides = [lift(tuple(int(i) for i in (s if not isinstance(s, int) else (s,) * nd))) for s in arch_kwargs['strides']]
     enc = arch_kwargs['n_blocks_per_stage' if resenc else 'n_conv_per_stage']
     enc = [int(enc)] * n if isinstance(enc, int) else [int(i) for i in enc]
     dec = arch_kwargs['n_conv_per_stage_decoder']
     dec = [int(dec)] * (n - 1) if isinstance(dec, int) else [int(i) for i in dec]
     eps = float((arch_kwargs.get('norm_op_kwargs') or {}).get('eps', 1e-5))
     return ArchSpec(capi.FNN_NET_RESENC if resenc else capi.FNN_NET_PLAIN, in_channels, num_heads, feats, kernels,
-                    strides, enc, dec, tuple(int(i) for i in patch), eps)
+                    strides, enc, dec, lift(tuple(int(i) for i in patch)), eps, 0.01, nd)

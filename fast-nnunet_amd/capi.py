@@ -32,7 +32,7 @@ class ArchDesc(C.Structure):
                 ('n_conv_enc', C.c_int32 * FNN_MAX_STAGES),
                 ('n_conv_dec', C.c_int32 * FNN_MAX_STAGES),
                 ('patch', C.c_int32 * 3),
-                ('eps', C.c_float), ('slope', C.c_float)]
+                ('eps', C.c_float), ('slope', C.c_float), ('spatial_dims', C.c_int32)]
 
 
 class Opts(C.Structure):
@@ -136,8 +136,10 @@ def compute_steps(image_size: int, patch_size: int, step: float):
 
 
 def plan_volume(patch: Sequence[int], shape_sp: Sequence[int], step: float):
-    """-> (padded shape, low pads, origins [n,3]) exactly as the engine will visit them."""
+    """-> (padded shape, low pads, origins [n,3]) exactly as the engine will visit them.  A patch with two
+    entries is a `2d` configuration: every slice of the first axis, tiles over the other two."""
     lib = load_library()
+    patch = [0, *patch] if len(patch) == 2 else list(patch)
     p = (C.c_int32 * 3)(*[int(i) for i in patch])
     s = (C.c_int64 * 3)(*[int(i) for i in shape_sp])
     padded, lo, n = (C.c_int64 * 3)(), (C.c_int64 * 3)(), C.c_int64(0)

@@ -138,6 +138,13 @@ int build_plan(fnn_engine *e) {
             if (a.strides[s][d] != 1 && a.strides[s][d] != 2) return fail(e, FNN_E_UNSUPPORTED, "strides must be 1 or 2");
             if (s == 0 && a.strides[s][d] != 1) return fail(e, FNN_E_UNSUPPORTED, "stage 0 must have stride 1");
         }
+    if (a.spatial_dims != 0 && a.spatial_dims != 2 && a.spatial_dims != 3) return fail(e, FNN_E_INVALID, "spatial_dims must be 2 or 3");
+    if (a.spatial_dims == 2) {
+        if (a.patch[0] != 1) return fail(e, FNN_E_INVALID, "a 2-D configuration has patch[0] == 1");
+        for (int s = 0; s < a.n_stages; ++s)
+            if (a.kernels[s][0] != 1 || a.strides[s][0] != 1)
+                return fail(e, FNN_E_INVALID, "a 2-D configuration has kernel and stride 1 along the first axis");
+    }
     int dims[FNN_MAX_STAGES][3];
     for (int d = 0; d < 3; ++d) dims[0][d] = a.patch[d];
     for (int s = 1; s < a.n_stages; ++s)
@@ -542,18 +549,26 @@ struct VolPlan {
     int64_t n_patches = 0;
 };
 
-int plan_volume_p(const int32_t patch[3], const int64_t sp[3], double step, VolPlan &vp);
+int plan_volume_p(const int32_t patch[3], const int64_t sp[3], double step, bool two_d, VolPlan &vp);
 int plan_volume(const fnn_arch_desc &a, const int64_t sp[3], double step, VolPlan &vp) {
-    return plan_volume_p(a.patch, sp, step, vp);
+    return plan_volume_p(a.patch, sp, step, a.spatial_dims == 2, vp);
 }
-int plan_volume_p(const int32_t patch[3], const int64_t sp[3], double step, VolPlan &vp) {
-    struct { const int32_t *patch; } a{patch};
+// _internal_get_sliding_window_slicers (:506-538): padding to >= patch, tile starts per axis, x-major order.
+// two_d: the `2d` branch (:508-524) - the first axis is not tiled, every slice is visited once.
+int plan_volume_p(const int32_t patch[3], const int64_t sp[3], double step, bool two_d, VolPlan &vp) {
     for (int d = 0; d < 3; ++d) {
+        if (two_d && d == 0) {
+            if (sp[0] < 1) return -1;
+            vp.padded[0] = sp[0]; vp.lo[0] = 0;
+            vp.steps[0].clear();
+            for (int64_t i = 0; i < sp[0]; ++i) vp.steps[0].push_back(i);
+            continue;
+        }
         if (sp[d] < 1 || patch[d] < 1) return -1;
-        const int64_t target = sp[d] > a.patch[d] ? sp[d] : a.patch[d];
+        const int64_t target = sp[d] > patch[d] ? sp[d] : patch[d];
         const int64_t diff = target - sp[d];
         vp.padded[d] = target; vp.lo[d] = diff / 2;        // the odd voxel goes to the high side
-        if (steps_1d(target, a.patch[d], step, vp.steps[d]) != 0) return -1;
+        if (steps_1d(target, patch[d], step, vp.steps[d]) != 0) return -1;
     }
     vp.origins.clear();
     for (int64_t x : vp.steps[0])
@@ -1084,7 +1099,9 @@ int fnn_plan_volume(const int32_t patch[3], const int64_t shape_sp[3], double st
                     int64_t *n_patches, int32_t *origins, int64_t origins_cap) {
     if (!patch || !shape_sp) return fail(nullptr, FNN_E_INVALID, "NULL argument");
     VolPlan vp;
-    if (plan_volume_p(patch, shape_sp, step, vp) != 0) return fail(nullptr, FNN_E_INVALID, "invalid volume shape / patch / step size");
+    const bool two_d = patch[0] == 0;
+    const int32_t pp[3] = {two_d ? 1 : patch[0], patch[1], patch[2]};
+    if (plan_volume_p(pp, shape_sp, step, two_d, vp) != 0) return fail(nullptr, FNN_E_INVALID, "invalid volume shape / patch / step size");
     for (int d = 0; d < 3; ++d) { if (padded) padded[d] = vp.padded[d]; if (pad_lo) pad_lo[d] = vp.lo[d]; }
     if (n_patches) *n_patches = vp.n_patches;
     if (origins) {

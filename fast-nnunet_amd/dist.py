@@ -179,7 +179,7 @@ class ShardedPredictor:
         patch = p._spec.patch
         with torch.cuda.device(p.device):
             x = input_image.to(device=p.device, dtype=torch.float32).contiguous()
-            padded, pad_lo, origins = capi.plan_volume(patch, x.shape[1:], p.tile_step_size)
+            padded, pad_lo, origins = capi.plan_volume(patch[3 - p._spec.spatial_dims:], x.shape[1:], p.tile_step_size)
             steps = [sorted(set(int(v) for v in origins[:, d])) for d in range(3)]
             dec = Decomposition.build(patch, padded, steps, self.world)
             opts = p._opts()                                  # accumulator dtype follows predictor.accumulate_in

@@ -148,8 +148,8 @@ class nnUNetPredictor(object):
     def _build_engine(self):
         sds = self._state_dicts()
         patch = tuple(self.configuration_manager.patch_size)
-        if len(patch) != 3:
-            raise NotImplementedError('the HIP engine implements 3-D (3d_fullres / 3d_lowres) configurations')
+        if len(patch) not in (2, 3):
+            raise NotImplementedError('patch_size must have two (2d) or three (3d_fullres / 3d_lowres) entries')
         kw = {}
         try:
             kw = self.configuration_manager.network_arch_init_kwargs or {}
@@ -184,10 +184,11 @@ class nnUNetPredictor(object):
         o.use_gaussian = int(bool(self.use_gaussian))
         axes = self.allowed_mirroring_axes if self.use_mirroring else None
         if axes is not None:
-            assert max(axes) <= 2, 'mirror_axes does not match the dimension of the input!'
+            nd = self._spec.spatial_dims
+            assert max(axes) <= nd - 1, 'mirror_axes does not match the dimension of the input!'
             o.n_mirror_axes = len(axes)
             for i, a in enumerate(axes):
-                o.mirror_axes[i] = int(a)
+                o.mirror_axes[i] = int(a) + (3 - nd)           # 2-D network axes (y, z) are engine axes 1, 2
         o.accum = capi.FNN_ACC_FP16_REFERENCE if self.accumulate_in == 'fp16' else capi.FNN_ACC_FP32
         o.out_dtype = capi.FNN_OUT_F16
         o.batch = self.patches_per_forward
@@ -195,8 +196,14 @@ class nnUNetPredictor(object):
         return o
 
     def _internal_get_sliding_window_slicers(self, image_size: Tuple[int, ...]):
-        """Patch windows in visit order (:506-538, 3-D branch)."""
+        """Patch windows in visit order (:506-538, both branches)."""
         patch = self.configuration_manager.patch_size
+        if len(patch) < len(image_size):
+            assert len(patch) == len(image_size) - 1, 'if tile_size has less entries than image_size, len(tile_size) ' \
+                                                      'must be one shorter than len(image_size)'
+            steps = compute_steps_for_sliding_window(image_size[1:], patch, self.tile_step_size)
+            return [tuple([slice(None), d, *[slice(s, s + p) for s, p in zip(st, patch)]])
+                    for d in range(image_size[0]) for st in itertools.product(*steps)]
         steps = compute_steps_for_sliding_window(image_size, patch, self.tile_step_size)
         return [tuple([slice(None), *[slice(s, s + p) for s, p in zip(st, patch)]])
                 for st in itertools.product(*steps)]
@@ -280,8 +287,11 @@ class nnUNetPredictor(object):
 
     @torch.inference_mode()
     def forward_patches(self, x: torch.Tensor) -> torch.Tensor:
-        """``self.network(x)`` for a batch of patches: [n,C,px,py,pz] -> fp32 logits [n,heads,px,py,pz]."""
-        assert x.ndim == 5 and tuple(x.shape[2:]) == tuple(self._spec.patch)
+        """``self.network(x)`` for a batch of patches: [n,C,px,py,pz] -> fp32 logits [n,heads,px,py,pz]
+        ([n,C,py,pz] -> [n,heads,py,pz] for a 2-D configuration)."""
+        two_d = self._spec.spatial_dims == 2
+        sp = tuple(self._spec.patch[1:]) if two_d else tuple(self._spec.patch)
+        assert x.ndim == len(sp) + 2 and tuple(x.shape[2:]) == sp
         with torch.cuda.device(self.device):
             xd = x.to(device=self.device, dtype=torch.float32).contiguous()
             out = torch.empty((x.shape[0], self._spec.num_heads, *x.shape[2:]), dtype=torch.float32, device=self.device)

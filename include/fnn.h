@@ -63,6 +63,11 @@ typedef struct fnn_arch_desc {
     int32_t patch[3];                           /* ConfigurationManager.patch_size            */
     float eps;                                  /* InstanceNorm eps (1e-5)                    */
     float slope;                                /* LeakyReLU negative slope (0.01)            */
+    int32_t spatial_dims;                       /* 0 or 3: 3-D configuration.  2: a `2d` configuration
+                                                 * (Conv2d network, patch_size with two entries): patch[0],
+                                                 * kernels[s][0] and strides[s][0] are 1 and EVERY slice of
+                                                 * the first image axis is a tile position
+                                                 * (predict_from_raw_data.py:508-524)               */
 } fnn_arch_desc;
 
 /* Knobs of nnUNetPredictor.__init__ (:40-65) + engine-side choices. */
@@ -182,6 +187,7 @@ int fnn_compute_steps(int64_t image_size, int64_t patch_size, double step, int64
 /* Padded shape, low-side pad, number of patches and (optionally) the patch
  * origins [n][3] in the reference's visit order - x slowest, z fastest - for a
  * volume (pad_nd_image use at :657-659 and the slicer loop :525-537). */
+/* patch[0] == 0 denotes a 2-D configuration (patch = {0, py, pz}): every slice of the first axis. */
 int fnn_plan_volume(const int32_t patch[3], const int64_t shape_sp[3], double step, int64_t padded[3],
                     int64_t pad_lo[3], int64_t *n_patches, int32_t *origins, int64_t origins_cap);
 

@@ -58,7 +58,9 @@ def pad_to_patch(shape_sp: Sequence[int], patch: Sequence[int]) -> Tuple[List[Tu
     high side.  Returns the pads and the slicer that undoes them.
     """
     pads, undo = [], []
-    for size, p in zip(shape_sp, patch):
+    lead = len(shape_sp) - len(patch)          # 2-D configuration: new_shape applies to the trailing axes only
+    for ax, size in enumerate(shape_sp):
+        p = patch[ax - lead] if ax >= lead else size
         missing = max(p, size) - size
         lo = missing // 2
         hi = missing // 2 + missing % 2
@@ -70,11 +72,21 @@ def pad_to_patch(shape_sp: Sequence[int], patch: Sequence[int]) -> Tuple[List[Tu
 def patch_slicers(shape_sp: Sequence[int], patch: Sequence[int], step: float) -> List[Tuple[slice, ...]]:
     """All patch windows in the reference's visit order (x, then y, then z).
 
-    Restates the 3-D branch of ``_internal_get_sliding_window_slicers``
-    (predict_from_raw_data.py:525-537).
+    Restates ``_internal_get_sliding_window_slicers``
+    (predict_from_raw_data.py:506-538), both branches.
     """
-    starts = tile_starts(shape_sp, patch, step)
     out = []
+    if len(patch) < len(shape_sp):
+        # 2-D configuration (:508-524): every slice of the first axis, tiles over the other two
+        assert len(patch) == len(shape_sp) - 1, 'if tile_size has less entries than image_size, len(tile_size) ' \
+                                                'must be one shorter than len(image_size)'
+        starts = tile_starts(shape_sp[1:], patch, step)
+        for d in range(shape_sp[0]):
+            for sx in starts[0]:
+                for sy in starts[1]:
+                    out.append((slice(None), d, slice(sx, sx + patch[0]), slice(sy, sy + patch[1])))
+        return out
+    starts = tile_starts(shape_sp, patch, step)
     for sx in starts[0]:
         for sy in starts[1]:
             for sz in starts[2]:

@@ -17,7 +17,10 @@ a real checkpoint:
 
 Arithmetic is torch's own CPU kernels in fp32: Conv3d(padding=(k-1)//2) ->
 InstanceNorm3d(eps, affine, no running stats) -> LeakyReLU(0.01);
-ConvTranspose3d(kernel=stride); torch.cat((upsampled, skip), 1).
+ConvTranspose3d(kernel=stride); torch.cat((upsampled, skip), 1).  A spec whose
+kernels have two entries builds the 2-D network of a `2d` configuration
+(Conv2d / InstanceNorm2d / ConvTranspose2d, get_network_from_plans.py:17-38
+with conv_op = torch.nn.modules.conv.Conv2d).
 """
 from __future__ import annotations
 
@@ -29,11 +32,18 @@ from torch import nn
 from .topology import UNetSpec
 
 
+_CONV = {2: nn.Conv2d, 3: nn.Conv3d}
+_NORM = {2: nn.InstanceNorm2d, 3: nn.InstanceNorm3d}
+_TCONV = {2: nn.ConvTranspose2d, 3: nn.ConvTranspose3d}
+_POOL = {2: nn.AvgPool2d, 3: nn.AvgPool3d}
+
+
 class ConvNormAct(nn.Module):
     def __init__(self, cin, cout, k, stride, bias, eps, slope, act=True):
         super().__init__()
-        self.conv = nn.Conv3d(cin, cout, k, stride, padding=[(i - 1) // 2 for i in k], bias=bias)
-        self.norm = nn.InstanceNorm3d(cout, eps=eps, affine=True)
+        nd = len(k)
+        self.conv = _CONV[nd](cin, cout, tuple(k), tuple(stride), padding=[(i - 1) // 2 for i in k], bias=bias)
+        self.norm = _NORM[nd](cout, eps=eps, affine=True)
         self.slope = slope
         self.act = act
 
@@ -48,7 +58,7 @@ class ConvStack(nn.Module):
     def __init__(self, n, cin, cout, k, stride, bias, eps, slope):
         super().__init__()
         self.convs = nn.Sequential(*[
-            ConvNormAct(cin if i == 0 else cout, cout, k, stride if i == 0 else (1, 1, 1), bias, eps, slope)
+            ConvNormAct(cin if i == 0 else cout, cout, k, stride if i == 0 else (1,) * len(k), bias, eps, slope)
             for i in range(n)])
 
     def forward(self, x):
@@ -79,13 +89,13 @@ class ResBlock(nn.Module):
     def __init__(self, cin, cout, k, stride, bias, eps, slope):
         super().__init__()
         self.conv1 = ConvNormAct(cin, cout, k, stride, bias, eps, slope, act=True)
-        self.conv2 = ConvNormAct(cout, cout, k, (1, 1, 1), bias, eps, slope, act=False)
+        self.conv2 = ConvNormAct(cout, cout, k, (1,) * len(k), bias, eps, slope, act=False)
         self.slope = slope
         ops = []
         if any(s != 1 for s in stride):
-            ops.append(nn.AvgPool3d(stride, stride))
+            ops.append(_POOL[len(k)](tuple(stride), tuple(stride)))
         if cin != cout:
-            ops.append(ConvNormAct(cin, cout, (1, 1, 1), (1, 1, 1), False, eps, slope, act=False))
+            ops.append(ConvNormAct(cin, cout, (1,) * len(k), (1,) * len(k), False, eps, slope, act=False))
         self.skip = nn.Sequential(*ops) if ops else nn.Identity()
 
     def forward(self, x):
@@ -96,7 +106,7 @@ class ResBlockStack(nn.Module):
     def __init__(self, n, cin, cout, k, stride, bias, eps, slope):
         super().__init__()
         self.blocks = nn.Sequential(*[
-            ResBlock(cin if i == 0 else cout, cout, k, stride if i == 0 else (1, 1, 1), bias, eps, slope)
+            ResBlock(cin if i == 0 else cout, cout, k, stride if i == 0 else (1,) * len(k), bias, eps, slope)
             for i in range(n)])
 
     def forward(self, x):
@@ -107,7 +117,7 @@ class ResEncoder(nn.Module):
     def __init__(self, spec: UNetSpec):
         super().__init__()
         f0 = spec.features[0]
-        self.stem = ConvStack(1, spec.in_channels, f0, spec.kernels[0], (1, 1, 1), spec.conv_bias, spec.eps,
+        self.stem = ConvStack(1, spec.in_channels, f0, spec.kernels[0], (1,) * len(spec.kernels[0]), spec.conv_bias, spec.eps,
                               spec.slope)
         stages, cin = [], f0
         for s in range(spec.n_stages):
@@ -133,10 +143,11 @@ class Decoder(nn.Module):
         for d in range(n - 1):
             below, skip = spec.features[-(d + 1)], spec.features[-(d + 2)]
             st = spec.strides[-(d + 1)]
-            tconvs.append(nn.ConvTranspose3d(below, skip, st, st, bias=spec.conv_bias))
-            stages.append(ConvStack(spec.n_conv_dec[d], 2 * skip, skip, spec.kernels[-(d + 2)], (1, 1, 1),
+            nd = len(st)
+            tconvs.append(_TCONV[nd](below, skip, tuple(st), tuple(st), bias=spec.conv_bias))
+            stages.append(ConvStack(spec.n_conv_dec[d], 2 * skip, skip, spec.kernels[-(d + 2)], (1,) * nd,
                                     spec.conv_bias, spec.eps, spec.slope))
-            segs.append(nn.Conv3d(skip, spec.num_heads, 1, 1, 0, bias=True))
+            segs.append(_CONV[nd](skip, spec.num_heads, 1, 1, 0, bias=True))
         self.transpconvs = nn.ModuleList(tconvs)
         self.stages = nn.ModuleList(stages)
         self.seg_layers = nn.ModuleList(segs)
@@ -181,7 +192,7 @@ def synthetic_state_dict(spec: UNetSpec, seed: int = 1234, affine_jitter: bool =
     sd = net.state_dict()
     out = {}
     for k, v in sd.items():
-        if v.ndim == 5:
+        if v.ndim >= 4:
             w = torch.empty_like(v)
             fan_in = v.shape[1] * v[0, 0].numel()
             if 'transpconvs' in k:

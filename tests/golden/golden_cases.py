@@ -127,13 +127,25 @@ SW_CASES = [
 ]
 
 
+# 2-D configurations (patch_size with two entries: every slice of the first axis is tiled, predict_from_raw_data.py
+# :508-524); fixtures in sliding_window_2d.npz
+SW_CASES_2D = [
+    _c('exact2d_basic', 'exact', (5, 36, 44), (16, 16), seed=20),
+    _c('exact2d_mirror01', 'exact', (3, 30, 21), (24, 16), mirror=[0, 1], seed=21, heads=4, channels=2),
+    _c('exact2d_smaller_than_patch', 'exact', (4, 11, 30), (16, 16), seed=22, heads=2, act='lrelu_half'),
+    _c('exact2d_2folds_nogauss', 'exact', (3, 24, 27), (16, 16), folds=2, seed=23, gaussian=False, step=0.3),
+    _c('unet2d_basic', 'unet', (6, 40, 44), (16, 32), heads=3, seed=24),
+    _c('unet2d_mirror1', 'unet', (2, 20, 70), (16, 32), heads=2, channels=2, mirror=[1], seed=25),
+]
+
+
 class ExactConvNet(nn.Module):
-    """Zero-padded 3x3x3 conv (+ optional LeakyReLU(1/2)) with dyadic weights:
+    """Zero-padded 3x3x3 (or 3x3) conv (+ optional LeakyReLU(1/2)) with dyadic weights:
     every fp32 sum is exact, so results do not depend on summation order."""
 
-    def __init__(self, cin, heads, act=None):
+    def __init__(self, cin, heads, act=None, nd=3):
         super().__init__()
-        self.conv = nn.Conv3d(cin, heads, 3, padding=1, bias=True)
+        self.conv = (nn.Conv3d if nd == 3 else nn.Conv2d)(cin, heads, 3, padding=1, bias=True)
         self.act = act
 
     def forward(self, x):
@@ -141,11 +153,15 @@ class ExactConvNet(nn.Module):
         return nn.functional.leaky_relu(y, 0.5) if self.act == 'lrelu_half' else y
 
 
-def exact_state_dict(cin, heads, seed):
+def exact_state_dict(cin, heads, seed, nd=3):
     g = torch.Generator().manual_seed(seed)
-    w = torch.randint(-4, 5, (heads, cin, 3, 3, 3), generator=g).float() / 8
+    w = torch.randint(-4, 5, (heads, cin) + (3,) * nd, generator=g).float() / 8
     b = torch.randint(-8, 9, (heads,), generator=g).float() / 4
     return {'conv.weight': w, 'conv.bias': b}
+
+
+def toy_unet_spec_2d(cin, heads):
+    return UNetSpec('plain', cin, heads, [8, 16, 16], [(3, 3)] * 3, [(1, 1), (2, 2), (1, 2)], [2, 2, 2], [2, 2])
 
 
 def toy_unet_spec(cin, heads):
@@ -166,11 +182,12 @@ def make_case_networks(case):
     nets, params = [], []
     for f in range(case['folds']):
         seed = 77 * case['seed'] + f
+        nd = len(case['patch'])
         if case['kind'] == 'exact':
-            net = ExactConvNet(case['channels'], case['heads'], case['act'])
-            sd = exact_state_dict(case['channels'], case['heads'], seed)
+            net = ExactConvNet(case['channels'], case['heads'], case['act'], nd)
+            sd = exact_state_dict(case['channels'], case['heads'], seed, nd)
         else:
-            spec = toy_unet_spec(case['channels'], case['heads'])
+            spec = (toy_unet_spec if nd == 3 else toy_unet_spec_2d)(case['channels'], case['heads'])
             net = OracleUNet(spec)
             sd = synthetic_state_dict(spec, seed)
         net.load_state_dict(sd)

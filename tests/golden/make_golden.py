@@ -48,7 +48,7 @@ from nnunetv2.utilities.plans_handling.plans_handler import PlansManager  # noqa
 from nnunetv2.utilities.label_handling.label_handling import LabelManager, determine_num_input_channels  # noqa: E402
 from nnunetv2.experiment_planning.experiment_planners.network_topology import get_pool_and_conv_props  # noqa: E402
 
-from golden_cases import (SW_CASES, STEP_CASES, GAUSS_FULL, GAUSS_SUMMARY, TOPOLOGY_CASES, PLANS_NEW,  # noqa: E402
+from golden_cases import (SW_CASES, SW_CASES_2D, STEP_CASES, GAUSS_FULL, GAUSS_SUMMARY, TOPOLOGY_CASES, PLANS_NEW,  # noqa: E402
                           PLANS_OLD, DATASET_JSONS, make_case_inputs, make_case_networks)
 
 
@@ -86,14 +86,19 @@ def gen_gaussian():
         json.dump(summary, f)
 
 
-def gen_sliding_window():
+def gen_sliding_window_2d():
+    gen_sliding_window(SW_CASES_2D, 'sliding_window_2d.npz', '2d')
+
+
+def gen_sliding_window(cases=None, fname='sliding_window.npz', config='3d_fullres'):
     arrays = {}
-    for case in SW_CASES:
+    cases = SW_CASES if cases is None else cases
+    for case in cases:
         name = case['name']
         image = make_case_inputs(case)
         nets, params = make_case_networks(case)
         plans = PlansManager({'dataset_name': 'Dataset999_Golden', 'plans_name': 'nnUNetPlans',
-                              'configurations': {'3d_fullres': {'patch_size': list(case['patch']),
+                              'configurations': {config: {'patch_size': list(case['patch']),
                                                                 'architecture': {'network_class_name': 'toy',
                                                                                  'arch_kwargs': {},
                                                                                  '_kw_requires_import': []}}}})
@@ -102,7 +107,7 @@ def gen_sliding_window():
         pred = nnUNetPredictor(tile_step_size=case['step'], use_gaussian=case['gaussian'],
                                use_mirroring=case['mirror'] is not None, perform_everything_on_device=False,
                                device=torch.device('cpu'), verbose=False, allow_tqdm=False)
-        pred.manual_initialization(nets[0], plans, plans.get_configuration('3d_fullres'), params, dataset_json,
+        pred.manual_initialization(nets[0], plans, plans.get_configuration(config), params, dataset_json,
                                    'nnUNetTrainer', tuple(case['mirror']) if case['mirror'] is not None else None)
         compute_gaussian.cache_clear()
         torch.set_num_threads(4)
@@ -115,6 +120,9 @@ def gen_sliding_window():
         lm = pred.label_manager
         arrays[name + '__seg'] = lm.convert_logits_to_segmentation(out).numpy().astype(np.int16)
         print(name, tuple(out.shape), float(out.float().abs().max()))
+    if fname != 'sliding_window.npz':
+        np.savez_compressed(os.path.join(HERE, fname), **arrays)
+        return
     # region-based label conversion on one case's logits
     case = SW_CASES[0]
     logits = torch.from_numpy(arrays[case['name']].view(np.int16)).view(torch.half)
@@ -181,7 +189,7 @@ def gen_label_rules():
 if __name__ == '__main__':
     if len(sys.argv) > 1:                                   # regenerate single fixtures: labels, plans
         for what in sys.argv[1:]:
-            {'labels': gen_label_rules, 'plans': gen_plans}[what]()
+            {'labels': gen_label_rules, 'plans': gen_plans, 'sw2d': gen_sliding_window_2d}[what]()
         sys.exit(0)
     gen_label_rules()
     gen_steps()
@@ -189,4 +197,5 @@ if __name__ == '__main__':
     gen_topology()
     gen_plans()
     gen_sliding_window()
+    gen_sliding_window_2d()
     print('golden vectors written to', HERE)

@@ -23,7 +23,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_cases import SW_CASES, make_case_inputs, make_case_networks, toy_unet_spec
+from golden_cases import SW_CASES, SW_CASES_2D, make_case_inputs, make_case_networks, toy_unet_spec, toy_unet_spec_2d
 from oracle import sliding_window as osw
 from oracle.topology import UNetSpec, student_spec
 from oracle.unet import build as build_oracle, synthetic_state_dict
@@ -474,3 +474,66 @@ def test_initialize_from_trained_model_folder_distilled_student(tmp_path):
     torch.save(ck, folder / 'fold_0' / 'checkpoint_best.pth')
     with pytest.raises(RuntimeError, match='do not match'):
         p.initialize_from_trained_model_folder(str(folder), use_folds=(0,), checkpoint_name='checkpoint_best.pth')
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# `2d` configurations: Conv2d network, patch_size with two entries, every slice of the first axis is tiled
+# (predict_from_raw_data.py:508-524).  The engine runs them as depth-1 3-D patches.
+# ---------------------------------------------------------------------------------------------------------------
+def test_2d_network_forward_matches_fp32_oracle():
+    spec = UNetSpec('plain', 2, 5, [16, 32, 64, 64], [(3, 3)] * 4, [(1, 1), (2, 2), (2, 2), (1, 2)], [2, 2, 2, 2], [2, 2, 2])
+    patch = (48, 64)
+    sd = synthetic_state_dict(spec, 31)
+    p = _predictor(spec, patch, [sd], batch=5)
+    assert p._spec.spatial_dims == 2 and tuple(p._spec.patch) == (1, 48, 64)
+    x = torch.randn(5, 2, *patch, generator=torch.Generator().manual_seed(0))
+    got = p.forward_patches(x).cpu()
+    with torch.inference_mode():
+        ref = build_oracle(spec, sd)(x)
+    mr, rr = _report('2d forward', got, ref)
+    assert mr <= MAX_REL and rr <= RMSE_REL
+
+
+@pytest.mark.parametrize('shape,mirror,step,folds', [((5, 36, 44), None, 0.5, 1), ((3, 30, 21), [0, 1], 0.5, 1),
+                                                     ((4, 11, 30), [1], 0.3, 2), ((1, 16, 32), None, 1.0, 1)])
+def test_2d_driver_bit_identical_to_oracle_driver_on_engine_logits(shape, mirror, step, folds):
+    spec, patch = toy_unet_spec_2d(1, 3), (16, 32)
+    sds = [synthetic_state_dict(spec, 90 + f) for f in range(folds)]
+    p = _predictor(spec, patch, sds, mirror=mirror, step=step)
+    image = torch.randn(1, *shape, generator=torch.Generator().manual_seed(9))
+
+    def engine_net(fold):
+        def f(x):
+            p._active_fold = fold
+            return p.forward_patches(x).cpu()
+        return f
+
+    nets = [engine_net(f) for f in range(folds)]
+    kw = dict(step=step, mirror_axes=mirror, accum='fp16')
+    if folds > 1:
+        want = osw.ensemble_logits(nets, image, patch, spec.num_heads, **kw)
+        got = p.predict_logits_from_preprocessed_data(image)
+    else:
+        want = osw.sliding_window_logits(nets[0], image, patch, spec.num_heads, **kw)
+        p._active_fold = 0
+        got = p.predict_sliding_window_return_logits(image)
+    assert got.dtype == torch.half and tuple(got.shape) == tuple(want.shape)
+    assert (_bits(got) == _bits(want)).all()
+    # the slicer list of the mirror class is the reference's 2-D branch
+    padded = [s + a + b for s, (a, b) in zip(image.shape[1:], osw.pad_to_patch(image.shape[1:], patch)[0])]
+    assert p._internal_get_sliding_window_slicers(tuple(padded)) == osw.patch_slicers(padded, patch, step)
+
+
+@pytest.mark.parametrize('case', [c for c in SW_CASES_2D if c['kind'] == 'unet'], ids=lambda c: c['name'])
+def test_2d_reference_golden_volumes(case, golden_dir):
+    """Outputs of the reference's own predictor on a `2d` configuration (fp32 CPU Conv2d network) vs the HIP engine."""
+    z = np.load(os.path.join(golden_dir, 'sliding_window_2d.npz'))
+    ref = torch.from_numpy(z[case['name']].view(np.int16)).view(torch.half).float()
+    spec = toy_unet_spec_2d(case['channels'], case['heads'])
+    _, params = make_case_networks(case)
+    p = _predictor(spec, case['patch'], params, mirror=case['mirror'], step=case['step'], gaussian=case['gaussian'])
+    got = p.predict_sliding_window_return_logits(make_case_inputs(case)).float().cpu()
+    m = 3
+    inner = (slice(None), slice(None), slice(m, -m), slice(m, -m))
+    mr, rr = _report(case['name'] + ' interior', got[inner], ref[inner])
+    assert mr <= MAX_REL and rr <= RMSE_REL

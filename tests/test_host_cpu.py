@@ -65,6 +65,30 @@ def test_plan_volume_matches_oracle_slicers(capi, shape, patch, step):
     assert origins.tolist() == [[s[1].start, s[2].start, s[3].start] for s in sl]
 
 
+@pytest.mark.parametrize('shape,patch,step', [((5, 36, 44), (16, 16), 0.5), ((3, 11, 30), (16, 16), 0.5), ((1, 16, 40), (16, 32), 1.0)])
+def test_plan_volume_2d_configuration_matches_oracle_slicers(capi, shape, patch, step):
+    padded, lo, origins = capi.plan_volume(patch, shape, step)
+    pads, _ = osw.pad_to_patch(shape, patch)
+    assert lo == [p[0] for p in pads] and lo[0] == 0
+    assert padded == [s + p[0] + p[1] for s, p in zip(shape, pads)]
+    sl = osw.patch_slicers(padded, patch, step)
+    assert origins.tolist() == [[s[1], s[2].start, s[3].start] for s in sl]
+
+
+def test_spec_from_2d_checkpoint():
+    from fast_nnunet_amd.arch import spec_from_state_dict, weight_blob
+    from golden_cases import toy_unet_spec_2d
+    ospec = toy_unet_spec_2d(2, 3)
+    sd = synthetic_state_dict(ospec, 5)
+    spec = spec_from_state_dict(sd, (16, 32))
+    assert spec.spatial_dims == 2 and tuple(spec.patch) == (1, 16, 32)
+    assert [tuple(k) for k in spec.kernels] == [(1, *k) for k in ospec.kernels]
+    assert [tuple(s) for s in spec.strides] == [(1, *s) for s in ospec.strides]
+    assert weight_blob(spec, sd).size == sum(v.numel() for k, v in sd.items() if 'seg_layers.0' not in k)
+    with pytest.raises(RuntimeError, match='does not match'):
+        spec_from_state_dict(sd, (16, 16, 32))
+
+
 def test_patch_counts_of_the_benchmark_configs(capi):
     # 343 (128^3), 216 (160^3), 600 (160x96x96) patches on a 512^3 volume
     for patch, n in (((128,) * 3, 343), ((160,) * 3, 216), ((160, 96, 96), 600)):

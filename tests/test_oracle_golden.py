@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_cases import SW_CASES, DATASET_JSONS, make_case_inputs, make_case_networks
+from golden_cases import SW_CASES, SW_CASES_2D, DATASET_JSONS, make_case_inputs, make_case_networks
 from oracle import sliding_window as osw
 from oracle import topology as otopo
 
@@ -143,3 +143,20 @@ def test_label_rules_match_reference_golden(golden_dir):
     assert torch.equal(torch.sigmoid(x) > 0.5, x > 1.5 * 2.0 ** -24)
     x = inp['regions_f32']
     assert torch.equal(torch.sigmoid(x) > 0.5, x > 1.5 * 2.0 ** -24)
+
+
+@pytest.mark.parametrize('case', SW_CASES_2D, ids=lambda c: c['name'])
+def test_sliding_window_2d_configuration_matches_reference(case, golden_dir):
+    """`2d` configurations (patch_size with two entries): every slice of the first axis is tiled
+    (predict_from_raw_data.py:508-524), padding and Gaussian are 2-D, mirror axes index (y, z)."""
+    z = np.load(os.path.join(golden_dir, 'sliding_window_2d.npz'))
+    out = _run_case(case)
+    assert out.dtype == torch.half and tuple(out.shape) == (case['heads'], *case['shape'])
+    if case['kind'] == 'exact':
+        assert np.array_equal(_bits(out), z[case['name']])
+        assert np.array_equal(osw.logits_to_labels(out).numpy().astype(np.int16), z[case['name'] + '__seg'])
+    else:
+        ref = torch.from_numpy(z[case['name']].view(np.int16)).view(torch.half).float().numpy()
+        err = np.abs(out.float().numpy() - ref)
+        assert np.median(err) < 1e-3
+        assert (err > 0.02 * max(1.0, np.abs(ref).max())).mean() < 2e-3
