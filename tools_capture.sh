@@ -1,0 +1,27 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): bash tools_capture.sh <tag>
+# Collects everything profiles/ holds for a round: kernel trace + stats, the two PMC passes for HBM traffic
+# (separate runs, no trace domains next to --pmc), and the plain bench line.
+tag=$1
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/cap_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $out/trace.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $out/pmc_$c.log 2>&1
+done
+cd $root
+kt=$(find $out/trace -name "*kernel_trace.csv" | head -1)
+ks=$(find $out/trace -name "*kernel_stats.csv" | head -1)
+python tools_trace_summary.py $kt > $out/trace_summary.txt 2>&1
+cp $ks $out/kernel_stats.csv
+f=$(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
+w=$(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+python tools_traffic.py $f $w $out/traffic.json > $out/traffic.txt 2>&1
+cp $out/traffic.json profiles/r01_traffic.json            # bench.py reads the traffic figure from here
+python bench.py > $out/bench.json 2> $out/bench.err
+rm -rf $out/trace $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
+tail -1 $out/bench.json | cut -c1-1500
+head -12 $out/trace_summary.txt
+cat $out/traffic.txt | head -20
