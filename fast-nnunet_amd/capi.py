@@ -19,6 +19,7 @@ FNN_ACC_FP16_REFERENCE, FNN_ACC_FP32 = 0, 1
 FNN_OUT_F16, FNN_OUT_F32 = 0, 1
 FNN_LABELS_ARGMAX, FNN_LABELS_REGIONS = 0, 1
 FNN_LABEL_U8, FNN_LABEL_U16 = 0, 1
+FNN_NORM_NONE, FNN_NORM_ZSCORE, FNN_NORM_CT, FNN_NORM_RESCALE01, FNN_NORM_RGB01 = 0, 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libfnn_hip.so')
@@ -35,6 +36,10 @@ class ArchDesc(C.Structure):
                 ('eps', C.c_float), ('slope', C.c_float), ('spatial_dims', C.c_int32)]
 
 
+class NormDesc(C.Structure):
+    _fields_ = [('scheme', C.c_int32), ('mean', C.c_float), ('std', C.c_float), ('lower', C.c_float), ('upper', C.c_float)]
+
+
 class Opts(C.Structure):
     _fields_ = [('tile_step_size', C.c_float), ('use_gaussian', C.c_int32), ('n_mirror_axes', C.c_int32),
                 ('mirror_axes', C.c_int32 * 3), ('accum', C.c_int32), ('out_dtype', C.c_int32),
@@ -49,7 +54,7 @@ class Profile(C.Structure):
 
 EXPORTS = ['fnn_abi_version', 'fnn_last_error', 'fnn_create', 'fnn_destroy', 'fnn_weight_count', 'fnn_load_weights',
            'fnn_set_gaussian', 'fnn_predict_volume', 'fnn_predict_volume_ensemble', 'fnn_predict_labels',
-           'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_compute_steps', 'fnn_plan_volume',
+           'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_compute_steps', 'fnn_plan_volume',
            'fnn_set_profiling', 'fnn_get_profile', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d']
 
 _lib = None
@@ -91,6 +96,9 @@ def load_library() -> C.CDLL:
     lib.fnn_normalize_box.argtypes = [vp, vp, P64, C.POINTER(Opts), P64, P64, P64, P64, vp]
     lib.fnn_forward_patches.argtypes = [vp, i32, vp, i32, vp, vp]
     lib.fnn_argmax_labels.argtypes = [vp, vp, i32, i32, i64, vp, vp]
+    lib.fnn_nonzero_bbox.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64), vp]
+    lib.fnn_preprocess.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64), C.POINTER(NormDesc), vp, vp]
+    lib.fnn_revert_labels.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), vp, vp]
     lib.fnn_compute_steps.argtypes = [i64, i64, C.c_double, C.POINTER(i64), i32]
     lib.fnn_plan_volume.argtypes = [C.POINTER(C.c_int32), C.POINTER(i64), C.c_double, C.POINTER(i64), C.POINTER(i64),
                                     C.POINTER(i64), C.POINTER(C.c_int32), i64]
@@ -148,6 +156,32 @@ def plan_volume(patch: Sequence[int], shape_sp: Sequence[int], step: float):
     check(lib.fnn_plan_volume(p, s, float(step), padded, lo, C.byref(n),
                               org.ctypes.data_as(C.POINTER(C.c_int32)), n.value), lib)
     return list(padded), list(lo), org
+
+
+def nonzero_bbox(raw_ptr: int, shape, transpose_forward, stream: int = 0):
+    """-> [[lo, hi], ...] per TRANSPOSED axis (properties['bbox_used_for_cropping'])."""
+    lib = load_library()
+    bbox = (C.c_int64 * 6)()
+    check(lib.fnn_nonzero_bbox(raw_ptr, (C.c_int64 * 4)(*[int(i) for i in shape]),
+                               (C.c_int32 * 3)(*[int(i) for i in transpose_forward]), bbox, stream), lib)
+    return [[int(bbox[2 * a]), int(bbox[2 * a + 1])] for a in range(3)]
+
+
+def preprocess(raw_ptr: int, shape, transpose_forward, bbox, norms, out_ptr: int, stream: int = 0):
+    """norms: one (scheme, mean, std, lower, upper) per channel."""
+    lib = load_library()
+    nd = (NormDesc * len(norms))(*[NormDesc(int(n[0]), float(n[1]), float(n[2]), float(n[3]), float(n[4])) for n in norms])
+    flat = (C.c_int64 * 6)(*[int(v) for ab in bbox for v in ab])
+    check(lib.fnn_preprocess(raw_ptr, (C.c_int64 * 4)(*[int(i) for i in shape]),
+                             (C.c_int32 * 3)(*[int(i) for i in transpose_forward]), flat, nd, out_ptr, stream), lib)
+
+
+def revert_labels(seg_ptr: int, uint16: bool, bbox, shape_before_cropping, transpose_backward, out_ptr: int, stream: int = 0):
+    lib = load_library()
+    flat = (C.c_int64 * 6)(*[int(v) for ab in bbox for v in ab])
+    check(lib.fnn_revert_labels(seg_ptr, FNN_LABEL_U16 if uint16 else FNN_LABEL_U8, flat,
+                                (C.c_int64 * 3)(*[int(i) for i in shape_before_cropping]),
+                                (C.c_int32 * 3)(*[int(i) for i in transpose_backward]), out_ptr, stream), lib)
 
 
 def op_conv3d(x, w, bias, k, stride, gamma=None, beta=None, slope=1.0, x2=None, gamma2=None, beta2=None, slope2=1.0,

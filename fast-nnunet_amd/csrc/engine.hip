@@ -89,6 +89,9 @@ struct fnn_engine {
     fnn_profile prof{};
 };
 
+// message of an entry point that has no engine handle (prep.hip)
+void fnn_set_global_error(const char *msg) { g_err = msg ? msg : ""; }
+
 namespace {
 
 int fail(fnn_engine *e, int code, const char *fmt, ...) {

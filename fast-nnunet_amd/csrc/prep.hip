@@ -1,0 +1,288 @@
+// prep.hip - whole-volume steps on either side of the sliding window, gfx950.
+//
+//   fnn_nonzero_bbox    crop_to_nonzero's bounding box (preprocessing/cropping/cropping.py:7-39)
+//   fnn_preprocess      transpose_forward + crop + per-channel intensity normalisation
+//                       (preprocessing/preprocessors/default_preprocessor.py:45-93 without the resampling call;
+//                       preprocessing/normalization/default_normalization_schemes.py:27-109)
+//   fnn_revert_labels   label map back to the uncropped, untransposed grid (inference/export_prediction.py:43-53)
+//
+// All three are HBM-bound element-wise / reduction kernels: one pass over the raw volume for the box, one pass
+// for the statistics of the schemes that need them, one read + one write for the result.
+#include "fnn_device.h"
+#include "../../include/fnn.h"
+#include <cfloat>
+#include <climits>
+#include <cstdio>
+#include <cmath>
+
+extern "C" const char *fnn_last_error(const fnn_engine *e);
+void fnn_set_global_error(const char *msg);      // engine.hip
+
+namespace {
+
+struct PrepGeom {
+    long long s[3];              // raw spatial shape
+    int tf[3];                   // transposed axis a = raw axis tf[a]
+    int C;
+};
+
+static bool dev_ptr(const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+static int fail_msg(int code, const char *msg) { fnn_set_global_error(msg); return code; }
+
+// ---- bounding box of the voxels where any channel is non-zero, in transposed coordinates
+__global__ __launch_bounds__(256) void bbox_kernel(const float *raw, PrepGeom g, int *box /* lo[3], hi[3] (inclusive) */) {
+    __shared__ int sbox[6];
+    if (threadIdx.x < 3) sbox[threadIdx.x] = INT_MAX;
+    else if (threadIdx.x < 6) sbox[threadIdx.x] = -1;
+    __syncthreads();
+    const long long n = g.s[0] * g.s[1] * g.s[2];
+    int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {-1, -1, -1};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        bool nz = false;
+        for (int c = 0; c < g.C; ++c) nz |= raw[c * n + i] != 0.f;           // NaN != 0 is true, like numpy
+        if (nz) {
+            const int r[3] = {(int)(i / (g.s[1] * g.s[2])), (int)((i / g.s[2]) % g.s[1]), (int)(i % g.s[2])};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int t = r[g.tf[a]];
+                lo[a] = t < lo[a] ? t : lo[a];
+                hi[a] = t > hi[a] ? t : hi[a];
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (hi[a] >= 0) { atomicMin(&sbox[a], lo[a]); atomicMax(&sbox[3 + a], hi[a]); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) { if (sbox[threadIdx.x] != INT_MAX) atomicMin(&box[threadIdx.x], sbox[threadIdx.x]); }
+    else if (threadIdx.x < 6) { if (sbox[threadIdx.x] >= 0) atomicMax(&box[threadIdx.x], sbox[threadIdx.x]); }
+}
+
+struct PrepParams {
+    PrepGeom g;
+    long long lo[3], ext[3];     // crop box in transposed coordinates: origin and extent
+    int scheme[8];
+    float a[8], b[8], lower[8], upper[8];     // per channel: out = (clip(x) - a) / b
+};
+
+// raw offset of transposed-cropped voxel (t0, t1, t2)
+static __device__ __forceinline__ long long raw_index(const PrepParams &p, long long t0, long long t1, long long t2) {
+    long long r[3];
+    r[p.g.tf[0]] = t0 + p.lo[0]; r[p.g.tf[1]] = t1 + p.lo[1]; r[p.g.tf[2]] = t2 + p.lo[2];
+    return (r[0] * p.g.s[1] + r[1]) * p.g.s[2] + r[2];
+}
+
+// ---- per-channel statistics over the crop box: sum, sum of squares (double), min, max
+__global__ __launch_bounds__(256) void stats_kernel(const float *raw, PrepParams p, int c, double *sums /*[2]*/, unsigned *mm /*[2] ordered*/) {
+    __shared__ double ssum[2][4];
+    __shared__ unsigned smm[2];
+    if (threadIdx.x == 0) { smm[0] = 0xffffffffu; smm[1] = 0u; }
+    __syncthreads();
+    const long long n = p.ext[0] * p.ext[1] * p.ext[2], nraw = p.g.s[0] * p.g.s[1] * p.g.s[2];
+    double s1 = 0, s2 = 0;
+    float mn = FLT_MAX, mx = -FLT_MAX;
+    bool any = false;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long t2 = i % p.ext[2], t1 = (i / p.ext[2]) % p.ext[1], t0 = i / (p.ext[2] * p.ext[1]);
+        const float v = raw[(long long)c * nraw + raw_index(p, t0, t1, t2)];
+        s1 += (double)v; s2 += (double)v * (double)v;
+        mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+        any = true;
+    }
+    // order-preserving map float -> unsigned for the atomics
+    auto ord = [](float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+    if (any) { atomicMin(&smm[0], ord(mn)); atomicMax(&smm[1], ord(mx)); }
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+    if ((threadIdx.x & 63) == 0) { ssum[0][threadIdx.x >> 6] = s1; ssum[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsafeAtomicAdd(&sums[0], ssum[0][0] + ssum[0][1] + ssum[0][2] + ssum[0][3]);
+        unsafeAtomicAdd(&sums[1], ssum[1][0] + ssum[1][1] + ssum[1][2] + ssum[1][3]);
+        atomicMin(&mm[0], smm[0]); atomicMax(&mm[1], smm[1]);
+    }
+}
+
+// ---- out[c][t0][t1][t2] = normalise_c(raw[c][transposed, cropped])
+__global__ __launch_bounds__(256) void apply_kernel(const float *raw, PrepParams p, float *out) {
+    const long long n = p.ext[0] * p.ext[1] * p.ext[2], nraw = p.g.s[0] * p.g.s[1] * p.g.s[2];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * p.g.C) return;
+    const int c = (int)(i / n);
+    const long long j = i - (long long)c * n;
+    const long long t2 = j % p.ext[2], t1 = (j / p.ext[2]) % p.ext[1], t0 = j / (p.ext[2] * p.ext[1]);
+    float v = raw[(long long)c * nraw + raw_index(p, t0, t1, t2)];
+    switch (p.scheme[c]) {
+    case FNN_NORM_CT:                       // np.clip, -= mean, /= max(std, 1e-8): three fp32 roundings
+        v = v < p.lower[c] ? p.lower[c] : (v > p.upper[c] ? p.upper[c] : v);      // NaN stays NaN like np.clip
+        v = __fdiv_rn(__fsub_rn(v, p.a[c]), p.b[c]);
+        break;
+    case FNN_NORM_ZSCORE:
+    case FNN_NORM_RESCALE01:
+        v = __fdiv_rn(__fsub_rn(v, p.a[c]), p.b[c]);
+        break;
+    case FNN_NORM_RGB01:
+        v = __fdiv_rn(v, 255.f);
+        break;
+    default: break;
+    }
+    out[i] = v;
+}
+
+// ---- labels [b0][b1][b2] (transposed, cropped) -> out [s0][s1][s2] in the original axis order
+template <typename LT>
+__global__ __launch_bounds__(256) void revert_kernel(const LT *seg, long long lo0, long long lo1, long long lo2, long long e0,
+                                                     long long e1, long long e2, long long o0, long long o1, long long o2,
+                                                     int tb0, int tb1, int tb2, LT *out) {
+    const long long n = o0 * o1 * o2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long oc[3] = {i / (o1 * o2), (i / o2) % o1, i % o2};
+    long long t[3];
+    t[tb0] = oc[0]; t[tb1] = oc[1]; t[tb2] = oc[2];                     // out axis j = transposed axis tb[j]
+    const long long d0 = t[0] - lo0, d1 = t[1] - lo1, d2 = t[2] - lo2;
+    LT v = 0;
+    if (d0 >= 0 && d0 < e0 && d1 >= 0 && d1 < e1 && d2 >= 0 && d2 < e2) v = seg[(d0 * e1 + d1) * e2 + d2];
+    out[i] = v;
+}
+
+static int check_perm(const int32_t t[3]) {
+    int seen = 0;
+    for (int i = 0; i < 3; ++i) { if (t[i] < 0 || t[i] > 2) return -1; seen |= 1 << t[i]; }
+    return seen == 7 ? 0 : -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fnn_nonzero_bbox(const float *raw, const int64_t shape[4], const int32_t transpose_forward[3], int64_t bbox[6], void *stream) {
+    if (!raw || !shape || !transpose_forward || !bbox) return fail_msg(FNN_E_INVALID, "NULL argument");
+    if (check_perm(transpose_forward) != 0) return fail_msg(FNN_E_INVALID, "transpose_forward is not a permutation of (0, 1, 2)");
+    if (shape[0] < 1 || shape[0] > 8 || shape[1] < 1 || shape[2] < 1 || shape[3] < 1) return fail_msg(FNN_E_INVALID, "bad shape (1..8 channels)");
+    if (!dev_ptr(raw)) return fail_msg(FNN_E_INVALID, "fnn_nonzero_bbox needs a device pointer (no CPU path)");
+    hipStream_t st = (hipStream_t)stream;
+    PrepGeom g{};
+    for (int d = 0; d < 3; ++d) { g.s[d] = shape[1 + d]; g.tf[d] = transpose_forward[d]; }
+    g.C = (int)shape[0];
+    int *box = nullptr;
+    if (hipMalloc((void **)&box, 6 * sizeof(int)) != hipSuccess) return fail_msg(FNN_E_HIP, "hipMalloc failed");
+    const int init[6] = {INT_MAX, INT_MAX, INT_MAX, -1, -1, -1};
+    int h[6];
+    hipError_t r = hipMemcpyAsync(box, init, sizeof(init), hipMemcpyHostToDevice, st);
+    const long long n = g.s[0] * g.s[1] * g.s[2];
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (r == hipSuccess) { hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)blocks), dim3(256), 0, st, raw, g, box); r = hipGetLastError(); }
+    if (r == hipSuccess) r = hipMemcpyAsync(h, box, sizeof(h), hipMemcpyDeviceToHost, st);
+    if (r == hipSuccess) r = hipStreamSynchronize(st);
+    (void)hipFree(box);
+    if (r != hipSuccess) return fail_msg(FNN_E_HIP, hipGetErrorString(r));
+    for (int a = 0; a < 3; ++a) {
+        if (h[3 + a] < 0) { bbox[2 * a] = 0; bbox[2 * a + 1] = shape[1 + transpose_forward[a]]; }   // empty mask: the full extent
+        else { bbox[2 * a] = h[a]; bbox[2 * a + 1] = h[3 + a] + 1; }
+    }
+    return FNN_OK;
+}
+
+int fnn_preprocess(const float *raw, const int64_t shape[4], const int32_t transpose_forward[3], const int64_t bbox[6],
+                   const fnn_norm_desc *norm, float *out, void *stream) {
+    if (!raw || !shape || !transpose_forward || !bbox || !norm || !out) return fail_msg(FNN_E_INVALID, "NULL argument");
+    if (check_perm(transpose_forward) != 0) return fail_msg(FNN_E_INVALID, "transpose_forward is not a permutation of (0, 1, 2)");
+    if (shape[0] < 1 || shape[0] > 8) return fail_msg(FNN_E_INVALID, "1..8 channels");
+    if (!dev_ptr(raw) || !dev_ptr(out)) return fail_msg(FNN_E_INVALID, "fnn_preprocess needs device pointers (no CPU path)");
+    hipStream_t st = (hipStream_t)stream;
+    PrepParams p{};
+    for (int d = 0; d < 3; ++d) { p.g.s[d] = shape[1 + d]; p.g.tf[d] = transpose_forward[d]; }
+    p.g.C = (int)shape[0];
+    for (int a = 0; a < 3; ++a) {
+        p.lo[a] = bbox[2 * a]; p.ext[a] = bbox[2 * a + 1] - bbox[2 * a];
+        if (p.lo[a] < 0 || p.ext[a] < 1 || bbox[2 * a + 1] > shape[1 + transpose_forward[a]]) return fail_msg(FNN_E_INVALID, "bbox outside the (transposed) image");
+    }
+    const long long n = p.ext[0] * p.ext[1] * p.ext[2];
+    double *sums = nullptr;
+    if (hipMalloc((void **)&sums, 8 * 4 * sizeof(double)) != hipSuccess) return fail_msg(FNN_E_HIP, "hipMalloc failed");
+    hipError_t r = hipSuccess;
+    for (int c = 0; c < p.g.C && r == hipSuccess; ++c) {
+        const fnn_norm_desc &d = norm[c];
+        p.scheme[c] = d.scheme;
+        p.a[c] = 0.f; p.b[c] = 1.f; p.lower[c] = d.lower; p.upper[c] = d.upper;
+        if (d.scheme == FNN_NORM_CT) {
+            p.a[c] = d.mean; p.b[c] = d.std > 1e-8f ? d.std : 1e-8f;           // max(std_intensity, 1e-8)
+        } else if (d.scheme == FNN_NORM_ZSCORE || d.scheme == FNN_NORM_RESCALE01) {
+            // statistics of this channel over the crop box
+            double *sc = sums + c * 4;
+            unsigned *mm = (unsigned *)(sc + 2);
+            const double z[2] = {0, 0};
+            const unsigned mi[2] = {0xffffffffu, 0u};
+            double hs[2]; unsigned hm[2];
+            r = hipMemcpyAsync(sc, z, sizeof(z), hipMemcpyHostToDevice, st);
+            if (r == hipSuccess) r = hipMemcpyAsync(mm, mi, sizeof(mi), hipMemcpyHostToDevice, st);
+            long long blocks = (n + 255) / 256;
+            if (blocks > 256 * 16) blocks = 256 * 16;
+            if (r == hipSuccess) { hipLaunchKernelGGL(stats_kernel, dim3((unsigned)blocks), dim3(256), 0, st, raw, p, c, sc, mm); r = hipGetLastError(); }
+            if (r == hipSuccess) r = hipMemcpyAsync(hs, sc, sizeof(hs), hipMemcpyDeviceToHost, st);
+            if (r == hipSuccess) r = hipMemcpyAsync(hm, mm, sizeof(hm), hipMemcpyDeviceToHost, st);
+            if (r == hipSuccess) r = hipStreamSynchronize(st);
+            if (r != hipSuccess) break;
+            auto unord = [](unsigned u) { u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; return __builtin_bit_cast(float, u); };
+            if (d.scheme == FNN_NORM_ZSCORE) {
+                const double mean = hs[0] / (double)n;
+                double var = hs[1] / (double)n - mean * mean;
+                var = var > 0 ? var : 0;
+                const float stdf = (float)sqrt(var);
+                p.a[c] = (float)mean; p.b[c] = stdf > 1e-8f ? stdf : 1e-8f;
+            } else {
+                const float mn = unord(hm[0]), mx = unord(hm[1]);
+                const float range = mx - mn;                                   // = (image - image.min()).max() in fp32
+                p.a[c] = mn; p.b[c] = range > 1e-8f ? range : 1e-8f;
+            }
+        } else if (d.scheme != FNN_NORM_NONE && d.scheme != FNN_NORM_RGB01) {
+            (void)hipFree(sums);
+            return fail_msg(FNN_E_UNSUPPORTED, "unknown normalisation scheme");
+        }
+    }
+    if (r == hipSuccess) {
+        const long long total = n * p.g.C;
+        hipLaunchKernelGGL(apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, raw, p, out);
+        r = hipGetLastError();
+    }
+    if (r == hipSuccess) r = hipStreamSynchronize(st);
+    (void)hipFree(sums);
+    if (r != hipSuccess) return fail_msg(FNN_E_HIP, hipGetErrorString(r));
+    return FNN_OK;
+}
+
+int fnn_revert_labels(const void *seg, int label_dtype, const int64_t bbox[6], const int64_t shape_before_cropping[3],
+                      const int32_t transpose_backward[3], void *out, void *stream) {
+    if (!seg || !bbox || !shape_before_cropping || !transpose_backward || !out) return fail_msg(FNN_E_INVALID, "NULL argument");
+    if (check_perm(transpose_backward) != 0) return fail_msg(FNN_E_INVALID, "transpose_backward is not a permutation of (0, 1, 2)");
+    if (label_dtype != FNN_LABEL_U8 && label_dtype != FNN_LABEL_U16) return fail_msg(FNN_E_INVALID, "unknown label dtype");
+    if (!dev_ptr(seg) || !dev_ptr(out)) return fail_msg(FNN_E_INVALID, "fnn_revert_labels needs device pointers (no CPU path)");
+    long long lo[3], ext[3], o[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = bbox[2 * a]; ext[a] = bbox[2 * a + 1] - bbox[2 * a];
+        if (lo[a] < 0 || ext[a] < 1 || bbox[2 * a + 1] > shape_before_cropping[a]) return fail_msg(FNN_E_INVALID, "bbox outside shape_before_cropping");
+    }
+    for (int j = 0; j < 3; ++j) o[j] = shape_before_cropping[transpose_backward[j]];
+    const long long n = o[0] * o[1] * o[2];
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (label_dtype == FNN_LABEL_U16)
+        hipLaunchKernelGGL(revert_kernel<uint16_t>, grid, dim3(256), 0, st, (const uint16_t *)seg, lo[0], lo[1], lo[2], ext[0], ext[1], ext[2],
+                           o[0], o[1], o[2], transpose_backward[0], transpose_backward[1], transpose_backward[2], (uint16_t *)out);
+    else
+        hipLaunchKernelGGL(revert_kernel<uint8_t>, grid, dim3(256), 0, st, (const uint8_t *)seg, lo[0], lo[1], lo[2], ext[0], ext[1], ext[2],
+                           o[0], o[1], o[2], transpose_backward[0], transpose_backward[1], transpose_backward[2], (uint8_t *)out);
+    hipError_t r = hipGetLastError();
+    if (r == hipSuccess) r = hipStreamSynchronize(st);
+    if (r != hipSuccess) return fail_msg(FNN_E_HIP, hipGetErrorString(r));
+    return FNN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+"""Whole-volume steps on either side of the sliding window, on the device.
+
+Mirrors, with the reference's argument names and property keys,
+
+* ``DefaultPreprocessor.run_case_npy`` (preprocessing/preprocessors/default_preprocessor.py:45-118) up to - and
+  excluding - the resampling call: float32 copy, ``transpose_forward``, ``crop_to_nonzero``, per-channel intensity
+  normalisation.  A case that needs resampling (``compute_new_shape`` != cropped shape) raises
+  ``NotImplementedError``: the reference resamples with skimage's order-3 ``resize``, which is neither installed here
+  nor restated;
+* the label half of ``convert_predicted_logits_to_segmentation_with_correct_shape``
+  (inference/export_prediction.py:43-53): dtype rule, revert cropping, ``transpose_backward``.
+
+Every numerical step is a HIP kernel behind ``include/fnn.h`` (``fnn_nonzero_bbox``, ``fnn_preprocess``,
+``fnn_revert_labels``); torch only owns the device buffers.  No CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import capi
+
+_SCHEMES = {'NoNormalization': capi.FNN_NORM_NONE, 'ZScoreNormalization': capi.FNN_NORM_ZSCORE,
+            'CTNormalization': capi.FNN_NORM_CT, 'RescaleTo01Normalization': capi.FNN_NORM_RESCALE01,
+            'RGBTo01Normalization': capi.FNN_NORM_RGB01}
+
+
+def compute_new_shape(old_shape: Sequence[int], old_spacing: Sequence[float], new_spacing: Sequence[float]):
+    """preprocessing/resampling/default_resampling.py:25-31 (python ``round``: half to even)."""
+    assert len(old_spacing) == len(old_shape) and len(old_shape) == len(new_spacing)
+    return [int(round(i / j * k)) for i, j, k in zip(old_spacing, new_spacing, old_shape)]
+
+
+class DevicePreprocessor:
+    def __init__(self, device: torch.device = torch.device('cuda'), verbose: bool = False):
+        if device.type != 'cuda':
+            raise RuntimeError('DevicePreprocessor has no CPU path: pass a GPU device')
+        self.device = device
+        self.verbose = verbose
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    @torch.inference_mode()
+    def run_case_npy(self, data: Union[np.ndarray, torch.Tensor], seg, properties: dict, plans_manager,
+                     configuration_manager, dataset_json=None) -> Tuple[torch.Tensor, None, dict]:
+        """-> (float32 ``[C, x, y, z]`` on the device, None, properties) - the ``data`` the predictor consumes."""
+        if seg is not None:
+            raise NotImplementedError('inference-time preprocessing only (seg=None)')
+        with torch.cuda.device(self.device):
+            raw = torch.as_tensor(data).to(device=self.device, dtype=torch.float32).contiguous()   # :49 astype(float32)
+            assert raw.ndim == 4, 'data must have shape (C, X, Y, Z)'
+            tf = [int(i) for i in plans_manager.transpose_forward]
+            original_spacing = [properties['spacing'][i] for i in tf]
+            shape_t = [int(raw.shape[1 + i]) for i in tf]
+            properties['shape_before_cropping'] = tuple(shape_t)
+            bbox = capi.nonzero_bbox(raw.data_ptr(), raw.shape, tf, self._stream())
+            properties['bbox_used_for_cropping'] = bbox
+            cropped = [hi - lo for lo, hi in bbox]
+            properties['shape_after_cropping_and_before_resampling'] = tuple(cropped)
+            target_spacing = list(configuration_manager.spacing)
+            if len(target_spacing) < 3:                     # 2d configurations keep the slice spacing (:74-77)
+                target_spacing = [original_spacing[0]] + target_spacing
+            new_shape = compute_new_shape(cropped, original_spacing, target_spacing)
+            if list(new_shape) != cropped:
+                raise NotImplementedError(f'this case needs resampling ({cropped} -> {new_shape}); resampling is not '
+                                          f'implemented on the device')
+            schemes = configuration_manager.normalization_schemes
+            masks = configuration_manager.use_mask_for_norm
+            props = plans_manager.foreground_intensity_properties_per_channel
+            norms = []
+            for c in range(raw.shape[0]):
+                if schemes[c] not in _SCHEMES:
+                    raise RuntimeError(f"Unable to locate class '{schemes[c]}' for normalization")
+                if schemes[c] == 'ZScoreNormalization' and masks[c]:
+                    raise NotImplementedError('ZScoreNormalization with use_mask_for_norm needs the filled non-zero mask '
+                                              '(binary_fill_holes): not implemented on the device')
+                ip = props.get(str(c), {}) if props else {}
+                if schemes[c] == 'CTNormalization':
+                    assert ip, 'CTNormalization requires intensity properties'
+                    norms.append((_SCHEMES[schemes[c]], ip['mean'], ip['std'], ip['percentile_00_5'], ip['percentile_99_5']))
+                else:
+                    norms.append((_SCHEMES[schemes[c]], 0., 1., 0., 0.))
+            out = torch.empty((raw.shape[0], *cropped), dtype=torch.float32, device=self.device)
+            capi.preprocess(raw.data_ptr(), raw.shape, tf, bbox, norms, out.data_ptr(), self._stream())
+        return out, None, properties
+
+    @torch.inference_mode()
+    def revert_labels(self, segmentation: torch.Tensor, properties: dict, plans_manager, label_manager) -> torch.Tensor:
+        """Cropped label map (uint8, or the int32-carried uint16 of the predictor) -> the original image grid."""
+        u16 = len(label_manager.foreground_labels) >= 255                      # export_prediction.py:45-46
+        with torch.cuda.device(self.device):
+            seg = segmentation.to(self.device)
+            seg = (seg.to(torch.int16) if u16 else seg.to(torch.uint8)).contiguous()
+            before = [int(i) for i in properties['shape_before_cropping']]
+            tb = [int(i) for i in plans_manager.transpose_backward]
+            out = torch.empty([before[j] for j in tb], dtype=seg.dtype, device=self.device)
+            capi.revert_labels(seg.data_ptr(), u16, properties['bbox_used_for_cropping'], before, tb, out.data_ptr(),
+                               self._stream())
+            if u16:
+                out = out.to(torch.int32) & 0xffff
+        return out

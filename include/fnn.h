@@ -179,6 +179,41 @@ int fnn_normalize_box(fnn_engine *e, const void *acc, const int64_t shape[4], co
 int fnn_argmax_labels(fnn_engine *e, const void *logits, int dtype, int heads, int64_t n_vox,
                       void *labels, void *stream);
 
+/* ---- whole-volume steps around the sliding window ----
+ * DefaultPreprocessor.run_case_npy WITHOUT its resampling call
+ * (preprocessing/preprocessors/default_preprocessor.py:45-93): float32 image
+ * [C][s0][s1][s2] -> transpose_forward -> crop to the bounding box of the non-zero
+ * region (preprocessing/cropping/cropping.py:7-39) -> per-channel intensity
+ * normalisation (preprocessing/normalization/default_normalization_schemes.py).
+ * Device pointers only.  `use_mask_for_norm` (normalise inside the filled non-zero
+ * mask only) and resampling to the target spacing are not implemented. */
+enum { FNN_NORM_NONE = 0,        /* NoNormalization                                   :70-74 */
+       FNN_NORM_ZSCORE = 1,      /* ZScoreNormalization, whole-image branch            :45-49 */
+       FNN_NORM_CT = 2,          /* CTNormalization: clip, - mean, / max(std, 1e-8)    :53-67 */
+       FNN_NORM_RESCALE01 = 3,   /* RescaleTo01Normalization                           :77-84 */
+       FNN_NORM_RGB01 = 4 };     /* RGBTo01Normalization                               :87-98 */
+typedef struct fnn_norm_desc {
+    int32_t scheme;              /* FNN_NORM_*                                                 */
+    float mean, std;             /* CT: intensityproperties['mean'], ['std']                   */
+    float lower, upper;          /* CT: ['percentile_00_5'], ['percentile_99_5']               */
+} fnn_norm_desc;
+
+/* bbox[2a], bbox[2a+1] = [lo, hi) along TRANSPOSED axis a of the voxels where any
+ * channel is non-zero (the full extent for an all-zero image): properties
+ * ['bbox_used_for_cropping'] of the reference. */
+int fnn_nonzero_bbox(const float *raw, const int64_t shape[4], const int32_t transpose_forward[3],
+                     int64_t bbox[6], void *stream);
+/* out: float32 [C][bbox extents] = normalise(crop(transpose(raw))); norm[C]. */
+int fnn_preprocess(const float *raw, const int64_t shape[4], const int32_t transpose_forward[3],
+                   const int64_t bbox[6], const fnn_norm_desc *norm, float *out, void *stream);
+/* The label half of convert_predicted_logits_to_segmentation_with_correct_shape
+ * (inference/export_prediction.py:43-53): seg [bbox extents] (FNN_LABEL_U8 / U16)
+ * -> zeros of shape_before_cropping with seg inserted at bbox -> transpose_backward.
+ * out: [shape_before_cropping[transpose_backward[j]] for j in 0..2]. */
+int fnn_revert_labels(const void *seg, int label_dtype, const int64_t bbox[6],
+                      const int64_t shape_before_cropping[3], const int32_t transpose_backward[3],
+                      void *out, void *stream);
+
 /* ---- host-side integer logic (no GPU needed) ------------------------------ */
 /* compute_steps_for_sliding_window (sliding_window_prediction.py:30-54) for one
  * axis; returns the number of steps written (<= cap) or a negative error. */

@@ -215,3 +215,49 @@ def label_rule_inputs():
     am[4, 1, 0, :4] = float('nan')
     am[0, 2, 0, :4] = float('nan')
     return {'regions_f16': regions_f16, 'regions_f32': f32, 'argmax_f16': am}
+
+
+# ---- preprocessing without resampling (f-2) and label un-cropping (f-3): fixtures in preprocess.npz
+PREP_CASES = [
+    dict(name='ct_identity', shape=(1, 24, 20, 28), margins=((3, 2), (0, 4), (5, 1)), tf=(0, 1, 2), schemes=['CTNormalization'],
+         props={'0': {'mean': 418.6798400878906, 'std': 412.1883239746094, 'percentile_00_5': -60.0, 'percentile_99_5': 3068.0}},
+         scale=900.0, offset=300.0, seed=1),
+    dict(name='zscore_rescale_transposed', shape=(2, 18, 22, 26), margins=((0, 5), (2, 2), (1, 0)), tf=(2, 0, 1),
+         schemes=['ZScoreNormalization', 'RescaleTo01Normalization'], props={'0': {}, '1': {}}, scale=50.0, offset=10.0, seed=2),
+    dict(name='rgb_none', shape=(3, 8, 30, 33), margins=((1, 1), (4, 0), (0, 6)), tf=(1, 2, 0),
+         schemes=['RGBTo01Normalization', 'NoNormalization', 'RGBTo01Normalization'], props={'0': {}, '1': {}, '2': {}},
+         scale=None, offset=None, seed=3),
+    dict(name='all_zero', shape=(1, 6, 7, 9), margins=None, tf=(0, 1, 2), schemes=['NoNormalization'], props={'0': {}},
+         scale=0.0, offset=0.0, seed=4),
+    dict(name='ct_single_voxel_holes', shape=(1, 12, 12, 12), margins=((4, 4), (3, 5), (2, 2)), tf=(0, 2, 1),
+         schemes=['CTNormalization'],
+         props={'0': {'mean': 10.0, 'std': 0.0, 'percentile_00_5': -5.0, 'percentile_99_5': 5.0}}, scale=8.0, offset=0.0,
+         seed=5, holes=True),
+]
+
+
+def prep_case_input(case):
+    """Raw image [C, s0, s1, s2] (float32) with exact-zero margins (and optionally zero holes inside)."""
+    import numpy as np
+    rng = np.random.default_rng(4000 + case['seed'])
+    shape = case['shape']
+    if case['scale'] is None:                                   # uint8-like RGB
+        x = rng.integers(1, 256, shape).astype(np.float32)
+    else:
+        x = (rng.standard_normal(shape) * case['scale'] + case['offset']).astype(np.float32)
+        x[x == 0] = 1.0
+    if case['margins'] is None:
+        return np.zeros(shape, np.float32)
+    m = case['margins']
+    keep = np.zeros(shape[1:], bool)
+    keep[m[0][0]:shape[1] - m[0][1], m[1][0]:shape[2] - m[1][1], m[2][0]:shape[3] - m[2][1]] = True
+    if case.get('holes'):
+        keep[shape[1] // 2, shape[2] // 2 - 1:shape[2] // 2 + 1, shape[3] // 2] = False
+    x[:, ~keep] = 0
+    return x
+
+
+def prep_label_input(case, cropped_shape, n_labels=7):
+    import numpy as np
+    rng = np.random.default_rng(5000 + case['seed'])
+    return rng.integers(0, n_labels, cropped_shape).astype(np.uint8)

@@ -186,10 +186,43 @@ def gen_label_rules():
     print('label rules', {k: (v.shape, int(v.max())) for k, v in arrays.items()})
 
 
+def gen_preprocess():
+    """crop_to_nonzero + the normalisation scheme classes + the label half of export_prediction, called in the order
+    DefaultPreprocessor.run_case_npy / convert_predicted_logits_to_segmentation_with_correct_shape use them."""
+    from golden_cases import PREP_CASES, prep_case_input, prep_label_input
+    from nnunetv2.preprocessing.cropping.cropping import crop_to_nonzero
+    from nnunetv2.preprocessing.normalization import default_normalization_schemes as dns
+    from acvl_utils.cropping_and_padding.bounding_boxes import insert_crop_into_image
+    arrays = {}
+    for case in PREP_CASES:
+        raw = prep_case_input(case)
+        data = raw.astype(np.float32)                                             # default_preprocessor.py:49
+        tf = list(case['tf'])
+        data = data.transpose([0, *[i + 1 for i in tf]])                          # :57
+        shape_before = data.shape[1:]
+        data, seg, bbox = crop_to_nonzero(data, None)                             # :66
+        for c in range(data.shape[0]):                                            # :228-240
+            cls = getattr(dns, case['schemes'][c])
+            norm = cls(use_mask_for_norm=False, intensityproperties=case['props'][str(c)])
+            data[c] = norm.run(data[c], seg[0])
+        arrays[case['name'] + '__data'] = data.astype(np.float32)
+        arrays[case['name'] + '__bbox'] = np.asarray(bbox, np.int64)
+        arrays[case['name'] + '__shape_before'] = np.asarray(shape_before, np.int64)
+        # export_prediction.py:43-53 on a label map of the cropped shape
+        tb = [int(i) for i in np.argsort(tf)]
+        for n_fg, tag in ((6, 'u8'), (300, 'u16')):
+            lab = prep_label_input(case, data.shape[1:])
+            full = np.zeros(shape_before, dtype=np.uint8 if n_fg < 255 else np.uint16)
+            full = insert_crop_into_image(full, lab, bbox)
+            arrays[case['name'] + '__labels_' + tag] = full.transpose(tb)
+    np.savez_compressed(os.path.join(HERE, 'preprocess.npz'), **arrays)
+    print('preprocess', {k: v.shape for k, v in arrays.items() if k.endswith('__data')})
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:                                   # regenerate single fixtures: labels, plans
         for what in sys.argv[1:]:
-            {'labels': gen_label_rules, 'plans': gen_plans, 'sw2d': gen_sliding_window_2d}[what]()
+            {'labels': gen_label_rules, 'plans': gen_plans, 'sw2d': gen_sliding_window_2d, 'prep': gen_preprocess}[what]()
         sys.exit(0)
     gen_label_rules()
     gen_steps()
@@ -198,4 +231,5 @@ if __name__ == '__main__':
     gen_plans()
     gen_sliding_window()
     gen_sliding_window_2d()
+    gen_preprocess()
     print('golden vectors written to', HERE)

@@ -154,6 +154,32 @@ def install():
     pad = types.ModuleType('acvl_utils.cropping_and_padding.padding')
     pad.pad_nd_image = pad_nd_image
     real['acvl_utils.cropping_and_padding.padding'] = pad
+    # acvl_utils.cropping_and_padding.bounding_boxes (used by preprocessing/cropping/cropping.py:3 and
+    # inference/export_prediction.py:5): own restatement of the package's published helpers
+    bb = types.ModuleType('acvl_utils.cropping_and_padding.bounding_boxes')
+
+    def get_bbox_from_mask(mask):
+        """[[lo, hi), ...] of the True region per axis; the full extent for an empty mask."""
+        out = []
+        for ax in range(mask.ndim):
+            proj = np.any(mask, axis=tuple(a for a in range(mask.ndim) if a != ax))
+            idx = np.where(proj)[0]
+            out.append([int(idx[0]), int(idx[-1]) + 1] if idx.size else [0, int(mask.shape[ax])])
+        return out
+
+    def bounding_box_to_slice(bbox):
+        return tuple(slice(*i) for i in bbox)
+
+    def insert_crop_into_image(image, crop, bbox):
+        """Writes `crop` into `image` at `bbox` (bbox indexes the trailing axes of `image`)."""
+        lead = image.ndim - len(bbox)
+        sl = tuple([slice(None)] * lead + [slice(b[0], b[1]) for b in bbox])
+        image[sl] = crop
+        return image
+
+    bb.get_bbox_from_mask, bb.bounding_box_to_slice, bb.insert_crop_into_image = (
+        get_bbox_from_mask, bounding_box_to_slice, insert_crop_into_image)
+    real['acvl_utils.cropping_and_padding.bounding_boxes'] = bb
     # the two one-line lookups plans_handler.py:22 needs for old-format plans
     hp = types.ModuleType('dynamic_network_architectures.building_blocks.helper')
     hp.convert_dim_to_conv_op = lambda dim: {1: torch.nn.Conv1d, 2: torch.nn.Conv2d, 3: torch.nn.Conv3d}[dim]

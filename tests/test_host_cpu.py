@@ -116,6 +116,18 @@ def test_engine_fails_loudly_without_gpu(capi):
         nnUNetPredictor(device=torch.device('cpu'))
 
 
+def test_preprocess_entry_points_fail_loudly_on_host_memory(capi):
+    raw = np.ones((1, 4, 4, 4), np.float32)
+    with pytest.raises(AssertionError, match='device pointer'):
+        capi.nonzero_bbox(raw.ctypes.data, raw.shape, (0, 1, 2))
+    from fast_nnunet_amd.preprocess import DevicePreprocessor, compute_new_shape
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        DevicePreprocessor(torch.device('cpu'))
+    # compute_new_shape (default_resampling.py:25-31): python round, half to even
+    assert compute_new_shape((100, 51, 7), (1.0, 1.0, 2.5), (2.0, 1.0, 1.0)) == [50, 51, 18]
+    assert compute_new_shape((5,), (1.0,), (2.0,)) == [2]
+
+
 def test_spec_from_state_dict_roundtrip_and_aliases():
     from fast_nnunet_amd.arch import spec_from_state_dict, weight_blob
     ospec = toy_unet_spec(2, 4)

@@ -160,3 +160,24 @@ def test_sliding_window_2d_configuration_matches_reference(case, golden_dir):
         err = np.abs(out.float().numpy() - ref)
         assert np.median(err) < 1e-3
         assert (err > 0.02 * max(1.0, np.abs(ref).max())).mean() < 2e-3
+
+
+def test_preprocess_and_label_revert_match_reference_golden(golden_dir):
+    """f-2 / f-3 restatements against vectors made by the reference's crop_to_nonzero, normalisation classes
+    and export_prediction steps."""
+    from golden_cases import PREP_CASES, prep_case_input, prep_label_input
+    from oracle import preprocess as opre
+    z = np.load(os.path.join(golden_dir, 'preprocess.npz'))
+    for case in PREP_CASES:
+        data, bbox, before = opre.preprocess_case(prep_case_input(case), case['tf'], case['schemes'], case['props'])
+        assert np.array_equal(np.asarray(bbox), z[case['name'] + '__bbox']), case['name']
+        assert list(before) == z[case['name'] + '__shape_before'].tolist()
+        ref = z[case['name'] + '__data']
+        assert data.dtype == np.float32 and data.shape == ref.shape
+        assert np.array_equal(data.view(np.uint32), ref.view(np.uint32)), case['name']
+        tb = [int(i) for i in np.argsort(case['tf'])]
+        for n_fg, tag in ((6, 'u8'), (300, 'u16')):
+            lab = prep_label_input(case, data.shape[1:])
+            full = opre.revert_labels(lab, bbox, before, tb, n_fg)
+            want = z[case['name'] + '__labels_' + tag]
+            assert full.dtype == want.dtype and np.array_equal(full, want)
