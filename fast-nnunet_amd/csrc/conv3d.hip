@@ -731,7 +731,7 @@ static int launch_pipe(ConvParams p, hipStream_t st) {
 //     runs on the matrix cores; one barrier per item;
 //   * InstanceNorm statistics are kept in registers across the tiles of one
 //     batch item and flushed with one set of atomics per workgroup.
-template <int NB, int MB, bool WRES, int KS>
+template <int NB, int MB, bool WRES, int KS, int CH>
 __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams p, const int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -873,14 +873,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
             for (int u = 0; u < WPF; ++u) wr[u] = ((const f16x8 *)p.wpk)[wofs[u] + ch * per_nb];
         }
         slope_next = p.src[s].slope;
-        if (p.src[s].ss) {
-            const float *q4 = p.src[s].ss + (size_t)(2 * n) * sC + c_loc;
-            scr[0] = *(const float4 *)q4; scr[1] = *(const float4 *)(q4 + 4);
-            shr[0] = *(const float4 *)(q4 + sC); shr[1] = *(const float4 *)(q4 + sC + 4);
-        } else {
-            scr[0] = scr[1] = make_float4(1.f, 1.f, 1.f, 1.f);
-            shr[0] = shr[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        // unconditional loads: the identity table stands in for a source without InstanceNorm
+        const float *qs = p.src[s].ss ? p.src[s].ss + (size_t)(2 * n) * sC + c_loc : p.ident_ss + c_loc;
+        const float *qh = p.src[s].ss ? qs + sC : p.ident_ss + 512 + c_loc;
+        scr[0] = *(const float4 *)qs; scr[1] = *(const float4 *)(qs + 4);
+        shr[0] = *(const float4 *)qh; shr[1] = *(const float4 *)(qh + 4);
     };
     auto commit = [&](char *dst) {
         const f16 slope_h = (f16)slope_next;
@@ -888,18 +885,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
         const float sh[8] = {shr[0].x, shr[0].y, shr[0].z, shr[0].w, shr[1].x, shr[1].y, shr[1].z, shr[1].w};
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            if (u * 256 >= IVOX * 2 || rel[u] < 0) continue;
+            if (u * 256 >= IVOX * 2) continue;                          // uniform: no thread has an element u
+            // branch-free: with `if (offv >= 0)` around the arithmetic the waits for the prefetch sat in conditional
+            // blocks, and hipcc then had to assume at the loop head that loads (and the stores behind them) were
+            // still pending - it drained the previous tile's stores before every prefetch
             f16x8 o;
-            if (offv[u] >= 0) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)xr[u][j], sc[j], sh[j]);
-                o = __builtin_elementwise_max(o, o * slope_h);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
-            }
+            for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)xr[u][j], sc[j], sh[j]);
+            o = __builtin_elementwise_max(o, o * slope_h);
+            if (offv[u] < 0) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};             // the conv's zero padding
             const int zd = rel[u] >> 16, zh = (rel[u] >> 8) & 255, zw = rel[u] & 255;
-            *(f16x8 *)(dst + ((zd * IH + zh) * PWp + zw) * 32 + ((cg ^ (swz & zh & 1)) * 16)) = o;
+            if (rel[u] >= 0) *(f16x8 *)(dst + ((zd * IH + zh) * PWp + zw) * 32 + ((cg ^ (swz & zh & 1)) * 16)) = o;
         }
         if (!WRES) {
 #pragma unroll
@@ -942,14 +938,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
         int n_next = n_cur, nod0 = od0, noh0 = oh0, now0 = ow0;
-        for (int ch = 0; ch < p.chunks; ++ch) {
+        constexpr int CHU = CH ? CH : 1;
+#pragma unroll CHU
+        for (int ch = 0; ch < (CH ? CH : p.chunks); ++ch) {
             // prefetch the next work item.  The very last item prefetches itself again (a few redundant, cached
             // loads) so that issue / commit sit on an unconditional path: hipcc's waitcnt pass is then exact
 #ifdef FNN_STAMPS
             const bool stamp_it = t == t_begin + 2 && ch == 0;
             if (stamp_it) FNN_STAMP();                           // 0: item start
 #endif
-            const bool last_chunk = ch + 1 == p.chunks;
+            const bool last_chunk = ch + 1 == (CH ? CH : p.chunks);
             if (last_chunk) {
                 if (t + 1 < t_end) next_tile(n_next, nod0, noh0, now0);
                 set_offsets(nod0, noh0, now0);
@@ -1030,23 +1028,25 @@ static size_t persist_lds_bytes(const ConvParams &p, int nb, int mb, bool wres) 
     return (wres ? 2 : 1) * ab + (size_t)nb * (wres ? p.chunks : 1) * p.ksteps * 1024 + 256 + (size_t)4 * nb * 16 * 2 * 8;
 }
 
-template <int NB, int MB, bool WRES, int KS>
+template <int NB, int MB, bool WRES, int KS, int CH = 0>
 static int launch_persist_ks(ConvParams p, int wgs_per_cu, hipStream_t st) {
     p.tile_d = MB;
     p.tiles_d = (p.Do + MB - 1) / MB;
     p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
     p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
     const int total = p.N * p.tiles_d * p.tiles_h * p.tiles_w;
+    p.ident_ss = conv3d_identity_ss();
+    if (!p.ident_ss) return -2;
     const size_t lds = persist_lds_bytes(p, NB, MB, WRES);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)conv3d_persist_kernel<NB, MB, WRES, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv3d_persist_kernel<NB, MB, WRES, KS, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     int gx = 256 * wgs_per_cu;
     if (gx > total) gx = total;
     dim3 grid(gx, (p.Cout / 16) / NB);
-    hipLaunchKernelGGL((conv3d_persist_kernel<NB, MB, WRES, KS>), grid, dim3(256), lds, st, p, total);
+    hipLaunchKernelGGL((conv3d_persist_kernel<NB, MB, WRES, KS, CH>), grid, dim3(256), lds, st, p, total);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -1054,6 +1054,8 @@ template <int NB, int MB, bool WRES>
 static int launch_persist(const ConvParams &p, int wgs_per_cu, hipStream_t st) {
     // fully unrolled k-loops for the two common tap counts (9 taps = 5 k-steps, 27 taps = 14); only instantiated
     // for the thin single-cout-block layers that the persistent kernel is used for
+    if (NB == 1 && MB == 8 && WRES && p.ksteps == 5 && p.chunks == 1) return launch_persist_ks<NB, MB, WRES, (NB == 1 ? 5 : 0), (NB == 1 && MB == 8 && WRES ? 1 : 0)>(p, wgs_per_cu, st);
+    if (NB == 1 && MB == 8 && WRES && p.ksteps == 5 && p.chunks == 2) return launch_persist_ks<NB, MB, WRES, (NB == 1 ? 5 : 0), (NB == 1 && MB == 8 && WRES ? 2 : 0)>(p, wgs_per_cu, st);
     if (NB == 1 && p.ksteps == 5) return launch_persist_ks<NB, MB, WRES, (NB == 1 ? 5 : 0)>(p, wgs_per_cu, st);
     if (NB == 1 && p.ksteps == 14) return launch_persist_ks<NB, MB, WRES, (NB == 1 ? 14 : 0)>(p, wgs_per_cu, st);
     return launch_persist_ks<NB, MB, WRES, 0>(p, wgs_per_cu, st);
@@ -1071,6 +1073,24 @@ size_t conv3d_lds_bytes(const ConvParams &p, int nb) {
     b += 2 * p.ksteps * 4 + 64;
     const size_t red = (size_t)4 * nb * 16 * 2 * 4;
     return b > red ? b : red;
+}
+
+// [0, 512): ones, [512, 1024): zeros - the "no InstanceNorm on this source" scale / shift rows, so that kernels
+// can load scale / shift unconditionally (a branch around those loads makes the waitcnt bookkeeping of the
+// persistent kernel conservative: it then waited for the previous tile's store acknowledgements before every prefetch)
+const float *conv3d_identity_ss() {
+    static const float *tab[16] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!tab[dev]) {
+        float h[1024];
+        for (int i = 0; i < 512; ++i) { h[i] = 1.f; h[512 + i] = 0.f; }
+        float *d = nullptr;
+        if (hipMalloc((void **)&d, sizeof(h)) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+        tab[dev] = d;
+    }
+    return tab[dev];
 }
 
 int conv3d_pick_nb(int nblk) { return (nblk % 4 == 0) ? 4 : (nblk % 2 == 0) ? 2 : 1; }
@@ -1131,7 +1151,8 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
             for (int mb = mbsel < persist_mb ? mbsel : persist_mb; mb >= 4; mb -= 4) {
                 const long long tiles = (long long)plan_n * ((p.Do + mb - 1) / mb) * p.tiles_h * p.tiles_w;
                 if (tiles < 256LL * 2 * 4) continue;
-                for (int wres = 1; wres >= 0; --wres) {
+                static const int persist_wres = getenv("FNN_PERSIST_WRES") ? atoi(getenv("FNN_PERSIST_WRES")) : 1;
+                for (int wres = persist_wres; wres >= 0; --wres) {
                     const size_t lds = persist_lds_bytes(p, nb, mb, wres != 0);
                     const int per_cu = (int)((160 * 1024) / lds);
                     if (per_cu < 2) continue;

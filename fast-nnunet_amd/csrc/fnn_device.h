@@ -54,6 +54,7 @@ struct ConvParams {
     unsigned long long *dbg;     // diagnostic builds only (-DFNN_STAMPS): per-workgroup s_memtime stamps
     int chunks;                  // 16-channel chunks over all sources
     int ksteps;                  // MFMA k-steps per chunk: conv3d_ksteps(packing, taps)
+    const float *ident_ss;       // conv3d_identity_ss(): ones[512] then zeros[512] (set by the launchers that need it)
     int packing;                 // FNN_PACK_*: which taps share a k-step (fixed per layer when the weights are packed)
 };
 
@@ -186,6 +187,7 @@ int launch_combine(const CombineParams &p, hipStream_t st);
 int launch_conv3d(const ConvParams &p, hipStream_t st);
 size_t conv3d_lds_bytes(const ConvParams &p, int nb);
 int conv3d_pick_nb(int nblk);
+const float *conv3d_identity_ss();
 // packing the launcher will expect for a layer of this shape (decided from the PLANNED batch size)
 int conv3d_packing(const ConvParams &p);
 int conv3d_ksteps(int packing, int taps);
