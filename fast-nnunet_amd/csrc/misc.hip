@@ -44,6 +44,22 @@ int launch_stats_finalize(const StatsFinalizeParams &p, int N, hipStream_t st) {
 
 // Activation fragment (MFMA B operand) of 16 voxels x 32 channels, read from a
 // channels-last tensor with the producer's norm + LeakyReLU applied.
+// Normalise + LeakyReLU of a raw fragment of 8 channels starting at c0 (zero beyond the source's channels).
+static __device__ __forceinline__ f16x8 norm_act_frag(const SrcDesc &s, const f16x8 &x, int c0, const float2 *sSS) {
+    const bool live = c0 < s.C;
+    const int cc = live ? c0 : 0;
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float2 ss = sSS[cc + j];
+        o[j] = (f16)fmaf((float)x[j], ss.x, ss.y);
+    }
+    o = __builtin_elementwise_max(o, o * (f16)s.slope);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = live ? o[j] : (f16)0.f;
+    return o;
+}
+
 static __device__ __forceinline__ f16x8 load_act_frag(const SrcDesc &s, size_t vox, bool vox_ok, int c0,
                                                       const float2 *sSS) {
     // unconditional load from a clamped (always valid) address, zeroed afterwards: a per-lane branch around
@@ -477,6 +493,131 @@ __global__ __launch_bounds__(256) void seg_head_acc_kernel(const HeadParams p) {
     }
 }
 
+// One-k-step (C <= 32) version of seg_head_acc_kernel with every global load of BOTH rounds issued up front.
+// vmcnt retires in order, so a load issued after a store cannot be consumed before that store has been
+// acknowledged: with the loads of round 1 behind the stores of round 0 (the loop above), every wave waited for a
+// full write round trip in the middle of its life.  Here the only waits are for loads that were issued before any
+// store; the stores of both rounds drain while the wave finishes.
+template <bool ACC32>
+__global__ __launch_bounds__(256) void seg_head_acc1_kernel(const HeadParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float2 *sSS = (float2 *)smem;
+    float *sT = (float *)(smem + ((p.src.C * 8 + 255) & ~255)) + wave * (32 * HEAD_LD);      // [32 voxels][64 ch]
+    const int P = p.PD * p.PH * p.PW;
+    load_scale_shift(p.src, p.b, sSS, tid, 256);
+    __syncthreads();
+
+    const int v0 = (blockIdx.x * 4 + wave) * 64;
+    if (v0 >= P) return;
+    const int r = lane & 15, q = lane >> 4;
+    const int grp = lane & 7, vsub = lane >> 3;
+
+    for (int cb0 = 0; cb0 < p.HP; cb0 += 64) {
+        const int hb_first = cb0 >> 4;
+        const int grp_c = cb0 + grp * 8 < p.HP ? grp : 0;
+        const bool grp_ok = cb0 + grp * 8 < p.HP;
+        // ---- phase A: every address, then every load (accumulator lines, Gaussian weights, activation fragments)
+        size_t aelem[2][4];
+        bool ok[2][4];
+        f16 graw[2][4];
+        f16x8 a16[2][4];
+        f32x4 a32[ACC32 ? 2 : 1][4][2];
+        f16x8 xraw[2][2];
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int v = v0 + rd * 32 + 8 * i + vsub;
+                ok[rd][i] = v < P && grp_ok;
+                const int vv = v < P ? v : P - 1;
+                const int w = vv % p.PW, h = (vv / p.PW) % p.PH, d = vv / (p.PW * p.PH);
+                aelem[rd][i] = (((size_t)(p.ox + d) * p.Y + (p.oy + h)) * p.Z + (p.oz + w)) * p.HP + cb0 + grp_c * 8;
+                graw[rd][i] = p.gauss ? p.gauss[vv] : (f16)1.f;
+            }
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (ACC32) {
+                    a32[ACC32 ? rd : 0][i][0] = *(const f32x4 *)((const float *)p.acc + aelem[rd][i]);
+                    a32[ACC32 ? rd : 0][i][1] = *(const f32x4 *)((const float *)p.acc + aelem[rd][i] + 4);
+                } else a16[rd][i] = *(const f16x8 *)((const f16 *)p.acc + aelem[rd][i]);
+            }
+        const int c0 = q * 8 < p.src.C ? q * 8 : 0;
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd)
+#pragma unroll
+            for (int vb = 0; vb < 2; ++vb) {
+                const int v = v0 + (rd * 2 + vb) * 16 + r;
+                xraw[rd][vb] = *(const f16x8 *)(p.src.ptr + ((size_t)p.b * P + (v < P ? v : P - 1)) * p.src.C + c0);
+            }
+        f16x8 wf[4];
+        f32x4 bv[4];
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb) {
+            const int hbc = hb_first + hb < p.hblocks ? hb_first + hb : p.hblocks - 1;
+            wf[hb] = *(const f16x8 *)(p.wpk + ((size_t)hbc * 64 + lane) * 8);
+            bv[hb] = *(const f32x4 *)(p.bias + hbc * 16 + q * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase B: per round MFMA -> LDS transpose -> read-modify-write -> store
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int vb = 0; vb < 2; ++vb) {
+                const f16x8 xf = norm_act_frag(p.src, xraw[rd][vb], q * 8, sSS);
+#pragma unroll
+                for (int hb = 0; hb < 4; ++hb)
+                    acc[hb][vb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[hb], xf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            }
+#pragma unroll
+            for (int hb = 0; hb < 4; ++hb)
+#pragma unroll
+                for (int vb = 0; vb < 2; ++vb) {
+                    const f32x4 t = hb_first + hb < p.hblocks ? acc[hb][vb] + bv[hb] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    *(f32x4 *)(sT + (vb * 16 + r) * HEAD_LD + hb * 16 + q * 4) = t;
+                }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 t0 = *(const f32x4 *)(sT + (8 * i + vsub) * HEAD_LD + grp_c * 8);
+                const f32x4 t1 = *(const f32x4 *)(sT + (8 * i + vsub) * HEAD_LD + grp_c * 8 + 4);
+                const float g = (float)graw[rd][i];
+                float c[8];
+                unsigned mask = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = cb0 + grp_c * 8 + e;
+                    const float t = e < 4 ? t0[e] : t1[e - 4];
+                    c[e] = ch == p.heads ? g : __fmul_rn(t, g);            // channel `heads` accumulates the weight
+                    if (ch <= p.heads) mask |= 1u << e;                      // padding channels keep their bits
+                }
+                if (ACC32) {
+                    f32x4 b0 = a32[ACC32 ? rd : 0][i][0], b1 = a32[ACC32 ? rd : 0][i][1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        b0[e] = (mask >> e) & 1 ? __fadd_rn(b0[e], c[e]) : b0[e];
+                        b1[e] = (mask >> (4 + e)) & 1 ? __fadd_rn(b1[e], c[4 + e]) : b1[e];
+                    }
+                    if (ok[rd][i]) {
+                        *(f32x4 *)((float *)p.acc + aelem[rd][i]) = b0;
+                        *(f32x4 *)((float *)p.acc + aelem[rd][i] + 4) = b1;
+                    }
+                } else {
+                    f16x8 bq = a16[rd][i];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bq[e] = (mask >> e) & 1 ? (f16)__fadd_rn((float)bq[e], c[e]) : bq[e];
+                    if (ok[rd][i]) *(f16x8 *)((f16 *)p.acc + aelem[rd][i]) = bq;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 int launch_head(const HeadParams &p, hipStream_t st) {
     const int P = p.PD * p.PH * p.PW;
     static bool attr_set = false;
@@ -487,7 +628,11 @@ int launch_head(const HeadParams &p, hipStream_t st) {
     dim3 grid((P + 255) / 256);
     if (p.mode == 0) {
         const size_t lds = (size_t)((p.src.C * 8 + 255) & ~255) + (size_t)4 * 32 * HEAD_LD * 4;
-        if (p.acc_fp32) hipLaunchKernelGGL(seg_head_acc_kernel<true>, grid, dim3(256), lds, st, p);
+        static const bool head_v1 = getenv("FNN_HEAD_V1") != nullptr;            // A-B aid
+        if (p.ksteps == 1 && !head_v1) {
+            if (p.acc_fp32) hipLaunchKernelGGL(seg_head_acc1_kernel<true>, grid, dim3(256), lds, st, p);
+            else hipLaunchKernelGGL(seg_head_acc1_kernel<false>, grid, dim3(256), lds, st, p);
+        } else if (p.acc_fp32) hipLaunchKernelGGL(seg_head_acc_kernel<true>, grid, dim3(256), lds, st, p);
         else hipLaunchKernelGGL(seg_head_acc_kernel<false>, grid, dim3(256), lds, st, p);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
