@@ -71,6 +71,7 @@ struct fnn_engine {
     double *stats = nullptr;
     float *ss = nullptr;                    // [layer][max_batch][2][C]
     f16 *gauss = nullptr;
+    f16 *ones = nullptr;                    // weight map of use_gaussian = 0 (the kernels load the map unconditionally)
     int *inf_flag = nullptr;
     // label rule of the label-map entry points (fnn_set_label_rule)
     int label_mode = FNN_LABELS_ARGMAX, label_u16 = 0;
@@ -653,7 +654,7 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
             for (int b = 0; b < nb; ++b) {
                 HeadParams h = make_head(e, fold, b);
                 const int *oo = &vp.origins[ids[p0 + b] * 3];
-                h.gauss = o.use_gaussian ? e->gauss : nullptr;
+                h.gauss = o.use_gaussian ? e->gauss : e->ones;
                 h.acc = acc; h.AX = box.hi[0] - box.lo[0]; h.Y = box.hi[1] - box.lo[1]; h.Z = box.hi[2] - box.lo[2];
                 h.HP = acc_hp(a);
                 h.ox = oo[0] - (int)box.lo[0]; h.oy = oo[1] - (int)box.lo[1]; h.oz = oo[2] - (int)box.lo[2];
@@ -671,7 +672,7 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
                 q.patch_buf = e->patch_buf + (size_t)b * a.num_heads * P;
                 q.n_div = (int)combos.size() + 1;
                 q.PD = a.patch[0]; q.PH = a.patch[1]; q.PW = a.patch[2]; q.heads = a.num_heads;
-                q.gauss = o.use_gaussian ? e->gauss : nullptr;
+                q.gauss = o.use_gaussian ? e->gauss : e->ones;
                 q.acc = acc; q.AX = box.hi[0] - box.lo[0]; q.Y = box.hi[1] - box.lo[1]; q.Z = box.hi[2] - box.lo[2];
                 q.HP = acc_hp(a);
                 q.ox = oo[0] - (int)box.lo[0]; q.oy = oo[1] - (int)box.lo[1]; q.oz = oo[2] - (int)box.lo[2];
@@ -867,6 +868,12 @@ int fnn_create(const fnn_arch_desc *arch, int device, int max_batch, fnn_engine 
     if ((r = hipMalloc((void **)&e->stats, e->stats_doubles * max_batch * sizeof(double))) != hipSuccess) return bail("hipMalloc(stats)", r);
     if ((r = hipMalloc((void **)&e->ss, (e->ss_count * max_batch * 2 + 4) * sizeof(float))) != hipSuccess) return bail("hipMalloc(scale/shift)", r);
     if ((r = hipMalloc((void **)&e->inf_flag, sizeof(int))) != hipSuccess) return bail("hipMalloc(flag)", r);
+    {
+        const size_t P = (size_t)arch->patch[0] * arch->patch[1] * arch->patch[2];
+        std::vector<uint16_t> one(P, 0x3c00);                                       // fp16 1.0
+        if ((r = hipMalloc((void **)&e->ones, P * 2)) != hipSuccess) return bail("hipMalloc(ones)", r);
+        if ((r = hipMemcpy(e->ones, one.data(), P * 2, hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy(ones)", r);
+    }
     *out = e;
     return 0;
 }
@@ -875,7 +882,7 @@ void fnn_destroy(fnn_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     for (auto &f : e->folds) { if (f.wpk) (void)hipFree(f.wpk); if (f.fparam) (void)hipFree(f.fparam); }
-    void *ptrs[] = {e->label_order, e->act, e->stats, e->ss, e->gauss, e->inf_flag, e->origins, e->acc, e->vol_tmp, e->vol_pad, e->out_tmp, e->patch_buf};
+    void *ptrs[] = {e->ones, e->label_order, e->act, e->stats, e->ss, e->gauss, e->inf_flag, e->origins, e->acc, e->vol_tmp, e->vol_pad, e->out_tmp, e->patch_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ev : e->evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     delete e;

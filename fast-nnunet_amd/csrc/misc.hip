@@ -42,8 +42,6 @@ int launch_stats_finalize(const StatsFinalizeParams &p, int N, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-// Activation fragment (MFMA B operand) of 16 voxels x 32 channels, read from a
-// channels-last tensor with the producer's norm + LeakyReLU applied.
 // Normalise + LeakyReLU of a raw fragment of 8 channels starting at c0 (zero beyond the source's channels).
 static __device__ __forceinline__ f16x8 norm_act_frag(const SrcDesc &s, const f16x8 &x, int c0, const float2 *sSS) {
     const bool live = c0 < s.C;
@@ -60,6 +58,8 @@ static __device__ __forceinline__ f16x8 norm_act_frag(const SrcDesc &s, const f1
     return o;
 }
 
+// Activation fragment (MFMA B operand) of 16 voxels x 32 channels, read from a
+// channels-last tensor with the producer's norm + LeakyReLU applied.
 static __device__ __forceinline__ f16x8 load_act_frag(const SrcDesc &s, size_t vox, bool vox_ok, int c0,
                                                       const float2 *sSS) {
     // unconditional load from a clamped (always valid) address, zeroed afterwards: a per-lane branch around
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void seg_head_acc1_kernel(const HeadParams p) 
                 const int vv = v < P ? v : P - 1;
                 const int w = vv % p.PW, h = (vv / p.PW) % p.PH, d = vv / (p.PW * p.PH);
                 aelem[rd][i] = (((size_t)(p.ox + d) * p.Y + (p.oy + h)) * p.Z + (p.oz + w)) * p.HP + cb0 + grp_c * 8;
-                graw[rd][i] = p.gauss ? p.gauss[vv] : (f16)1.f;
+                graw[rd][i] = p.gauss[vv];                              // always a map (all ones without Gaussian weighting)
             }
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd)
