@@ -731,19 +731,18 @@ static int launch_pipe(ConvParams p, hipStream_t st) {
 //     runs on the matrix cores; one barrier per item;
 //   * InstanceNorm statistics are kept in registers across the tiles of one
 //     batch item and flushed with one set of atomics per workgroup.
-template <int NB, int MB, bool WRES, int KS, int CH>
+template <int NB, int MB, bool WRES, int KS, int CH, int PF = 8>
 __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams p, const int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     FNN_STAMP_DECL
-    constexpr int TD = MB;
-    constexpr int PF = 8;
+    constexpr int TD = MB;                                            // MB = 2: the strided 2 x 8 x 8 tile (mb_coords<2>)
 
-    const int ID = TD - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
+    const int ID = (TD - 1) * p.sd + p.kd, IH = (FNN_TILE_H - 1) * p.sh + p.kh, IW = (FNN_TILE_W - 1) * p.sw + p.kw;
     const int IVOX = ID * IH * IW;
     const int T = p.kd * p.kh * p.kw;
     const int TS = p.chunks * p.ksteps;
-    const int swz = (IW & 7) != 0;                                    // LDS image: see conv3d_pipe_kernel
+    const int swz = p.sw == 1 && (IW & 7) != 0;                       // LDS image: see conv3d_pipe_kernel
     const int PWp = swz ? ((IW + 3) & ~7) + 4 : IW;
     const int abytes = (ID * IH * PWp * 32 + 1023) & ~1023;
     const int cb0 = blockIdx.y * NB;
@@ -809,8 +808,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int r = lane & 15;
-        const int od_l = wave + 4 * (mb >> 2), oh_l = 2 * (mb & 3) + (r >> 3), ow_l = r & 7;
-        base[mb] = ((od_l * IH + oh_l) * PWp + ow_l) * 32;
+        int od_l, oh_l, ow_l;
+        mb_coords<MB>(wave, mb, r, od_l, oh_l, ow_l);
+        base[mb] = ((od_l * p.sd * IH + oh_l * p.sh) * PWp + ow_l * p.sw) * 32;
     }
     const int kgp = ((lane >> 4) & 1) ^ (swz & ((lane & 15) >> 3));
 
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
     };
     // offv = voxel index inside batch item n (or -1 for conv padding); the item's base pointer is uniform
     auto set_offsets = [&](int od0, int oh0, int ow0) {
-        const int id0 = od0 - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
+        const int id0 = od0 * p.sd - p.pd, ih0 = oh0 * p.sh - p.ph, iw0 = ow0 * p.sw - p.pw;
         const int base_vox = (id0 * p.Hi + ih0) * p.Wi + iw0;
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
@@ -1023,13 +1023,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
 }
 
 static size_t persist_lds_bytes(const ConvParams &p, int nb, int mb, bool wres) {
-    const int ID = mb - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
-    const size_t ab = (size_t)((ID * IH * lds_pitch(IW) * 32 + 1023) & ~1023);
+    const int ID = (mb - 1) * p.sd + p.kd, IH = (FNN_TILE_H - 1) * p.sh + p.kh, IW = (FNN_TILE_W - 1) * p.sw + p.kw;
+    const size_t ab = (size_t)((ID * IH * (p.sw == 1 ? lds_pitch(IW) : IW) * 32 + 1023) & ~1023);
     return (wres ? 2 : 1) * ab + (size_t)nb * (wres ? p.chunks : 1) * p.ksteps * 1024 + 256 + (size_t)4 * nb * 16 * 2 * 8;
 }
 
-template <int NB, int MB, bool WRES, int KS, int CH = 0>
-static int launch_persist_ks(ConvParams p, int wgs_per_cu, hipStream_t st) {
+template <int NB, int MB, bool WRES, int KS, int CH = 0, int PF = 8>
+static int launch_persist_ks(ConvParams p, int wgs_per_cu, hipStream_t st, int gx_exact = 0) {
     p.tile_d = MB;
     p.tiles_d = (p.Do + MB - 1) / MB;
     p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
@@ -1040,13 +1040,13 @@ static int launch_persist_ks(ConvParams p, int wgs_per_cu, hipStream_t st) {
     const size_t lds = persist_lds_bytes(p, NB, MB, WRES);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)conv3d_persist_kernel<NB, MB, WRES, KS, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv3d_persist_kernel<NB, MB, WRES, KS, CH, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    int gx = 256 * wgs_per_cu;
+    int gx = gx_exact > 0 ? gx_exact : 256 * wgs_per_cu;
     if (gx > total) gx = total;
     dim3 grid(gx, (p.Cout / 16) / NB);
-    hipLaunchKernelGGL((conv3d_persist_kernel<NB, MB, WRES, KS, CH>), grid, dim3(256), lds, st, p, total);
+    hipLaunchKernelGGL((conv3d_persist_kernel<NB, MB, WRES, KS, CH, PF>), grid, dim3(256), lds, st, p, total);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -1180,6 +1180,20 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
         // strided convs: 2 x 8 x 8 output tile, up to 16 halo elements per thread, <= 2 cout blocks
         const int nbs = (p.Cout / 16) % 2 == 0 ? 2 : 1;
         const int ID = (2 - 1) * p.sd + p.kd, IH = (FNN_TILE_H - 1) * p.sh + p.kh, IW = (FNN_TILE_W - 1) * p.sw + p.kw;
+        {
+            // persistent form (tile ranges, cross-tile prefetch) when every workgroup gets a good number of tiles:
+            // with one tile per workgroup and a single 16-channel chunk nothing hides the halo round trip
+            static const bool no_sp = getenv("FNN_STRIDED_NO_PERSIST") != nullptr;            // A-B aid
+            const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;
+            const long long tiles = (long long)plan_n * ((p.Do + 1) / 2) * p.tiles_h * p.tiles_w;
+            const int groups = (p.Cout / 16) / nbs;
+            if (!no_sp && nbs == 2 && ID * IH * IW * 2 <= 12 * 256 && persist_lds_bytes(p, 2, 2, false) <= 80 * 1024 &&
+                tiles >= 8LL * (512 / groups) && 512 / groups >= 8) {
+                const int gx = 512 / groups;                       // 2 resident workgroups per CU over all cout groups
+                if (p.chunks == 1) return launch_persist_ks<2, 2, false, 0, 1, 12>(p, 2, st, gx);
+                // (two-chunk layers: the unrolled variant spills and measured slower than one tile per workgroup)
+            }
+        }
         if (ID * IH * IW * 2 <= 16 * 256 && ldsk_lds_bytes(p, nbs, 2) <= 80 * 1024) {
             if (ID * IH * IW * 2 <= 8 * 256) return nbs == 2 ? launch_ldsk<2, 2, 8>(p, st) : launch_ldsk<1, 2, 8>(p, st);
             return nbs == 2 ? launch_ldsk<2, 2, 16>(p, st) : launch_ldsk<1, 2, 16>(p, st);
