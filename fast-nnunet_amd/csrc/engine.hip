@@ -70,6 +70,15 @@ struct fnn_engine {
     f16 *act = nullptr;
     double *stats = nullptr;
     float *ss = nullptr;                    // [layer][max_batch][2][C]
+    // Two batches in flight (fnn_accumulate / predict): a second activation arena and two internal streams.  The
+    // network alternates between HBM-bound (thin full-resolution convs, seg head) and MFMA-bound kernels; with
+    // batch k+1's forward on the other stream they overlap.  The heads stay ordered (events), so the accumulation
+    // order - and with it every rounding - is the reference's.  288 GB of HBM make the second arena free.
+    static constexpr int MAXP = 4;
+    int n_pipe = 0;                         // arenas / streams allocated (0 until the first multi-batch run)
+    f16 *actp[MAXP] = {}; double *statsp[MAXP] = {}; float *ssp[MAXP] = {};      // [0] aliases act / stats / ss
+    hipStream_t pipe[MAXP] = {};
+    hipEvent_t ev_start = nullptr, ev_head[MAXP] = {}, ev_done[MAXP] = {};
     f16 *gauss = nullptr;
     f16 *ones = nullptr;                    // weight map of use_gaussian = 0 (the kernels load the map unconditionally)
     int *inf_flag = nullptr;
@@ -644,13 +653,50 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
             if (oo[d] < box.lo[d] || oo[d] + a.patch[d] > box.hi[d])
                 return fail(e, FNN_E_INVALID, "patch %lld lies outside the accumulator box", (long long)ids[i]);
     }
-    for (int64_t p0 = 0; p0 < np; p0 += B) {
+    // ---- two batches in flight (see fnn_engine::pipe)
+    static const bool no_pipe = getenv("FNN_NO_PIPELINE") != nullptr;                // A-B aid
+    const bool pipelined = !no_pipe && !tta && !e->profiling && np > B;
+    f16 *const act0 = e->act; double *const stats0 = e->stats; float *const ss0 = e->ss;
+    static const int want_pipes = getenv("FNN_PIPES") ? atoi(getenv("FNN_PIPES")) : 2;
+    const int NP = want_pipes < 2 ? 2 : (want_pipes > fnn_engine::MAXP ? fnn_engine::MAXP : want_pipes);
+    if (pipelined) {
+        if (e->n_pipe < NP) {
+            if (!e->ev_start) HIPCHK(e, hipEventCreateWithFlags(&e->ev_start, hipEventDisableTiming));
+            for (int k = e->n_pipe; k < NP; ++k) {
+                if (k > 0) {
+                    HIPCHK(e, hipMalloc((void **)&e->actp[k], e->act_halves * e->max_batch * sizeof(f16)));
+                    HIPCHK(e, hipMalloc((void **)&e->statsp[k], e->stats_doubles * e->max_batch * sizeof(double)));
+                    HIPCHK(e, hipMalloc((void **)&e->ssp[k], (e->ss_count * e->max_batch * 2 + 4) * sizeof(float)));
+                }
+                HIPCHK(e, hipStreamCreateWithFlags(&e->pipe[k], hipStreamNonBlocking));
+                HIPCHK(e, hipEventCreateWithFlags(&e->ev_head[k], hipEventDisableTiming));
+                HIPCHK(e, hipEventCreateWithFlags(&e->ev_done[k], hipEventDisableTiming));
+                e->n_pipe = k + 1;
+            }
+        }
+        e->actp[0] = act0; e->statsp[0] = stats0; e->ssp[0] = ss0;
+        HIPCHK(e, hipEventRecord(e->ev_start, st));
+        for (int k = 0; k < NP; ++k) HIPCHK(e, hipStreamWaitEvent(e->pipe[k], e->ev_start, 0));
+    }
+    struct Restore {                                      // whatever happens, the engine ends on its first arena
+        fnn_engine *e; f16 *a; double *s; float *ss;
+        ~Restore() { e->act = a; e->stats = s; e->ss = ss; }
+    } restore{e, act0, stats0, ss0};
+    hipStream_t user_st = st;
+    int64_t bi = 0;
+    for (int64_t p0 = 0; p0 < np; p0 += B, ++bi) {
         const int nb = (int)((np - p0 < B) ? np - p0 : B);
         const int *org = ids_origins_dev + p0 * 3;
+        const int k = (int)(bi % NP);
+        if (pipelined) {
+            st = e->pipe[k];
+            e->act = e->actp[k]; e->stats = e->statsp[k]; e->ss = e->ssp[k];
+        }
         for (size_t ci = 0; ci <= (tta ? combos.size() : 0); ++ci) {
             int flip[3] = {0, 0, 0};
             if (ci > 0) for (int ax : combos[ci - 1]) flip[ax] = 1;
             if (int rc = forward_batch(e, fold, vol_dev, 0, vdim, org, nb, flip, st)) return rc;
+            if (pipelined && bi > 0) HIPCHK(e, hipStreamWaitEvent(st, e->ev_head[(bi - 1) % NP], 0));   // heads in patch order
             for (int b = 0; b < nb; ++b) {
                 HeadParams h = make_head(e, fold, b);
                 const int *oo = &vp.origins[ids[p0 + b] * 3];
@@ -664,6 +710,7 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
                 Scope sc(e, st, FAM_HEAD, e->head_flops);
                 if (launch_head(h, st) != 0) return fail(e, FNN_E_HIP, "seg head launch failed");
             }
+            if (pipelined) HIPCHK(e, hipEventRecord(e->ev_head[k], st));
         }
         if (tta) {
             for (int b = 0; b < nb; ++b) {
@@ -680,6 +727,12 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
                 Scope sc(e, st, FAM_HEAD, 0);
                 if (launch_patch_acc(q, st) != 0) return fail(e, FNN_E_HIP, "patch accumulate launch failed");
             }
+        }
+    }
+    if (pipelined) {
+        for (int k = 0; k < NP; ++k) {
+            HIPCHK(e, hipEventRecord(e->ev_done[k], e->pipe[k]));
+            HIPCHK(e, hipStreamWaitEvent(user_st, e->ev_done[k], 0));
         }
     }
     return 0;
@@ -882,6 +935,13 @@ void fnn_destroy(fnn_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     for (auto &f : e->folds) { if (f.wpk) (void)hipFree(f.wpk); if (f.fparam) (void)hipFree(f.fparam); }
+    for (int k = 0; k < fnn_engine::MAXP; ++k) {
+        if (e->pipe[k]) (void)hipStreamDestroy(e->pipe[k]);
+        if (e->ev_head[k]) (void)hipEventDestroy(e->ev_head[k]);
+        if (e->ev_done[k]) (void)hipEventDestroy(e->ev_done[k]);
+        if (k > 0) { (void)hipFree(e->actp[k]); (void)hipFree(e->statsp[k]); (void)hipFree(e->ssp[k]); }
+    }
+    if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     void *ptrs[] = {e->ones, e->label_order, e->act, e->stats, e->ss, e->gauss, e->inf_flag, e->origins, e->acc, e->vol_tmp, e->vol_pad, e->out_tmp, e->patch_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ev : e->evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
