@@ -40,6 +40,10 @@ class NormDesc(C.Structure):
     _fields_ = [('scheme', C.c_int32), ('mean', C.c_float), ('std', C.c_float), ('lower', C.c_float), ('upper', C.c_float)]
 
 
+class ResampleDesc(C.Structure):
+    _fields_ = [('order', C.c_int32), ('separate_axis', C.c_int32), ('order_z', C.c_int32), ('dtype', C.c_int32)]
+
+
 class Opts(C.Structure):
     _fields_ = [('tile_step_size', C.c_float), ('use_gaussian', C.c_int32), ('n_mirror_axes', C.c_int32),
                 ('mirror_axes', C.c_int32 * 3), ('accum', C.c_int32), ('out_dtype', C.c_int32),
@@ -54,7 +58,7 @@ class Profile(C.Structure):
 
 EXPORTS = ['fnn_abi_version', 'fnn_last_error', 'fnn_create', 'fnn_destroy', 'fnn_weight_count', 'fnn_load_weights',
            'fnn_set_gaussian', 'fnn_predict_volume', 'fnn_predict_volume_ensemble', 'fnn_predict_labels',
-           'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_compute_steps', 'fnn_plan_volume',
+           'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_resample', 'fnn_compute_steps', 'fnn_plan_volume',
            'fnn_set_profiling', 'fnn_get_profile', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d']
 
 _lib = None
@@ -99,6 +103,7 @@ def load_library() -> C.CDLL:
     lib.fnn_nonzero_bbox.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64), vp]
     lib.fnn_preprocess.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64), C.POINTER(NormDesc), vp, vp]
     lib.fnn_revert_labels.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), vp, vp]
+    lib.fnn_resample.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(ResampleDesc), vp, vp]
     lib.fnn_compute_steps.argtypes = [i64, i64, C.c_double, C.POINTER(i64), i32]
     lib.fnn_plan_volume.argtypes = [C.POINTER(C.c_int32), C.POINTER(i64), C.c_double, C.POINTER(i64), C.POINTER(i64),
                                     C.POINTER(i64), C.POINTER(C.c_int32), i64]
@@ -182,6 +187,15 @@ def revert_labels(seg_ptr: int, uint16: bool, bbox, shape_before_cropping, trans
     check(lib.fnn_revert_labels(seg_ptr, FNN_LABEL_U16 if uint16 else FNN_LABEL_U8, flat,
                                 (C.c_int64 * 3)(*[int(i) for i in shape_before_cropping]),
                                 (C.c_int32 * 3)(*[int(i) for i in transpose_backward]), out_ptr, stream), lib)
+
+
+def resample(in_ptr: int, shape, new_shape, order: int, separate_axis, half: bool, out_ptr: int, stream: int = 0, order_z: int = 0):
+    """resample_data_or_seg(is_seg=False) of a [C, ...] tensor (fp32, or fp16 when `half`)."""
+    lib = load_library()
+    d = ResampleDesc(int(order), -1 if separate_axis is None else int(separate_axis), int(order_z),
+                     FNN_OUT_F16 if half else FNN_OUT_F32)
+    check(lib.fnn_resample(in_ptr, (C.c_int64 * 4)(*[int(i) for i in shape]), (C.c_int64 * 3)(*[int(i) for i in new_shape]),
+                           C.byref(d), out_ptr, stream), lib)
 
 
 def op_conv3d(x, w, bias, k, stride, gamma=None, beta=None, slope=1.0, x2=None, gamma2=None, beta2=None, slope2=1.0,

@@ -90,6 +90,25 @@ class ConfigurationManager:
     def use_mask_for_norm(self) -> List[bool]:
         return self.configuration['use_mask_for_norm']
 
+    # resampling (plans_handler.py:100-120 builds partials of default_resampling functions from these)
+    @property
+    def resampling_fn_data_name(self) -> str:
+        return self.configuration.get('resampling_fn_data', 'resample_data_or_seg_to_shape')
+
+    @property
+    def resampling_fn_data_kwargs(self) -> dict:
+        return self.configuration.get('resampling_fn_data_kwargs', {'is_seg': False, 'order': 3, 'order_z': 0,
+                                                                       'force_separate_z': None})
+
+    @property
+    def resampling_fn_probabilities_name(self) -> str:
+        return self.configuration.get('resampling_fn_probabilities', 'resample_data_or_seg_to_shape')
+
+    @property
+    def resampling_fn_probabilities_kwargs(self) -> dict:
+        return self.configuration.get('resampling_fn_probabilities_kwargs', {'is_seg': False, 'order': 1, 'order_z': 0,
+                                                                                'force_separate_z': None})
+
     @property
     def network_arch_class_name(self) -> str:
         return self.configuration['architecture']['network_class_name']

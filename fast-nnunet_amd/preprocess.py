@@ -4,14 +4,15 @@ Mirrors, with the reference's argument names and property keys,
 
 * ``DefaultPreprocessor.run_case_npy`` (preprocessing/preprocessors/default_preprocessor.py:45-118) up to - and
   excluding - the resampling call: float32 copy, ``transpose_forward``, ``crop_to_nonzero``, per-channel intensity
-  normalisation.  A case that needs resampling (``compute_new_shape`` != cropped shape) raises
-  ``NotImplementedError``: the reference resamples with skimage's order-3 ``resize``, which is neither installed here
-  nor restated (DESIGN.md 6);
-* the label half of ``convert_predicted_logits_to_segmentation_with_correct_shape``
-  (inference/export_prediction.py:43-53): dtype rule, revert cropping, ``transpose_backward``.
+  normalisation, then ``resample_data_or_seg_to_shape`` to the configuration's spacing
+  (preprocessing/resampling/default_resampling.py:88-196: per-channel order-3 ``resize``, or per-slice resize + an
+  order-0 pass along the anisotropic axis);
+* ``convert_predicted_logits_to_segmentation_with_correct_shape`` (inference/export_prediction.py:16-53): logits
+  resampled back to ``shape_after_cropping_and_before_resampling`` (order 1 by default), label rule, dtype rule,
+  revert cropping, ``transpose_backward``.
 
 Every numerical step is a HIP kernel behind ``include/fnn.h`` (``fnn_nonzero_bbox``, ``fnn_preprocess``,
-``fnn_revert_labels``); torch only owns the device buffers.  No CPU path.
+``fnn_resample``, ``fnn_argmax_labels``, ``fnn_revert_labels``); torch only owns the device buffers.  No CPU path.
 """
 from __future__ import annotations
 
@@ -25,6 +26,35 @@ from . import capi
 _SCHEMES = {'NoNormalization': capi.FNN_NORM_NONE, 'ZScoreNormalization': capi.FNN_NORM_ZSCORE,
             'CTNormalization': capi.FNN_NORM_CT, 'RescaleTo01Normalization': capi.FNN_NORM_RESCALE01,
             'RGBTo01Normalization': capi.FNN_NORM_RGB01}
+
+
+ANISO_THRESHOLD = 3           # nnunetv2/configuration.py
+
+
+def determine_do_sep_z_and_axis(force_separate_z, current_spacing, new_spacing,
+                                separate_z_anisotropy_threshold: float = ANISO_THRESHOLD):
+    """preprocessing/resampling/default_resampling.py:14-71."""
+    def aniso(sp):
+        return (np.max(sp) / np.min(sp)) > separate_z_anisotropy_threshold
+
+    def lowres_axis(sp):
+        return np.where(max(sp) / np.array(sp) == 1)[0]
+
+    if force_separate_z is not None:
+        do_separate_z = force_separate_z
+        axis = lowres_axis(current_spacing) if force_separate_z else None
+    elif aniso(current_spacing):
+        do_separate_z, axis = True, lowres_axis(current_spacing)
+    elif aniso(new_spacing):
+        do_separate_z, axis = True, lowres_axis(new_spacing)
+    else:
+        do_separate_z, axis = False, None
+    if axis is not None:
+        if len(axis) in (2, 3):
+            do_separate_z, axis = False, None
+        else:
+            axis = int(axis[0])
+    return do_separate_z, axis
 
 
 def compute_new_shape(old_shape: Sequence[int], old_spacing: Sequence[float], new_spacing: Sequence[float]):
@@ -64,9 +94,6 @@ class DevicePreprocessor:
             if len(target_spacing) < 3:                     # 2d configurations keep the slice spacing (:74-77)
                 target_spacing = [original_spacing[0]] + target_spacing
             new_shape = compute_new_shape(cropped, original_spacing, target_spacing)
-            if list(new_shape) != cropped:
-                raise NotImplementedError(f'this case needs resampling ({cropped} -> {new_shape}); resampling is not '
-                                          f'implemented on the device')
             schemes = configuration_manager.normalization_schemes
             masks = configuration_manager.use_mask_for_norm
             props = plans_manager.foreground_intensity_properties_per_channel
@@ -85,7 +112,46 @@ class DevicePreprocessor:
                     norms.append((_SCHEMES[schemes[c]], 0., 1., 0., 0.))
             out = torch.empty((raw.shape[0], *cropped), dtype=torch.float32, device=self.device)
             capi.preprocess(raw.data_ptr(), raw.shape, tf, bbox, norms, out.data_ptr(), self._stream())
+            # normalisation happens before resampling, like the reference (:83-91)
+            out = self.resample(out, new_shape, original_spacing, target_spacing,
+                                getattr(configuration_manager, 'resampling_fn_data_kwargs', None) or
+                                {'is_seg': False, 'order': 3, 'order_z': 0, 'force_separate_z': None})
         return out, None, properties
+
+    @torch.inference_mode()
+    def resample(self, data: torch.Tensor, new_shape, current_spacing, new_spacing, kwargs: dict) -> torch.Tensor:
+        """``resample_data_or_seg_to_shape(data, new_shape, current_spacing, new_spacing, **kwargs)`` for images /
+        logits (``is_seg`` False): fp32 or fp16 ``[C, x, y, z]`` on the device."""
+        if kwargs.get('is_seg', False):
+            raise NotImplementedError('segmentation resampling (resize_segmentation) is not implemented on the device')
+        do_sep, axis = determine_do_sep_z_and_axis(kwargs.get('force_separate_z', None), current_spacing, new_spacing,
+                                                   kwargs.get('separate_z_anisotropy_threshold', ANISO_THRESHOLD))
+        with torch.cuda.device(self.device):
+            x = data.to(self.device)
+            if x.dtype not in (torch.float32, torch.half):
+                x = x.float()
+            x = x.contiguous()
+            out = torch.empty((x.shape[0], *[int(i) for i in new_shape]), dtype=x.dtype, device=self.device)
+            capi.resample(x.data_ptr(), x.shape, new_shape, kwargs.get('order', 3), axis if do_sep else None,
+                          x.dtype == torch.half, out.data_ptr(), self._stream(), order_z=kwargs.get('order_z', 0))
+        return out
+
+    @torch.inference_mode()
+    def convert_predicted_logits_to_segmentation_with_correct_shape(self, predicted_logits: torch.Tensor, predictor,
+                                                                    plans_manager, configuration_manager,
+                                                                    properties_dict: dict) -> torch.Tensor:
+        """inference/export_prediction.py:16-53 on the device: logits ``[heads, x, y, z]`` of the network grid ->
+        label map on the original image grid.  ``predictor`` supplies the label rule (its ``label_manager``)."""
+        spacing_transposed = [properties_dict['spacing'][i] for i in plans_manager.transpose_forward]
+        target = list(configuration_manager.spacing)
+        current_spacing = target if len(target) == len(properties_dict['shape_after_cropping_and_before_resampling']) \
+            else [spacing_transposed[0], *target]
+        kw = getattr(configuration_manager, 'resampling_fn_probabilities_kwargs', None) or \
+            {'is_seg': False, 'order': 1, 'order_z': 0, 'force_separate_z': None}
+        logits = self.resample(predicted_logits, properties_dict['shape_after_cropping_and_before_resampling'],
+                               current_spacing, spacing_transposed, kw)
+        seg = predictor.convert_logits_to_segmentation(logits)
+        return self.revert_labels(seg, properties_dict, plans_manager, predictor.label_manager)
 
     @torch.inference_mode()
     def revert_labels(self, segmentation: torch.Tensor, properties: dict, plans_manager, label_manager) -> torch.Tensor:

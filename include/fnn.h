@@ -214,6 +214,23 @@ int fnn_revert_labels(const void *seg, int label_dtype, const int64_t bbox[6],
                       const int64_t shape_before_cropping[3], const int32_t transpose_backward[3],
                       void *out, void *stream);
 
+/* resample_data_or_seg(..., is_seg=False) of the reference
+ * (preprocessing/resampling/default_resampling.py:113-196): per channel
+ * skimage.transform.resize(order, mode='edge', anti_aliasing=False) - evaluated as
+ * scipy.ndimage.zoom(float64, out/in, order, mode='nearest', grid_mode=True) + clip
+ * to the input range - or, with separate_axis >= 0, that resize per 2-D slice and
+ * an order-0 pass along the axis (:147-188).  in / out: [C][...] of `dtype`
+ * (FNN_OUT_F32 for images, FNN_OUT_F16 for fp16 logits), device pointers.
+ * The caller decides separate_axis (determine_do_sep_z_and_axis, :34-71). */
+typedef struct fnn_resample_desc {
+    int32_t order;               /* 0, 1 or 3 (resampling_fn_*_kwargs['order'])               */
+    int32_t separate_axis;       /* -1, or the anisotropic axis                                */
+    int32_t order_z;             /* 0 (the only value the reference's plans use)               */
+    int32_t dtype;               /* FNN_OUT_F16 / FNN_OUT_F32                                  */
+} fnn_resample_desc;
+int fnn_resample(const void *in, const int64_t shape[4], const int64_t new_shape[3],
+                 const fnn_resample_desc *desc, void *out, void *stream);
+
 /* ---- host-side integer logic (no GPU needed) ------------------------------ */
 /* compute_steps_for_sliding_window (sliding_window_prediction.py:30-54) for one
  * axis; returns the number of steps written (<= cap) or a negative error. */

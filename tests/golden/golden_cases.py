@@ -261,3 +261,20 @@ def prep_label_input(case, cropped_shape, n_labels=7):
     import numpy as np
     rng = np.random.default_rng(5000 + case['seed'])
     return rng.integers(0, n_labels, cropped_shape).astype(np.uint8)
+
+
+# ---- resampling decisions (pure-numpy functions of preprocessing/resampling/default_resampling.py): resample_logic.json
+RESAMPLE_LOGIC_CASES = [
+    # (shape, current spacing, new spacing, force_separate_z)
+    ((30, 44, 36), (0.8, 3.0, 0.8), (1.0, 2.0, 1.0), None),
+    ((160, 96, 96), (2.0, 0.9765625, 0.9765625), (2.0, 0.9765625, 0.9765625), None),
+    ((55, 512, 512), (5.0, 0.7, 0.7), (2.5, 0.8, 0.8), None),
+    ((55, 512, 512), (1.0, 0.7, 0.7), (4.0, 0.8, 0.8), None),
+    ((100, 100, 100), (1.0, 1.0, 1.0), (1.5, 1.5, 1.5), None),
+    ((100, 100, 100), (0.24, 1.25, 1.25), (1.0, 1.0, 1.0), None),       # two low-res axes: no separate z
+    ((40, 41, 43), (3.0, 3.0, 3.0), (1.0, 1.0, 1.0), True),             # forced, but all axes equal
+    ((40, 41, 43), (4.0, 1.0, 1.1), (1.0, 1.0, 1.0), True),
+    ((40, 41, 43), (4.0, 1.0, 1.1), (1.0, 1.0, 1.0), False),
+    ((7, 9, 5), (1.0, 1.0, 2.5), (2.0, 1.0, 1.0), None),               # round-half-even in compute_new_shape
+    ((101, 51, 7), (1.0, 1.0, 2.5), (2.0, 1.0, 1.0), None),
+]

@@ -219,10 +219,23 @@ def gen_preprocess():
     print('preprocess', {k: v.shape for k, v in arrays.items() if k.endswith('__data')})
 
 
+def gen_resample_logic():
+    from golden_cases import RESAMPLE_LOGIC_CASES
+    from nnunetv2.preprocessing.resampling.default_resampling import compute_new_shape, determine_do_sep_z_and_axis
+    out = []
+    for shape, cur, new, force in RESAMPLE_LOGIC_CASES:
+        do_sep, axis = determine_do_sep_z_and_axis(force, cur, new)
+        out.append({'shape': list(shape), 'current': list(cur), 'new': list(new), 'force': force,
+                    'new_shape': [int(i) for i in compute_new_shape(shape, cur, new)],
+                    'do_separate_z': bool(do_sep), 'axis': None if axis is None else int(axis)})
+    json.dump(out, open(os.path.join(HERE, 'resample_logic.json'), 'w'), indent=1)
+    print('resample logic', [(o['do_separate_z'], o['axis'], o['new_shape']) for o in out])
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:                                   # regenerate single fixtures: labels, plans
         for what in sys.argv[1:]:
-            {'labels': gen_label_rules, 'plans': gen_plans, 'sw2d': gen_sliding_window_2d, 'prep': gen_preprocess}[what]()
+            {'labels': gen_label_rules, 'plans': gen_plans, 'sw2d': gen_sliding_window_2d, 'prep': gen_preprocess, 'resample': gen_resample_logic}[what]()
         sys.exit(0)
     gen_label_rules()
     gen_steps()
@@ -232,4 +245,5 @@ if __name__ == '__main__':
     gen_sliding_window()
     gen_sliding_window_2d()
     gen_preprocess()
+    gen_resample_logic()
     print('golden vectors written to', HERE)

@@ -88,8 +88,6 @@ def test_preprocess_refuses_what_it_does_not_implement():
     from fast_nnunet_amd.preprocess import DevicePreprocessor
     pp = DevicePreprocessor(torch.device('cuda', 0))
     raw = torch.ones(1, 8, 8, 8)
-    with pytest.raises(NotImplementedError, match='resampling'):
-        pp.run_case_npy(raw, None, {'spacing': [2.0, 1.0, 1.0]}, _PM((0, 1, 2), {'0': {}}), _CM(['NoNormalization']))
     cm = _CM(['ZScoreNormalization'])
     cm.use_mask_for_norm = [True]
     with pytest.raises(NotImplementedError, match='use_mask_for_norm'):
@@ -98,3 +96,82 @@ def test_preprocess_refuses_what_it_does_not_implement():
         pp.run_case_npy(raw, None, {'spacing': [1.0, 1.0, 1.0]}, _PM((0, 1, 2), {'0': {}}), _CM(['FancyNorm']))
     with pytest.raises(RuntimeError, match='no CPU path'):
         DevicePreprocessor(torch.device('cpu'))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# resampling (f-2 / f-3): device kernels vs the scipy-based restatement of skimage.transform.resize (oracle/resample.py;
+# parity unpinned against skimage itself, which is not installed).  Both sides compute in fp64, so the results are the
+# same fp32 / fp16 numbers except on rounding boundaries: tolerance 4 fp32 ulps of the data range / 1 fp16 ulp.
+# ---------------------------------------------------------------------------------------------------------------
+RESAMPLE_CASES = [
+    # shape (C, ...), new_shape, order, separate axis
+    ((2, 19, 23, 17), (25, 20, 30), 3, None),
+    ((1, 40, 12, 33), (18, 12, 50), 3, None),            # one axis unchanged
+    ((1, 7, 20, 22), (12, 31, 17), 3, 0),                # anisotropic: per-slice resize + order-0 along axis 0
+    ((2, 16, 18, 6), (24, 11, 9), 3, 2),
+    ((1, 9, 14, 11), (9, 21, 16), 3, 0),                 # separate axis keeps its length
+    ((3, 13, 10, 12), (20, 15, 9), 1, None),
+    ((1, 11, 11, 11), (7, 16, 5), 0, None),
+]
+
+
+@pytest.mark.parametrize('shape,new_shape,order,axis', RESAMPLE_CASES)
+def test_resample_matches_scipy_restatement(shape, new_shape, order, axis):
+    from fast_nnunet_amd import capi
+    from oracle import resample as ores
+    rng = np.random.default_rng(hash((shape, new_shape, order)) % 2 ** 31)
+    x = (rng.standard_normal(shape) * 50 + 10).astype(np.float32)
+    want = ores.resample_data(x, new_shape, axis=axis, order=order, do_separate_z=axis is not None)
+    xd = torch.from_numpy(x).cuda()
+    out = torch.empty((shape[0], *new_shape), dtype=torch.float32, device='cuda')
+    capi.resample(xd.data_ptr(), shape, new_shape, order, axis, False, out.data_ptr())
+    got = out.cpu().numpy()
+    assert np.abs(got - want).max() <= 4 * 6e-8 * np.abs(want).max(), np.abs(got - want).max()
+    # fp16 logits (the probabilities path): output rounded to fp16 like reshaped_final.dtype = data.dtype
+    xh = x.astype(np.float16)
+    wanth = ores.resample_data(xh, new_shape, axis=axis, order=order, do_separate_z=axis is not None)
+    assert wanth.dtype == np.float16
+    outh = torch.empty((shape[0], *new_shape), dtype=torch.half, device='cuda')
+    capi.resample(torch.from_numpy(xh).cuda().data_ptr(), shape, new_shape, order, axis, True, outh.data_ptr())
+    goth = outh.cpu().numpy()
+    ulp = np.spacing(np.abs(wanth).astype(np.float16)).astype(np.float32)
+    assert (np.abs(goth.astype(np.float32) - wanth.astype(np.float32)) <= ulp).all()
+    assert (goth != wanth).mean() < 5e-3            # exact half-ulp ties of the fp16 inputs' linear blends
+
+
+def test_run_case_npy_with_resampling_and_export_round_trip():
+    """The whole f-2 -> hot path stand-in -> f-3 chain against the oracle: transpose, crop, CT normalisation,
+    order-3 resampling to the target spacing; then logits -> order-1 resampling back -> argmax -> un-crop -> transpose."""
+    from fast_nnunet_amd.preprocess import DevicePreprocessor
+    from oracle import resample as ores
+    rng = np.random.default_rng(3)
+    raw = (rng.standard_normal((1, 30, 44, 36)) * 300 + 200).astype(np.float32)
+    raw[:, :4] = 0; raw[:, :, -6:] = 0
+    tf = (1, 0, 2)
+    ip = {'0': {'mean': 150.0, 'std': 280.0, 'percentile_00_5': -500.0, 'percentile_99_5': 900.0}}
+    spacing = [3.0, 0.8, 0.8]                                  # of the raw axes; transposed: [0.8, 3.0, 0.8]
+    pm, cm = _PM(tf, ip), _CM(['CTNormalization'], spacing=(1.0, 2.0, 1.0))
+    props = {'spacing': spacing}
+    pp = DevicePreprocessor(torch.device('cuda', 0))
+    data, _, props = pp.run_case_npy(raw, None, props, pm, cm)
+    ref, bbox, before = opre.preprocess_case(raw, tf, ['CTNormalization'], ip)
+    sp_t = [spacing[i] for i in tf]
+    new_shape = ores.compute_new_shape(ref.shape[1:], sp_t, cm.spacing)
+    do_sep, axis = ores.determine_do_sep_z_and_axis(None, sp_t, cm.spacing)
+    assert do_sep and axis == 1                                  # 3.0 / 0.8 > 3
+    want = ores.resample_data(ref, new_shape, axis=axis, order=3, do_separate_z=do_sep)
+    assert tuple(data.shape[1:]) == tuple(new_shape)
+    assert np.abs(data.cpu().numpy() - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+
+    # f-3: fake logits on the network grid -> label map on the raw grid
+    class _P:
+        label_manager = _LM(3)
+
+        def convert_logits_to_segmentation(self, lg):
+            return lg.float().argmax(0).to(torch.uint8)
+    logits = torch.randn(4, *new_shape, generator=torch.Generator().manual_seed(1)).half()
+    seg = pp.convert_predicted_logits_to_segmentation_with_correct_shape(logits.cuda(), _P(), pm, cm, props).cpu().numpy()
+    back = ores.resample_data(logits.numpy(), ref.shape[1:], axis=axis, order=1, do_separate_z=do_sep)
+    lab = back.astype(np.float32).argmax(0).astype(np.uint8)
+    full = opre.revert_labels(lab, bbox, before, [int(i) for i in np.argsort(tf)], 3)
+    assert seg.shape == raw.shape[1:] and (seg != full).mean() < 2e-3       # ties flip on fp16 rounding boundaries only

@@ -181,3 +181,50 @@ def test_preprocess_and_label_revert_match_reference_golden(golden_dir):
             full = opre.revert_labels(lab, bbox, before, tb, n_fg)
             want = z[case['name'] + '__labels_' + tag]
             assert full.dtype == want.dtype and np.array_equal(full, want)
+
+
+def test_resampling_decisions_match_reference_golden(golden_dir):
+    """compute_new_shape / determine_do_sep_z_and_axis of the oracle AND of the product's host mirror against the
+    reference's own functions (default_resampling.py:14-71)."""
+    from oracle import resample as ores
+    from fast_nnunet_amd import preprocess as ppre
+    for c in json.load(open(os.path.join(golden_dir, 'resample_logic.json'))):
+        for mod in (ores, ppre):
+            assert list(mod.compute_new_shape(c['shape'], c['current'], c['new'])) == c['new_shape'], c
+            do_sep, axis = mod.determine_do_sep_z_and_axis(c['force'], c['current'], c['new'])
+            assert bool(do_sep) == c['do_separate_z'] and (None if axis is None else int(axis)) == c['axis'], c
+
+
+def test_resize_restatement_is_the_cubic_spline_it_claims():
+    """The order-3 path of oracle/resample.py (scipy zoom, grid_mode) against an independent evaluation of the same
+    definition: 12 edge-padded samples, B-spline coefficients by the truncated impulse response of the recursive
+    filter (what the HIP kernel does), 4 taps per axis at x = (o + 0.5) in/out - 0.5."""
+    from oracle import resample as ores
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((9, 12, 7)) * 10
+    out_shape = (13, 8, 11)
+    z = np.sqrt(3.0) - 2.0
+    K = 30
+    h = np.array([(-6 * z / (1 - z * z)) * z ** abs(k) for k in range(-K, K + 1)])
+    p = np.pad(x, 12, mode='edge')
+    for ax in range(3):
+        n = p.shape[ax]
+        idx = np.mod(np.arange(n)[:, None] + np.arange(-K, K + 1)[None, :], 2 * n - 2)
+        idx = np.where(idx >= n, 2 * n - 2 - idx, idx)
+        p = np.moveaxis((np.moveaxis(p, ax, -1)[..., idx] * h).sum(-1), -1, ax)
+    res = np.zeros(out_shape)
+    tabs = []
+    for d in range(3):
+        zoom = x.shape[d] / out_shape[d]
+        c = np.arange(out_shape[d]) * zoom + 0.5 * zoom - 0.5 + 12
+        f = np.floor(c)
+        t = c - f
+        tabs.append((f.astype(int) - 1, np.stack([(1 - t) ** 3 / 6, (3 * t ** 3 - 6 * t ** 2 + 4) / 6,
+                                                  (-3 * t ** 3 + 3 * t ** 2 + 3 * t + 1) / 6, t ** 3 / 6], -1)))
+    for a in range(4):
+        for b in range(4):
+            for c in range(4):
+                res += (tabs[0][1][:, a][:, None, None] * tabs[1][1][:, b][None, :, None] * tabs[2][1][:, c][None, None, :]) * \
+                    p[np.ix_(tabs[0][0] + a, tabs[1][0] + b, tabs[2][0] + c)]
+    res = np.clip(res, x.min(), x.max())
+    assert np.abs(res - ores.skimage_resize(x, out_shape, 3)).max() < 1e-10
