@@ -237,6 +237,46 @@ class nnUNetPredictor(object):
         return out.to('cpu')
 
     @torch.inference_mode()
+    @torch.inference_mode()
+    def predict_single_npy_array(self, input_image: np.ndarray, image_properties: dict,
+                                 segmentation_previous_stage: np.ndarray = None,
+                                 output_file_truncated: str = None,
+                                 save_or_return_probabilities: bool = False):
+        """Raw image ``[C, s0, s1, s2]`` + ``{'spacing': ...}`` -> label map on the raw grid (numpy, uint8 / uint16) -
+        predict_from_raw_data.py:423-468 with every step on the device: ``DevicePreprocessor.run_case_npy``
+        (transpose, crop, normalise, resample), the sliding window, then
+        ``convert_predicted_logits_to_segmentation_with_correct_shape`` (export_prediction.py:16-53).  When the case
+        needs no resampling the labels are taken straight from the accumulators (no logits are materialised)."""
+        from .preprocess import DevicePreprocessor
+        if segmentation_previous_stage is not None:
+            raise NotImplementedError('cascade input (one-hot previous-stage segmentation) is not implemented on the device')
+        if output_file_truncated is not None:
+            raise NotImplementedError('image file export is the caller\'s side (SURVEY.md 8: image I/O out of scope)')
+        if save_or_return_probabilities:
+            raise NotImplementedError('returning probabilities is not implemented: label maps only')
+        pp = DevicePreprocessor(self.device, verbose=self.verbose)
+        props = dict(image_properties)
+        if self.verbose:
+            print('preprocessing')
+        data, _, props = pp.run_case_npy(input_image, None, props, self.plans_manager, self.configuration_manager,
+                                         self.dataset_json)
+        if self.verbose:
+            print('predicting')
+        if tuple(data.shape[1:]) == tuple(props['shape_after_cropping_and_before_resampling']):
+            seg = self.predict_segmentation_from_preprocessed_data(data)
+            out = pp.revert_labels(seg, props, self.plans_manager, self.label_manager)
+        else:
+            self._check_input(data)
+            with torch.cuda.device(self.device):
+                logits = torch.empty((self._spec.num_heads, *data.shape[1:]), dtype=torch.half, device=self.device)
+                self._engine.predict_volume(data.data_ptr(), data.shape, self._opts(), logits.data_ptr(), n_folds=self._n_folds)
+            if self.verbose:
+                print('resampling to original shape')
+            out = pp.convert_predicted_logits_to_segmentation_with_correct_shape(logits, self, self.plans_manager,
+                                                                                 self.configuration_manager, props)
+        u16 = len(self.label_manager.foreground_labels) >= 255
+        return out.cpu().numpy().astype(np.uint16 if u16 else np.uint8)
+
     def _label_rule(self):
         """(regions_class_order or None, uint16?) - LabelManager.convert_logits_to_segmentation
         (label_handling.py:163-181) and the dtype rule of export_prediction.py:45-46."""
