@@ -237,296 +237,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
     FNN_STAMP_FLUSH(p.dbg);
 }
 
-// ----------------------------------------------------------------------------
-// warp-specialised variant: 4 MFMA waves + 4 staging waves per workgroup
-// ----------------------------------------------------------------------------
-// conv3d_zr_kernel's k-loops run at the matrix-core rate but are ~40 % of a workgroup's life: the same four
-// waves also wait for the halo, normalise it, write LDS and run the epilogue, and with two workgroups per CU the
-// phases overlap only by chance.  Here a 512-thread workgroup owns a CU: waves 0-3 ("consumers") do nothing but
-// ds_read + MFMA + the tile epilogue, waves 4-7 ("producers") prefetch, normalise and stage the NEXT work item
-// (tile, 16-channel chunk) into the other half of a double-buffered LDS image (2 x (halo + weights) = 136 KB of the
-// 160 KB).  One s_barrier per item hands a buffer over.  The workgroup walks a contiguous tile range, so the
-// pipeline never drains between tiles.  Statistics: per consumer wave, fp32 within a tile, double across tiles
-// (wave-private LDS slots), atomics per (wave, batch item).
-template <int NB>
-__global__ __launch_bounds__(512, 1) void conv3d_zrs_kernel(const ConvParams p, const int total_tiles) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TD = 8;
-    constexpr int IH = 10, IW = 10, PW = 12, ID = TD + 2;
-    constexpr int PS = IH * PW * 32;
-    constexpr int ABYTES = (ID * PS + 1023) & ~1023;
-    constexpr int KS = 15;
-    constexpr int WBYTES = NB * KS * 1024;
-    constexpr int IELEM = ID * IH * IW * 2;
-    constexpr int PF = (IELEM + 255) / 256;
-    constexpr int WTOT = NB * KS * 64;
-    constexpr int WPF = (WTOT + 255) / 256;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    auto bufp = [&](int b) -> char * { return smem + (b & 1) * (ABYTES + WBYTES); };   // buffer b: [halo image][weights]
-    float *sBias = (float *)(smem + 2 * (ABYTES + WBYTES));
-    double *sRed = (double *)(sBias + NB * 16);               // [4 consumer waves][NB * 16][2]
-    const int cb0 = blockIdx.y * NB;
-
-    int t_begin, t_end;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        const int g = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
-        t_begin = (int)((long long)total_tiles * g / nwg);
-        t_end = (int)((long long)total_tiles * (g + 1) / nwg);
-    }
-    if (t_begin >= t_end) return;
-    const int n_items = (t_end - t_begin) * p.chunks;
-
-    auto tile_coords = [&](int t, int &n, int &od0, int &oh0, int &ow0) {
-        const int tw = t % p.tiles_w; t /= p.tiles_w;
-        const int th = t % p.tiles_h; t /= p.tiles_h;
-        const int td = t % p.tiles_d;
-        n = t / p.tiles_d;
-        od0 = td * TD; oh0 = th * 8; ow0 = tw * 8;
-    };
-    auto next_tile = [&](int &n, int &od0, int &oh0, int &ow0) {
-        ow0 += 8;
-        if (ow0 >= p.tiles_w * 8) {
-            ow0 = 0; oh0 += 8;
-            if (oh0 >= p.tiles_h * 8) {
-                oh0 = 0; od0 += TD;
-                if (od0 >= p.tiles_d * TD) { od0 = 0; ++n; }
-            }
-        }
-    };
-
-    if (tid < NB * 16) sBias[tid] = p.bias[cb0 * 16 + tid];
-    for (int i = tid; i < 4 * NB * 16 * 2; i += 512) sRed[i] = 0.0;
-    __syncthreads();
-
-    if (wave >= 4) {
-        // =============================== producers ===============================
-        const int ptid = tid - 256;
-        const int cg = ptid & 1;
-        const unsigned cg_b = (unsigned)cg * 16u;
-        int rel[PF];                                          // LDS byte offset | zw << 16 | zh << 20 | zd << 24, -1 = none
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int idx = ptid + u * 256;
-            const int v = idx >> 1;
-            const int zd = v / (IH * IW), rem = v - zd * (IH * IW), zh = rem / IW, zw = rem - zh * IW;
-            const int lo = zd * PS + (zh * PW + zw) * 32 + ((cg ^ (zh & 1)) * 16);
-            rel[u] = idx < IELEM ? lo | (zw << 16) | (zh << 20) | (zd << 24) : -1;
-        }
-        const int wbase0 = cb0 * p.chunks * (KS * 64), wbase1 = (cb0 + 1) * p.chunks * (KS * 64) - KS * 64;
-        // Two items in flight per producer thread: an item period (~4 k cycles of MFMAs) is shorter than a loaded-HBM
-        // round trip, so the data of item i + 1 AND i + 2 is requested while item i multiplies.
-        struct Set {
-            int offv[PF];
-            f16x8 xr[PF], wr[WPF];
-            float4 scr[2], shr[2];
-            float slope;
-        } X0, X1;
-        auto request = [&](Set &S, int n, int ch, int od0, int oh0, int ow0) {
-            const int id0 = od0 - 1, ih0 = oh0 - 1, iw0 = ow0 - 1;
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int gd = id0 + (rel[u] >> 24), gh = ih0 + ((rel[u] >> 20) & 15), gw = iw0 + ((rel[u] >> 16) & 15);
-                const bool ok = rel[u] >= 0 && (unsigned)gd < (unsigned)p.Di && (unsigned)gh < (unsigned)p.Hi &&
-                                (unsigned)gw < (unsigned)p.Wi;
-                S.offv[u] = ok ? (gd * p.Hi + gh) * p.Wi + gw : -1;
-            }
-            const int c_glob = ch * 16;
-            const int s = (c_glob < p.src[0].C) ? 0 : 1;
-            const int c_uni = c_glob - (s ? p.src[0].C : 0);
-            const int sC = p.src[s].C;
-            const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + c_uni);
-#pragma unroll
-            for (int u = 0; u < PF; ++u)
-                S.xr[u] = *(const f16x8 *)(sp + ((unsigned)((S.offv[u] >= 0 ? S.offv[u] : 0) * sC * 2) + cg_b));
-#pragma unroll
-            for (int u = 0; u < WPF; ++u) {
-                const int idx = ptid + u * 256;
-                const int idc = idx < WTOT ? idx : WTOT - 1;
-                const int wo = (idc >= KS * 64 ? wbase1 : wbase0) + idc + ch * (KS * 64);
-                S.wr[u] = *(const f16x8 *)((const char *)p.wpk + (unsigned)(wo * 16));
-            }
-            S.slope = p.src[s].slope;
-            const float *qs = p.src[s].ss ? p.src[s].ss + (size_t)(2 * n) * sC + c_uni + cg * 8 : p.ident_ss + c_uni + cg * 8;
-            const float *qh = p.src[s].ss ? qs + sC : p.ident_ss + 512 + c_uni + cg * 8;
-            S.scr[0] = *(const float4 *)qs; S.scr[1] = *(const float4 *)(qs + 4);
-            S.shr[0] = *(const float4 *)qh; S.shr[1] = *(const float4 *)(qh + 4);
-        };
-        auto commit = [&](Set &S, char *buf) {
-            const f16 slope_h = (f16)S.slope;
-            const float sc[8] = {S.scr[0].x, S.scr[0].y, S.scr[0].z, S.scr[0].w, S.scr[1].x, S.scr[1].y, S.scr[1].z, S.scr[1].w};
-            const float sh[8] = {S.shr[0].x, S.shr[0].y, S.shr[0].z, S.shr[0].w, S.shr[1].x, S.shr[1].y, S.shr[1].z, S.shr[1].w};
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                f16x8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)S.xr[u][j], sc[j], sh[j]);
-                o = __builtin_elementwise_max(o, o * slope_h);
-                if (S.offv[u] < 0) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                if ((u + 1) * 256 <= IELEM || rel[u] >= 0) *(f16x8 *)(buf + (rel[u] & 0xffff)) = o;
-            }
-#pragma unroll
-            for (int u = 0; u < WPF; ++u) {
-                const int idx = ptid + u * 256;
-                if ((u + 1) * 256 <= WTOT || idx < WTOT) ((f16x8 *)(buf + ABYTES))[idx] = S.wr[u];
-            }
-        };
-        int n, od0, oh0, ow0, ch = 0;
-        tile_coords(t_begin, n, od0, oh0, ow0);
-        auto advance = [&]() {                                // the next item in (tile, chunk) order
-            if (++ch == p.chunks) { ch = 0; next_tile(n, od0, oh0, ow0); }
-        };
-        request(X0, n, ch, od0, oh0, ow0);                    // item 0
-        commit(X0, bufp(0));
-        if (n_items > 1) { advance(); request(X1, n, ch, od0, oh0, ow0); }      // item 1
-        if (n_items > 2) { advance(); request(X0, n, ch, od0, oh0, ow0); }      // item 2
-#pragma unroll 1
-        for (int it = 0; it < n_items; it += 2) {
-            __syncthreads();                                  // item `it` is visible; buffer (it + 1) & 1 is free
-            if (it + 1 < n_items) {
-                commit(X1, bufp(1));                          // item it + 1
-                if (it + 3 < n_items) { advance(); request(X1, n, ch, od0, oh0, ow0); }
-            } else break;
-            __syncthreads();                                  // item it + 1 visible; buffer 0 free
-            if (it + 2 < n_items) {
-                commit(X0, bufp(0));                          // item it + 2
-                if (it + 4 < n_items) { advance(); request(X0, n, ch, od0, oh0, ow0); }
-            }
-        }
-        return;
-    }
-
-    // ================================= consumers =================================
-    FNN_STAMP_DECL
-    int toff[5];
-    {
-        const int r = lane & 15, hl = lane >> 5, kh = (lane >> 4) & 1;
-#pragma unroll
-        for (int pr = 0; pr < 5; ++pr) {
-            const int tp = 2 * pr + hl < 9 ? 2 * pr + hl : 8;
-            const int row = 2 * wave + (r >> 3) + tp / 3, col = (r & 7) + tp % 3;
-            toff[pr] = (row * PW + col) * 32 + ((kh ^ (row & 1)) * 16);
-        }
-    }
-    f32x4 acc[TD][NB];
-#pragma unroll
-    for (int j = 0; j < TD; ++j)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[j][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 bv[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const float4 *)(sBias + nb * 16 + (lane >> 4) * 4);
-    double *myRed = sRed + wave * NB * 16 * 2;
-    auto flush_stats = [&](int n) {                           // wave-private slots: no workgroup barrier needed
-        if (!p.stats_out) return;
-        if (lane < NB * 16 * 2) {
-            const int c = lane >> 1, which = lane & 1;
-            const double v = myRed[c * 2 + which];
-            myRed[c * 2 + which] = 0.0;
-            unsafeAtomicAdd(p.stats_out + (((size_t)n * FNN_STAT_REPL + ((blockIdx.x + wave) & (FNN_STAT_REPL - 1))) * p.Cout
-                                           + cb0 * 16 + c) * 2 + which, v);
-        }
-    };
-    int n_cur, od0, oh0, ow0;
-    tile_coords(t_begin, n_cur, od0, oh0, ow0);
-    int ch = 0;
-#pragma unroll 1
-    for (int it = 0; it < n_items; ++it) {
-#ifdef FNN_STAMPS
-        const bool stamp_it = it >= 4 && it < 8;
-        if (stamp_it) FNN_STAMP();                            // before the barrier
-#endif
-        __syncthreads();
-#ifdef FNN_STAMPS
-        if (stamp_it) FNN_STAMP();                            // item visible
-#endif
-        const char *sA = bufp(it);
-        const char *sW = sA + ABYTES;
-        // software pipeline over the 5 in-plane tap pairs: the fragments of pair p + 1 are read while pair p multiplies
-        f16x8 xf[2][ID];
-#pragma unroll
-        for (int pl = 0; pl < ID; ++pl) xf[0][pl] = *(const f16x8 *)(sA + toff[0] + pl * PS);
-#pragma unroll
-        for (int pr = 0; pr < 5; ++pr) {
-            if (pr + 1 < 5) {
-#pragma unroll
-                for (int pl = 0; pl < ID; ++pl) xf[(pr + 1) & 1][pl] = *(const f16x8 *)(sA + toff[pr + 1] + pl * PS);
-            }
-#pragma unroll
-            for (int dz = 0; dz < 3; ++dz) {
-                f16x8 wf[NB];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) wf[nb] = *(const f16x8 *)(sW + ((nb * KS + pr * 3 + dz) * 64 + lane) * 16);
-#pragma unroll
-                for (int j = 0; j < TD; ++j)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nb], xf[pr & 1][j + dz], acc[j][nb], 0, 0, 0);
-            }
-        }
-#ifdef FNN_STAMPS
-        if (stamp_it) FNN_STAMP();                            // k-loop done
-#endif
-        if (++ch == p.chunks) {
-            ch = 0;
-            float t1[NB][4], t2[NB][4];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
-            tile_epilogue<NB, TD, true>(p, acc, bv, n_cur, od0, oh0, ow0, cb0, wave, lane, t1, t2);
-            if (p.stats_out) {
-                const int q = lane >> 4;
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float sa = row16_sum(t1[nb][j]), sb = row16_sum(t2[nb][j]);
-                        if ((lane & 15) == 0) {
-                            double *slot = myRed + (nb * 16 + q * 4 + j) * 2;
-                            slot[0] += (double)sa;
-                            slot[1] += (double)sb;
-                        }
-                    }
-            }
-#pragma unroll
-            for (int j = 0; j < TD; ++j)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[j][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int n_prev = n_cur;
-            next_tile(n_cur, od0, oh0, ow0);
-            if (n_cur != n_prev || it + 1 == n_items) flush_stats(n_prev);
-        }
-    }
-    FNN_STAMP_FLUSH(p.dbg);
-}
-
-template <int NB>
-static int launch_zrs(ConvParams p, hipStream_t st) {
-    p.tile_d = 8;
-    p.tiles_d = (p.Do + 7) / 8;
-    p.tiles_h = (p.Ho + 7) / 8;
-    p.tiles_w = (p.Wo + 7) / 8;
-    p.ident_ss = conv3d_identity_ss();
-    if (!p.ident_ss) return -2;
-    const int total = p.N * p.tiles_d * p.tiles_h * p.tiles_w;
-    const int groups = (p.Cout / 16) / NB;
-    const size_t lds = 2 * ((size_t)((10 * 10 * 12 * 32 + 1023) & ~1023) + (size_t)NB * 15 * 1024) + (size_t)NB * 64 +
-                       (size_t)4 * NB * 16 * 2 * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)conv3d_zrs_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    int gx = 256 / groups;                                    // one workgroup per CU over all cout groups
-    if (gx < 1) gx = 1;
-    if (gx > total) gx = total;
-    dim3 grid(gx, groups);
-    hipLaunchKernelGGL((conv3d_zrs_kernel<NB>), grid, dim3(512), lds, st, p, total);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
-}
-
 template <int NB, int TD>
 static int launch_zr(ConvParams p, hipStream_t st) {
     p.tile_d = TD;
@@ -551,16 +261,6 @@ static int launch_zr(ConvParams p, hipStream_t st) {
 int launch_conv3d_zr(const ConvParams &p, hipStream_t st) {
     int nb, td;
     if (p.packing != FNN_PACK_ZR || p.ksteps != 15 || !zr_pick(p, nb, td)) return -1;
-    {
-        // warp-specialised persistent variant when every CU gets a few tiles per cout group
-        static const bool no_zrs = getenv("FNN_NO_ZRS") != nullptr;                 // A-B aids
-        static const int zrs_min = getenv("FNN_ZRS_MIN_TILES") ? atoi(getenv("FNN_ZRS_MIN_TILES")) : 4;
-        const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;
-        const int groups = (p.Cout / 16) / nb;
-        const long long tiles = (long long)plan_n * ((p.Do + 7) / 8) * ((p.Ho + 7) / 8) * ((p.Wo + 7) / 8);
-        if (!no_zrs && td == 8 && groups <= 256 && tiles * groups >= (long long)zrs_min * 256)
-            return nb == 2 ? launch_zrs<2>(p, st) : launch_zrs<1>(p, st);
-    }
     if (nb == 2) return td == 8 ? launch_zr<2, 8>(p, st) : launch_zr<2, 4>(p, st);
     return td == 8 ? launch_zr<1, 8>(p, st) : launch_zr<1, 4>(p, st);
 }
