@@ -7,6 +7,9 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/cap_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+# per-kernel durations and counters are taken with the two-batch pipelining off: kernels of the two internal streams
+# otherwise overlap and the trace reports their stretched durations.  The headline bench line below has it on.
+export FNN_NO_PIPELINE=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $out/trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $out/pmc_$c.log 2>&1
@@ -20,6 +23,7 @@ f=$(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 w=$(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python tools_traffic.py $f $w $out/traffic.json > $out/traffic.txt 2>&1
 cp $out/traffic.json profiles/r01_traffic.json            # bench.py reads the traffic figure from here
+unset FNN_NO_PIPELINE
 python bench.py > $out/bench.json 2> $out/bench.err
 rm -rf $out/trace $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
 tail -1 $out/bench.json | cut -c1-1500
