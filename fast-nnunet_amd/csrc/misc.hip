@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void seg_head_acc_kernel(const HeadParams p) {
 // acknowledged: with the loads of round 1 behind the stores of round 0 (the loop above), every wave waited for a
 // full write round trip in the middle of its life.  Here the only waits are for loads that were issued before any
 // store; the stores of both rounds drain while the wave finishes.
-template <bool ACC32>
+template <bool ACC32, int RD>
 __global__ __launch_bounds__(256) void seg_head_acc1_kernel(const HeadParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void seg_head_acc1_kernel(const HeadParams p) 
     load_scale_shift(p.src, p.b, sSS, tid, 256);
     __syncthreads();
 
-    const int v0 = (blockIdx.x * 4 + wave) * 64;
+    const int v0 = (blockIdx.x * 4 + wave) * (32 * RD);
     if (v0 >= P) return;
     const int r = lane & 15, q = lane >> 4;
     const int grp = lane & 7, vsub = lane >> 3;
@@ -518,14 +518,14 @@ __global__ __launch_bounds__(256) void seg_head_acc1_kernel(const HeadParams p) 
         const int grp_c = cb0 + grp * 8 < p.HP ? grp : 0;
         const bool grp_ok = cb0 + grp * 8 < p.HP;
         // ---- phase A: every address, then every load (accumulator lines, Gaussian weights, activation fragments)
-        size_t aelem[2][4];
-        bool ok[2][4];
-        f16 graw[2][4];
-        f16x8 a16[2][4];
-        f32x4 a32[ACC32 ? 2 : 1][4][2];
-        f16x8 xraw[2][2];
+        size_t aelem[RD][4];
+        bool ok[RD][4];
+        f16 graw[RD][4];
+        f16x8 a16[RD][4];
+        f32x4 a32[ACC32 ? RD : 1][4][2];
+        f16x8 xraw[RD][2];
 #pragma unroll
-        for (int rd = 0; rd < 2; ++rd)
+        for (int rd = 0; rd < RD; ++rd)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int v = v0 + rd * 32 + 8 * i + vsub;
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void seg_head_acc1_kernel(const HeadParams p) 
                 graw[rd][i] = p.gauss[vv];                              // always a map (all ones without Gaussian weighting)
             }
 #pragma unroll
-        for (int rd = 0; rd < 2; ++rd)
+        for (int rd = 0; rd < RD; ++rd)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (ACC32) {
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void seg_head_acc1_kernel(const HeadParams p) 
             }
         const int c0 = q * 8 < p.src.C ? q * 8 : 0;
 #pragma unroll
-        for (int rd = 0; rd < 2; ++rd)
+        for (int rd = 0; rd < RD; ++rd)
 #pragma unroll
             for (int vb = 0; vb < 2; ++vb) {
                 const int v = v0 + (rd * 2 + vb) * 16 + r;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void seg_head_acc1_kernel(const HeadParams p) 
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase B: per round MFMA -> LDS transpose -> read-modify-write -> store
 #pragma unroll
-        for (int rd = 0; rd < 2; ++rd) {
+        for (int rd = 0; rd < RD; ++rd) {
             f32x4 acc[4][2];
 #pragma unroll
             for (int vb = 0; vb < 2; ++vb) {
@@ -630,8 +630,13 @@ int launch_head(const HeadParams &p, hipStream_t st) {
         const size_t lds = (size_t)((p.src.C * 8 + 255) & ~255) + (size_t)4 * 32 * HEAD_LD * 4;
         static const bool head_v1 = getenv("FNN_HEAD_V1") != nullptr;            // A-B aid
         if (p.ksteps == 1 && !head_v1) {
-            if (p.acc_fp32) hipLaunchKernelGGL(seg_head_acc1_kernel<true>, grid, dim3(256), lds, st, p);
-            else hipLaunchKernelGGL(seg_head_acc1_kernel<false>, grid, dim3(256), lds, st, p);
+            static const int head_rd = getenv("FNN_HEAD_RD") ? atoi(getenv("FNN_HEAD_RD")) : 2;      // A-B aid (1: one 32-voxel round per wave - faster alone, slower next to the other stream)
+            if (head_rd == 1) {
+                const dim3 g1((P + 127) / 128);
+                if (p.acc_fp32) hipLaunchKernelGGL((seg_head_acc1_kernel<true, 1>), g1, dim3(256), lds, st, p);
+                else hipLaunchKernelGGL((seg_head_acc1_kernel<false, 1>), g1, dim3(256), lds, st, p);
+            } else if (p.acc_fp32) hipLaunchKernelGGL((seg_head_acc1_kernel<true, 2>), grid, dim3(256), lds, st, p);
+            else hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2>), grid, dim3(256), lds, st, p);
         } else if (p.acc_fp32) hipLaunchKernelGGL(seg_head_acc_kernel<true>, grid, dim3(256), lds, st, p);
         else hipLaunchKernelGGL(seg_head_acc_kernel<false>, grid, dim3(256), lds, st, p);
         return hipGetLastError() == hipSuccess ? 0 : -2;
