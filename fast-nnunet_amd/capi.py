@@ -37,7 +37,8 @@ class ArchDesc(C.Structure):
 
 
 class NormDesc(C.Structure):
-    _fields_ = [('scheme', C.c_int32), ('mean', C.c_float), ('std', C.c_float), ('lower', C.c_float), ('upper', C.c_float)]
+    _fields_ = [('scheme', C.c_int32), ('mean', C.c_float), ('std', C.c_float), ('lower', C.c_float), ('upper', C.c_float),
+                ('use_mask', C.c_int32)]
 
 
 class ResampleDesc(C.Structure):
@@ -173,9 +174,10 @@ def nonzero_bbox(raw_ptr: int, shape, transpose_forward, stream: int = 0):
 
 
 def preprocess(raw_ptr: int, shape, transpose_forward, bbox, norms, out_ptr: int, stream: int = 0):
-    """norms: one (scheme, mean, std, lower, upper) per channel."""
+    """norms: one (scheme, mean, std, lower, upper[, use_mask]) per channel."""
     lib = load_library()
-    nd = (NormDesc * len(norms))(*[NormDesc(int(n[0]), float(n[1]), float(n[2]), float(n[3]), float(n[4])) for n in norms])
+    nd = (NormDesc * len(norms))(*[NormDesc(int(n[0]), float(n[1]), float(n[2]), float(n[3]), float(n[4]),
+                                            int(n[5]) if len(n) > 5 else 0) for n in norms])
     flat = (C.c_int64 * 6)(*[int(v) for ab in bbox for v in ab])
     check(lib.fnn_preprocess(raw_ptr, (C.c_int64 * 4)(*[int(i) for i in shape]),
                              (C.c_int32 * 3)(*[int(i) for i in transpose_forward]), flat, nd, out_ptr, stream), lib)

@@ -69,6 +69,8 @@ struct PrepParams {
     long long lo[3], ext[3];     // crop box in transposed coordinates: origin and extent
     int scheme[8];
     float a[8], b[8], lower[8], upper[8];     // per channel: out = (clip(x) - a) / b
+    int use_mask[8];             // ZScore inside the filled non-zero mask only (use_mask_for_norm)
+    const uint8_t *mask;         // [ext0][ext1][ext2]: 2 = outside, anything else = inside (or nullptr)
 };
 
 // raw offset of transposed-cropped voxel (t0, t1, t2)
@@ -79,33 +81,85 @@ static __device__ __forceinline__ long long raw_index(const PrepParams &p, long 
 }
 
 // ---- per-channel statistics over the crop box: sum, sum of squares (double), min, max
-__global__ __launch_bounds__(256) void stats_kernel(const float *raw, PrepParams p, int c, double *sums /*[2]*/, unsigned *mm /*[2] ordered*/) {
-    __shared__ double ssum[2][4];
+__global__ __launch_bounds__(256) void stats_kernel(const float *raw, PrepParams p, int c, double *sums /*[3]: sum, sumsq, count*/, unsigned *mm /*[2] ordered*/) {
+    __shared__ double ssum[3][4];
     __shared__ unsigned smm[2];
     if (threadIdx.x == 0) { smm[0] = 0xffffffffu; smm[1] = 0u; }
     __syncthreads();
     const long long n = p.ext[0] * p.ext[1] * p.ext[2], nraw = p.g.s[0] * p.g.s[1] * p.g.s[2];
-    double s1 = 0, s2 = 0;
+    double s1 = 0, s2 = 0, cnt = 0;
     float mn = FLT_MAX, mx = -FLT_MAX;
     bool any = false;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const long long t2 = i % p.ext[2], t1 = (i / p.ext[2]) % p.ext[1], t0 = i / (p.ext[2] * p.ext[1]);
         const float v = raw[(long long)c * nraw + raw_index(p, t0, t1, t2)];
-        s1 += (double)v; s2 += (double)v * (double)v;
+        if (p.use_mask[c] && p.mask[i] == 2) continue;          // outside the filled non-zero mask
+        s1 += (double)v; s2 += (double)v * (double)v; cnt += 1.0;
         mn = v < mn ? v : mn; mx = v > mx ? v : mx;
         any = true;
     }
     // order-preserving map float -> unsigned for the atomics
     auto ord = [](float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
     if (any) { atomicMin(&smm[0], ord(mn)); atomicMax(&smm[1], ord(mx)); }
-    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
-    if ((threadIdx.x & 63) == 0) { ssum[0][threadIdx.x >> 6] = s1; ssum[1][threadIdx.x >> 6] = s2; }
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); cnt += __shfl_down(cnt, off); }
+    if ((threadIdx.x & 63) == 0) { ssum[0][threadIdx.x >> 6] = s1; ssum[1][threadIdx.x >> 6] = s2; ssum[2][threadIdx.x >> 6] = cnt; }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsafeAtomicAdd(&sums[0], ssum[0][0] + ssum[0][1] + ssum[0][2] + ssum[0][3]);
         unsafeAtomicAdd(&sums[1], ssum[1][0] + ssum[1][1] + ssum[1][2] + ssum[1][3]);
+        unsafeAtomicAdd(&sums[2], ssum[2][0] + ssum[2][1] + ssum[2][2] + ssum[2][3]);
         atomicMin(&mm[0], smm[0]); atomicMax(&mm[1], smm[1]);
     }
+}
+
+// ---- create_nonzero_mask (cropping.py:7-17) inside the crop box: 0 = some channel non-zero, 1 = background, and the
+// background voxels on the box faces start as 2 = outside.  binary_fill_holes == "background that cannot reach the
+// border through 6-connected background stays inside"; restricting it to the box is exact because everything beyond
+// a box face that is not the image border is background connected to the image border.
+__global__ __launch_bounds__(256) void mask_init_kernel(const float *raw, PrepParams p, uint8_t *m) {
+    const long long n = p.ext[0] * p.ext[1] * p.ext[2], nraw = p.g.s[0] * p.g.s[1] * p.g.s[2];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long t2 = i % p.ext[2], t1 = (i / p.ext[2]) % p.ext[1], t0 = i / (p.ext[2] * p.ext[1]);
+    const long long r = raw_index(p, t0, t1, t2);
+    bool nz = false;
+    for (int c = 0; c < p.g.C; ++c) nz |= raw[(long long)c * nraw + r] != 0.f;
+    const bool face = t0 == 0 || t1 == 0 || t2 == 0 || t0 == p.ext[0] - 1 || t1 == p.ext[1] - 1 || t2 == p.ext[2] - 1;
+    m[i] = nz ? 0 : (face ? 2 : 1);
+}
+
+// One sweep: every thread owns a line along `axis` and carries "outside" forwards and backwards through runs of
+// background; a voxel also turns outside when a neighbour on another line already is (checked along the way).
+__global__ __launch_bounds__(256) void mask_sweep_kernel(PrepParams p, int axis, uint8_t *m, int *changed) {
+    const long long e[3] = {p.ext[0], p.ext[1], p.ext[2]};
+    const int a1 = axis == 0 ? 1 : 0, a2 = axis == 2 ? 1 : 2;
+    const long long lines = e[a1] * e[a2];
+    const long long l = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (l >= lines) return;
+    const long long c1 = l / e[a2], c2 = l % e[a2];
+    const long long st[3] = {e[1] * e[2], e[2], 1};
+    const long long base = c1 * st[a1] + c2 * st[a2];
+    bool any = false;
+    for (int dir = 0; dir < 2; ++dir) {
+        bool carry = false;
+        for (long long k = 0; k < e[axis]; ++k) {
+            const long long pos = dir ? e[axis] - 1 - k : k;
+            const long long i = base + pos * st[axis];
+            uint8_t v = m[i];
+            if (v == 1) {
+                bool out = carry;
+                if (!out) {                                   // side neighbours on the two other axes
+                    if (c1 > 0) out |= m[i - st[a1]] == 2;
+                    if (c1 < e[a1] - 1) out |= m[i + st[a1]] == 2;
+                    if (c2 > 0) out |= m[i - st[a2]] == 2;
+                    if (c2 < e[a2] - 1) out |= m[i + st[a2]] == 2;
+                }
+                if (out) { m[i] = 2; v = 2; any = true; }
+            }
+            carry = v == 2;
+        }
+    }
+    if (any) *changed = 1;
 }
 
 // ---- out[c][t0][t1][t2] = normalise_c(raw[c][transposed, cropped])
@@ -122,7 +176,9 @@ __global__ __launch_bounds__(256) void apply_kernel(const float *raw, PrepParams
         v = v < p.lower[c] ? p.lower[c] : (v > p.upper[c] ? p.upper[c] : v);      // NaN stays NaN like np.clip
         v = __fdiv_rn(__fsub_rn(v, p.a[c]), p.b[c]);
         break;
-    case FNN_NORM_ZSCORE:
+    case FNN_NORM_ZSCORE:                   // image[mask] = (image[mask] - mean) / max(std, 1e-8): outside stays as it is
+        if (!(p.use_mask[c] && p.mask[j] == 2)) v = __fdiv_rn(__fsub_rn(v, p.a[c]), p.b[c]);
+        break;
     case FNN_NORM_RESCALE01:
         v = __fdiv_rn(__fsub_rn(v, p.a[c]), p.b[c]);
         break;
@@ -206,8 +262,37 @@ int fnn_preprocess(const float *raw, const int64_t shape[4], const int32_t trans
     }
     const long long n = p.ext[0] * p.ext[1] * p.ext[2];
     double *sums = nullptr;
-    if (hipMalloc((void **)&sums, 8 * 4 * sizeof(double)) != hipSuccess) return fail_msg(FNN_E_HIP, "hipMalloc failed");
+    if (hipMalloc((void **)&sums, 8 * 5 * sizeof(double)) != hipSuccess) return fail_msg(FNN_E_HIP, "hipMalloc failed");
     hipError_t r = hipSuccess;
+    bool want_mask = false;
+    for (int c = 0; c < p.g.C; ++c) {
+        p.use_mask[c] = norm[c].scheme == FNN_NORM_ZSCORE && norm[c].use_mask;
+        want_mask |= p.use_mask[c] != 0;
+    }
+    uint8_t *mask = nullptr;
+    if (want_mask) {
+        // seg = where(binary_fill_holes(nonzero_mask), 0, -1) of crop_to_nonzero (cropping.py:19-39), as a byte map
+        int *changed = nullptr;
+        if (hipMalloc((void **)&mask, (size_t)n) != hipSuccess || hipMalloc((void **)&changed, sizeof(int)) != hipSuccess) {
+            (void)hipFree(sums); (void)hipFree(mask);
+            return fail_msg(FNN_E_HIP, "hipMalloc failed");
+        }
+        hipLaunchKernelGGL(mask_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, raw, p, mask);
+        for (int iter = 0; iter < 4096 && r == hipSuccess; ++iter) {
+            int h = 0;
+            r = hipMemcpyAsync(changed, &h, sizeof(int), hipMemcpyHostToDevice, st);
+            for (int axis = 0; axis < 3 && r == hipSuccess; ++axis) {
+                const long long lines = n / p.ext[axis];
+                hipLaunchKernelGGL(mask_sweep_kernel, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, st, p, axis, mask, changed);
+                r = hipGetLastError();
+            }
+            if (r == hipSuccess) r = hipMemcpyAsync(&h, changed, sizeof(int), hipMemcpyDeviceToHost, st);
+            if (r == hipSuccess) r = hipStreamSynchronize(st);
+            if (r != hipSuccess || !h) break;
+        }
+        (void)hipFree(changed);
+        p.mask = mask;
+    }
     for (int c = 0; c < p.g.C && r == hipSuccess; ++c) {
         const fnn_norm_desc &d = norm[c];
         p.scheme[c] = d.scheme;
@@ -216,11 +301,11 @@ int fnn_preprocess(const float *raw, const int64_t shape[4], const int32_t trans
             p.a[c] = d.mean; p.b[c] = d.std > 1e-8f ? d.std : 1e-8f;           // max(std_intensity, 1e-8)
         } else if (d.scheme == FNN_NORM_ZSCORE || d.scheme == FNN_NORM_RESCALE01) {
             // statistics of this channel over the crop box
-            double *sc = sums + c * 4;
-            unsigned *mm = (unsigned *)(sc + 2);
-            const double z[2] = {0, 0};
+            double *sc = sums + c * 5;
+            unsigned *mm = (unsigned *)(sc + 3);
+            const double z[3] = {0, 0, 0};
             const unsigned mi[2] = {0xffffffffu, 0u};
-            double hs[2]; unsigned hm[2];
+            double hs[3]; unsigned hm[2];
             r = hipMemcpyAsync(sc, z, sizeof(z), hipMemcpyHostToDevice, st);
             if (r == hipSuccess) r = hipMemcpyAsync(mm, mi, sizeof(mi), hipMemcpyHostToDevice, st);
             long long blocks = (n + 255) / 256;
@@ -232,8 +317,9 @@ int fnn_preprocess(const float *raw, const int64_t shape[4], const int32_t trans
             if (r != hipSuccess) break;
             auto unord = [](unsigned u) { u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; return __builtin_bit_cast(float, u); };
             if (d.scheme == FNN_NORM_ZSCORE) {
-                const double mean = hs[0] / (double)n;
-                double var = hs[1] / (double)n - mean * mean;
+                const double cntd = hs[2] > 0 ? hs[2] : 1.0;             // voxels inside the mask (all of them without one)
+                const double mean = hs[0] / cntd;
+                double var = hs[1] / cntd - mean * mean;
                 var = var > 0 ? var : 0;
                 const float stdf = (float)sqrt(var);
                 p.a[c] = (float)mean; p.b[c] = stdf > 1e-8f ? stdf : 1e-8f;
@@ -243,7 +329,7 @@ int fnn_preprocess(const float *raw, const int64_t shape[4], const int32_t trans
                 p.a[c] = mn; p.b[c] = range > 1e-8f ? range : 1e-8f;
             }
         } else if (d.scheme != FNN_NORM_NONE && d.scheme != FNN_NORM_RGB01) {
-            (void)hipFree(sums);
+            (void)hipFree(sums); (void)hipFree(mask);
             return fail_msg(FNN_E_UNSUPPORTED, "unknown normalisation scheme");
         }
     }
@@ -254,6 +340,7 @@ int fnn_preprocess(const float *raw, const int64_t shape[4], const int32_t trans
     }
     if (r == hipSuccess) r = hipStreamSynchronize(st);
     (void)hipFree(sums);
+    (void)hipFree(mask);
     if (r != hipSuccess) return fail_msg(FNN_E_HIP, hipGetErrorString(r));
     return FNN_OK;
 }

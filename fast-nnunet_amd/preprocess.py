@@ -101,15 +101,12 @@ class DevicePreprocessor:
             for c in range(raw.shape[0]):
                 if schemes[c] not in _SCHEMES:
                     raise RuntimeError(f"Unable to locate class '{schemes[c]}' for normalization")
-                if schemes[c] == 'ZScoreNormalization' and masks[c]:
-                    raise NotImplementedError('ZScoreNormalization with use_mask_for_norm needs the filled non-zero mask '
-                                              '(binary_fill_holes): not implemented on the device')
                 ip = props.get(str(c), {}) if props else {}
                 if schemes[c] == 'CTNormalization':
                     assert ip, 'CTNormalization requires intensity properties'
                     norms.append((_SCHEMES[schemes[c]], ip['mean'], ip['std'], ip['percentile_00_5'], ip['percentile_99_5']))
                 else:
-                    norms.append((_SCHEMES[schemes[c]], 0., 1., 0., 0.))
+                    norms.append((_SCHEMES[schemes[c]], 0., 1., 0., 0., int(bool(masks[c]))))
             out = torch.empty((raw.shape[0], *cropped), dtype=torch.float32, device=self.device)
             capi.preprocess(raw.data_ptr(), raw.shape, tf, bbox, norms, out.data_ptr(), self._stream())
             # normalisation happens before resampling, like the reference (:83-91)

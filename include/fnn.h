@@ -185,8 +185,7 @@ int fnn_argmax_labels(fnn_engine *e, const void *logits, int dtype, int heads, i
  * [C][s0][s1][s2] -> transpose_forward -> crop to the bounding box of the non-zero
  * region (preprocessing/cropping/cropping.py:7-39) -> per-channel intensity
  * normalisation (preprocessing/normalization/default_normalization_schemes.py).
- * Device pointers only.  `use_mask_for_norm` (normalise inside the filled non-zero
- * mask only) and resampling to the target spacing are not implemented. */
+ * Device pointers only.  Resampling to the target spacing is fnn_resample. */
 enum { FNN_NORM_NONE = 0,        /* NoNormalization                                   :70-74 */
        FNN_NORM_ZSCORE = 1,      /* ZScoreNormalization, whole-image branch            :45-49 */
        FNN_NORM_CT = 2,          /* CTNormalization: clip, - mean, / max(std, 1e-8)    :53-67 */
@@ -196,6 +195,8 @@ typedef struct fnn_norm_desc {
     int32_t scheme;              /* FNN_NORM_*                                                 */
     float mean, std;             /* CT: intensityproperties['mean'], ['std']                   */
     float lower, upper;          /* CT: ['percentile_00_5'], ['percentile_99_5']               */
+    int32_t use_mask;            /* ZScore: use_mask_for_norm - statistics and normalisation only inside
+                                  * binary_fill_holes(non-zero mask) (cropping.py:7-39, schemes :36-44)   */
 } fnn_norm_desc;
 
 /* bbox[2a], bbox[2a+1] = [lo, hi) along TRANSPOSED axis a of the voxels where any

@@ -19,6 +19,7 @@ from __future__ import annotations
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
+from scipy.ndimage import binary_fill_holes
 
 
 def nonzero_bbox(data: np.ndarray) -> List[List[int]]:
@@ -35,15 +36,27 @@ def nonzero_bbox(data: np.ndarray) -> List[List[int]]:
     return out
 
 
-def normalize_channel(image: np.ndarray, scheme: str, props: Optional[dict]) -> np.ndarray:
-    """One channel, in place semantics of the reference's ``ImageNormalization.run`` without a mask
-    (``use_mask_for_norm`` False / None)."""
+def filled_nonzero_mask(data: np.ndarray) -> np.ndarray:
+    """``create_nonzero_mask`` (cropping.py:7-17): any channel non-zero, holes filled."""
+    mask = data[0] != 0
+    for c in range(1, data.shape[0]):
+        mask |= data[c] != 0
+    return binary_fill_holes(mask)
+
+
+def normalize_channel(image: np.ndarray, scheme: str, props: Optional[dict], mask: Optional[np.ndarray] = None) -> np.ndarray:
+    """One channel, in place semantics of the reference's ``ImageNormalization.run``; ``mask`` = the filled non-zero
+    mask of the cropped image when ``use_mask_for_norm`` is set for the channel (only ZScore looks at it)."""
     image = image.astype(np.float32, copy=True)
     if scheme == 'CTNormalization':                                                      # :53-67
         np.clip(image, props['percentile_00_5'], props['percentile_99_5'], out=image)
         image -= props['mean']
         image /= max(props['std'], 1e-8)
-    elif scheme == 'ZScoreNormalization':                                                # :30-50, no-mask branch
+    elif scheme == 'ZScoreNormalization' and mask is not None:                           # :36-44, use_mask_for_norm
+        mean = image[mask].mean()
+        std = image[mask].std()
+        image[mask] = (image[mask] - mean) / (max(std, 1e-8))
+    elif scheme == 'ZScoreNormalization':                                                # :45-49
         mean = image.mean()
         std = image.std()
         image -= mean
@@ -62,16 +75,20 @@ def normalize_channel(image: np.ndarray, scheme: str, props: Optional[dict]) -> 
 
 
 def preprocess_case(data: np.ndarray, transpose_forward: Sequence[int], schemes: Sequence[str],
-                    intensity_props: Dict[str, dict]) -> Tuple[np.ndarray, List[List[int]], Tuple[int, ...]]:
+                    intensity_props: Dict[str, dict], use_mask: Optional[Sequence[bool]] = None
+                    ) -> Tuple[np.ndarray, List[List[int]], Tuple[int, ...]]:
     """-> (cropped + normalised float32 data, bbox_used_for_cropping, shape_before_cropping)."""
     data = data.astype(np.float32)
     data = data.transpose([0, *[i + 1 for i in transpose_forward]])
     shape_before_cropping = tuple(data.shape[1:])
     bbox = nonzero_bbox(data)
-    data = data[(slice(None), *[slice(lo, hi) for lo, hi in bbox])]
+    crop = (slice(None), *[slice(lo, hi) for lo, hi in bbox])
+    mask = filled_nonzero_mask(data)[crop[1:]] if use_mask is not None and any(use_mask) else None
+    data = data[crop]
     out = np.empty(data.shape, np.float32)
     for c in range(data.shape[0]):
-        out[c] = normalize_channel(data[c], schemes[c], intensity_props.get(str(c)))
+        out[c] = normalize_channel(data[c], schemes[c], intensity_props.get(str(c)),
+                                   mask if (use_mask is not None and use_mask[c]) else None)
     return out, bbox, shape_before_cropping
 
 

@@ -229,6 +229,9 @@ PREP_CASES = [
          scale=None, offset=None, seed=3),
     dict(name='all_zero', shape=(1, 6, 7, 9), margins=None, tf=(0, 1, 2), schemes=['NoNormalization'], props={'0': {}},
          scale=0.0, offset=0.0, seed=4),
+    dict(name='zscore_masked_holes', shape=(2, 20, 24, 22), margins=((2, 3), (1, 4), (3, 2)), tf=(1, 2, 0),
+         schemes=['ZScoreNormalization', 'ZScoreNormalization'], props={'0': {}, '1': {}}, scale=40.0, offset=90.0, seed=6,
+         use_mask=[True, False], blobs=True),
     dict(name='ct_single_voxel_holes', shape=(1, 12, 12, 12), margins=((4, 4), (3, 5), (2, 2)), tf=(0, 2, 1),
          schemes=['CTNormalization'],
          props={'0': {'mean': 10.0, 'std': 0.0, 'percentile_00_5': -5.0, 'percentile_99_5': 5.0}}, scale=8.0, offset=0.0,
@@ -253,7 +256,16 @@ def prep_case_input(case):
     keep[m[0][0]:shape[1] - m[0][1], m[1][0]:shape[2] - m[1][1], m[2][0]:shape[3] - m[2][1]] = True
     if case.get('holes'):
         keep[shape[1] // 2, shape[2] // 2 - 1:shape[2] // 2 + 1, shape[3] // 2] = False
+    if case.get('blobs'):
+        # an enclosed zero blob (a hole: stays inside the mask), a zero tunnel that reaches the margin (outside), and an
+        # enclosed blob that is zero in channel 0 only (non-zero somewhere: foreground)
+        keep[8:12, 9:14, 9:13] = False
+        keep[5:7, 0:12, 6:8] = False
+        keep[14:16, 16:19, 5:17] = False
+        keep[15, 17, 17:shape[3]] = False
     x[:, ~keep] = 0
+    if case.get('blobs'):
+        x[0, 3:6, 15:18, 12:15] = 0                                  # zero in one channel only
     return x
 
 

@@ -203,7 +203,8 @@ def gen_preprocess():
         data, seg, bbox = crop_to_nonzero(data, None)                             # :66
         for c in range(data.shape[0]):                                            # :228-240
             cls = getattr(dns, case['schemes'][c])
-            norm = cls(use_mask_for_norm=False, intensityproperties=case['props'][str(c)])
+            norm = cls(use_mask_for_norm=bool(case.get('use_mask', [False] * data.shape[0])[c]),
+                       intensityproperties=case['props'][str(c)])
             data[c] = norm.run(data[c], seg[0])
         arrays[case['name'] + '__data'] = data.astype(np.float32)
         arrays[case['name'] + '__bbox'] = np.asarray(bbox, np.int64)

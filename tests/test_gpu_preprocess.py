@@ -50,6 +50,7 @@ def test_preprocess_matches_reference_golden(case, golden_dir):
     pp = DevicePreprocessor(torch.device('cuda', 0))
     props = {'spacing': [1.0, 1.0, 1.0]}
     pm, cm = _PM(case['tf'], case['props']), _CM(case['schemes'])
+    cm.use_mask_for_norm = list(case.get('use_mask', cm.use_mask_for_norm))
     data, seg, props = pp.run_case_npy(prep_case_input(case), None, props, pm, cm)
     assert seg is None and data.is_cuda
     assert np.array_equal(np.asarray(props['bbox_used_for_cropping']), z[case['name'] + '__bbox'])
@@ -88,10 +89,6 @@ def test_preprocess_refuses_what_it_does_not_implement():
     from fast_nnunet_amd.preprocess import DevicePreprocessor
     pp = DevicePreprocessor(torch.device('cuda', 0))
     raw = torch.ones(1, 8, 8, 8)
-    cm = _CM(['ZScoreNormalization'])
-    cm.use_mask_for_norm = [True]
-    with pytest.raises(NotImplementedError, match='use_mask_for_norm'):
-        pp.run_case_npy(raw, None, {'spacing': [1.0, 1.0, 1.0]}, _PM((0, 1, 2), {'0': {}}), cm)
     with pytest.raises(RuntimeError, match='Unable to locate class'):
         pp.run_case_npy(raw, None, {'spacing': [1.0, 1.0, 1.0]}, _PM((0, 1, 2), {'0': {}}), _CM(['FancyNorm']))
     with pytest.raises(RuntimeError, match='no CPU path'):
@@ -175,3 +172,33 @@ def test_run_case_npy_with_resampling_and_export_round_trip():
     lab = back.astype(np.float32).argmax(0).astype(np.uint8)
     full = opre.revert_labels(lab, bbox, before, [int(i) for i in np.argsort(tf)], 3)
     assert seg.shape == raw.shape[1:] and (seg != full).mean() < 2e-3       # ties flip on fp16 rounding boundaries only
+
+
+def test_masked_zscore_with_a_maze_of_background():
+    """use_mask_for_norm on a volume whose background winds through the foreground: the sweeps have to carry
+    "outside" around many corners before they converge; enclosed chambers stay inside (binary_fill_holes)."""
+    from fast_nnunet_amd.preprocess import DevicePreprocessor
+    rng = np.random.default_rng(12)
+    shape = (1, 48, 40, 44)
+    raw = (rng.standard_normal(shape) * 30 + 200).astype(np.float32)
+    raw[raw == 0] = 1
+    # a serpentine zero corridor entering from the border, plus sealed zero rooms
+    for i in range(4, 44, 8):
+        raw[0, i:i + 2, 2:38, 20:23] = 0
+        raw[0, i:i + 10, (36 if (i // 8) % 2 == 0 else 2):(38 if (i // 8) % 2 == 0 else 4), 20:23] = 0
+    raw[0, 0:6, 2:4, 20:23] = 0
+    raw[0, 20:24, 10:14, 30:36] = 0                                  # sealed room
+    raw[0, 30:33, 25:28, 5:9] = 0                                    # sealed room
+    want, bbox, before = opre.preprocess_case(raw, (0, 1, 2), ['ZScoreNormalization'], {'0': {}}, [True])
+    cm = _CM(['ZScoreNormalization'])
+    cm.use_mask_for_norm = [True]
+    pp = DevicePreprocessor(torch.device('cuda', 0))
+    got, _, props = pp.run_case_npy(torch.from_numpy(raw), None, {'spacing': [1.0, 1.0, 1.0]}, _PM((0, 1, 2), {'0': {}}), cm)
+    assert props['bbox_used_for_cropping'] == bbox
+    g = got.cpu().numpy()
+    assert np.abs(g - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+    # outside the mask the zeros are untouched; inside (sealed rooms included) everything was normalised - an exact zero
+    # there needs a voxel equal to the mean, which the oracle's fp32 mean and the kernel's fp64 mean may disagree on
+    outside = ~opre.filled_nonzero_mask(raw)
+    assert outside.sum() > 1000 and (g[0][outside] == 0).all() and (want[0][outside] == 0).all()
+    assert (g[0][~outside] == 0).sum() <= 1 and (want[0][~outside] == 0).sum() <= 1

@@ -169,7 +169,8 @@ def test_preprocess_and_label_revert_match_reference_golden(golden_dir):
     from oracle import preprocess as opre
     z = np.load(os.path.join(golden_dir, 'preprocess.npz'))
     for case in PREP_CASES:
-        data, bbox, before = opre.preprocess_case(prep_case_input(case), case['tf'], case['schemes'], case['props'])
+        data, bbox, before = opre.preprocess_case(prep_case_input(case), case['tf'], case['schemes'], case['props'],
+                                                  case.get('use_mask'))
         assert np.array_equal(np.asarray(bbox), z[case['name'] + '__bbox']), case['name']
         assert list(before) == z[case['name'] + '__shape_before'].tolist()
         ref = z[case['name'] + '__data']
