@@ -1191,7 +1191,9 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
                 tiles >= 8LL * (512 / groups) && 512 / groups >= 8) {
                 const int gx = 512 / groups;                       // 2 resident workgroups per CU over all cout groups
                 if (p.chunks == 1) return launch_persist_ks<2, 2, false, 0, 1, 12>(p, 2, st, gx);
-                // (two-chunk layers: the unrolled variant spills and measured slower than one tile per workgroup)
+                // more chunks: the generic (runtime chunk count) form; the unrolled two-chunk variant spilled and lost
+                static const bool sp_single = getenv("FNN_STRIDED_PERSIST_SINGLE") != nullptr;   // A-B aid
+                if (!sp_single) return launch_persist_ks<2, 2, false, 0, 0, 12>(p, 2, st, gx);
             }
         }
         if (ID * IH * IW * 2 <= 16 * 256 && ldsk_lds_bytes(p, nbs, 2) <= 80 * 1024) {

@@ -208,12 +208,14 @@ def test_conv3d_zr_operand_map_with_exact_integers():
 
 
 @pytest.mark.parametrize('stride', [(1, 2, 2), (2, 2, 2)])
-def test_conv3d_strided_persistent_variant(stride):
-    """16 -> 32 strided conv with enough tiles for the persistent strided kernel (tile ranges per workgroup,
-    cross-tile prefetch): ragged tiles on every axis, fused InstanceNorm + LeakyReLU on load, statistics."""
+@pytest.mark.parametrize('cin,cout', [(16, 32), (32, 64)])
+def test_conv3d_strided_persistent_variant(stride, cin, cout):
+    """Strided convs with enough tiles for the persistent strided kernel (tile ranges per workgroup, cross-tile
+    prefetch; one chunk = templated, two chunks = generic form with two cout groups): ragged tiles on every axis, fused
+    InstanceNorm + LeakyReLU on load, statistics."""
     from fast_nnunet_amd import capi
     g = torch.Generator().manual_seed(21 + stride[0])
-    n, cin, cout, dims = 8, 16, 32, (61, 93, 90)
+    n, dims = 8, (61, 93, 90)
     x = _h(torch.randn(n, cin, *dims, generator=g) * 2 + 0.5)
     gamma = torch.rand(cin, generator=g) + 0.5
     beta = torch.randn(cin, generator=g) * 0.1
