@@ -647,6 +647,10 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
         e->patch_buf = (float *)pbuf;
     }
     const int64_t np = (int64_t)ids.size();
+    if (np > B) {                                           // balanced batches: 75 patches run as 19+19+19+18, not 24+24+24+3
+        const int64_t nbat = (np + B - 1) / B;
+        B = (int)((np + nbat - 1) / nbat);
+    }
     for (int64_t i = 0; i < np; ++i) {
         const int *oo = &vp.origins[ids[i] * 3];
         for (int d = 0; d < 3; ++d)
