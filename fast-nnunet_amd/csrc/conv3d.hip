@@ -1264,30 +1264,40 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
     float t1[16], t2[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) { t1[j] = 0.f; t2[j] = 0.f; }
-    for (int dd = 0; dd < 4; ++dd) {
-        const int od_l = wave * 4 + dd;
-        const int od = td * STEM_TD + od_l;
-        float acc[16];
+    // taps outermost: a tap's 16 weights are read from LDS once and serve the thread's 4 depth slices (they were
+    // re-read per slice: 144 ds_read_b128 per thread against 576 FMAs)
+    float acc[4][16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = bias[j];
-        for (int c = 0; c < p.C; ++c)
-            for (int a = 0; a < p.kd; ++a)
-                for (int b = 0; b < p.kh; ++b)
-                    for (int e = 0; e < p.kw; ++e) {
-                        const float x = sIn[c * IVOX + ((od_l + a) * IH + (oh_l + b)) * IW + (ow_l + e)];
-                        const float4 *wv = (const float4 *)(sW + ((c * T) + (a * p.kh + b) * p.kw + e) * 16);
+    for (int dd = 0; dd < 4; ++dd)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const float4 w4 = wv[g];
-                            acc[4 * g + 0] = fmaf(x, w4.x, acc[4 * g + 0]); acc[4 * g + 1] = fmaf(x, w4.y, acc[4 * g + 1]);
-                            acc[4 * g + 2] = fmaf(x, w4.z, acc[4 * g + 2]); acc[4 * g + 3] = fmaf(x, w4.w, acc[4 * g + 3]);
-                        }
+        for (int j = 0; j < 16; ++j) acc[dd][j] = bias[j];
+    for (int c = 0; c < p.C; ++c)
+        for (int a = 0; a < p.kd; ++a)
+            for (int b = 0; b < p.kh; ++b)
+                for (int e = 0; e < p.kw; ++e) {
+                    const float4 *wv = (const float4 *)(sW + ((c * T) + (a * p.kh + b) * p.kw + e) * 16);
+                    const float4 w0 = wv[0], w1 = wv[1], w2 = wv[2], w3 = wv[3];
+#pragma unroll
+                    for (int dd = 0; dd < 4; ++dd) {
+                        const float x = sIn[c * IVOX + ((wave * 4 + dd + a) * IH + (oh_l + b)) * IW + (ow_l + e)];
+                        acc[dd][0] = fmaf(x, w0.x, acc[dd][0]); acc[dd][1] = fmaf(x, w0.y, acc[dd][1]);
+                        acc[dd][2] = fmaf(x, w0.z, acc[dd][2]); acc[dd][3] = fmaf(x, w0.w, acc[dd][3]);
+                        acc[dd][4] = fmaf(x, w1.x, acc[dd][4]); acc[dd][5] = fmaf(x, w1.y, acc[dd][5]);
+                        acc[dd][6] = fmaf(x, w1.z, acc[dd][6]); acc[dd][7] = fmaf(x, w1.w, acc[dd][7]);
+                        acc[dd][8] = fmaf(x, w2.x, acc[dd][8]); acc[dd][9] = fmaf(x, w2.y, acc[dd][9]);
+                        acc[dd][10] = fmaf(x, w2.z, acc[dd][10]); acc[dd][11] = fmaf(x, w2.w, acc[dd][11]);
+                        acc[dd][12] = fmaf(x, w3.x, acc[dd][12]); acc[dd][13] = fmaf(x, w3.y, acc[dd][13]);
+                        acc[dd][14] = fmaf(x, w3.z, acc[dd][14]); acc[dd][15] = fmaf(x, w3.w, acc[dd][15]);
                     }
+                }
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {
+        const int od = td * STEM_TD + wave * 4 + dd;
         const bool ok = od < p.PD && oh < p.PH && ow < p.PW;
         f16x8 o0, o1;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const f16 hv = (f16)acc[j];
+            const f16 hv = (f16)acc[dd][j];
             if (j < 8) o0[j] = hv; else o1[j - 8] = hv;
             const float f = ok ? (float)hv : 0.f;
             t1[j] += f;
