@@ -1112,6 +1112,16 @@ static int launch_conv_nb(const ConvParams &p, hipStream_t st) {
 
 int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
     ConvParams p = p_in;
+    {
+        // the kernels address one batch item with 32-bit byte offsets (buffer stores, SGPR base + VGPR offset loads)
+        const unsigned long long out_item = 2ull * p.Do * p.Ho * p.Wo * p.Cout;
+        unsigned long long in_item = 0;
+        for (int i = 0; i < p.n_src; ++i) {
+            const unsigned long long b = 2ull * p.Di * p.Hi * p.Wi * p.src[i].C;
+            in_item = b > in_item ? b : in_item;
+        }
+        if (out_item >= (1ull << 31) || in_item >= (1ull << 32)) return -1;
+    }
     p.tile_d = FNN_TILE_D;
     p.tiles_d = (p.Do + FNN_TILE_D - 1) / FNN_TILE_D;
     p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;

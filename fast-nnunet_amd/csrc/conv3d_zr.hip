@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
             const int zd = v / (IH * IW), rem = v - zd * (IH * IW), zh = rem / IW, zw = rem - zh * IW;
             const int gd = id0 + zd, gh = ih0 + zh, gw = iw0 + zw;
             const bool ok = gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 && gw < p.Wi;
-            offv[u] = idx < IELEM ? (ok ? ((n * p.Di + gd) * p.Hi + gh) * p.Wi + gw : -1) : -2;
+            offv[u] = idx < IELEM ? (ok ? (gd * p.Hi + gh) * p.Wi + gw : -1) : -2;      // inside batch item n
             ldso[u] = zd * PS + (zh * PW + zw) * 32 + ((cg ^ (zh & 1)) * 16);
         }
     }
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
         const int c_loc = c_uni + cg * 8;
         const int sC = p.src[s].C;
         // uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset: one address VGPR per load (tensors < 4 GiB)
-        const char *sp = (const char *)(p.src[s].ptr + c_uni);
+        const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + c_uni);
 #pragma unroll
         for (int u = 0; u < PF; ++u)                          // unconditional: branches around loads make hipcc drain vmcnt
             xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * sC + cg * 8) * 2));
