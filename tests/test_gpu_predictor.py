@@ -122,6 +122,29 @@ def test_c1_sized_student_forward_matches_oracle():
     assert (got.argmax(1) != ref.argmax(1)).float().mean() < 5e-3
 
 
+def test_forward_is_bit_stable_while_another_engine_shares_the_gpu():
+    """Two engines driven from two host threads on two streams: every forward must reproduce the engine's
+    solo result bit for bit.  (Found a stem-conv build whose accumulators went wrong when other kernels
+    shared the CU - DESIGN.md section 3; the engine's own two-batches-in-flight pipelining relies on this.)"""
+    import threading
+    spec, patch = SPECS['toy3']
+    sd = synthetic_state_dict(spec, 50)
+    ps = [_predictor(spec, patch, [sd], batch=3) for _ in range(2)]
+    xs = [torch.randn(3, spec.in_channels, *patch, generator=torch.Generator().manual_seed(9 + i)) for i in range(2)]
+    solo = [ps[i].forward_patches(xs[i]).cpu() for i in range(2)]
+    bad = [0, 0]
+
+    def work(i):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for _ in range(40):
+                bad[i] += int(not torch.equal(ps[i].forward_patches(xs[i]).cpu(), solo[i]))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert bad == [0, 0]
+
+
 DRIVER_CASES = [
     dict(shape=(40, 36, 44), mirror=None, step=0.5, gaussian=True, folds=1),
     dict(shape=(40, 36, 44), mirror=None, step=1.0, gaussian=False, folds=1),
