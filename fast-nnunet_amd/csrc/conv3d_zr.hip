@@ -40,7 +40,8 @@ static bool zr_pick(const ConvParams &p, int &nb, int &td) {
     nb = nblk % 2 == 0 ? 2 : 1;
     const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;
     const long long th = (p.Ho + 7) / 8, tw = (p.Wo + 7) / 8;
-    for (td = 8; td >= 4; td -= 4) {
+    static const int td_max = getenv("FNN_ZR_TD") ? atoi(getenv("FNN_ZR_TD")) : 8;       // A-B aid
+    for (td = td_max; td >= 4; td -= 4) {
         if (p.Do < td) continue;
         if ((long long)plan_n * ((p.Do + td - 1) / td) * th * tw * (nblk / nb) >= 768) return true;
     }

@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void seg_head_acc_kernel(const HeadParams p) {
 // acknowledged: with the loads of round 1 behind the stores of round 0 (the loop above), every wave waited for a
 // full write round trip in the middle of its life.  Here the only waits are for loads that were issued before any
 // store; the stores of both rounds drain while the wave finishes.
-template <bool ACC32, int RD>
+template <bool ACC32, int RD, int NT = 0>
 __global__ __launch_bounds__(256) void seg_head_acc1_kernel(const HeadParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -542,7 +542,8 @@ __global__ __launch_bounds__(256) void seg_head_acc1_kernel(const HeadParams p) 
                 if (ACC32) {
                     a32[ACC32 ? rd : 0][i][0] = *(const f32x4 *)((const float *)p.acc + aelem[rd][i]);
                     a32[ACC32 ? rd : 0][i][1] = *(const f32x4 *)((const float *)p.acc + aelem[rd][i] + 4);
-                } else a16[rd][i] = *(const f16x8 *)((const f16 *)p.acc + aelem[rd][i]);
+                } else if (NT & 2) a16[rd][i] = __builtin_nontemporal_load((const f16x8 *)((const f16 *)p.acc + aelem[rd][i]));
+                else a16[rd][i] = *(const f16x8 *)((const f16 *)p.acc + aelem[rd][i]);
             }
         const int c0 = q * 8 < p.src.C ? q * 8 : 0;
 #pragma unroll
@@ -610,7 +611,10 @@ __global__ __launch_bounds__(256) void seg_head_acc1_kernel(const HeadParams p) 
                     f16x8 bq = a16[rd][i];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) bq[e] = (mask >> e) & 1 ? (f16)__fadd_rn((float)bq[e], c[e]) : bq[e];
-                    if (ok[rd][i]) *(f16x8 *)((f16 *)p.acc + aelem[rd][i]) = bq;
+                    if (ok[rd][i]) {
+                        if (NT & 1) __builtin_nontemporal_store(bq, (f16x8 *)((f16 *)p.acc + aelem[rd][i]));
+                        else *(f16x8 *)((f16 *)p.acc + aelem[rd][i]) = bq;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -636,7 +640,14 @@ int launch_head(const HeadParams &p, hipStream_t st) {
                 if (p.acc_fp32) hipLaunchKernelGGL((seg_head_acc1_kernel<true, 1>), g1, dim3(256), lds, st, p);
                 else hipLaunchKernelGGL((seg_head_acc1_kernel<false, 1>), g1, dim3(256), lds, st, p);
             } else if (p.acc_fp32) hipLaunchKernelGGL((seg_head_acc1_kernel<true, 2>), grid, dim3(256), lds, st, p);
-            else hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2>), grid, dim3(256), lds, st, p);
+            else {
+                // non-temporal accumulator traffic (each line is touched once per patch): +1.3 % on the benchmark
+                static const int nt = getenv("FNN_HEAD_NT") ? atoi(getenv("FNN_HEAD_NT")) : 3;      // A-B aid
+                if (nt == 1) hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 1>), grid, dim3(256), lds, st, p);
+                else if (nt == 2) hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 2>), grid, dim3(256), lds, st, p);
+                else if (nt == 3) hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 3>), grid, dim3(256), lds, st, p);
+                else hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2>), grid, dim3(256), lds, st, p);
+            }
         } else if (p.acc_fp32) hipLaunchKernelGGL(seg_head_acc_kernel<true>, grid, dim3(256), lds, st, p);
         else hipLaunchKernelGGL(seg_head_acc_kernel<false>, grid, dim3(256), lds, st, p);
         return hipGetLastError() == hipSuccess ? 0 : -2;
