@@ -185,7 +185,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='bone_turbo_r2', choices=list(WORKLOADS))
     ap.add_argument('--volume', type=int, default=512)
-    ap.add_argument('--batch', type=int, default=24)
+    ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--accum', default='fp16', choices=['fp16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -277,7 +277,7 @@ def main():
         achieved = pr.conv_flops / (pr.conv_ms * 1e-3) / 1e12 if pr.conv_ms > 0 else 0.0
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        if os.path.isfile(tpath) and args.workload == 'bone_turbo_r2' and args.volume == 512 and args.batch == 24:
+        if os.path.isfile(tpath) and args.workload == 'bone_turbo_r2' and args.volume == 512 and args.batch == 32:
             try:                                  # HBM bytes per launch of the same kernel family from separate PMC passes
                 fam = json.load(open(tpath))['families']['conv3d_mfma']
                 traffic, traffic_src = int(fam['bytes_per_launch']), 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, reads x2)'

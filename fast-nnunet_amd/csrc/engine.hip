@@ -70,10 +70,11 @@ struct fnn_engine {
     f16 *act = nullptr;
     double *stats = nullptr;
     float *ss = nullptr;                    // [layer][max_batch][2][C]
-    // Two batches in flight (fnn_accumulate / predict): a second activation arena and two internal streams.  The
-    // network alternates between HBM-bound (thin full-resolution convs, seg head) and MFMA-bound kernels; with
-    // batch k+1's forward on the other stream they overlap.  The heads stay ordered (events), so the accumulation
-    // order - and with it every rounding - is the reference's.  288 GB of HBM make the second arena free.
+    // Batches in flight (fnn_accumulate / predict): one activation arena and one internal stream per batch in flight
+    // (three by default, FNN_PIPES = 2..4; measured 2 -> 3: +1.5 %, 4: no better).  The network alternates between
+    // HBM-bound (thin full-resolution convs, seg head) and MFMA-bound kernels; with the following batches' forwards on
+    // the other streams they overlap.  The heads stay ordered (events), so the accumulation order - and with it every
+    // rounding - is the reference's.  288 GB of HBM make the extra arenas free.
     static constexpr int MAXP = 4;
     int n_pipe = 0;                         // arenas / streams allocated (0 until the first multi-batch run)
     f16 *actp[MAXP] = {}; double *statsp[MAXP] = {}; float *ssp[MAXP] = {};      // [0] aliases act / stats / ss
@@ -657,11 +658,11 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
             if (oo[d] < box.lo[d] || oo[d] + a.patch[d] > box.hi[d])
                 return fail(e, FNN_E_INVALID, "patch %lld lies outside the accumulator box", (long long)ids[i]);
     }
-    // ---- two batches in flight (see fnn_engine::pipe)
+    // ---- several batches in flight (see fnn_engine::pipe)
     static const bool no_pipe = getenv("FNN_NO_PIPELINE") != nullptr;                // A-B aid
     const bool pipelined = !no_pipe && !tta && !e->profiling && np > B;
     f16 *const act0 = e->act; double *const stats0 = e->stats; float *const ss0 = e->ss;
-    static const int want_pipes = getenv("FNN_PIPES") ? atoi(getenv("FNN_PIPES")) : 2;
+    static const int want_pipes = getenv("FNN_PIPES") ? atoi(getenv("FNN_PIPES")) : 3;
     const int NP = want_pipes < 2 ? 2 : (want_pipes > fnn_engine::MAXP ? fnn_engine::MAXP : want_pipes);
     if (pipelined) {
         if (e->n_pipe < NP) {
