@@ -107,6 +107,7 @@ class nnUNetPredictor(object):
         self.label_manager = plans_manager.get_label_manager(dataset_json)
         self.network = None
         self._reduction = init_args.get('feature_reduction_factor')
+        self._configuration_name = configuration_name
         self._build_engine()
 
     def manual_initialization(self, network, plans_manager: PlansManager,
@@ -236,7 +237,6 @@ class nnUNetPredictor(object):
             print('Prediction done')
         return out.to('cpu')
 
-    @torch.inference_mode()
     @torch.inference_mode()
     def predict_single_npy_array(self, input_image: np.ndarray, image_properties: dict,
                                  segmentation_previous_stage: np.ndarray = None,

@@ -620,3 +620,119 @@ def test_predict_single_npy_array_matches_the_oracle_chain(spacing_raw, spacing_
     # near-tie voxels may flip
     assert mismatch == 0.0 if list(new_shape) == list(data.shape[1:]) else mismatch < 5e-3
     assert len(np.unique(got)) >= 2
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# engine .ini front-end (SURVEY.md 8 f-4): set_config -> set_workspace -> infer, the call order of the
+# reference's engine/fast_nnunet.cpp:16-27
+# ---------------------------------------------------------------------------------------------------------------
+def _toy_model_folder(tmp_path, patch, num_heads, plans_spacing, seed=5):
+    import json
+    teacher_feats = [32, 64, 64]
+    kernels = [[3, 3, 3]] * 3
+    strides = [[1, 1, 1], [2, 2, 2], [1, 2, 2]]
+    spec = UNetSpec('plain', 1, num_heads, [16, 32, 32], [tuple(k) for k in kernels], [tuple(s) for s in strides],
+                    [2, 2, 2], [2, 2])
+    plans = {'dataset_name': 'Dataset124_Toy', 'plans_name': 'nnUNetPlans', 'transpose_forward': [0, 1, 2],
+             'transpose_backward': [0, 1, 2], 'label_manager': 'LabelManager',
+             'foreground_intensity_properties_per_channel': {'0': {'mean': 0.0, 'std': 1.0, 'percentile_00_5': -1.0,
+                                                                   'percentile_99_5': 1.0}},
+             'configurations': {'3d_fullres': {
+                 'patch_size': list(patch), 'spacing': list(plans_spacing), 'batch_size': 2,
+                 'normalization_schemes': ['ZScoreNormalization'], 'use_mask_for_norm': [False],
+                 'resampling_fn_data': 'resample_data_or_seg_to_shape',
+                 'resampling_fn_data_kwargs': {'is_seg': False, 'order': 3, 'order_z': 0, 'force_separate_z': None},
+                 'resampling_fn_probabilities': 'resample_data_or_seg_to_shape',
+                 'resampling_fn_probabilities_kwargs': {'is_seg': False, 'order': 1, 'order_z': 0, 'force_separate_z': None},
+                 'architecture': {'network_class_name': 'dynamic_network_architectures.architectures.unet.PlainConvUNet',
+                                  'arch_kwargs': {'n_stages': 3, 'features_per_stage': teacher_feats, 'kernel_sizes': kernels,
+                                                  'strides': strides, 'n_conv_per_stage': [2, 2, 2],
+                                                  'n_conv_per_stage_decoder': [2, 2], 'conv_bias': True,
+                                                  'norm_op_kwargs': {'eps': 1e-5, 'affine': True}},
+                                  '_kw_requires_import': []}}}}
+    dataset_json = {'labels': {('background' if i == 0 else f'c{i}'): i for i in range(num_heads)},
+                    'channel_names': {'0': 'CT'}, 'file_ending': '.nii.gz'}
+    folder = tmp_path / 'nnUNetDistillationTrainer__nnUNetPlans__3d_fullres'
+    folder.mkdir()
+    (folder / 'plans.json').write_text(json.dumps(plans))
+    (folder / 'dataset.json').write_text(json.dumps(dataset_json))
+    sd = synthetic_state_dict(spec, seed)
+    (folder / 'fold_0').mkdir()
+    torch.save({'network_weights': sd, 'init_args': {'configuration': '3d_fullres', 'feature_reduction_factor': 2, 'fold': 0},
+                'trainer_name': 'nnUNetDistillationTrainer', 'inference_allowed_mirroring_axes': (0, 1, 2)},
+               folder / 'fold_0' / 'checkpoint_final.pth')
+    return folder, plans, dataset_json, sd, spec
+
+
+_INI = """[model]
+file_name = toy.trt
+input_name = input
+output_name = output
+num_class = {num_class}
+
+[input]
+depth = {p[0]}
+height = {p[1]}
+width = {p[2]}
+patch_size = {p[0]}, {p[1]}, {p[2]}
+target_spacing = {s[0]}, {s[1]}, {s[2]}
+
+[preprocessing]
+mean = 150.0
+std_dev = 300.0
+lower_bound = -400.0
+upper_bound = 700.0
+
+[inference]
+use_mirroring = {mirror}
+step_size = 0.5
+use_gaussian = true
+"""
+
+
+@pytest.mark.parametrize('spacing_raw,target,mirror', [((1.0, 1.0, 1.0), (1.0, 1.0, 1.0), False),
+                                                       ((1.4, 0.8, 0.8), (1.0, 1.0, 1.0), True)])
+def test_engine_ini_front_end_matches_the_predictor_it_configures(tmp_path, spacing_raw, target, mirror):
+    from fast_nnunet_amd import nnUNetPredictor
+    from fast_nnunet_amd.engine_config import Engine, load_engine_config, plans_with_engine_config
+    from fast_nnunet_amd.plans import PlansManager
+    patch = (16, 16, 32)
+    folder, plans, dj, sd, spec = _toy_model_folder(tmp_path, patch, 4, plans_spacing=(3.0, 3.0, 3.0))
+    ini = tmp_path / 'toy.ini'
+    ini.write_text(_INI.format(num_class=4, p=patch, s=target, mirror=str(mirror).lower()))
+    eng = Engine(device=torch.device('cuda', 0), patches_per_forward=3)
+    eng.set_config(str(ini))
+    eng.set_workspace(str(folder))
+    rng = np.random.default_rng(3)
+    raw = (rng.standard_normal((30, 36, 44)) * 300 + 150).astype(np.float32)
+    raw[:2] = 0; raw[:, -4:] = 0
+    got = eng.infer(raw, spacing_raw)
+    assert got.dtype == np.uint8 and got.shape == raw.shape and len(np.unique(got)) >= 2
+
+    # the same model driven through the predictor API with plans that state what the ini states
+    pm = PlansManager(plans_with_engine_config(plans, '3d_fullres', load_engine_config(str(ini))))
+    p = nnUNetPredictor(tile_step_size=0.5, use_gaussian=True, use_mirroring=mirror, device=torch.device('cuda', 0),
+                        allow_tqdm=False, patches_per_forward=3)
+    p.manual_initialization(None, pm, pm.get_configuration('3d_fullres'), [sd], dj, 'nnUNetDistillationTrainer',
+                            (0, 1, 2) if mirror else None)
+    want = p.predict_single_npy_array(raw[None], {'spacing': list(spacing_raw)})
+    assert np.array_equal(got, want)
+    # and not what the untouched plans (3 mm spacing, z-score) would have produced
+    p0 = nnUNetPredictor(tile_step_size=0.5, use_gaussian=True, use_mirroring=mirror, device=torch.device('cuda', 0),
+                         allow_tqdm=False, patches_per_forward=3)
+    p0.initialize_from_trained_model_folder(str(folder), use_folds=(0,))
+    other = p0.predict_single_npy_array(raw[None], {'spacing': list(spacing_raw)})
+    assert other.shape == got.shape and (other != got).mean() > 0.01
+
+
+def test_engine_ini_front_end_rejects_a_model_that_disagrees_with_the_ini(tmp_path):
+    from fast_nnunet_amd.engine_config import Engine
+    patch = (16, 16, 32)
+    folder, *_ = _toy_model_folder(tmp_path, patch, 4, plans_spacing=(1.0, 1.0, 1.0))
+    for kw, err in ((dict(num_class=5, p=patch), 'segmentation heads'), (dict(num_class=4, p=(16, 16, 16)), 'patch size')):
+        ini = tmp_path / 'bad.ini'
+        ini.write_text(_INI.format(s=(1.0, 1.0, 1.0), mirror='false', **kw))
+        eng = Engine(device=torch.device('cuda', 0))
+        eng.set_config(str(ini))
+        with pytest.raises(RuntimeError, match=err):
+            eng.set_workspace(str(folder))

@@ -208,3 +208,83 @@ def test_student_reduction_rule():
     assert spec_from_plans('PlainConvUNet', kw, 1, 61, (160, 96, 96), reduction=2).features == [16, 32, 64, 128, 160, 160]
     assert spec_from_plans('PlainConvUNet', kw, 1, 61, (160, 96, 96), reduction=8).features == [8, 8, 16, 32, 40, 40]
     assert spec_from_plans('PlainConvUNet', kw, 1, 61, (160, 96, 96), reduction=1).features == [32, 64, 128, 256, 320, 320]
+
+
+# ---- engine .ini front-end (SURVEY.md 8 f-4; keys of the reference's engine/config/fast_nnunet_bone_turbo.ini)
+ENGINE_INI = """[model]
+file_name = fast_nnunet_bone_turbo.trt
+input_name = input
+output_name = output
+num_class = 61
+
+[input]
+depth = 160
+height = 96
+width = 96
+patch_size = 160, 96, 96
+target_spacing = 2.0, 0.9765625, 0.9765625
+
+[preprocessing]
+mean = 418.6798400878906
+std_dev = 412.1883239746094
+lower_bound = -60.0
+upper_bound = 3068.0
+
+[inference]
+use_mirroring = false
+step_size = 0.5
+use_gaussian = true
+"""
+
+
+def test_engine_ini_is_read_like_the_reference_config(tmp_path):
+    from fast_nnunet_amd.engine_config import load_engine_config, plans_with_engine_config
+    from fast_nnunet_amd.plans import PlansManager
+    path = tmp_path / 'fast_nnunet_bone_turbo.ini'
+    path.write_text(ENGINE_INI)
+    cfg = load_engine_config(str(path))
+    assert cfg.num_class == 61 and cfg.patch_size == [160, 96, 96]
+    assert cfg.target_spacing == [2.0, 0.9765625, 0.9765625]
+    assert (cfg.mean, cfg.std_dev, cfg.lower_bound, cfg.upper_bound) == (418.6798400878906, 412.1883239746094, -60.0, 3068.0)
+    assert cfg.use_mirroring is False and cfg.use_gaussian is True and cfg.step_size == 0.5
+    # the ini overrides what the plans say about spacing and normalisation, and nothing else
+    plans = {'configurations': {'3d_fullres': {'patch_size': [160, 96, 96], 'spacing': [1.0, 1.0, 1.0],
+                                               'normalization_schemes': ['ZScoreNormalization'], 'batch_size': 2,
+                                               'architecture': {'network_class_name': 'PlainConvUNet', 'arch_kwargs': {},
+                                                                '_kw_requires_import': []}}},
+             'foreground_intensity_properties_per_channel': {'0': {'mean': 1.0, 'std': 2.0, 'median': 7.0}}}
+    pm = PlansManager(plans_with_engine_config(plans, '3d_fullres', cfg))
+    cm = pm.get_configuration('3d_fullres')
+    assert cm.spacing == cfg.target_spacing and cm.normalization_schemes == ['CTNormalization'] and cm.batch_size == 2
+    ip = pm.foreground_intensity_properties_per_channel['0']
+    assert (ip['mean'], ip['std'], ip['percentile_00_5'], ip['percentile_99_5'], ip['median']) == \
+        (cfg.mean, cfg.std_dev, cfg.lower_bound, cfg.upper_bound, 7.0)
+    assert plans['configurations']['3d_fullres']['spacing'] == [1.0, 1.0, 1.0]          # the input is not mutated
+
+
+@pytest.mark.parametrize('old, new, err', [
+    ('depth = 160', 'depth = 128', 'disagrees with patch_size'),
+    ('step_size = 0.5', 'step_size = 0', 'step_size'),
+    ('use_gaussian = true', 'use_gaussian = maybe', 'use_gaussian'),
+    ('[preprocessing]', '[preprocessing_x]', r'section \[preprocessing\] is missing'),
+    ('target_spacing = 2.0, 0.9765625, 0.9765625', 'target_spacing = 2.0, 1.0', 'target_spacing'),
+    ('std_dev = 412.1883239746094', 'std_dev = 0', 'std_dev'),
+])
+def test_engine_ini_errors(tmp_path, old, new, err):
+    from fast_nnunet_amd.engine_config import load_engine_config
+    assert old in ENGINE_INI
+    path = tmp_path / 'bad.ini'
+    path.write_text(ENGINE_INI.replace(old, new))
+    with pytest.raises(ValueError, match=err):
+        load_engine_config(str(path))
+    with pytest.raises(FileNotFoundError):
+        load_engine_config(str(tmp_path / 'absent.ini'))
+
+
+def test_engine_front_end_call_order():
+    from fast_nnunet_amd.engine_config import Engine
+    e = Engine(device=torch.device('cuda'))
+    with pytest.raises(RuntimeError, match='set_config'):
+        e.set_workspace('/nonexistent')
+    with pytest.raises(RuntimeError, match='set_workspace'):
+        e.infer(np.zeros((4, 4, 4), np.float32), (1, 1, 1))
