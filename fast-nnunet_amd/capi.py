@@ -59,7 +59,7 @@ class Profile(C.Structure):
 
 EXPORTS = ['fnn_abi_version', 'fnn_last_error', 'fnn_create', 'fnn_destroy', 'fnn_weight_count', 'fnn_load_weights',
            'fnn_set_gaussian', 'fnn_predict_volume', 'fnn_predict_volume_ensemble', 'fnn_predict_labels',
-           'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_resample', 'fnn_compute_steps', 'fnn_plan_volume',
+           'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_export_probabilities', 'fnn_resample', 'fnn_compute_steps', 'fnn_plan_volume',
            'fnn_set_profiling', 'fnn_get_profile', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d']
 
 _lib = None
@@ -104,6 +104,8 @@ def load_library() -> C.CDLL:
     lib.fnn_nonzero_bbox.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64), vp]
     lib.fnn_preprocess.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64), C.POINTER(NormDesc), vp, vp]
     lib.fnn_revert_labels.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), vp, vp]
+    lib.fnn_export_probabilities.argtypes = [vp, i32, i32, C.POINTER(C.c_int32), C.POINTER(i64), C.POINTER(i64),
+                                             C.POINTER(i32), vp, vp, i32, vp]
     lib.fnn_resample.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(ResampleDesc), vp, vp]
     lib.fnn_compute_steps.argtypes = [i64, i64, C.c_double, C.POINTER(i64), i32]
     lib.fnn_plan_volume.argtypes = [C.POINTER(C.c_int32), C.POINTER(i64), C.c_double, C.POINTER(i64), C.POINTER(i64),
@@ -189,6 +191,21 @@ def revert_labels(seg_ptr: int, uint16: bool, bbox, shape_before_cropping, trans
     check(lib.fnn_revert_labels(seg_ptr, FNN_LABEL_U16 if uint16 else FNN_LABEL_U8, flat,
                                 (C.c_int64 * 3)(*[int(i) for i in shape_before_cropping]),
                                 (C.c_int32 * 3)(*[int(i) for i in transpose_backward]), out_ptr, stream), lib)
+
+
+def export_probabilities(logits_ptr: int, half: bool, heads: int, regions_class_order, bbox, shape_before_cropping,
+                         transpose_backward, probs_ptr: int, labels_ptr: int, uint16: bool, stream: int = 0):
+    """Probabilities + labels on the original grid from logits of the cropped grid (export_prediction.py:36-70)."""
+    lib = load_library()
+    order = None
+    if regions_class_order is not None:
+        assert len(regions_class_order) == heads
+        order = (C.c_int32 * heads)(*[int(c) for c in regions_class_order])
+    flat = (C.c_int64 * 6)(*[int(v) for ab in bbox for v in ab])
+    check(lib.fnn_export_probabilities(logits_ptr, FNN_OUT_F16 if half else FNN_OUT_F32, int(heads), order, flat,
+                                       (C.c_int64 * 3)(*[int(i) for i in shape_before_cropping]),
+                                       (C.c_int32 * 3)(*[int(i) for i in transpose_backward]), probs_ptr, labels_ptr,
+                                       FNN_LABEL_U16 if uint16 else FNN_LABEL_U8, stream), lib)
 
 
 def resample(in_ptr: int, shape, new_shape, order: int, separate_axis, half: bool, out_ptr: int, stream: int = 0, order_z: int = 0):

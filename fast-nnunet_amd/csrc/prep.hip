@@ -207,6 +207,52 @@ __global__ __launch_bounds__(256) void revert_kernel(const LT *seg, long long lo
     out[i] = v;
 }
 
+// ---- logits [H][b0][b1][b2] (transposed, cropped grid) -> probabilities [H][s0][s1][s2] + labels [s0][s1][s2] on the
+// original grid: apply_inference_nonlin (fp32 softmax over the heads / sigmoid for regions), the label rule on the
+// probabilities, both reverted croppings (background probability 1 outside the box for plain labels), transposes back.
+// expf / the division follow the device's fp32 library: probabilities agree with torch's CPU softmax to ~1e-7.
+template <typename IT, typename LT>
+__global__ __launch_bounds__(256) void export_prob_kernel(const IT *logits, int H, const int *order, long long lo0, long long lo1,
+                                                          long long lo2, long long e0, long long e1, long long e2, long long o0,
+                                                          long long o1, long long o2, int tb0, int tb1, int tb2, float *probs,
+                                                          LT *labels) {
+    const long long n = o0 * o1 * o2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long oc[3] = {i / (o1 * o2), (i / o2) % o1, i % o2};
+    long long t[3];
+    t[tb0] = oc[0]; t[tb1] = oc[1]; t[tb2] = oc[2];
+    const long long d0 = t[0] - lo0, d1 = t[1] - lo1, d2 = t[2] - lo2;
+    if (!(d0 >= 0 && d0 < e0 && d1 >= 0 && d1 < e1 && d2 >= 0 && d2 < e2)) {
+        for (int h = 0; h < H; ++h) probs[(size_t)h * n + i] = (!order && h == 0) ? 1.f : 0.f;
+        labels[i] = 0;
+        return;
+    }
+    const size_t plane = (size_t)e0 * e1 * e2, v = ((size_t)d0 * e1 + d1) * e2 + d2;
+    if (order) {
+        int seg = 0;
+        for (int h = 0; h < H; ++h) {
+            const float x = (float)logits[h * plane + v];
+            const float pr = 1.f / (1.f + expf(-x));
+            probs[(size_t)h * n + i] = pr;
+            if (pr > 0.5f) seg = order[h];
+        }
+        labels[i] = (LT)seg;
+        return;
+    }
+    float mx = (float)logits[v];
+    for (int h = 1; h < H; ++h) mx = fmaxf(mx, (float)logits[h * plane + v]);
+    float sum = 0.f;
+    for (int h = 0; h < H; ++h) sum += expf((float)logits[h * plane + v] - mx);
+    float best = -1.f; int arg = 0;
+    for (int h = 0; h < H; ++h) {
+        const float pr = expf((float)logits[h * plane + v] - mx) / sum;
+        probs[(size_t)h * n + i] = pr;
+        if (pr > best) { best = pr; arg = h; }                   // first maximum wins (numpy / torch argmax)
+    }
+    labels[i] = (LT)arg;
+}
+
 static int check_perm(const int32_t t[3]) {
     int seen = 0;
     for (int i = 0; i < 3; ++i) { if (t[i] < 0 || t[i] > 2) return -1; seen |= 1 << t[i]; }
@@ -368,6 +414,49 @@ int fnn_revert_labels(const void *seg, int label_dtype, const int64_t bbox[6], c
                            o[0], o[1], o[2], transpose_backward[0], transpose_backward[1], transpose_backward[2], (uint8_t *)out);
     hipError_t r = hipGetLastError();
     if (r == hipSuccess) r = hipStreamSynchronize(st);
+    if (r != hipSuccess) return fail_msg(FNN_E_HIP, hipGetErrorString(r));
+    return FNN_OK;
+}
+
+int fnn_export_probabilities(const void *logits, int logits_dtype, int heads, const int32_t *regions_class_order,
+                             const int64_t bbox[6], const int64_t shape_before_cropping[3],
+                             const int32_t transpose_backward[3], float *probs, void *labels, int label_dtype, void *stream) {
+    if (!logits || !bbox || !shape_before_cropping || !transpose_backward || !probs || !labels) return fail_msg(FNN_E_INVALID, "NULL argument");
+    if (check_perm(transpose_backward) != 0) return fail_msg(FNN_E_INVALID, "transpose_backward is not a permutation of (0, 1, 2)");
+    if (label_dtype != FNN_LABEL_U8 && label_dtype != FNN_LABEL_U16) return fail_msg(FNN_E_INVALID, "unknown label dtype");
+    if (logits_dtype != FNN_OUT_F16 && logits_dtype != FNN_OUT_F32) return fail_msg(FNN_E_INVALID, "unknown logits dtype");
+    if (heads < 1 || heads > 4096) return fail_msg(FNN_E_INVALID, "bad number of heads");
+    if (!dev_ptr(logits) || !dev_ptr(probs) || !dev_ptr(labels)) return fail_msg(FNN_E_INVALID, "fnn_export_probabilities needs device pointers (no CPU path)");
+    long long lo[3], ext[3], o[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = bbox[2 * a]; ext[a] = bbox[2 * a + 1] - bbox[2 * a];
+        if (lo[a] < 0 || ext[a] < 1 || bbox[2 * a + 1] > shape_before_cropping[a]) return fail_msg(FNN_E_INVALID, "bbox outside shape_before_cropping");
+    }
+    for (int j = 0; j < 3; ++j) o[j] = shape_before_cropping[transpose_backward[j]];
+    const long long n = o[0] * o[1] * o[2];
+    hipStream_t st = (hipStream_t)stream;
+    int *order = nullptr;
+    hipError_t r = hipSuccess;
+    if (regions_class_order) {
+        if (hipMalloc((void **)&order, heads * sizeof(int)) != hipSuccess) return fail_msg(FNN_E_HIP, "hipMalloc failed");
+        r = hipMemcpyAsync(order, regions_class_order, heads * sizeof(int), hipMemcpyHostToDevice, st);
+    }
+    const dim3 grid((unsigned)((n + 255) / 256));
+    const int tb0 = transpose_backward[0], tb1 = transpose_backward[1], tb2 = transpose_backward[2];
+#define FNN_EXPORT_LAUNCH(IT, LT)                                                                                              \
+    hipLaunchKernelGGL((export_prob_kernel<IT, LT>), grid, dim3(256), 0, st, (const IT *)logits, heads, order, lo[0], lo[1],   \
+                       lo[2], ext[0], ext[1], ext[2], o[0], o[1], o[2], tb0, tb1, tb2, probs, (LT *)labels)
+    if (r == hipSuccess) {
+        if (logits_dtype == FNN_OUT_F16) {
+            if (label_dtype == FNN_LABEL_U16) FNN_EXPORT_LAUNCH(_Float16, uint16_t); else FNN_EXPORT_LAUNCH(_Float16, uint8_t);
+        } else {
+            if (label_dtype == FNN_LABEL_U16) FNN_EXPORT_LAUNCH(float, uint16_t); else FNN_EXPORT_LAUNCH(float, uint8_t);
+        }
+        r = hipGetLastError();
+    }
+#undef FNN_EXPORT_LAUNCH
+    if (r == hipSuccess) r = hipStreamSynchronize(st);
+    if (order) (void)hipFree(order);
     if (r != hipSuccess) return fail_msg(FNN_E_HIP, hipGetErrorString(r));
     return FNN_OK;
 }

@@ -246,14 +246,14 @@ class nnUNetPredictor(object):
         predict_from_raw_data.py:423-468 with every step on the device: ``DevicePreprocessor.run_case_npy``
         (transpose, crop, normalise, resample), the sliding window, then
         ``convert_predicted_logits_to_segmentation_with_correct_shape`` (export_prediction.py:16-53).  When the case
-        needs no resampling the labels are taken straight from the accumulators (no logits are materialised)."""
+        needs no resampling the labels are taken straight from the accumulators (no logits are materialised).
+        ``save_or_return_probabilities=True`` returns ``(labels, float32 probabilities [heads, s0, s1, s2])`` like the
+        reference (softmax / sigmoid, background probability 1 outside the crop box)."""
         from .preprocess import DevicePreprocessor
         if segmentation_previous_stage is not None:
             raise NotImplementedError('cascade input (one-hot previous-stage segmentation) is not implemented on the device')
         if output_file_truncated is not None:
             raise NotImplementedError('image file export is the caller\'s side (SURVEY.md 8: image I/O out of scope)')
-        if save_or_return_probabilities:
-            raise NotImplementedError('returning probabilities is not implemented: label maps only')
         pp = DevicePreprocessor(self.device, verbose=self.verbose)
         props = dict(image_properties)
         if self.verbose:
@@ -262,19 +262,24 @@ class nnUNetPredictor(object):
                                          self.dataset_json)
         if self.verbose:
             print('predicting')
-        if tuple(data.shape[1:]) == tuple(props['shape_after_cropping_and_before_resampling']):
+        u16 = len(self.label_manager.foreground_labels) >= 255
+        same_grid = tuple(data.shape[1:]) == tuple(props['shape_after_cropping_and_before_resampling'])
+        if same_grid and not save_or_return_probabilities:
             seg = self.predict_segmentation_from_preprocessed_data(data)
             out = pp.revert_labels(seg, props, self.plans_manager, self.label_manager)
-        else:
-            self._check_input(data)
-            with torch.cuda.device(self.device):
-                logits = torch.empty((self._spec.num_heads, *data.shape[1:]), dtype=torch.half, device=self.device)
-                self._engine.predict_volume(data.data_ptr(), data.shape, self._opts(), logits.data_ptr(), n_folds=self._n_folds)
-            if self.verbose:
-                print('resampling to original shape')
-            out = pp.convert_predicted_logits_to_segmentation_with_correct_shape(logits, self, self.plans_manager,
-                                                                                 self.configuration_manager, props)
-        u16 = len(self.label_manager.foreground_labels) >= 255
+            return out.cpu().numpy().astype(np.uint16 if u16 else np.uint8)
+        self._check_input(data)
+        with torch.cuda.device(self.device):
+            logits = torch.empty((self._spec.num_heads, *data.shape[1:]), dtype=torch.half, device=self.device)
+            self._engine.predict_volume(data.data_ptr(), data.shape, self._opts(), logits.data_ptr(), n_folds=self._n_folds)
+        if self.verbose:
+            print('resampling to original shape')
+        if save_or_return_probabilities:
+            out, probs = pp.convert_predicted_logits_to_segmentation_and_probabilities(
+                logits, self, self.plans_manager, self.configuration_manager, props)
+            return out.cpu().numpy().astype(np.uint16 if u16 else np.uint8), probs.cpu().numpy()
+        out = pp.convert_predicted_logits_to_segmentation_with_correct_shape(logits, self, self.plans_manager,
+                                                                             self.configuration_manager, props)
         return out.cpu().numpy().astype(np.uint16 if u16 else np.uint8)
 
     def _label_rule(self):

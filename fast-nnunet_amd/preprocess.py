@@ -151,6 +151,39 @@ class DevicePreprocessor:
         return self.revert_labels(seg, properties_dict, plans_manager, predictor.label_manager)
 
     @torch.inference_mode()
+    def convert_predicted_logits_to_segmentation_and_probabilities(self, predicted_logits: torch.Tensor, predictor,
+                                                                   plans_manager, configuration_manager,
+                                                                   properties_dict: dict) -> Tuple[torch.Tensor, torch.Tensor]:
+        """export_prediction.py:16-70 with ``return_probabilities=True``: -> (label map, float32 probabilities
+        ``[heads, s0, s1, s2]``), both on the original image grid, both on the device."""
+        spacing_transposed = [properties_dict['spacing'][i] for i in plans_manager.transpose_forward]
+        target = list(configuration_manager.spacing)
+        cropped = [int(i) for i in properties_dict['shape_after_cropping_and_before_resampling']]
+        current_spacing = target if len(target) == len(cropped) else [spacing_transposed[0], *target]
+        kw = getattr(configuration_manager, 'resampling_fn_probabilities_kwargs', None) or \
+            {'is_seg': False, 'order': 1, 'order_z': 0, 'force_separate_z': None}
+        logits = predicted_logits
+        if [int(i) for i in logits.shape[1:]] != cropped:
+            logits = self.resample(logits, cropped, current_spacing, spacing_transposed, kw)
+        order, u16 = predictor._label_rule()
+        with torch.cuda.device(self.device):
+            lg = logits.to(self.device)
+            if lg.dtype not in (torch.half, torch.float32):
+                lg = lg.float()
+            lg = lg.contiguous()
+            before = [int(i) for i in properties_dict['shape_before_cropping']]
+            tb = [int(i) for i in plans_manager.transpose_backward]
+            grid = [before[j] for j in tb]
+            probs = torch.empty((lg.shape[0], *grid), dtype=torch.float32, device=self.device)
+            labels = torch.empty(grid, dtype=torch.int16 if u16 else torch.uint8, device=self.device)
+            capi.export_probabilities(lg.data_ptr(), lg.dtype == torch.half, lg.shape[0], order,
+                                      properties_dict['bbox_used_for_cropping'], before, tb, probs.data_ptr(),
+                                      labels.data_ptr(), u16, self._stream())
+            if u16:
+                labels = labels.to(torch.int32) & 0xffff
+        return labels, probs
+
+    @torch.inference_mode()
     def revert_labels(self, segmentation: torch.Tensor, properties: dict, plans_manager, label_manager) -> torch.Tensor:
         """Cropped label map (uint8, or the int32-carried uint16 of the predictor) -> the original image grid."""
         u16 = len(label_manager.foreground_labels) >= 255                      # export_prediction.py:45-46

@@ -215,6 +215,18 @@ int fnn_revert_labels(const void *seg, int label_dtype, const int64_t bbox[6],
                       const int64_t shape_before_cropping[3], const int32_t transpose_backward[3],
                       void *out, void *stream);
 
+/* convert_predicted_logits_to_segmentation_with_correct_shape(..., return_probabilities=True)
+ * after its resampling step (inference/export_prediction.py:36-70): logits [heads][bbox
+ * extents] (FNN_OUT_F16 / FNN_OUT_F32) -> apply_inference_nonlin (fp32 softmax over the heads;
+ * sigmoid when regions_class_order != NULL, label_handling.py:125-139), the label rule on the
+ * probabilities (:163-181), revert_cropping_on_probabilities (:197-221: background probability
+ * 1 outside the box for plain labels, 0 for regions), both transposes back.
+ * probs: float32 [heads][shape_before_cropping[transpose_backward[j]]]; labels: the same grid. */
+int fnn_export_probabilities(const void *logits, int logits_dtype, int heads,
+                             const int32_t *regions_class_order, const int64_t bbox[6],
+                             const int64_t shape_before_cropping[3], const int32_t transpose_backward[3],
+                             float *probs, void *labels, int label_dtype, void *stream);
+
 /* resample_data_or_seg(..., is_seg=False) of the reference
  * (preprocessing/resampling/default_resampling.py:113-196): per channel
  * skimage.transform.resize(order, mode='edge', anti_aliasing=False) - evaluated as

@@ -99,3 +99,31 @@ def revert_labels(seg: np.ndarray, bbox: Sequence[Sequence[int]], shape_before_c
     full = np.zeros(tuple(shape_before_cropping), dtype=np.uint8 if n_foreground_labels < 255 else np.uint16)
     full[tuple(slice(lo, hi) for lo, hi in bbox)] = seg
     return full.transpose(list(transpose_backward))
+
+
+def export_with_probabilities(logits: np.ndarray, bbox: Sequence[Sequence[int]], shape_before_cropping: Sequence[int],
+                              transpose_backward: Sequence[int], n_foreground_labels: int,
+                              regions_class_order: Optional[Sequence[int]] = None):
+    """export_prediction.py:36-70 with ``return_probabilities=True`` on logits of the cropped grid (after the
+    resampling step): ``apply_inference_nonlin`` (label_handling.py:125-139: fp32 softmax over the heads, sigmoid
+    for regions), the label rule ON THE PROBABILITIES (``convert_probabilities_to_segmentation``,
+    label_handling.py:163-181), revert cropping of the labels (zeros outside the box) and of the probabilities
+    (``revert_cropping_on_probabilities``, label_handling.py:197-221: background probability 1 outside the box for
+    plain labels, all zeros for regions), transposes back.  -> (segmentation, float32 probabilities)."""
+    import torch
+    lg = torch.from_numpy(np.asarray(logits)).float()
+    if regions_class_order is None:
+        probs = torch.softmax(lg, 0)
+        seg = probs.argmax(0).numpy()
+    else:
+        probs = torch.sigmoid(lg)
+        seg = np.zeros(probs.shape[1:], np.int64)
+        for i, c in enumerate(regions_class_order):
+            seg[(probs[i] > 0.5).numpy()] = c
+    probs = probs.numpy()
+    seg_full = revert_labels(seg, bbox, shape_before_cropping, transpose_backward, n_foreground_labels)
+    full = np.zeros((probs.shape[0], *shape_before_cropping), np.float32)
+    if regions_class_order is None:
+        full[0] = 1
+    full[(slice(None), *[slice(lo, hi) for lo, hi in bbox])] = probs
+    return seg_full, full.transpose([0] + [i + 1 for i in transpose_backward])

@@ -290,3 +290,23 @@ RESAMPLE_LOGIC_CASES = [
     ((7, 9, 5), (1.0, 1.0, 2.5), (2.0, 1.0, 1.0), None),               # round-half-even in compute_new_shape
     ((101, 51, 7), (1.0, 1.0, 2.5), (2.0, 1.0, 1.0), None),
 ]
+
+
+# ---- export with probabilities (export_prediction.py:16-70 with return_probabilities=True, no resampling): export.npz
+EXPORT_CASES = [
+    dict(name='labels_transposed', dataset='two_mod', cropped=(10, 12, 9), bbox=[[2, 12], [1, 13], [3, 12]],
+         before=(14, 15, 13), tf=(2, 0, 1), seed=1),
+    dict(name='regions_identity', dataset='regions', cropped=(8, 9, 10), bbox=[[0, 8], [2, 11], [1, 11]],
+         before=(8, 12, 11), tf=(0, 1, 2), seed=2),
+    dict(name='labels_no_crop', dataset='labels3', cropped=(6, 7, 8), bbox=[[0, 6], [0, 7], [0, 8]],
+         before=(6, 7, 8), tf=(1, 2, 0), seed=3),
+]
+
+
+def export_case_logits(case, heads):
+    """fp16 logits [heads, *cropped] with a few exact ties between heads."""
+    import numpy as np
+    rng = np.random.default_rng(6000 + case['seed'])
+    x = (rng.standard_normal((heads, *case['cropped'])) * 3).astype(np.float16)
+    x[1, 0] = x[0, 0]                                           # ties: the first maximum wins
+    return x

@@ -220,6 +220,43 @@ def gen_preprocess():
     print('preprocess', {k: v.shape for k, v in arrays.items() if k.endswith('__data')})
 
 
+def gen_export():
+    """convert_predicted_logits_to_segmentation_with_correct_shape(..., return_probabilities=True) on logits that need
+    no resampling (the resize itself is skimage's, absent here): apply_inference_nonlin, the label rule on the
+    probabilities, revert cropping of labels and probabilities (background probability 1 outside the box for plain
+    labels, 0 for regions), both transposes back."""
+    from golden_cases import EXPORT_CASES, export_case_logits
+    from nnunetv2.inference.export_prediction import convert_predicted_logits_to_segmentation_with_correct_shape
+    arrays = {}
+    for case in EXPORT_CASES:
+        dj = DATASET_JSONS[case['dataset']]
+        tf = list(case['tf'])
+        tb = [int(i) for i in np.argsort(tf)]
+        plans = {'dataset_name': 'Dataset998_Export', 'plans_name': 'nnUNetPlans', 'transpose_forward': tf,
+                 'transpose_backward': tb, 'label_manager': 'LabelManager',
+                 'configurations': {'3d_fullres': {
+                     'patch_size': [8, 8, 8], 'spacing': [1.0, 1.0, 1.0],
+                     'resampling_fn_probabilities': 'resample_data_or_seg_to_shape',
+                     'resampling_fn_probabilities_kwargs': {'is_seg': False, 'order': 1, 'order_z': 0, 'force_separate_z': None},
+                     'architecture': {'network_class_name': 'x', 'arch_kwargs': {}, '_kw_requires_import': []}}}}
+        pm = PlansManager(plans)
+        cm = pm.get_configuration('3d_fullres')
+        lm = pm.get_label_manager(dj)
+        logits = export_case_logits(case, lm.num_segmentation_heads)
+        props = {'spacing': [1.0, 1.0, 1.0], 'shape_before_cropping': tuple(case['before']),
+                 'bbox_used_for_cropping': [list(b) for b in case['bbox']],
+                 'shape_after_cropping_and_before_resampling': tuple(case['cropped'])}
+        seg, probs = convert_predicted_logits_to_segmentation_with_correct_shape(
+            torch.from_numpy(logits), pm, cm, lm, props, return_probabilities=True)
+        seg_only = convert_predicted_logits_to_segmentation_with_correct_shape(
+            torch.from_numpy(logits), pm, cm, lm, props, return_probabilities=False)
+        arrays[case['name'] + '__seg'] = np.asarray(seg)
+        arrays[case['name'] + '__seg_from_logits'] = np.asarray(seg_only)
+        arrays[case['name'] + '__probs'] = np.asarray(probs, dtype=np.float32)
+    np.savez_compressed(os.path.join(HERE, 'export.npz'), **arrays)
+    print('export', {k: (v.shape, str(v.dtype)) for k, v in arrays.items()})
+
+
 def gen_resample_logic():
     from golden_cases import RESAMPLE_LOGIC_CASES
     from nnunetv2.preprocessing.resampling.default_resampling import compute_new_shape, determine_do_sep_z_and_axis
@@ -236,7 +273,7 @@ def gen_resample_logic():
 if __name__ == '__main__':
     if len(sys.argv) > 1:                                   # regenerate single fixtures: labels, plans
         for what in sys.argv[1:]:
-            {'labels': gen_label_rules, 'plans': gen_plans, 'sw2d': gen_sliding_window_2d, 'prep': gen_preprocess, 'resample': gen_resample_logic}[what]()
+            {'labels': gen_label_rules, 'plans': gen_plans, 'sw2d': gen_sliding_window_2d, 'prep': gen_preprocess, 'resample': gen_resample_logic, 'export': gen_export}[what]()
         sys.exit(0)
     gen_label_rules()
     gen_steps()
@@ -247,4 +284,5 @@ if __name__ == '__main__':
     gen_sliding_window_2d()
     gen_preprocess()
     gen_resample_logic()
+    gen_export()
     print('golden vectors written to', HERE)

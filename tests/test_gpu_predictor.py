@@ -621,6 +621,16 @@ def test_predict_single_npy_array_matches_the_oracle_chain(spacing_raw, spacing_
     assert mismatch == 0.0 if list(new_shape) == list(data.shape[1:]) else mismatch < 5e-3
     assert len(np.unique(got)) >= 2
 
+    # save_or_return_probabilities=True: (labels, fp32 probabilities) on the raw grid, like the reference's export
+    seg2, probs = p.predict_single_npy_array(raw, {'spacing': list(spacing_raw)}, save_or_return_probabilities=True)
+    want_seg2, want_probs = opre.export_with_probabilities(back, bbox, before, tb, spec.num_heads - 1)
+    assert probs.dtype == np.float32 and probs.shape == (spec.num_heads, *raw.shape[1:])
+    assert np.abs(probs.sum(0) - 1).max() < 1e-5
+    assert (seg2 != got).mean() < 1e-4                         # argmax of probabilities vs argmax of logits: ties only
+    same = list(new_shape) == list(data.shape[1:])
+    assert np.abs(probs - want_probs).mean() < (1e-6 if same else 2e-3)
+    assert (seg2 != want_seg2).mean() < (1e-4 if same else 5e-3)
+
 
 # ---------------------------------------------------------------------------------------------------------------
 # engine .ini front-end: set_config -> set_workspace -> infer, the call order of the

@@ -202,3 +202,56 @@ def test_masked_zscore_with_a_maze_of_background():
     outside = ~opre.filled_nonzero_mask(raw)
     assert outside.sum() > 1000 and (g[0][outside] == 0).all() and (want[0][outside] == 0).all()
     assert (g[0][~outside] == 0).sum() <= 1 and (want[0][~outside] == 0).sum() <= 1
+
+
+# ---- f-3 with return_probabilities=True (export_prediction.py:36-70)
+@pytest.mark.parametrize('half', [True, False])
+def test_export_probabilities_match_reference_golden(golden_dir, half):
+    """Probabilities and labels on the original grid against vectors made by the reference's
+    convert_predicted_logits_to_segmentation_with_correct_shape(..., return_probabilities=True).  The device's expf and
+    division are not torch's CPU kernels: probabilities within 5e-7; labels equal wherever the top two reference
+    probabilities differ by more than that (and in the crafted exact ties, where the first maximum wins)."""
+    from golden_cases import DATASET_JSONS, EXPORT_CASES, export_case_logits
+    from fast_nnunet_amd import capi
+    from fast_nnunet_amd.plans import LabelManager
+    z = np.load(os.path.join(golden_dir, 'export.npz'))
+    for case in EXPORT_CASES:
+        dj = DATASET_JSONS[case['dataset']]
+        lm = LabelManager(dj['labels'], dj.get('regions_class_order'))
+        H = lm.num_segmentation_heads
+        logits = export_case_logits(case, H)
+        lg = torch.from_numpy(logits).cuda()
+        if not half:
+            lg = lg.float()
+        tb = [int(i) for i in np.argsort(case['tf'])]
+        grid = [case['before'][j] for j in tb]
+        probs = torch.empty((H, *grid), dtype=torch.float32, device='cuda')
+        labels = torch.empty(grid, dtype=torch.uint8, device='cuda')
+        capi.export_probabilities(lg.data_ptr(), half, H, dj.get('regions_class_order'), case['bbox'], case['before'], tb,
+                                  probs.data_ptr(), labels.data_ptr(), False, torch.cuda.current_stream().cuda_stream)
+        got_p, got_l = probs.cpu().numpy(), labels.cpu().numpy()
+        ref_p, ref_l = z[case['name'] + '__probs'], z[case['name'] + '__seg']
+        assert np.abs(got_p - ref_p).max() <= 5e-7, case['name']
+        if dj.get('regions_class_order') is None:
+            top2 = np.sort(ref_p, 0)[-2:]
+            decided = (top2[1] - top2[0] > 1e-6) | (top2[1] == top2[0])
+        else:
+            decided = (np.abs(ref_p - 0.5) > 1e-6).all(0)
+        assert decided.mean() > 0.99 and np.array_equal(got_l[decided], ref_l[decided]), case['name']
+
+
+def test_export_probabilities_rejects_bad_arguments():
+    from fast_nnunet_amd import capi
+    lg = torch.zeros((2, 4, 4, 4), dtype=torch.half, device='cuda')
+    probs = torch.empty((2, 6, 6, 6), dtype=torch.float32, device='cuda')
+    labels = torch.empty((6, 6, 6), dtype=torch.uint8, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(AssertionError, match='bbox outside'):
+        capi.export_probabilities(lg.data_ptr(), True, 2, None, [[3, 7], [0, 4], [0, 4]], (6, 6, 6), (0, 1, 2), probs.data_ptr(),
+                                  labels.data_ptr(), False, st)
+    with pytest.raises(AssertionError, match='permutation'):
+        capi.export_probabilities(lg.data_ptr(), True, 2, None, [[0, 4], [0, 4], [0, 4]], (6, 6, 6), (0, 1, 1), probs.data_ptr(),
+                                  labels.data_ptr(), False, st)
+    with pytest.raises(AssertionError, match='device pointers'):
+        capi.export_probabilities(np.zeros(128, np.float16).ctypes.data, True, 2, None, [[0, 4], [0, 4], [0, 4]], (6, 6, 6),
+                                  (0, 1, 2), probs.data_ptr(), labels.data_ptr(), False, st)

@@ -229,3 +229,29 @@ def test_resize_restatement_is_the_cubic_spline_it_claims():
                     p[np.ix_(tabs[0][0] + a, tabs[1][0] + b, tabs[2][0] + c)]
     res = np.clip(res, x.min(), x.max())
     assert np.abs(res - ores.skimage_resize(x, out_shape, 3)).max() < 1e-10
+
+
+def test_export_with_probabilities_matches_reference_golden(golden_dir):
+    """f-3 with ``return_probabilities=True``: vectors made by the reference's
+    convert_predicted_logits_to_segmentation_with_correct_shape (no resampling needed)."""
+    from golden_cases import DATASET_JSONS, EXPORT_CASES, export_case_logits
+    from fast_nnunet_amd.plans import LabelManager
+    from oracle import preprocess as opre
+    z = np.load(os.path.join(golden_dir, 'export.npz'))
+    for case in EXPORT_CASES:
+        dj = DATASET_JSONS[case['dataset']]
+        lm = LabelManager(dj['labels'], dj.get('regions_class_order'))
+        logits = export_case_logits(case, lm.num_segmentation_heads)
+        tb = [int(i) for i in np.argsort(case['tf'])]
+        seg, probs = opre.export_with_probabilities(logits, case['bbox'], case['before'], tb, len(lm.foreground_labels),
+                                                    dj.get('regions_class_order'))
+        assert seg.dtype == z[case['name'] + '__seg'].dtype and np.array_equal(seg, z[case['name'] + '__seg']), case['name']
+        ref = z[case['name'] + '__probs']
+        assert probs.shape == ref.shape and probs.dtype == np.float32
+        assert np.abs(probs - ref).max() <= 2e-7, case['name']          # torch's softmax kernel varies with the CPU's ISA
+        outside = np.ones(ref.shape[1:], bool)
+        tf = list(case['tf'])
+        outside_t = np.ones(case['before'], bool)
+        outside_t[tuple(slice(lo, hi) for lo, hi in case['bbox'])] = False
+        outside = outside_t.transpose(tb)
+        assert np.array_equal(probs[:, outside], ref[:, outside])
