@@ -11,7 +11,8 @@ cut into a 3-D grid of rank blocks.  Every rank
 2. exchanges ONLY the overlap regions with the ranks whose boxes intersect its
    own: each voxel of the padded volume has exactly one owner, and every other
    rank that touched it sends its partial sums to the owner (point-to-point over
-   RCCL/xGMI, ``batch_isend_irecv``).  A full-buffer all-reduce would move
+   RCCL/xGMI, ``batch_isend_irecv``).  The patches that touch a region the rank
+   sends run first, so the transfers overlap the rest of its patches;  A full-buffer all-reduce would move
    ~57 GB per GPU for 61 classes on 512^3 (SURVEY.md H6); the halos are a few GB;
 3. normalises and writes the box it owns.
 
@@ -116,6 +117,17 @@ class Decomposition:
                 recvs.append((peer, inc))
         return sends, recvs
 
+    def split_patches(self, rank: int, patch: Sequence[int], origins) -> Tuple[List[int], List[int]]:
+        """-> (boundary, interior) patch ids of `rank` in visiting order: a boundary patch touches a region this
+        rank sends to another rank; once they are accumulated the sends can leave while the interior computes."""
+        sends, _ = self.transfers(rank)
+        boundary, interior = [], []
+        for i in self.patch_ids[rank]:
+            o = [int(v) for v in origins[i]]
+            ext: Box = (tuple(o), tuple(o[d] + patch[d] for d in range(3)))
+            (boundary if any(_intersect(ext, reg) is not None for _, reg in sends) else interior).append(i)
+        return boundary, interior
+
     def halo_voxels(self, rank: int) -> int:
         return sum(int(np.prod([h - l for l, h in zip(*reg)])) for _, reg in self.transfers(rank)[0])
 
@@ -125,30 +137,47 @@ def _view(acc: torch.Tensor, box: Box, region: Box) -> torch.Tensor:
     return acc[sl]
 
 
+class HaloExchange:
+    """The exchange in two halves so that compute can run in between: ``start()`` posts every send and receive
+    (the sends read `acc` as the current stream leaves it - call it once every patch that touches a region this
+    rank sends has been accumulated, see ``Decomposition.split_patches``), ``finish()`` waits and adds the other
+    ranks' contributions to the part of `acc` this rank owns.  `acc` is [bx, by, bz, HP] over ``dec.boxes[rank]``."""
+
+    def __init__(self, acc: torch.Tensor, dec: Decomposition, rank: int, group=None):
+        self.acc, self.dec, self.rank, self.group = acc, dec, rank, group
+        self.reqs, self.landing, self.keep = [], [], []
+
+    def start(self) -> 'HaloExchange':
+        sends, recvs = self.dec.transfers(self.rank)
+        if not sends and not recvs:
+            return self
+        box, group, acc = self.dec.boxes[self.rank], self.group, self.acc
+        ops = []
+        for peer, region in sends:
+            buf = _view(acc, box, region).contiguous()
+            self.keep.append(buf)
+            ops.append(dist.P2POp(dist.isend, buf, dist.get_global_rank(group, peer) if group is not None else peer, group))
+        for peer, region in recvs:
+            shape = tuple(region[1][d] - region[0][d] for d in range(3)) + (acc.shape[3],)
+            buf = torch.empty(shape, dtype=acc.dtype, device=acc.device)
+            ops.append(dist.P2POp(dist.irecv, buf, dist.get_global_rank(group, peer) if group is not None else peer, group))
+            self.landing.append((region, buf))
+        self.reqs = dist.batch_isend_irecv(ops)
+        return self
+
+    def finish(self) -> None:
+        for req in self.reqs:
+            req.wait()
+        box = self.dec.boxes[self.rank]
+        # fixed (peer-rank) order -> the sums are reproducible run to run
+        for region, buf in self.landing:
+            _view(self.acc, box, region).add_(buf)
+        self.reqs, self.landing, self.keep = [], [], []
+
+
 def exchange_halos(acc: torch.Tensor, dec: Decomposition, rank: int, group=None) -> None:
-    """Adds the other ranks' contributions to the part of `acc` this rank owns.  `acc` is
-    [bx, by, bz, HP] over ``dec.boxes[rank]``."""
-    sends, recvs = dec.transfers(rank)
-    if not sends and not recvs:
-        return
-    box = dec.boxes[rank]
-    ops, landing = [], []
-    for peer, region in sends:
-        buf = _view(acc, box, region).contiguous()
-        ops.append(dist.P2POp(dist.isend, buf, dist.get_global_rank(group, peer) if group is not None else peer, group))
-        landing.append(None)
-    for peer, region in recvs:
-        shape = tuple(region[1][d] - region[0][d] for d in range(3)) + (acc.shape[3],)
-        buf = torch.empty(shape, dtype=acc.dtype, device=acc.device)
-        ops.append(dist.P2POp(dist.irecv, buf, dist.get_global_rank(group, peer) if group is not None else peer, group))
-        landing.append((region, buf))
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
-    # fixed (peer-rank) order -> the fp32 sums are reproducible run to run
-    for item in landing:
-        if item is not None:
-            region, buf = item
-            _view(acc, box, region).add_(buf)
+    """Adds the other ranks' contributions to the part of `acc` this rank owns (start + finish in one go)."""
+    HaloExchange(acc, dec, rank, group).start().finish()
 
 
 def unpadded(box: Box, pad_lo: Sequence[int], shape_sp: Sequence[int]) -> Optional[Box]:
@@ -192,9 +221,17 @@ class ShardedPredictor:
                 return out, None
             dims = tuple(box[1][d] - box[0][d] for d in range(3))
             acc = torch.zeros((*dims, eng.accumulator_channels), dtype=acc_dtype, device=p.device)
-            eng.accumulate_patches(x.data_ptr(), x.shape, opts, dec.patch_ids[self.rank], box[0], box[1], acc.data_ptr(),
-                                   fold=p._active_fold)
-            exchange_halos(acc, dec, self.rank, self.group)
+            # patches that feed another rank's box first; their halos travel over xGMI while the interior computes
+            boundary, interior = dec.split_patches(self.rank, patch, origins)
+            hx = HaloExchange(acc, dec, self.rank, self.group)
+            if boundary:
+                eng.accumulate_patches(x.data_ptr(), x.shape, opts, boundary, box[0], box[1], acc.data_ptr(),
+                                       fold=p._active_fold)
+            hx.start()
+            if interior:
+                eng.accumulate_patches(x.data_ptr(), x.shape, opts, interior, box[0], box[1], acc.data_ptr(),
+                                       fold=p._active_fold)
+            hx.finish()
             own = unpadded(dec.owned[self.rank], pad_lo, x.shape[1:])
             if own is not None:
                 eng.normalize_box(acc.data_ptr(), x.shape, opts, box[0], box[1], own[0], own[1], out.data_ptr())

@@ -80,6 +80,27 @@ def test_benchmark_decomposition_is_balanced_and_cheap():
     assert worst < 8.0, worst
 
 
+def test_boundary_patches_are_exactly_those_that_feed_another_rank():
+    from fast_nnunet_amd.dist import Decomposition, _intersect
+    patch = (160, 96, 96)
+    padded, pad_lo, steps = _geometry((512, 512, 512), patch, 0.5)
+    origins = [(x, y, z) for x in steps[0] for y in steps[1] for z in steps[2]]
+    for world in (1, 2, 4, 8):
+        dec = Decomposition.build(patch, padded, steps, world)
+        for r in range(world):
+            boundary, interior = dec.split_patches(r, patch, origins)
+            assert sorted(boundary + interior) == sorted(dec.patch_ids[r]) and not set(boundary) & set(interior)
+            sends = dec.transfers(r)[0]
+            for i in dec.patch_ids[r]:
+                ext = (tuple(origins[i]), tuple(origins[i][d] + patch[d] for d in range(3)))
+                touches = any(_intersect(ext, reg) is not None for _, reg in sends)
+                assert touches == (i in boundary)
+            if world == 1:
+                assert not boundary
+            if world == 8:                       # 3 x 5 x 5 patches per rank, one layer per cut face is boundary
+                assert len(dec.patch_ids[r]) == 75 and len(interior) == 2 * 4 * 4
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -113,7 +134,7 @@ def _worker(rank, world, port, shape, patch, step, heads, q):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        from fast_nnunet_amd.dist import Decomposition, exchange_halos, unpadded
+        from fast_nnunet_amd.dist import Decomposition, HaloExchange, exchange_halos, unpadded
         padded, pad_lo, steps = _geometry(shape, patch, step)
         origins = [(x, y, z) for x in steps[0] for y in steps[1] for z in steps[2]]
         hp = (heads + 1 + 7) // 8 * 8
@@ -122,8 +143,13 @@ def _worker(rank, world, port, shape, patch, step, heads, q):
         box = dec.boxes[rank]
         out = torch.zeros((heads, *shape))
         if box is not None:
-            acc = _accumulate(dec.patch_ids[rank], origins, box, patch, heads, hp, gauss)
-            exchange_halos(acc, dec, rank, None)
+            # the order ShardedPredictor uses: boundary patches, sends leave, interior patches, receives are added
+            boundary, interior = dec.split_patches(rank, patch, origins)
+            assert sorted(boundary + interior) == sorted(dec.patch_ids[rank])
+            acc = _accumulate(boundary, origins, box, patch, heads, hp, gauss)
+            hx = HaloExchange(acc, dec, rank, None).start()
+            acc += _accumulate(interior, origins, box, patch, heads, hp, gauss)
+            hx.finish()
             own = unpadded(dec.owned[rank], pad_lo, shape)
             if own is not None:
                 ob = dec.owned[rank]

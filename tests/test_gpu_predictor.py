@@ -377,7 +377,12 @@ def test_sharded_boxes_through_c_abi_match_single_gpu(world, acc_mode):
         box = dec.boxes[r]
         dims = tuple(box[1][d] - box[0][d] for d in range(3))
         acc = torch.zeros((*dims, hp), dtype=adt, device='cuda')
-        p._engine.accumulate_patches(x.data_ptr(), x.shape, opts, dec.patch_ids[r], box[0], box[1], acc.data_ptr())
+        # ShardedPredictor's order: the patches that feed another rank first, then the interior (two calls)
+        boundary, interior = dec.split_patches(r, patch, origins)
+        assert boundary and sorted(boundary + interior) == sorted(dec.patch_ids[r])
+        for ids in (boundary, interior):
+            if ids:
+                p._engine.accumulate_patches(x.data_ptr(), x.shape, opts, ids, box[0], box[1], acc.data_ptr())
         accs.append(acc)
     torch.cuda.synchronize()
     for r in range(world):                       # local stand-in for exchange_halos
