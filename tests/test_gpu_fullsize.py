@@ -77,3 +77,35 @@ def test_full_size_volume_fp32_accumulators_are_exact_for_the_constant_network()
     out = p.predict_sliding_window_return_logits(vol)
     for h in (0, 2, 30, 60):
         assert torch.equal(out[h], torch.full_like(out[h], float(c[h])))           # c is fp16-representable
+
+
+def test_full_size_volume_is_reproduced_bit_for_bit_with_three_batches_in_flight():
+    """The benchmark network with its random weights: every kernel family of the hot path (stem, persistent thin and
+    strided convs, ZR convs, transposed convs, seg head, finalize) runs next to the other two streams' kernels.  A
+    kernel that is sensitive to what shares its CU ("stem under concurrency") corrupts different
+    voxels every run, so three runs that agree bit for bit - and with a fourth at another batch size, which changes
+    what overlaps what - rule that out."""
+    import bench
+    dev = torch.device('cuda', 0)
+    p, _, _ = bench.build_predictor('bone_turbo_r2', dev, 32, 'fp16')
+    vol = torch.randn((1, 512, 512, 512), generator=torch.Generator().manual_seed(0)).cuda()
+    first = p.predict_sliding_window_return_logits(vol)
+    assert bool(torch.isfinite(first[::7].float()).all())
+    for _ in range(2):
+        again = p.predict_sliding_window_return_logits(vol)
+        assert torch.equal(first, again)
+        del again
+    p.patches_per_forward = 20                    # other batch boundaries (what overlaps what), same kernels per layer
+    other = p.predict_sliding_window_return_logits(vol)
+    assert torch.equal(first, other)
+    del other
+    # an engine PLANNED for another batch size may pick other kernel variants per layer (other summation orders):
+    # same result within the fp16 network tolerance, not bit for bit
+    q, _, _ = bench.build_predictor('bone_turbo_r2', dev, 20, 'fp16')
+    other = q.predict_sliding_window_return_logits(vol)
+    scale = float(first[::5].float().abs().max())
+    m = 16                                                    # away from the subnormal-weight border (module docstring)
+    worst = max(float((first[h, m:-m, m:-m, m:-m].float() - other[h, m:-m, m:-m, m:-m].float()).abs().max())
+                for h in range(0, 61, 6))
+    print(f'planned batch 32 vs 20: max |diff| {worst:.3g} of max |logit| {scale:.3g}')
+    assert worst <= 1e-2 * scale
