@@ -730,7 +730,7 @@ static int launch_pipe(ConvParams p, hipStream_t st) {
 //     runs on the matrix cores; one barrier per item;
 //   * InstanceNorm statistics are kept in registers across the tiles of one
 //     batch item and flushed with one set of atomics per workgroup.
-template <int NB, int MB, bool WRES, int KS, int CH, int PF = 8>
+template <int NB, int MB, bool WRES, int KS, int CH, int PF = 8, bool SBUF = false>
 __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams p, const int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -748,7 +748,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
 
     // WRES: all weight fragments of the cout group stay in LDS, halo tile double buffered (one barrier per
     // item).  !WRES: the weights of one chunk travel with the halo prefetch, single buffers, two barriers.
-    constexpr int NBUF = WRES ? 2 : 1;
+    // SBUF (with WRES): resident weights next to a SINGLE halo buffer - for tiles whose double buffer would not leave
+    // room for two workgroups per CU (the strided full-resolution conv: 37 KB of halo, 28 KB of weights).
+    constexpr int NBUF = (WRES && !SBUF) ? 2 : 1;
     constexpr int WPF = WRES ? 1 : (NB * 14 * 64 + 255) / 256;
     char *sA0 = smem;
     char *sW = smem + NBUF * abytes;                                 // [NB][TS or ksteps][64 lanes][16 B]
@@ -957,7 +959,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
 #ifdef FNN_STAMPS
             if (stamp_it) FNN_STAMP();                           // 1: prefetch issued
 #endif
-            const char *sA = sA0 + (WRES ? buf * abytes : 0);
+            const char *sA = sA0 + (NBUF == 2 ? buf * abytes : 0);
 #pragma unroll
             for (int ks = 0; ks < (KS ? KS : p.ksteps); ++ks) {
                 const int toff = KS ? toffs[ks < 14 ? ks : 0] : sTap[(2 * ks + (lane >> 5)) * 2 + kgp];
@@ -1000,11 +1002,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
                 // commit() is duplicated on purpose: on this path hipcc can wait for the (older) prefetch loads
                 // alone - vmcnt(number of epilogue stores) - instead of vmcnt(0) after a merge point, which would
                 // expose the store acknowledgement latency once per tile
-                if (!WRES) __syncthreads();                      // single buffers: everybody is done reading
-                commit(sA0 + (WRES ? (buf ^ 1) * abytes : 0));
+                if (NBUF == 1) __syncthreads();                  // single buffers: everybody is done reading
+                commit(sA0 + (NBUF == 2 ? (buf ^ 1) * abytes : 0));
             } else {
-                if (!WRES) __syncthreads();
-                commit(sA0 + (WRES ? (buf ^ 1) * abytes : 0));
+                if (NBUF == 1) __syncthreads();
+                commit(sA0 + (NBUF == 2 ? (buf ^ 1) * abytes : 0));
             }
 #ifdef FNN_STAMPS
             if (stamp_it) FNN_STAMP();                           // 3: epilogue + commit done
@@ -1021,13 +1023,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams
     FNN_STAMP_FLUSH(p.dbg);
 }
 
-static size_t persist_lds_bytes(const ConvParams &p, int nb, int mb, bool wres) {
+static size_t persist_lds_bytes(const ConvParams &p, int nb, int mb, bool wres, bool sbuf = false) {
     const int ID = (mb - 1) * p.sd + p.kd, IH = (FNN_TILE_H - 1) * p.sh + p.kh, IW = (FNN_TILE_W - 1) * p.sw + p.kw;
     const size_t ab = (size_t)((ID * IH * (p.sw == 1 ? lds_pitch(IW) : IW) * 32 + 1023) & ~1023);
-    return (wres ? 2 : 1) * ab + (size_t)nb * (wres ? p.chunks : 1) * p.ksteps * 1024 + 256 + (size_t)4 * nb * 16 * 2 * 8;
+    return (wres && !sbuf ? 2 : 1) * ab + (size_t)nb * (wres ? p.chunks : 1) * p.ksteps * 1024 + 256 + (size_t)4 * nb * 16 * 2 * 8;
 }
 
-template <int NB, int MB, bool WRES, int KS, int CH = 0, int PF = 8>
+template <int NB, int MB, bool WRES, int KS, int CH = 0, int PF = 8, bool SBUF = false>
 static int launch_persist_ks(ConvParams p, int wgs_per_cu, hipStream_t st, int gx_exact = 0) {
     p.tile_d = MB;
     p.tiles_d = (p.Do + MB - 1) / MB;
@@ -1036,16 +1038,16 @@ static int launch_persist_ks(ConvParams p, int wgs_per_cu, hipStream_t st, int g
     const int total = p.N * p.tiles_d * p.tiles_h * p.tiles_w;
     p.ident_ss = conv3d_identity_ss();
     if (!p.ident_ss) return -2;
-    const size_t lds = persist_lds_bytes(p, NB, MB, WRES);
+    const size_t lds = persist_lds_bytes(p, NB, MB, WRES, SBUF);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)conv3d_persist_kernel<NB, MB, WRES, KS, CH, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv3d_persist_kernel<NB, MB, WRES, KS, CH, PF, SBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     int gx = gx_exact > 0 ? gx_exact : 256 * wgs_per_cu;
     if (gx > total) gx = total;
     dim3 grid(gx, (p.Cout / 16) / NB);
-    hipLaunchKernelGGL((conv3d_persist_kernel<NB, MB, WRES, KS, CH, PF>), grid, dim3(256), lds, st, p, total);
+    hipLaunchKernelGGL((conv3d_persist_kernel<NB, MB, WRES, KS, CH, PF, SBUF>), grid, dim3(256), lds, st, p, total);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -1199,7 +1201,14 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
             if (!no_sp && nbs == 2 && ID * IH * IW * 2 <= 12 * 256 && persist_lds_bytes(p, 2, 2, false) <= 80 * 1024 &&
                 tiles >= 8LL * (512 / groups) && 512 / groups >= 8) {
                 const int gx = 512 / groups;                       // 2 resident workgroups per CU over all cout groups
-                if (p.chunks == 1) return launch_persist_ks<2, 2, false, 0, 1, 12>(p, 2, st, gx);
+                if (p.chunks == 1) {
+                    // weights resident next to a single halo buffer: the 28 KB of weight fragments no longer travel with
+                    // every 37 KB halo tile (+1 % on the benchmark)
+                    static const bool wres = getenv("FNN_STRIDED_NO_WRES") == nullptr;              // A-B aid
+                    if (wres && persist_lds_bytes(p, 2, 2, true, true) <= 80 * 1024)
+                        return launch_persist_ks<2, 2, true, 0, 1, 12, true>(p, 2, st, gx);
+                    return launch_persist_ks<2, 2, false, 0, 1, 12>(p, 2, st, gx);
+                }
                 // more chunks: the generic (runtime chunk count) form; the unrolled two-chunk variant spilled and lost
                 static const bool sp_single = getenv("FNN_STRIDED_PERSIST_SINGLE") != nullptr;   // A-B aid
                 if (!sp_single) return launch_persist_ks<2, 2, false, 0, 0, 12>(p, 2, st, gx);
