@@ -112,6 +112,11 @@ struct HeadParams {
     int mode;                    // 0 fused accumulate, 1 patch buffer '=', 2 patch buffer '+='
     float *patch_buf;            // [heads][PD*PH*PW] fp32 (modes 1, 2)
     int acc_fp32;
+    // first-visit thresholds: a voxel (d, h, w) of this patch has not been touched by an earlier patch of the volume
+    // when d >= fx && h >= fy && w >= fz (fx = overlap with the previous patch position along x, ...).  Such voxels
+    // are written as 0 + contribution without reading the accumulator, which then needs no zero fill.
+    // INT_MAX = every voxel is read (accumulators that were zeroed or hold other patches' sums).
+    int fx, fy, fz;
 };
 
 struct PatchAccParams {          // patch buffer -> volume accumulators (mirroring path)
@@ -196,6 +201,7 @@ int launch_conv3d_zr(const ConvParams &p, hipStream_t st);
 int launch_stem(const StemParams &p, int N, hipStream_t st);
 int launch_tconv(const TconvParams &p, hipStream_t st);
 int launch_head(const HeadParams &p, hipStream_t st);
+bool launch_head_first_visit_ok(const HeadParams &p);   // does launch_head() honour fx / fy / fz for these parameters?
 int launch_patch_acc(const PatchAccParams &p, hipStream_t st);
 int launch_finalize(const FinalizeParams &p, hipStream_t st);
 int launch_labels_from_acc(const FinalizeParams &p, void *labels, int label_u16, const int *order, hipStream_t st);

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void seg_head_acc1_kernel(const HeadParams p) 
         const bool grp_ok = cb0 + grp * 8 < p.HP;
         // ---- phase A: every address, then every load (accumulator lines, Gaussian weights, activation fragments)
         size_t aelem[RD][4];
-        bool ok[RD][4];
+        bool ok[RD][4], first[RD][4];
         f16 graw[RD][4];
         f16x8 a16[RD][4];
         f32x4 a32[ACC32 ? RD : 1][4][2];
@@ -533,17 +533,22 @@ __global__ __launch_bounds__(256) void seg_head_acc1_kernel(const HeadParams p) 
                 const int vv = v < P ? v : P - 1;
                 const int w = vv % p.PW, h = (vv / p.PW) % p.PH, d = vv / (p.PW * p.PH);
                 aelem[rd][i] = (((size_t)(p.ox + d) * p.Y + (p.oy + h)) * p.Z + (p.oz + w)) * p.HP + cb0 + grp_c * 8;
+                first[rd][i] = d >= p.fx && h >= p.fy && w >= p.fz;     // nobody has written this voxel yet
                 graw[rd][i] = p.gauss[vv];                              // always a map (all ones without Gaussian weighting)
             }
+        // first-visit voxels read one (hot) line of the patch's first voxel instead of their own: the load stays
+        // unconditional (lesson 1 in DESIGN.md) and costs no HBM traffic; its value is discarded below
+        const size_t dummy = (((size_t)p.ox * p.Y + p.oy) * p.Z + p.oz) * p.HP + cb0 + grp_c * 8;
 #pragma unroll
         for (int rd = 0; rd < RD; ++rd)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                const size_t le = first[rd][i] ? dummy : aelem[rd][i];
                 if (ACC32) {
-                    a32[ACC32 ? rd : 0][i][0] = *(const f32x4 *)((const float *)p.acc + aelem[rd][i]);
-                    a32[ACC32 ? rd : 0][i][1] = *(const f32x4 *)((const float *)p.acc + aelem[rd][i] + 4);
-                } else if (NT & 2) a16[rd][i] = __builtin_nontemporal_load((const f16x8 *)((const f16 *)p.acc + aelem[rd][i]));
-                else a16[rd][i] = *(const f16x8 *)((const f16 *)p.acc + aelem[rd][i]);
+                    a32[ACC32 ? rd : 0][i][0] = *(const f32x4 *)((const float *)p.acc + le);
+                    a32[ACC32 ? rd : 0][i][1] = *(const f32x4 *)((const float *)p.acc + le + 4);
+                } else if (NT & 2) a16[rd][i] = __builtin_nontemporal_load((const f16x8 *)((const f16 *)p.acc + le));
+                else a16[rd][i] = *(const f16x8 *)((const f16 *)p.acc + le);
             }
         const int c0 = q * 8 < p.src.C ? q * 8 : 0;
 #pragma unroll
@@ -598,6 +603,7 @@ __global__ __launch_bounds__(256) void seg_head_acc1_kernel(const HeadParams p) 
                 }
                 if (ACC32) {
                     f32x4 b0 = a32[ACC32 ? rd : 0][i][0], b1 = a32[ACC32 ? rd : 0][i][1];
+                    if (first[rd][i]) { b0 = (f32x4){0.f, 0.f, 0.f, 0.f}; b1 = b0; }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         b0[e] = (mask >> e) & 1 ? __fadd_rn(b0[e], c[e]) : b0[e];
@@ -609,6 +615,7 @@ __global__ __launch_bounds__(256) void seg_head_acc1_kernel(const HeadParams p) 
                     }
                 } else {
                     f16x8 bq = a16[rd][i];
+                    if (first[rd][i]) bq = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};      // 0 + c, like the zero-filled accumulator
 #pragma unroll
                     for (int e = 0; e < 8; ++e) bq[e] = (mask >> e) & 1 ? (f16)__fadd_rn((float)bq[e], c[e]) : bq[e];
                     if (ok[rd][i]) {
@@ -620,6 +627,13 @@ __global__ __launch_bounds__(256) void seg_head_acc1_kernel(const HeadParams p) 
             __builtin_amdgcn_wave_barrier();
         }
     }
+}
+
+// Only the vectorised accumulate kernel knows the first-visit thresholds (one k-step: <= 32 input channels).
+bool launch_head_first_visit_ok(const HeadParams &p) {
+    static const bool head_v1 = getenv("FNN_HEAD_V1") != nullptr;
+    static const bool rd1 = getenv("FNN_HEAD_RD") && atoi(getenv("FNN_HEAD_RD")) == 1;
+    return p.mode == 0 && p.ksteps == 1 && !head_v1 && !rd1;
 }
 
 int launch_head(const HeadParams &p, hipStream_t st) {
