@@ -731,7 +731,7 @@ static int launch_pipe(ConvParams p, hipStream_t st) {
 //   * InstanceNorm statistics are kept in registers across the tiles of one
 //     batch item and flushed with one set of atomics per workgroup.
 template <int NB, int MB, bool WRES, int KS, int CH, int PF = 8, bool SBUF = false>
-__global__ __launch_bounds__(256, 2) void conv3d_persist_kernel(const ConvParams p, const int total_tiles) {
+__global__ __launch_bounds__(256, (NB == 1 && MB == 4 && WRES && PF == 4) ? 3 : 2) void conv3d_persist_kernel(const ConvParams p, const int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     FNN_STAMP_DECL
@@ -1055,6 +1055,16 @@ template <int NB, int MB, bool WRES>
 static int launch_persist(const ConvParams &p, int wgs_per_cu, hipStream_t st) {
     // fully unrolled k-loops for the two common tap counts (9 taps = 5 k-steps, 27 taps = 14); only instantiated
     // for the thin single-cout-block layers that the persistent kernel is used for
+    if (NB == 1 && MB == 8 && WRES && p.ksteps == 5 && (p.chunks == 1 || p.chunks == 2)) {
+        // 4-deep tiles with a 4-element prefetch need 138-151 VGPRs and 36 KB of LDS: three workgroups per CU instead
+        // of two - more bytes in flight for these HBM-bound layers (+0.8 % on the benchmark; four would need <= 128)
+        static const bool mb8 = getenv("FNN_THIN_MB8") != nullptr;                                             // A-B aid
+        const int ivox4 = (3 * p.sd + p.kd) * ((FNN_TILE_H - 1) * p.sh + p.kh) * ((FNN_TILE_W - 1) * p.sw + p.kw);
+        if (!mb8 && ivox4 * 2 <= 4 * 256 && persist_lds_bytes(p, 1, 4, true) * 3 <= 160 * 1024) {
+            if (p.chunks == 1) return launch_persist_ks<1, 4, true, 5, (NB == 1 && MB == 8 && WRES ? 1 : 0), (NB == 1 && MB == 8 && WRES ? 4 : 8)>(p, 3, st);
+            return launch_persist_ks<1, 4, true, 5, (NB == 1 && MB == 8 && WRES ? 2 : 0), (NB == 1 && MB == 8 && WRES ? 4 : 8)>(p, 3, st);
+        }
+    }
     if (NB == 1 && MB == 8 && WRES && p.ksteps == 5 && p.chunks == 1) return launch_persist_ks<NB, MB, WRES, (NB == 1 ? 5 : 0), (NB == 1 && MB == 8 && WRES ? 1 : 0)>(p, wgs_per_cu, st);
     if (NB == 1 && MB == 8 && WRES && p.ksteps == 5 && p.chunks == 2) return launch_persist_ks<NB, MB, WRES, (NB == 1 ? 5 : 0), (NB == 1 && MB == 8 && WRES ? 2 : 0)>(p, wgs_per_cu, st);
     if (NB == 1 && p.ksteps == 5) return launch_persist_ks<NB, MB, WRES, (NB == 1 ? 5 : 0)>(p, wgs_per_cu, st);
