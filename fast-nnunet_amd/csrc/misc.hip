@@ -498,8 +498,8 @@ __global__ __launch_bounds__(256) void seg_head_acc_kernel(const HeadParams p) {
 // acknowledged: with the loads of round 1 behind the stores of round 0 (the loop above), every wave waited for a
 // full write round trip in the middle of its life.  Here the only waits are for loads that were issued before any
 // store; the stores of both rounds drain while the wave finishes.
-template <bool ACC32, int RD, int NT = 0>
-__global__ __launch_bounds__(256) void seg_head_acc1_kernel(const HeadParams p) {
+template <bool ACC32, int RD, int NT = 0, int MINB = 1>
+__global__ __launch_bounds__(256, MINB) void seg_head_acc1_kernel(const HeadParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float2 *sSS = (float2 *)smem;
@@ -659,7 +659,13 @@ int launch_head(const HeadParams &p, hipStream_t st) {
                 static const int nt = getenv("FNN_HEAD_NT") ? atoi(getenv("FNN_HEAD_NT")) : 3;      // A-B aid
                 if (nt == 1) hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 1>), grid, dim3(256), lds, st, p);
                 else if (nt == 2) hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 2>), grid, dim3(256), lds, st, p);
-                else if (nt == 3) hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 3>), grid, dim3(256), lds, st, p);
+                else if (nt == 3) {
+                    // two workgroups per SIMD's worth of registers asked for: 177 VGPRs instead of 214 (three: 8 spills, slower)
+                    static const int minb = getenv("FNN_HEAD_MINB") ? atoi(getenv("FNN_HEAD_MINB")) : 2;            // A-B aid
+                    if (minb == 2) hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 3, 2>), grid, dim3(256), lds, st, p);
+                    else if (minb == 3) hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 3, 3>), grid, dim3(256), lds, st, p);
+                    else hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 3>), grid, dim3(256), lds, st, p);
+                }
                 else hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2>), grid, dim3(256), lds, st, p);
             }
         } else if (p.acc_fp32) hipLaunchKernelGGL(seg_head_acc_kernel<true>, grid, dim3(256), lds, st, p);
