@@ -244,9 +244,13 @@ int launch_tconv(const TconvParams &p, hipStream_t st) {
     const int vox_in = p.Di * p.Hi * p.Wi;
     const int taps = p.sd * p.sh * p.sw;
     const size_t lds = (size_t)p.src.C * 8;
-    // accumulators: 4 column blocks x TG taps x NBT cout blocks x 4 registers; keep TG * NBT <= 8
+    // accumulators: 4 column blocks x TG taps x NBT cout blocks x 4 registers; keep TG * NBT <= 4
     const int nbt = (p.nblk % 2 == 0) ? 2 : 1;
-    const int tg = taps >= 4 ? 4 : taps;               // taps is 1, 2, 4 or 8
+    // two cout blocks x 4 taps held 128 accumulator registers (276 VGPRs: one wave per SIMD); two taps: 152, three waves
+    // per SIMD, the activations are read once more - 6 % less tconv time on the benchmark net
+    static const int tg_max2 = getenv("FNN_TCONV_TG") ? atoi(getenv("FNN_TCONV_TG")) : 2;       // A-B aid
+    const int tg_cap = nbt == 2 ? tg_max2 : 4;
+    const int tg = taps >= tg_cap ? tg_cap : taps;     // taps is 1, 2, 4 or 8
     dim3 grid(p.N * ((vox_in + 255) / 256), (taps / tg) * (p.nblk / nbt));
 #define FNN_TCONV(NBTv, TGv) hipLaunchKernelGGL((tconv_mfma_kernel<NBTv, TGv>), grid, dim3(256), lds, st, p)
     if (nbt == 2) { if (tg == 4) FNN_TCONV(2, 4); else if (tg == 2) FNN_TCONV(2, 2); else FNN_TCONV(2, 1); }
