@@ -796,14 +796,13 @@ __global__ __launch_bounds__(256, (NB == 1 && MB == 4 && WRES && PF == 4) ? 3 : 
         sTap[tid * 2 + 1] = off + 16 * (1 - par);
     }
     const int cg = tid & 1;
-    int rel[PF], rvox[PF];                                            // packed halo coords / relative input voxel offset
+    int rel[PF];                                                      // packed halo coords of this thread's elements
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const int idx = tid + u * 256;
         const int v = idx >> 1;
         const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
         rel[u] = idx < IVOX * 2 ? (zd << 16) | (zh << 8) | zw : -1;
-        rvox[u] = (zd * p.Hi + zh) * p.Wi + zw;
     }
     int base[MB];
 #pragma unroll
@@ -851,13 +850,12 @@ __global__ __launch_bounds__(256, (NB == 1 && MB == 4 && WRES && PF == 4) ? 3 : 
     // offv = voxel index inside batch item n (or -1 for conv padding); the item's base pointer is uniform
     auto set_offsets = [&](int od0, int oh0, int ow0) {
         const int id0 = od0 * p.sd - p.pd, ih0 = oh0 * p.sh - p.ph, iw0 = ow0 * p.sw - p.pw;
-        const int base_vox = (id0 * p.Hi + ih0) * p.Wi + iw0;
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const unsigned gd = (unsigned)(id0 + (rel[u] >> 16)), gh = (unsigned)(ih0 + ((rel[u] >> 8) & 255)),
                            gw = (unsigned)(iw0 + (rel[u] & 255));
             const bool ok = rel[u] >= 0 && gd < (unsigned)p.Di && gh < (unsigned)p.Hi && gw < (unsigned)p.Wi;
-            offv[u] = ok ? base_vox + rvox[u] : -1;
+            offv[u] = ok ? (int)((gd * (unsigned)p.Hi + gh) * (unsigned)p.Wi + gw) : -1;     // two mads instead of a held offset
         }
     };
     auto issue = [&](int n, int ch) {
