@@ -48,6 +48,12 @@ static bool zr_pick(const ConvParams &p, int &nb, int &td) {
     return false;
 }
 
+int conv3d_stats_slots(const ConvParams &p) {
+    int nb, td;
+    if (!zr_pick(p, nb, td)) return FNN_STAT_REPL;
+    return ((p.Do + td - 1) / td) * ((p.Ho + 7) / 8) * ((p.Wo + 7) / 8);
+}
+
 int conv3d_packing(const ConvParams &p) {
     int nb, td;
     return zr_pick(p, nb, td) ? FNN_PACK_ZR : FNN_PACK_LINEAR;
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
         tile_epilogue<NB, TD, true>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
-        if (p.stats_out) stats_to_global<NB>(p, t1, t2, (float *)smem, n, cb0, wave, lane, tid);
+        if (p.stats_out) stats_to_global<NB, true>(p, t1, t2, (float *)smem, n, cb0, wave, lane, tid, (td * p.tiles_h + th) * p.tiles_w + tw);
     }
     FNN_STAMP();                                              // epilogue done
     FNN_STAMP_FLUSH(p.dbg);

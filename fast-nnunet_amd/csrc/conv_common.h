@@ -76,9 +76,11 @@ static __device__ __forceinline__ void tile_epilogue(const ConvParams &p, const 
 
 // Workgroup reduction of the statistics and the double atomics into replica (blockIdx.x & 7).
 // `sRed` = 4 * NB * 32 floats of LDS that nobody else uses between the two barriers.
-template <int NB>
+// SLOT: the workgroup owns row `slot` of the item's stats rows and stores its sums there (no atomics: the double
+// atomics of one-tile-per-workgroup kernels cost 5 % of the whole benchmark - 1.5 M of them per launch).
+template <int NB, bool SLOT = false>
 static __device__ __forceinline__ void stats_to_global(const ConvParams &p, float (&t1)[NB][4], float (&t2)[NB][4], float *sRed,
-                                                       int n, int cb0, int wave, int lane, int tid) {
+                                                       int n, int cb0, int wave, int lane, int tid, int slot = 0) {
     const int q = lane >> 4, r = lane & 15;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -97,7 +99,8 @@ static __device__ __forceinline__ void stats_to_global(const ConvParams &p, floa
         double v = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) v += (double)sRed[(w * NB * 16 + c) * 2 + which];
-        unsafeAtomicAdd(p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout + cb0 * 16 + c) * 2 + which, v);
+        if (SLOT) p.stats_out[(((size_t)n * p.stats_slots + slot) * p.Cout + cb0 * 16 + c) * 2 + which] = v;
+        else unsafeAtomicAdd(p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout + cb0 * 16 + c) * 2 + which, v);
     }
 }
 

@@ -41,6 +41,7 @@ struct Layer {
     size_t out_off = 0;               // halves, activation arena (for batch = 1)
     int64_t blob_w = 0, blob_b = 0, blob_g = 0, blob_beta = 0;
     int chunks = 0, ksteps = 0, packing = 0;
+    int stats_slots = FNN_STAT_REPL;  // rows per item in the stats buffer: atomics' replicas, or one row per tile
     double flops = 0;                 // 2*MACs per patch
 };
 
@@ -312,7 +313,16 @@ int build_plan(fnn_engine *e) {
         }
         L.bias_off = fp; fp += L.cout_pad;
         if (L.has_norm) { L.gamma_off = fp; fp += L.cout_pad; L.beta_off = fp; fp += L.cout_pad; }
-        L.stats_off = st; if (L.has_norm) st += (size_t)FNN_STAT_REPL * L.cout_pad * 2;
+        L.stats_slots = FNN_STAT_REPL;
+        if (L.type == Layer::STEM) L.stats_slots = stem_stats_slots(L.out_dims[0], L.out_dims[1], L.out_dims[2]);
+        else if (L.type == Layer::CONV) {
+            ConvParams q{};
+            q.plan_N = e->max_batch; q.N = e->max_batch; q.Cout = L.cout_pad;
+            q.Do = L.out_dims[0]; q.Ho = L.out_dims[1]; q.Wo = L.out_dims[2];
+            q.kd = L.k[0]; q.kh = L.k[1]; q.kw = L.k[2]; q.sd = L.s[0]; q.sh = L.s[1]; q.sw = L.s[2];
+            L.stats_slots = conv3d_stats_slots(q);
+        }
+        L.stats_off = st; if (L.has_norm) st += (size_t)L.stats_slots * L.cout_pad * 2;
         L.ss_off = ssn; if (L.has_norm) ssn += L.cout_pad;
         L.out_off = act; act += ovox * L.cout_pad;
         flops += L.flops;
@@ -486,7 +496,7 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.sd = L.s[0]; p.sh = L.s[1]; p.sw = L.s[2];
             p.pd = (L.k[0] - 1) / 2; p.ph = (L.k[1] - 1) / 2; p.pw = (L.k[2] - 1) / 2;
             p.wpk = fw.wpk + L.w_off; p.bias = fw.fparam + L.bias_off;
-            p.out = out; p.stats_out = stats_out;
+            p.out = out; p.stats_out = stats_out; p.stats_slots = L.stats_slots;
             p.tiles_d = (p.Do + FNN_TILE_D - 1) / FNN_TILE_D;
             p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
             p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
@@ -524,7 +534,7 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
         if (L.has_norm) {
             StatsFinalizeParams q{};
             q.stats = stats_out; q.gamma = fw.fparam + L.gamma_off; q.beta = fw.fparam + L.beta_off;
-            q.ss = e->ss + L.ss_off * e->max_batch * 2; q.C = L.cout_pad;
+            q.ss = e->ss + L.ss_off * e->max_batch * 2; q.C = L.cout_pad; q.nrep = L.stats_slots;
             q.inv_count = 1.f / ((float)L.out_dims[0] * L.out_dims[1] * L.out_dims[2]); q.eps = e->arch.eps;
             if (launch_stats_finalize(q, nb, st) != 0) return fail(e, FNN_E_HIP, "stats finalize launch failed");
         }

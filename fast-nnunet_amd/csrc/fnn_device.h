@@ -56,6 +56,8 @@ struct ConvParams {
     int ksteps;                  // MFMA k-steps per chunk: conv3d_ksteps(packing, taps)
     const float *ident_ss;       // conv3d_identity_ss(): ones[512] then zeros[512] (set by the launchers that need it)
     int packing;                 // FNN_PACK_*: which taps share a k-step (fixed per layer when the weights are packed)
+    int stats_slots;             // rows per batch item in stats_out (conv3d_stats_slots): FNN_STAT_REPL replicas filled by
+                                 // atomics, or one row per tile written with plain stores (ZR kernel)
 };
 
 // Weight packings of a conv layer.  One k-step (K = 32) always holds 2 taps x 16 input channels;
@@ -178,7 +180,8 @@ struct CombineParams {
 };
 
 struct StatsFinalizeParams {
-    const double *stats;         // [N][REPL][C][2]
+    const double *stats;         // [N][nrep][C][2]
+    int nrep;                    // rows per batch item (ConvParams::stats_slots of the producer)
     const float *gamma, *beta;   // [C]
     float *ss;                   // [N][2][C]
     int C;
@@ -198,6 +201,8 @@ int conv3d_packing(const ConvParams &p);
 int conv3d_ksteps(int packing, int taps);
 int conv3d_kstep_tap(int packing, int ks, int half, int taps);     // linear tap index, or -1 = zero padding
 int launch_conv3d_zr(const ConvParams &p, hipStream_t st);
+int conv3d_stats_slots(const ConvParams &p);                           // rows per item the layer's kernel writes into stats_out
+int stem_stats_slots(int PD, int PH, int PW);
 int launch_stem(const StemParams &p, int N, hipStream_t st);
 int launch_tconv(const TconvParams &p, hipStream_t st);
 int launch_head(const HeadParams &p, hipStream_t st);

@@ -16,17 +16,35 @@ static __device__ __forceinline__ void load_scale_shift(const SrcDesc &s, int n,
 
 // InstanceNorm statistics -> per (n, channel) (scale, shift):  y = x * scale + shift
 //   mean = sum / count, var = sumsq / count - mean^2 (biased, like torch), scale = gamma / sqrt(var + eps)
-// One thread per (n, channel); the 8 replicas were filled by the producer's epilogue atomics.
-__global__ void stats_finalize_kernel(const StatsFinalizeParams p) {
-    const int c = threadIdx.x + blockIdx.y * blockDim.x, n = blockIdx.x;
-    if (c >= p.C) return;
-    const double *st = p.stats + ((size_t)n * FNN_STAT_REPL * p.C + c) * 2;
+// The producer filled `nrep` rows per item: 8 replicas (atomics) or one row per tile (plain stores, up to a few
+// hundred).  A workgroup takes 16 channels of one item: thread = (row lane 0..63, channel), rows strided by 64, the 64
+// partial sums of a channel meet in LDS.  Sums of fp16-valued numbers in double are exact: any order gives the same bits.
+__global__ __launch_bounds__(1024) void stats_finalize_kernel(const StatsFinalizeParams p) {
+    constexpr int RL = 64;                                            // row lanes: 1024 threads = 64 x 16 channels
+    __shared__ double sred[RL][16][2];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 16 + cl, n = blockIdx.x;
     double s1 = 0, s2 = 0;
-#pragma unroll
-    for (int r = 0; r < FNN_STAT_REPL; ++r) {
-        s1 += st[(size_t)r * p.C * 2];
-        s2 += st[(size_t)r * p.C * 2 + 1];
+    if (c < p.C) {
+        const double *st = p.stats + ((size_t)n * p.nrep * p.C + c) * 2;
+#pragma unroll 4
+        for (int r = rl; r < p.nrep; r += RL) {                       // independent loads: several in flight
+            const double2 v = *(const double2 *)(st + (size_t)r * p.C * 2);
+            s1 += v.x; s2 += v.y;
+        }
     }
+    sred[rl][cl][0] = s1; sred[rl][cl][1] = s2;
+    __syncthreads();
+    if (rl >= 4) return;                                              // 4 lanes x 16 rows each, then 4 -> 1
+    s1 = 0; s2 = 0;
+#pragma unroll
+    for (int r = 0; r < RL / 4; ++r) { s1 += sred[rl * (RL / 4) + r][cl][0]; s2 += sred[rl * (RL / 4) + r][cl][1]; }
+    __syncthreads();
+    sred[rl][cl][0] = s1; sred[rl][cl][1] = s2;
+    __syncthreads();
+    if (rl != 0 || c >= p.C) return;
+    s1 = sred[0][cl][0] + sred[1][cl][0] + sred[2][cl][0] + sred[3][cl][0];
+    s2 = sred[0][cl][1] + sred[1][cl][1] + sred[2][cl][1] + sred[3][cl][1];
     const double mean = s1 * (double)p.inv_count;
     double var = s2 * (double)p.inv_count - mean * mean;
     var = var > 0 ? var : 0;
@@ -37,8 +55,7 @@ __global__ void stats_finalize_kernel(const StatsFinalizeParams p) {
 }
 
 int launch_stats_finalize(const StatsFinalizeParams &p, int N, hipStream_t st) {
-    const int bs = p.C < 256 ? ((p.C + 63) / 64) * 64 : 256;
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(N, (p.C + bs - 1) / bs), dim3(bs), 0, st, p);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(N, (p.C + 15) / 16), dim3(1024), 0, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -73,7 +73,7 @@ bool make_src(SrcHolder &h, const float *x, int n, int c, size_t vox, const floa
         if (!h.ss.alloc((size_t)n * cp * 8)) return false;
         StatsFinalizeParams q{};
         q.stats = h.stats.as<double>(); q.gamma = h.gamma.as<float>(); q.beta = h.beta.as<float>();
-        q.ss = h.ss.as<float>(); q.C = cp; q.inv_count = 1.f / (float)vox; q.eps = 1e-5f;
+        q.ss = h.ss.as<float>(); q.C = cp; q.nrep = FNN_STAT_REPL; q.inv_count = 1.f / (float)vox; q.eps = 1e-5f;
         if (launch_stats_finalize(q, n, 0) != 0) return false;
         h.d.ss = h.ss.as<float>();
         h.d.slope = slope;
@@ -108,6 +108,8 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
     p.Do = (p.Di + 2 * p.pd - p.kd) / p.sd + 1; p.Ho = (p.Hi + 2 * p.ph - p.kh) / p.sh + 1; p.Wo = (p.Wi + 2 * p.pw - p.kw) / p.sw + 1;
     p.Cout = cop; p.chunks = (cp1 + cp2) / 16;
     p.packing = conv3d_packing(p); p.ksteps = conv3d_ksteps(p.packing, T);
+    p.stats_slots = conv3d_stats_slots(p);
+    const size_t slots = (size_t)p.stats_slots;
     p.tiles_d = (p.Do + FNN_TILE_D - 1) / FNN_TILE_D; p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
     p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
     p.tile_d = FNN_TILE_D;
@@ -132,10 +134,10 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
     const size_t ovox = (size_t)p.Do * p.Ho * p.Wo;
     DevBuf dw, db, dout, dst;
     if (!dw.alloc(wp.size() * 2) || !db.alloc(cop * 4) || !dout.alloc((size_t)n * ovox * cop * 2) ||
-        !dst.alloc((size_t)n * FNN_STAT_REPL * cop * 16)) return FNN_E_HIP;
+        !dst.alloc((size_t)n * slots * cop * 16)) return FNN_E_HIP;
     (void)hipMemcpy(dw.p, wp.data(), wp.size() * 2, hipMemcpyHostToDevice);
     (void)hipMemcpy(db.p, bp.data(), cop * 4, hipMemcpyHostToDevice);
-    (void)hipMemset(dst.p, 0, (size_t)n * FNN_STAT_REPL * cop * 16);
+    (void)hipMemset(dst.p, 0, (size_t)n * slots * cop * 16);
     (void)hipMemset(dout.p, 0, (size_t)n * ovox * cop * 2);
     p.wpk = dw.as<f16>(); p.bias = db.as<float>(); p.out = dout.as<f16>(); p.stats_out = dst.as<double>();
 #ifdef FNN_STAMPS
@@ -146,7 +148,7 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
     p.dbg = ddbg.as<unsigned long long>();
     (void)launch_conv3d(p, 0);                      // warm-up
     (void)hipDeviceSynchronize();
-    (void)hipMemset(dst.p, 0, (size_t)n * FNN_STAT_REPL * cop * 16);
+    (void)hipMemset(dst.p, 0, (size_t)n * slots * cop * 16);
 #endif
     const int rc = launch_conv3d(p, 0);
     if (rc != 0) return rc == -1 ? FNN_E_UNSUPPORTED : FNN_E_HIP;
@@ -171,7 +173,7 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
     }
 #endif
     std::vector<uint16_t> ho((size_t)n * ovox * cop);
-    std::vector<double> hs((size_t)n * FNN_STAT_REPL * cop * 2);
+    std::vector<double> hs((size_t)n * slots * cop * 2);
     (void)hipMemcpy(ho.data(), dout.p, ho.size() * 2, hipMemcpyDeviceToHost);
     (void)hipMemcpy(hs.data(), dst.p, hs.size() * 8, hipMemcpyDeviceToHost);
     for (int b = 0; b < n; ++b)
@@ -179,9 +181,9 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
             for (size_t v = 0; v < ovox; ++v) y[((size_t)b * cout + co) * ovox + v] = h2f_bits(ho[((size_t)b * ovox + v) * cop + co]);
             if (stats_out) {
                 double a = 0, q = 0;
-                for (int r = 0; r < FNN_STAT_REPL; ++r) {
-                    a += hs[(((size_t)b * FNN_STAT_REPL + r) * cop + co) * 2];
-                    q += hs[(((size_t)b * FNN_STAT_REPL + r) * cop + co) * 2 + 1];
+                for (size_t r = 0; r < slots; ++r) {
+                    a += hs[(((size_t)b * slots + r) * cop + co) * 2];
+                    q += hs[(((size_t)b * slots + r) * cop + co) * 2 + 1];
                 }
                 stats_out[((size_t)b * cout + co) * 2] = a;
                 stats_out[((size_t)b * cout + co) * 2 + 1] = q;

@@ -125,10 +125,15 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
             double v = 0;
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) v += (double)sRed[(rr * 16 + c) * 2 + which];
-            unsafeAtomicAdd(p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout
-                                           + cb * 16 + c) * 2 + which, v);
+            // one stats row per tile, plain store (see stats_to_global in conv_common.h)
+            const int slot = (td * p.tiles_h + th) * p.tiles_w + tw;
+            p.stats_out[(((size_t)n * (p.tiles_d * p.tiles_h * p.tiles_w) + slot) * p.Cout + cb * 16 + c) * 2 + which] = v;
         }
     }
+}
+
+int stem_stats_slots(int PD, int PH, int PW) {
+    return ((PD + STEM_TD - 1) / STEM_TD) * ((PH + FNN_TILE_H - 1) / FNN_TILE_H) * ((PW + FNN_TILE_W - 1) / FNN_TILE_W);
 }
 
 int launch_stem(const StemParams &p_in, int N, hipStream_t st) {
