@@ -328,7 +328,7 @@ int build_plan(fnn_engine *e) {
         flops += L.flops;
         bytes += 2.0 * ovox * L.cout_real * 2.0;            // written once + read once, fp16
     }
-    e->hblocks = (a.num_heads + 15) / 16;
+    e->hblocks = (a.num_heads + 1 + 15) / 16;               // + the weight-sum channel (zero weights, bias 1: its "logit" is 1)
     e->head_ksteps = (pad16(a.features[0]) + 31) / 32;
     e->head_w_off = wpk; wpk += (size_t)e->hblocks * e->head_ksteps * 512;
     e->head_bias_off = fp; fp += (size_t)e->hblocks * 16;
@@ -1022,6 +1022,7 @@ int fnn_load_weights(fnn_engine *e, int fold, const float *blob, int64_t count) 
     }
     pack_head(e->arch.num_heads, e->arch.features[0], e->hblocks, e->head_ksteps, blob + e->blob_head_w, wpk.data() + e->head_w_off);
     for (int h = 0; h < e->arch.num_heads; ++h) fp[e->head_bias_off + h] = blob[e->blob_head_b + h];
+    fp[e->head_bias_off + e->arch.num_heads] = 1.f;         // accumulator channel `heads`: 1 * gaussian = the weight itself
     if (!fw.wpk) HIPCHK(e, hipMalloc((void **)&fw.wpk, wpk.size() * 2));
     if (!fw.fparam) HIPCHK(e, hipMalloc((void **)&fw.fparam, fp.size() * 4));
     HIPCHK(e, hipMemcpy(fw.wpk, wpk.data(), wpk.size() * 2, hipMemcpyHostToDevice));

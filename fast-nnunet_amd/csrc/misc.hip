@@ -9,6 +9,23 @@
 #include <cstdlib>
 #include <type_traits>
 
+// a + round(t * g): the product is rounded before the sum like the reference's `pred *= g; acc += pred`.  With the
+// multiply next to the add hipcc contracts the pair into an fma (even through __fmul_rn / __fadd_rn): contraction is
+// switched off for this block.
+static __device__ __forceinline__ float acc_add_product(float a, float t, float g) {
+#pragma clang fp contract(off)
+    const float c = t * g;
+    return a + c;
+}
+
+// division by a workgroup-uniform divisor through its float reciprocal, exact for 0 <= v < 2^24
+static __device__ __forceinline__ int recip_div(int v, int d, float rcp) {
+    int q = (int)((float)v * rcp);
+    q -= (q * d > v);
+    q += ((q + 1) * d <= v);
+    return q;
+}
+
 static __device__ __forceinline__ void load_scale_shift(const SrcDesc &s, int n, float2 *sSS, int tid, int nthreads) {
     for (int c = tid; c < s.C; c += nthreads)
         sSS[c] = s.ss ? make_float2(s.ss[(size_t)(2 * n) * s.C + c], s.ss[(size_t)(2 * n + 1) * s.C + c]) : make_float2(1.f, 0.f);
@@ -533,6 +550,7 @@ __global__ __launch_bounds__(256, MINB) void seg_head_acc1_kernel(const HeadPara
     if (v0 >= P) return;
     const int r = lane & 15, q = lane >> 4;
     const int grp = lane & 7, vsub = lane >> 3;
+    const float rcp_pw = 1.0f / (float)p.PW, rcp_ph = 1.0f / (float)p.PH;
 
     for (int cb0 = 0; cb0 < p.HP; cb0 += 64) {
         const int hb_first = cb0 >> 4;
@@ -552,7 +570,10 @@ __global__ __launch_bounds__(256, MINB) void seg_head_acc1_kernel(const HeadPara
                 const int v = v0 + rd * 32 + 8 * i + vsub;
                 ok[rd][i] = v < P && grp_ok;
                 const int vv = v < P ? v : P - 1;
-                const int w = vv % p.PW, h = (vv / p.PW) % p.PH, d = vv / (p.PW * p.PH);
+                // float-reciprocal division (P <= 2^24, checked by the launcher): three 32-bit integer divisions per voxel
+                // were a fifth of this kernel's instructions
+                const int row = recip_div(vv, p.PW, rcp_pw), w = vv - row * p.PW;
+                const int d = recip_div(row, p.PH, rcp_ph), h = row - d * p.PH;
                 aelem[rd][i] = (((size_t)(p.ox + d) * p.Y + (p.oy + h)) * p.Z + (p.oz + w)) * p.HP + cb0 + grp_c * 8;
                 first[rd][i] = d >= p.fx && h >= p.fy && w >= p.fz;     // nobody has written this voxel yet
                 graw[rd][i] = p.gauss[vv];                              // always a map (all ones without Gaussian weighting)
@@ -612,23 +633,16 @@ __global__ __launch_bounds__(256, MINB) void seg_head_acc1_kernel(const HeadPara
             for (int i = 0; i < 4; ++i) {
                 const f32x4 t0 = *(const f32x4 *)(sT + (8 * i + vsub) * HEAD_LD + grp_c * 8);
                 const f32x4 t1 = *(const f32x4 *)(sT + (8 * i + vsub) * HEAD_LD + grp_c * 8 + 4);
+                // No per-channel cases: channel `heads` (the weight sum) has zero weights and bias 1 (fnn_load_weights), so
+                // its product is 1 * g = g; padding channels have zero weights and bias and add 0.
                 const float g = (float)graw[rd][i];
-                float c[8];
-                unsigned mask = 0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int ch = cb0 + grp_c * 8 + e;
-                    const float t = e < 4 ? t0[e] : t1[e - 4];
-                    c[e] = ch == p.heads ? g : __fmul_rn(t, g);            // channel `heads` accumulates the weight
-                    if (ch <= p.heads) mask |= 1u << e;                      // padding channels keep their bits
-                }
                 if (ACC32) {
                     f32x4 b0 = a32[ACC32 ? rd : 0][i][0], b1 = a32[ACC32 ? rd : 0][i][1];
                     if (first[rd][i]) { b0 = (f32x4){0.f, 0.f, 0.f, 0.f}; b1 = b0; }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        b0[e] = (mask >> e) & 1 ? __fadd_rn(b0[e], c[e]) : b0[e];
-                        b1[e] = (mask >> (4 + e)) & 1 ? __fadd_rn(b1[e], c[4 + e]) : b1[e];
+                        b0[e] = acc_add_product(b0[e], t0[e], g);
+                        b1[e] = acc_add_product(b1[e], t1[e], g);
                     }
                     if (ok[rd][i]) {
                         *(f32x4 *)((float *)p.acc + aelem[rd][i]) = b0;
@@ -638,7 +652,7 @@ __global__ __launch_bounds__(256, MINB) void seg_head_acc1_kernel(const HeadPara
                     f16x8 bq = a16[rd][i];
                     if (first[rd][i]) bq = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};      // 0 + c, like the zero-filled accumulator
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) bq[e] = (mask >> e) & 1 ? (f16)__fadd_rn((float)bq[e], c[e]) : bq[e];
+                    for (int e = 0; e < 8; ++e) bq[e] = (f16)acc_add_product((float)bq[e], e < 4 ? t0[e] : t1[e - 4], g);
                     if (ok[rd][i]) {
                         if (NT & 1) __builtin_nontemporal_store(bq, (f16x8 *)((f16 *)p.acc + aelem[rd][i]));
                         else *(f16x8 *)((f16 *)p.acc + aelem[rd][i]) = bq;
@@ -654,7 +668,7 @@ __global__ __launch_bounds__(256, MINB) void seg_head_acc1_kernel(const HeadPara
 bool launch_head_first_visit_ok(const HeadParams &p) {
     static const bool head_v1 = getenv("FNN_HEAD_V1") != nullptr;
     static const bool rd1 = getenv("FNN_HEAD_RD") && atoi(getenv("FNN_HEAD_RD")) == 1;
-    return p.mode == 0 && p.ksteps == 1 && !head_v1 && !rd1;
+    return p.mode == 0 && p.ksteps == 1 && !head_v1 && !rd1 && (long long)p.PD * p.PH * p.PW <= (1 << 24);
 }
 
 int launch_head(const HeadParams &p, hipStream_t st) {
@@ -668,7 +682,7 @@ int launch_head(const HeadParams &p, hipStream_t st) {
     if (p.mode == 0) {
         const size_t lds = (size_t)((p.src.C * 8 + 255) & ~255) + (size_t)4 * 32 * HEAD_LD * 4;
         static const bool head_v1 = getenv("FNN_HEAD_V1") != nullptr;            // A-B aid
-        if (p.ksteps == 1 && !head_v1) {
+        if (p.ksteps == 1 && !head_v1 && P <= (1 << 24)) {
             static const int head_rd = getenv("FNN_HEAD_RD") ? atoi(getenv("FNN_HEAD_RD")) : 2;      // A-B aid (1: one 32-voxel round per wave - faster alone, slower next to the other stream)
             if (head_rd == 1) {
                 const dim3 g1((P + 127) / 128);
