@@ -21,8 +21,8 @@ static __device__ __forceinline__ float acc_add_product(float a, float t, float 
 // division by a workgroup-uniform divisor through its float reciprocal, exact for 0 <= v < 2^24
 static __device__ __forceinline__ int recip_div(int v, int d, float rcp) {
     int q = (int)((float)v * rcp);
-    q -= (q * d > v);
-    q += ((q + 1) * d <= v);
+    q -= ((int)__umul24(q, d) > v);                            // 24-bit multiplies: full rate (v_mul_lo_u32 is quarter rate)
+    q += ((int)__umul24(q + 1, d) <= v);
     return q;
 }
 
@@ -199,7 +199,7 @@ int launch_combine(const CombineParams &p, hipStream_t st) {
 // grid.x = N * ceil(vox / 256), grid.y = (taps / TG) * (nblk / NBT).
 // ----------------------------------------------------------------------------
 template <int NBT, int TG>
-__global__ __launch_bounds__(256) void tconv_mfma_kernel(const TconvParams p) {
+__global__ __launch_bounds__(256, 2) void tconv_mfma_kernel(const TconvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *sSS = (float2 *)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -216,15 +216,10 @@ __global__ __launch_bounds__(256) void tconv_mfma_kernel(const TconvParams p) {
     if (v0 >= vox_in) return;
 
     f32x4 acc[4][TG][NBT];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int tg = 0; tg < TG; ++tg)
-#pragma unroll
-            for (int nb = 0; nb < NBT; ++nb) acc[mb][tg][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     const int r = lane & 15, q = lane >> 4;
-    for (int ks = 0; ks < p.ksteps; ++ks) {
+    // the first k-step starts from the zero constant (no accumulator initialisation), the rest accumulate
+    auto kstep = [&](int ks, auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
         f16x8 wf[TG][NBT];
 #pragma unroll
         for (int tg = 0; tg < TG; ++tg)
@@ -243,24 +238,37 @@ __global__ __launch_bounds__(256) void tconv_mfma_kernel(const TconvParams p) {
             for (int nb = 0; nb < NBT; ++nb)
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)
-                    acc[mb][tg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tg][nb], xf[mb], acc[mb][tg][nb], 0, 0, 0);
-    }
+                    acc[mb][tg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tg][nb], xf[mb],
+                                          FIRST ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mb][tg][nb], 0, 0, 0);
+    };
+    kstep(0, std::true_type{});
+    for (int ks = 1; ks < p.ksteps; ++ks) kstep(ks, std::false_type{});
 
-    const int Do = p.Di * p.sd, Ho = p.Hi * p.sh, Wo = p.Wi * p.sw;
+    const int Ho = p.Hi * p.sh, Wo = p.Wi * p.sw;
     float4 bv[NBT];
 #pragma unroll
     for (int nb = 0; nb < NBT; ++nb) bv[nb] = *(const float4 *)(p.bias + (cb0 + nb) * 16 + q * 4);
-    f16 *outn = p.out + (size_t)n * Do * Ho * Wo * p.Cout + cb0 * 16 + q * 4;
+    f16 *outn = p.out + (size_t)n * p.Di * p.sd * Ho * Wo * p.Cout + cb0 * 16 + q * 4;
+    // output offsets: a per-voxel base (float-reciprocal division, 24-bit multiplies: input planes < 2^24 voxels, checked
+    // by the launcher) plus a wave-uniform offset per tap - the index arithmetic was most of this kernel's instructions
+    unsigned toff[TG];
+#pragma unroll
+    for (int tg = 0; tg < TG; ++tg) {
+        const int tap = tap0 + tg;
+        const int jd = tap / (p.sh * p.sw), jh = (tap / p.sw) % p.sh, jw = tap % p.sw;     // uniform: scalar unit
+        toff[tg] = (unsigned)(((jd * Ho + jh) * Wo + jw) * p.Cout);
+    }
+    const float rcp_wi = 1.0f / (float)p.Wi, rcp_hi = 1.0f / (float)p.Hi;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         const int v = v0 + mb * 16 + r;
         if (v >= vox_in) continue;
-        const int iw = v % p.Wi, ih = (v / p.Wi) % p.Hi, id = v / (p.Wi * p.Hi);
+        const int row = recip_div(v, p.Wi, rcp_wi), iw = v - (int)__umul24(row, p.Wi);
+        const int id = recip_div(row, p.Hi, rcp_hi), ih = row - (int)__umul24(id, p.Hi);
+        const unsigned ob = ((unsigned)(id * p.sd * Ho + ih * p.sh) * (unsigned)Wo + (unsigned)(iw * p.sw)) * (unsigned)p.Cout;
 #pragma unroll
         for (int tg = 0; tg < TG; ++tg) {
-            const int tap = tap0 + tg;
-            const int jd = tap / (p.sh * p.sw), jh = (tap / p.sw) % p.sh, jw = tap % p.sw;
-            const unsigned ov = (unsigned)((((id * p.sd + jd) * Ho + ih * p.sh + jh) * Wo + iw * p.sw + jw) * p.Cout);
+            const unsigned ov = ob + toff[tg];
 #pragma unroll
             for (int nb = 0; nb < NBT; ++nb) {
                 f16x4 o;
@@ -276,6 +284,7 @@ __global__ __launch_bounds__(256) void tconv_mfma_kernel(const TconvParams p) {
 
 int launch_tconv(const TconvParams &p, hipStream_t st) {
     const int vox_in = p.Di * p.Hi * p.Wi;
+    if ((long long)p.Di * p.Hi * p.Wi > (1 << 24)) return -1;       // the kernel's float-reciprocal index arithmetic
     const int taps = p.sd * p.sh * p.sw;
     const size_t lds = (size_t)p.src.C * 8;
     // accumulators: 4 column blocks x TG taps x NBT cout blocks x 4 registers; keep TG * NBT <= 4
