@@ -855,7 +855,8 @@ __global__ __launch_bounds__(256, (NB == 1 && MB == 4 && WRES && PF == 4) ? 3 : 
             const unsigned gd = (unsigned)(id0 + (rel[u] >> 16)), gh = (unsigned)(ih0 + ((rel[u] >> 8) & 255)),
                            gw = (unsigned)(iw0 + (rel[u] & 255));
             const bool ok = rel[u] >= 0 && gd < (unsigned)p.Di && gh < (unsigned)p.Hi && gw < (unsigned)p.Wi;
-            offv[u] = ok ? (int)((gd * (unsigned)p.Hi + gh) * (unsigned)p.Wi + gw) : -1;     // two mads instead of a held offset
+            // two 24-bit mads (full rate; v_mul_lo_u32 is quarter rate) instead of a held offset: Di * Hi < 2^24 (launcher)
+            offv[u] = ok ? (int)(__umul24(__umul24(gd, (unsigned)p.Hi) + gh, (unsigned)p.Wi) + gw) : -1;
         }
     };
     auto issue = [&](int n, int ch) {
@@ -1129,7 +1130,7 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
             const unsigned long long b = 2ull * p.Di * p.Hi * p.Wi * p.src[i].C;
             in_item = b > in_item ? b : in_item;
         }
-        if (out_item >= (1ull << 31) || in_item >= (1ull << 32)) return -1;
+        if (out_item >= (1ull << 31) || in_item >= (1ull << 32) || (long long)p.Di * p.Hi >= (1 << 24) || p.Wi >= (1 << 24)) return -1;
     }
     p.tile_d = FNN_TILE_D;
     p.tiles_d = (p.Do + FNN_TILE_D - 1) / FNN_TILE_D;
