@@ -49,26 +49,41 @@ static __device__ __forceinline__ void tile_epilogue(const ConvParams &p, const 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)n * (item_bytes >> 1), 0,
                                                                            item_bytes, 0x00020000);
     const unsigned coff = (unsigned)(cb0 * 16 + q * 4) * 2;
+    // Statistics of the fp16-rounded outputs with packed dot products: the values of one channel at two voxels (m-blocks
+    // mb, mb + 1) are packed into one register; v_dot2_f32_f16(pair, (1, 1), t1) adds both to the sum and
+    // v_dot2_f32_f16(pair, pair, t2) both squares to the sum of squares - 1.5 instructions per value instead of 4
+    // (convert back, select, add, fma); out-of-range voxels contribute a zeroed pair.
+    static_assert(MB % 2 == 0, "m-blocks are processed in pairs");
+    const f16x2 ones = {(f16)1.f, (f16)1.f};
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        int od_l, oh_l, ow_l;
-        mb_coords<MB, ZR>(wave, mb, r, od_l, oh_l, ow_l);
-        const int od = od0 + od_l, oh = oh0 + oh_l, ow = ow0 + ow_l;
-        const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
-        const unsigned voff = ok ? (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout) * 2 + coff : 0x80000000u;
+    for (int mb = 0; mb < MB; mb += 2) {
+        bool okv[2];
+        unsigned voff[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int od_l, oh_l, ow_l;
+            mb_coords<MB, ZR>(wave, mb + h, r, od_l, oh_l, ow_l);
+            const int od = od0 + od_l, oh = oh0 + oh_l, ow = ow0 + ow_l;
+            okv[h] = od < p.Do && oh < p.Ho && ow < p.Wo;
+            voff[h] = okv[h] ? (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout) * 2 + coff : 0x80000000u;
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            f16x4 o;
-            o[0] = (f16)(acc[mb][nb][0] + bv[nb].x);
-            o[1] = (f16)(acc[mb][nb][1] + bv[nb].y);
-            o[2] = (f16)(acc[mb][nb][2] + bv[nb].z);
-            o[3] = (f16)(acc[mb][nb][3] + bv[nb].w);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fnn_i32x2, o), rsrc, voff, nb * 32, 0);
+            f16x4 o[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                o[h][0] = (f16)(acc[mb + h][nb][0] + bv[nb].x);
+                o[h][1] = (f16)(acc[mb + h][nb][1] + bv[nb].y);
+                o[h][2] = (f16)(acc[mb + h][nb][2] + bv[nb].z);
+                o[h][3] = (f16)(acc[mb + h][nb][3] + bv[nb].w);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fnn_i32x2, o[h]), rsrc, voff[h], nb * 32, 0);
+                if (!okv[h]) o[h] = (f16x4){0, 0, 0, 0};
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float v = ok ? (float)o[j] : 0.f;
-                t1[nb][j] += v;
-                t2[nb][j] = fmaf(v, v, t2[nb][j]);
+                const f16x2 pr = {o[0][j], o[1][j]};
+                t1[nb][j] = __builtin_amdgcn_fdot2(pr, ones, t1[nb][j], false);
+                t2[nb][j] = __builtin_amdgcn_fdot2(pr, pr, t2[nb][j], false);
             }
         }
     }
