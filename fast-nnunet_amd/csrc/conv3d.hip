@@ -819,6 +819,13 @@ __global__ __launch_bounds__(256, (NB == 1 && MB == 4 && WRES && PF == 4) ? 3 : 
     // across tiles - sums of fp16-valued numbers in double are exact, so the result does not depend on how
     // tiles are distributed over workgroups.  The double accumulators live in LDS (one slot per wave).
     for (int i = tid; i < 4 * NB * 16 * 2; i += 256) sRed[i] = 0.0;
+    // per-lane running sums between flushes (double): a tile adds its fp32 lane partials, the 16 lanes of a row meet
+    // only when the statistics are flushed - instead of four DPP steps per value and an LDS read-add-write per tile
+    double dsum[NB][4][2];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dsum[nb][j][0] = 0.0; dsum[nb][j][1] = 0.0; }
 
     float4 bv[NB];                                                    // bias of this lane's 4 channels per cout block
 #pragma unroll
@@ -907,6 +914,20 @@ __global__ __launch_bounds__(256, (NB == 1 && MB == 4 && WRES && PF == 4) ? 3 : 
     };
     auto flush_stats = [&](int n) {
         if (!p.stats_out) return;
+        {
+            const int q = lane >> 4;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double a = row16_sum_f64(dsum[nb][j][0]), b = row16_sum_f64(dsum[nb][j][1]);
+                    if ((lane & 15) == 0) {                           // one lane per (wave, channel)
+                        double *slot = sRed + (wave * NB * 16 + nb * 16 + q * 4 + j) * 2;
+                        slot[0] = a; slot[1] = b;
+                    }
+                    dsum[nb][j][0] = 0.0; dsum[nb][j][1] = 0.0;
+                }
+        }
         __syncthreads();
         if (tid < NB * 16 * 2) {
             const int c = tid >> 1, which = tid & 1;
@@ -985,17 +1006,12 @@ __global__ __launch_bounds__(256, (NB == 1 && MB == 4 && WRES && PF == 4) ? 3 : 
                     for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
                 tile_epilogue<NB, MB>(p, acc, bv, n_cur, od0, oh0, ow0, cb0, wave, lane, t1, t2);
                 if (p.stats_out) {
-                    const int q = lane >> 4;
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float sa = row16_sum(t1[nb][j]), sb = row16_sum(t2[nb][j]);
-                            if ((lane & 15) == 0) {                  // one lane per (wave, channel): no atomics needed
-                                double *slot = sRed + (wave * NB * 16 + nb * 16 + q * 4 + j) * 2;
-                                slot[0] += (double)sa;
-                                slot[1] += (double)sb;
-                            }
+                            dsum[nb][j][0] += (double)t1[nb][j];
+                            dsum[nb][j][1] += (double)t2[nb][j];
                         }
                 }
                 // commit() is duplicated on purpose: on this path hipcc can wait for the (older) prefetch loads

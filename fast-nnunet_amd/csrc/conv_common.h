@@ -14,6 +14,20 @@ static __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// the same for a double (two 32-bit DPP moves per step)
+static __device__ __forceinline__ double row16_sum_f64(double v) {
+#define FNN_ROR64(ctrl)                                                                                              \
+    {                                                                                                                \
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);                                      \
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, ctrl, 0xF, 0xF, true);                       \
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), ctrl, 0xF, 0xF, true);               \
+        v += __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);                    \
+    }
+    FNN_ROR64(0x128) FNN_ROR64(0x124) FNN_ROR64(0x122) FNN_ROR64(0x121)
+#undef FNN_ROR64
+    return v;
+}
+
 // small-integer division by a workgroup-uniform divisor (0 <= v < 2^16): float reciprocal + correction
 static __device__ __forceinline__ int small_div(int v, int d, float rcp) {
     int q = (int)((float)v * rcp);
