@@ -22,7 +22,8 @@ FNN_LABEL_U8, FNN_LABEL_U16 = 0, 1
 FNN_NORM_NONE, FNN_NORM_ZSCORE, FNN_NORM_CT, FNN_NORM_RESCALE01, FNN_NORM_RGB01 = 0, 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libfnn_hip.so')
+# FNN_LIB: another build of the same library (A-B comparisons of two builds inside one GPU session)
+LIB_PATH = os.environ.get('FNN_LIB') or os.path.join(_HERE, 'csrc', 'libfnn_hip.so')
 
 
 class ArchDesc(C.Structure):
