@@ -872,6 +872,14 @@ __global__ __launch_bounds__(256, (NB == 1 && MB == 4 && WRES && PF == 4) ? 3 : 
         const int c_loc = c_glob - (s ? p.src[0].C : 0) + cg * 8;
         const int sC = p.src[s].C;
         const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + c_loc);   // uniform base
+        slope_next = p.src[s].slope;
+        // scale / shift first (vmcnt retires in order: commit() needs them before the first halo element) and
+        // unconditionally: the identity table stands in for a source without InstanceNorm
+        const float *qs = p.src[s].ss ? p.src[s].ss + (size_t)(2 * n) * sC + c_loc : p.ident_ss + c_loc;
+        const float *qh = p.src[s].ss ? qs + sC : p.ident_ss + 512 + c_loc;
+        scr[0] = *(const float4 *)qs; scr[1] = *(const float4 *)(qs + 4);
+        shr[0] = *(const float4 *)qh; shr[1] = *(const float4 *)(qh + 4);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < PF; ++u)                        // unconditional: branches around loads make hipcc drain vmcnt
             xr[u] = *(const f16x8 *)(sp + (unsigned)((offv[u] >= 0 ? offv[u] : 0) * sC * 2));
@@ -879,12 +887,6 @@ __global__ __launch_bounds__(256, (NB == 1 && MB == 4 && WRES && PF == 4) ? 3 : 
 #pragma unroll
             for (int u = 0; u < WPF; ++u) wr[u] = ((const f16x8 *)p.wpk)[wofs[u] + ch * per_nb];
         }
-        slope_next = p.src[s].slope;
-        // unconditional loads: the identity table stands in for a source without InstanceNorm
-        const float *qs = p.src[s].ss ? p.src[s].ss + (size_t)(2 * n) * sC + c_loc : p.ident_ss + c_loc;
-        const float *qh = p.src[s].ss ? qs + sC : p.ident_ss + 512 + c_loc;
-        scr[0] = *(const float4 *)qs; scr[1] = *(const float4 *)(qs + 4);
-        shr[0] = *(const float4 *)qh; shr[1] = *(const float4 *)(qh + 4);
     };
     auto commit = [&](char *dst) {
         const f16 slope_h = (f16)slope_next;

@@ -131,20 +131,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
         const int sC = p.src[s].C;
         // uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset: one address VGPR per load (tensors < 4 GiB)
         const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + c_uni);
+        // scale / shift FIRST and unconditionally (identity table for a source without InstanceNorm): vmcnt retires in
+        // order, so with these four loads last - and inside an `if` - commit() could not touch the first halo element
+        // before EVERY load of the chunk had landed; now it converts element u while elements u + 1.. are still in flight
+        slope_next = p.src[s].slope;
+        const float *qs = p.src[s].ss ? p.src[s].ss + (size_t)(2 * n) * sC + c_loc : p.ident_ss + c_loc;
+        const float *qh = p.src[s].ss ? qs + sC : p.ident_ss + 512 + c_loc;
+        scr[0] = *(const float4 *)qs; scr[1] = *(const float4 *)(qs + 4);
+        shr[0] = *(const float4 *)qh; shr[1] = *(const float4 *)(qh + 4);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < PF; ++u)                          // unconditional: branches around loads make hipcc drain vmcnt
             xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * sC + cg * 8) * 2));
 #pragma unroll
         for (int u = 0; u < WPF; ++u) wr[u] = *(const f16x8 *)((const char *)p.wpk + (unsigned)((wofs[u] + ch * (KS * 64)) * 16));
-        slope_next = p.src[s].slope;
-        if (p.src[s].ss) {
-            const float *q4 = p.src[s].ss + (size_t)(2 * n) * sC + c_loc;
-            scr[0] = *(const float4 *)q4; scr[1] = *(const float4 *)(q4 + 4);
-            shr[0] = *(const float4 *)(q4 + sC); shr[1] = *(const float4 *)(q4 + sC + 4);
-        } else {
-            scr[0] = scr[1] = make_float4(1.f, 1.f, 1.f, 1.f);
-            shr[0] = shr[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
     };
     auto commit = [&]() {
         const f16 slope_h = (f16)slope_next;
@@ -256,6 +256,8 @@ static int launch_zr(ConvParams p, hipStream_t st) {
         (void)hipFuncSetAttribute((const void *)conv3d_zr_kernel<NB, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    p.ident_ss = conv3d_identity_ss();
+    if (!p.ident_ss) return -2;
     dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
     hipLaunchKernelGGL((conv3d_zr_kernel<NB, TD>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
