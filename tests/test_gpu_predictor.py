@@ -216,6 +216,23 @@ def test_driver_with_61_heads_uses_the_tiled_finalize(shape, folds, accum):
         assert (got.float() - want.float()).abs().max() <= 2e-3 * float(want.abs().max()) + 1e-3
 
 
+@pytest.mark.parametrize('heads', [15, 16, 63, 64])
+def test_driver_with_head_counts_around_a_block_boundary(heads):
+    """The weight-sum channel is a seg head of its own (zero weights, bias 1) right after the last class: with 15 / 63
+    classes it fills the last slot of a 16-channel head block, with 16 / 64 it opens a new block (and 64 classes need a
+    second 64-channel pass over the accumulator row).  Driver vs the oracle driver on the engine's logits, bit for bit;
+    labels straight from the accumulators vs argmax of those logits."""
+    spec = UNetSpec('plain', 1, heads, [16, 32], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
+    patch = (16, 16, 32)
+    p = _predictor(spec, patch, [synthetic_state_dict(spec, 90 + heads)])
+    image = torch.randn(1, 21, 27, 50, generator=torch.Generator().manual_seed(17))
+    want = osw.sliding_window_logits(lambda x: p.forward_patches(x).cpu(), image, patch, heads, accum='fp16')
+    got = p.predict_sliding_window_return_logits(image).cpu()
+    assert (_bits(got) == _bits(want)).all()
+    labels = p.predict_segmentation_from_preprocessed_data(image).cpu()
+    assert torch.equal(labels.long(), osw.logits_to_labels(want.float()).long())
+
+
 def test_fp32_accumulators_match_exact_blend():
     spec, patch = SPECS['toy3']
     sd = synthetic_state_dict(spec, 3)
