@@ -11,7 +11,9 @@ Gaussian blending: 600 patches per volume.  Synthetic data, random-init weights
 (seed 1234).  One step = one whole volume through
 ``nnUNetPredictor.predict_sliding_window_return_logits`` with the volume already
 resident in HBM.  N > 1 shards the patches of the SAME volume over the ranks
-(strong scaling) with a halo exchange over RCCL.
+(strong scaling) with a halo exchange over RCCL and ends with every rank holding
+the assembled label map (``--gather``); without a launcher ``--gpus N`` starts
+the N ranks itself.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus ``roofline`` and
 ``cpu_baseline`` (N = 1 only).
@@ -32,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16, MI355X_MICROARCH.md "Chip-level parameters"
+TRAFFIC_FILE = 'r02_traffic.json'  # per-launch HBM bytes of the conv family from separate rocprofv3 --pmc passes
 
 WORKLOADS = {
     # name: (spacing, patch, heads, reduction)
@@ -144,9 +147,11 @@ def synthetic_volume(size, device):
     return out.to(device)
 
 
-def cpu_baseline(sd, info, seconds_budget=25.0):
+def cpu_baseline(sd, info, seconds_budget=60.0):
     """The oracle (CPU restatement of the reference path: fp32 network, fp16 Gaussian accumulate) timed on
-    the host cores on a bounded sample of the same workload."""
+    the host cores on a bounded sample of the same workload, at the two thread settings the reference uses:
+    all cores (its CLI, predict_from_raw_data.py:954-958) and 8 threads (default_num_processes inside
+    predict_logits_from_preprocessed_data, :479-480)."""
     from oracle import sliding_window as osw
     from oracle.topology import UNetSpec
     from oracle.unet import build as build_oracle
@@ -155,27 +160,57 @@ def cpu_baseline(sd, info, seconds_budget=25.0):
                     [tuple(s) for s in info['strides']], [2] * n, [2] * (n - 1))
     net = build_oracle(spec, sd)
     patch = info['patch']
-    threads = torch.get_num_threads()
+    all_threads = torch.get_num_threads()
     # sub-volume that holds exactly 2 x 2 x 2 = 8 patches at step 0.5
-    shape = tuple(int(p * 1.5) for p in patch)
-    image = synthetic_volume(max(shape), torch.device('cpu'))[:, :shape[0], :shape[1], :shape[2]].contiguous()
-    with torch.inference_mode():
+    shape8 = tuple(int(p * 1.5) for p in patch)
+    image8 = synthetic_volume(max(shape8), torch.device('cpu'))[:, :shape8[0], :shape8[1], :shape8[2]].contiguous()
+
+    def run(threads):
+        torch.set_num_threads(threads)
+        with torch.inference_mode():
+            t0 = time.perf_counter()
+            net(image8[:, :patch[0], :patch[1], :patch[2]][None])        # warm-up + per-patch estimate
+            one = time.perf_counter() - t0
+        shape, image, n_patches = shape8, image8, 8
+        if one * 9 > seconds_budget:                                      # slow setting: 2 patches instead of 8
+            shape = (patch[0], patch[1], int(patch[2] * 1.5))
+            image = image8[:, :shape[0], :shape[1], :shape[2]].contiguous()
+            n_patches = 2
         t0 = time.perf_counter()
-        net(image[:, :patch[0], :patch[1], :patch[2]][None])            # warm-up + per-patch estimate
-        one = time.perf_counter() - t0
-    n_patches = 8
-    if one * 9 > seconds_budget:                                          # slow host: shrink the sample
-        shape = (patch[0], patch[1], int(patch[2] * 1.5))
-        image = image[:, :shape[0], :shape[1], :shape[2]].contiguous()
-        n_patches = 2
-    t0 = time.perf_counter()
-    osw.sliding_window_logits(net, image, patch, info['heads'], step=0.5, use_gaussian=True, accum='fp16')
-    dt = time.perf_counter() - t0
-    return {'value': round(n_patches / dt, 4), 'unit': 'patches/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n_patches} patches ({shape[0]}x{shape[1]}x{shape[2]} sub-volume of the same synthetic CT), '
-                      f'fp32 network + fp16 accumulators, torch {torch.__version__} CPU, '
-                      f'{os.cpu_count()} host cpus visible',
-            's_per_patch': round(dt / n_patches, 4)}
+        osw.sliding_window_logits(net, image, patch, info['heads'], step=0.5, use_gaussian=True, accum='fp16')
+        dt = time.perf_counter() - t0
+        return {'value': round(n_patches / dt, 4), 'cores': threads, 's_per_patch': round(dt / n_patches, 4),
+                'sample': f'{n_patches} patches ({shape[0]}x{shape[1]}x{shape[2]} sub-volume of the same synthetic CT)'}
+
+    full = run(all_threads)
+    eight = run(min(8, all_threads)) if all_threads > 8 else dict(full)
+    torch.set_num_threads(all_threads)
+    return {'value': full['value'], 'unit': 'patches/s', 'cores': full['cores'], 'kind': 'port',
+            'sample': full['sample'] + f', fp32 network + fp16 accumulators, torch {torch.__version__} CPU, '
+                                       f'{os.cpu_count()} host cpus visible',
+            's_per_patch': full['s_per_patch'],
+            'threads_8_reference_default': {'value': eight['value'], 'unit': 'patches/s', 'cores': eight['cores'],
+                                            'sample': eight['sample'], 's_per_patch': eight['s_per_patch']}}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) BEFORE anything in
+    this process touches the GPU, wait for them, and leave with the worst exit code.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
 
 
 def main():
@@ -190,11 +225,19 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-sharded', action='store_true', help='run the multi-GPU code path even with one rank')
+    ap.add_argument('--gather', default='labels', choices=['labels', 'logits', 'none'],
+                    help='multi-GPU: what every rank holds when the step ends (labels: argmax on the owner, then '
+                         'all_gather of the uint8 slabs; logits: all_gather of the fp16 logits; none: owned boxes only)')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)                                  # does not return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU '
+                         f'(python -m torch.distributed.run --nproc-per-node {args.gpus} ...) or drop WORLD_SIZE')
     distributed = world > 1 or args.force_sharded
     if distributed:
         import torch.distributed as dist
@@ -214,11 +257,32 @@ def main():
     from fast_nnunet_amd import capi
     n_patches = capi.plan_volume(info['patch'], vol.shape[1:], 0.5)[2].shape[0]
 
+    def timed(step_fn, barrier, steps):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step_fn()
+            del out
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    dt_nogather = None
     if distributed:
         from fast_nnunet_amd.dist import ShardedPredictor
-        import torch.distributed as dist
         runner = ShardedPredictor(predictor, dist.group.WORLD)
-        step_fn = lambda: runner.predict_sliding_window_return_logits(vol)
+        if args.gather == 'labels':
+            step_fn = lambda: runner.predict_segmentation_from_preprocessed_data(vol)
+            bare_fn = lambda: runner.predict_segmentation_from_preprocessed_data(vol, gather=False)
+        else:
+            step_fn = lambda: runner.predict_sliding_window_return_logits(vol, gather=args.gather == 'logits')
+            bare_fn = lambda: runner.predict_sliding_window_return_logits(vol)
         barrier = lambda: dist.barrier()
     else:
         step_fn = lambda: predictor.predict_sliding_window_return_logits(vol)
@@ -227,22 +291,15 @@ def main():
     for _ in range(args.warmup):
         out = step_fn()
         del out
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step_fn()
-        del out
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if distributed:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed(step_fn, barrier, args.steps)
+    if distributed and args.gather != 'none':
+        dt_nogather = timed(bare_fn, barrier, args.steps)        # the same step without the assembly: compute + halo
 
     flops_patch, act_bytes_patch = predictor._engine.patch_work()
+    assembly = {'labels': 'labels on the owner of each box, all_gather of the uint8 slabs: the label map on every rank',
+                'logits': 'all_gather of the fp16 logits of the owned boxes: the logits on every rank',
+                'none': 'every rank keeps the logits of the box it owns'}[args.gather] if distributed else \
+        'fp16 logits [heads, X, Y, Z] in HBM (predict_sliding_window_return_logits)'
     result = {
         'metric': '3d_fullres patches/sec (distilled r=2 student, sliding window, one 512^3 CT)',
         'value': round(n_patches * args.steps / dt, 3),
@@ -255,19 +312,23 @@ def main():
         'vs_baseline': None,
         'dtype': 'f16',
         'data': 'synthetic',
-        'config': {'workload': f'{args.workload}: PlainConvUNet student r={info["r"]}, features {info["features"]}, '
+        'config': {'workload': f'{args.workload}: PlainConvUNet {"student" if info["r"] > 1 else "teacher"} r={info["r"]}, '
+                               f'features {info["features"]}, '
                                f'patch {"x".join(map(str, info["patch"]))}, {info["heads"]} classes, '
                                f'{args.volume}^3 volume, tile_step_size 0.5, Gaussian on, mirroring off, '
                                f'{n_patches} patches/volume',
                    'patches_per_forward': args.batch,
                    'accumulators': accumulate_in,
                    'gflop_per_patch': round(flops_patch / 1e9, 2),
-                   'parallelism': f'patch-sharded x{world}' if distributed else 'single GPU'},
+                   'step_output': assembly,
+                   'parallelism': f'patch-sharded x{world}, halo exchange + gather over RCCL' if distributed else 'single GPU'},
     }
+    if dt_nogather is not None:
+        result['ms_per_step_compute_and_halo_only'] = round(dt_nogather / args.steps * 1e3, 3)
 
     if rank == 0 and not distributed and not args.no_roofline:
         # one extra, identical step with HIP events around every launch (recorded by the engine on the
-        # launch stream) -> duration of the dominant kernel family (conv3d_mfma_kernel)
+        # launch stream) -> duration of the dominant kernel family (the MFMA convs)
         predictor._engine.set_profiling(True)
         out = step_fn()
         del out
@@ -275,23 +336,30 @@ def main():
         pr = predictor._engine.profile()
         predictor._engine.set_profiling(False)
         achieved = pr.conv_flops / (pr.conv_ms * 1e-3) / 1e12 if pr.conv_ms > 0 else 0.0
+        launches = max(1, pr.conv_launches)
+        algo_bytes = pr.conv_bytes / launches
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        tpath = os.path.join(ROOT, 'profiles', TRAFFIC_FILE)
         if os.path.isfile(tpath) and args.workload == 'bone_turbo_r2' and args.volume == 512 and args.batch == 32:
             try:                                  # HBM bytes per launch of the same kernel family from separate PMC passes
                 fam = json.load(open(tpath))['families']['conv3d_mfma']
-                traffic, traffic_src = int(fam['bytes_per_launch']), 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, reads x2)'
+                traffic = int(fam['bytes_per_launch'])
+                traffic_src = (f'profiles/{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on '
+                               f'the same build (reads x2 as MI355X_MICROARCH.md prescribes); not measured in this run')
             except Exception:
                 pass
         result['roofline'] = {
-            'kernel': 'conv3d_*_kernel (MFMA conv family: lds / persist / pipe / mfma variants)', 'bound': 'mfma',
+            'kernel': 'conv3d_*_kernel (MFMA conv family: zr / persist / lds variants)', 'bound': 'mfma',
             'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
             'traffic': traffic, 'traffic_source': traffic_src,
+            'algorithmic_bytes': int(algo_bytes),
+            'traffic_over_algorithmic': round(traffic / algo_bytes, 3) if traffic and algo_bytes else None,
+            'hbm_gbps_algorithmic': round(pr.conv_bytes / (pr.conv_ms * 1e-3) / 1e9, 1) if pr.conv_ms > 0 else None,
             'algorithmic_act_bytes_per_patch': int(act_bytes_patch),
             'launches': int(pr.conv_launches),
-            'avg_launch_us': round(pr.conv_ms * 1e3 / max(1, pr.conv_launches), 2),
-            'flop_per_launch': round(pr.conv_flops / max(1, pr.conv_launches) / 1e9, 3),
+            'avg_launch_us': round(pr.conv_ms * 1e3 / launches, 2),
+            'flop_per_launch': round(pr.conv_flops / launches / 1e9, 3),
             'flop_unit': 'GFLOP (2*MACs of the conv layers, SURVEY.md App. D method)',
             'time_share_ms': {'conv3d_mfma': round(pr.conv_ms, 2), 'stem': round(pr.stem_ms, 2),
                               'tconv': round(pr.tconv_ms, 2), 'seg_head_accumulate': round(pr.head_ms, 2),
@@ -301,9 +369,8 @@ def main():
     if rank == 0 and not distributed and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(sd, info)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if distributed:
-        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 

@@ -127,6 +127,31 @@ def spec_from_state_dict(state_dict: Mapping[str, object], patch: Sequence[int],
                     n_enc, n_dec, lift(patch), eps, slope, nd)
 
 
+def ops_from_plans(arch_kwargs: dict) -> Tuple[float, float]:
+    """-> (eps, negative_slope) of the plans' architecture block, after checking that its operators are the ones
+    the engine implements: affine InstanceNorm{2,3}d + LeakyReLU, no dropout (what the reference's planner writes,
+    experiment_planning/experiment_planners/default_experiment_planner.py:288-300; a checkpoint trained with
+    BatchNorm or ReLU would otherwise load and give silently wrong logits)."""
+    def name(v):
+        return v if isinstance(v, str) else getattr(v, '__name__', str(v))
+    norm = arch_kwargs.get('norm_op')
+    if norm is not None and 'InstanceNorm' not in name(norm):
+        raise NotImplementedError(f'norm_op {name(norm)}: the engine implements InstanceNorm2d / InstanceNorm3d only')
+    nkw = arch_kwargs.get('norm_op_kwargs') or {}
+    if norm is not None and not nkw.get('affine', True):
+        raise NotImplementedError('InstanceNorm without affine parameters is not supported')
+    nonlin = arch_kwargs.get('nonlin')
+    if nonlin is not None and 'LeakyReLU' not in name(nonlin):
+        raise NotImplementedError(f'nonlin {name(nonlin)}: the engine implements LeakyReLU only')
+    drop = arch_kwargs.get('dropout_op')
+    if drop is not None and float((arch_kwargs.get('dropout_op_kwargs') or {}).get('p', 0.0)) != 0.0:
+        pass                                                   # dropout is the identity at inference time
+    slope = float((arch_kwargs.get('nonlin_kwargs') or {}).get('negative_slope', 0.01))
+    if not 0.0 <= slope <= 1.0:
+        raise NotImplementedError(f'LeakyReLU negative_slope {slope} outside [0, 1]')
+    return float(nkw.get('eps', 1e-5)), slope
+
+
 def check_against_plans(spec: ArchSpec, arch_kwargs: dict, reduction: Optional[int] = None):
     """Raise if the checkpoint disagrees with the plans' architecture block."""
     n = int(arch_kwargs['n_stages'])
@@ -150,7 +175,20 @@ def check_against_plans(spec: ArchSpec, arch_kwargs: dict, reduction: Optional[i
 
 def weight_blob(spec: ArchSpec, state_dict: Mapping[str, object]) -> np.ndarray:
     """Flatten the parameters in the order ``fnn_load_weights`` documents."""
-    sd = canonical_state_dict(state_dict)
+    full = canonical_state_dict(state_dict)
+    used = set()
+
+    class _Tracked(dict):                                      # remembers which keys the blob consumed
+        def __getitem__(self, k):
+            used.add(k)
+            return dict.__getitem__(self, k)
+
+        def get(self, k, default=None):
+            if k in self:
+                used.add(k)
+            return dict.get(self, k, default)
+
+    sd = _Tracked(full)
     parts: List[np.ndarray] = []
 
     def conv_block(prefix):
@@ -190,6 +228,13 @@ def weight_blob(spec: ArchSpec, state_dict: Mapping[str, object]) -> np.ndarray:
             conv_block(f'decoder.stages.{d}.convs.{i}')
     parts.append(sd[f'decoder.seg_layers.{n - 2}.weight'].reshape(-1))
     parts.append(sd[f'decoder.seg_layers.{n - 2}.bias'])
+    # Anything left over that is not a deep-supervision head (decoder.seg_layers.<d>, unused at inference:
+    # the reference switches deep supervision off, predict_from_raw_data.py:118) is a module the engine does not
+    # implement - e.g. BatchNorm's running_mean / running_var - and would be dropped silently.
+    left = [k for k in full if k not in used and not k.startswith('decoder.seg_layers.')]
+    if left:
+        raise NotImplementedError(f'state dict has parameters / buffers the engine does not implement: {sorted(left)[:6]}'
+                                  f'{" ..." if len(left) > 6 else ""}')
     return np.concatenate([p.astype(np.float32, copy=False).reshape(-1) for p in parts])
 
 

@@ -47,7 +47,7 @@ class ResampleDesc(C.Structure):
 
 
 class Opts(C.Structure):
-    _fields_ = [('tile_step_size', C.c_float), ('use_gaussian', C.c_int32), ('n_mirror_axes', C.c_int32),
+    _fields_ = [('tile_step_size', C.c_double), ('use_gaussian', C.c_int32), ('n_mirror_axes', C.c_int32),
                 ('mirror_axes', C.c_int32 * 3), ('accum', C.c_int32), ('out_dtype', C.c_int32),
                 ('batch', C.c_int32), ('stream', C.c_void_p)]
 
@@ -55,12 +55,13 @@ class Opts(C.Structure):
 class Profile(C.Structure):
     _fields_ = [('total_ms', C.c_double), ('conv_ms', C.c_double), ('stem_ms', C.c_double),
                 ('tconv_ms', C.c_double), ('head_ms', C.c_double), ('finalize_ms', C.c_double),
-                ('conv_launches', C.c_int64), ('conv_flops', C.c_double), ('n_patches', C.c_int64)]
+                ('conv_launches', C.c_int64), ('conv_flops', C.c_double), ('n_patches', C.c_int64),
+                ('conv_bytes', C.c_double)]
 
 
 EXPORTS = ['fnn_abi_version', 'fnn_last_error', 'fnn_create', 'fnn_destroy', 'fnn_weight_count', 'fnn_load_weights',
            'fnn_set_gaussian', 'fnn_predict_volume', 'fnn_predict_volume_ensemble', 'fnn_predict_labels',
-           'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_export_probabilities', 'fnn_resample', 'fnn_compute_steps', 'fnn_plan_volume',
+           'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_labels_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_export_probabilities', 'fnn_resample', 'fnn_compute_steps', 'fnn_plan_volume',
            'fnn_set_profiling', 'fnn_get_profile', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d']
 
 _lib = None
@@ -100,6 +101,7 @@ def load_library() -> C.CDLL:
     P64 = C.POINTER(i64)
     lib.fnn_accumulate_patches.argtypes = [vp, i32, vp, P64, C.POINTER(Opts), P64, i64, P64, P64, vp]
     lib.fnn_normalize_box.argtypes = [vp, vp, P64, C.POINTER(Opts), P64, P64, P64, P64, vp]
+    lib.fnn_labels_box.argtypes = [vp, vp, P64, C.POINTER(Opts), P64, P64, P64, P64, vp]
     lib.fnn_forward_patches.argtypes = [vp, i32, vp, i32, vp, vp]
     lib.fnn_argmax_labels.argtypes = [vp, vp, i32, i32, i64, vp, vp]
     lib.fnn_nonzero_bbox.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64), vp]
@@ -118,7 +120,7 @@ def load_library() -> C.CDLL:
     lib.fnn_op_conv3d.argtypes = [i32, i32, I3, f32p, i32, f32p, f32p, C.c_float, f32p, i32, f32p, f32p, C.c_float,
                                   f32p, f32p, i32, I3, I3, f32p, C.POINTER(C.c_double)]
     lib.fnn_op_conv_transpose3d.argtypes = [i32, i32, I3, f32p, i32, f32p, f32p, C.c_float, f32p, f32p, i32, I3, f32p]
-    if lib.fnn_abi_version() != 1:
+    if lib.fnn_abi_version() != 2:
         raise EngineError('libfnn_hip.so has an unexpected ABI version')
     _lib = lib
     return lib
@@ -333,6 +335,12 @@ class Engine:
         shp = (C.c_int64 * 4)(*[int(i) for i in shape])
         a = [(C.c_int64 * 3)(*[int(i) for i in v]) for v in (box_lo, box_hi, out_lo, out_hi)]
         check(self.lib.fnn_normalize_box(self.handle, acc_ptr, shp, C.byref(opts), a[0], a[1], a[2], a[3], out_ptr),
+              self.lib, self.handle)
+
+    def labels_box(self, acc_ptr, shape, opts, box_lo, box_hi, out_lo, out_hi, labels_ptr):
+        shp = (C.c_int64 * 4)(*[int(i) for i in shape])
+        a = [(C.c_int64 * 3)(*[int(i) for i in v]) for v in (box_lo, box_hi, out_lo, out_hi)]
+        check(self.lib.fnn_labels_box(self.handle, acc_ptr, shp, C.byref(opts), a[0], a[1], a[2], a[3], labels_ptr),
               self.lib, self.handle)
 
     def forward_patches(self, x_ptr: int, n: int, out_ptr: int, fold: int = 0, stream: int = 0):

@@ -43,6 +43,7 @@ struct Layer {
     int chunks = 0, ksteps = 0, packing = 0;
     int stats_slots = FNN_STAT_REPL;  // rows per item in the stats buffer: atomics' replicas, or one row per tile
     double flops = 0;                 // 2*MACs per patch
+    double bytes = 0;                 // algorithmic HBM bytes per patch: every input read once + the output written once (fp16)
 };
 
 struct FoldWeights {
@@ -98,7 +99,7 @@ struct fnn_engine {
     double head_flops = 0, patch_flops = 0, patch_act_bytes = 0;
     // profiling
     bool profiling = false;
-    struct Ev { hipEvent_t a, b; int family; double flops; };
+    struct Ev { hipEvent_t a, b; int family; double flops, bytes; };
     std::vector<Ev> evs; size_t ev_used = 0;
     fnn_profile prof{};
 };
@@ -190,6 +191,8 @@ int build_plan(fnn_engine *e) {
         L.blob_g = blob; blob += cout;
         L.blob_beta = blob; blob += cout;
         L.flops = 2.0 * cout * cin_tot * T * out_d[0] * out_d[1] * out_d[2];
+        L.bytes = 2.0 * ((double)cin_tot * in_d[0] * in_d[1] * in_d[2] * (type == Layer::STEM ? 2 : 1)     // fp32 volume
+                         + (double)cout * out_d[0] * out_d[1] * out_d[2]);
         e->layers.push_back(L);
         return (int)e->layers.size() - 1;
     };
@@ -407,7 +410,7 @@ enum { FAM_CONV = 0, FAM_STEM, FAM_TCONV, FAM_HEAD, FAM_FINAL };
 
 struct Scope {
     fnn_engine *e; hipStream_t st; int idx = -1;
-    Scope(fnn_engine *e_, hipStream_t st_, int family, double flops) : e(e_), st(st_) {
+    Scope(fnn_engine *e_, hipStream_t st_, int family, double flops, double bytes = 0) : e(e_), st(st_) {
         if (!e->profiling) return;
         if (e->ev_used == e->evs.size()) {
             fnn_engine::Ev ev{};
@@ -415,7 +418,7 @@ struct Scope {
             e->evs.push_back(ev);
         }
         idx = (int)e->ev_used++;
-        e->evs[idx].family = family; e->evs[idx].flops = flops;
+        e->evs[idx].family = family; e->evs[idx].flops = flops; e->evs[idx].bytes = bytes;
         (void)hipEventRecord(e->evs[idx].a, st);
     }
     ~Scope() { if (idx >= 0) (void)hipEventRecord(e->evs[idx].b, st); }
@@ -430,7 +433,7 @@ void collect_profile(fnn_engine *e, int64_t n_patches) {
         if (hipEventElapsedTime(&ms, e->evs[i].a, e->evs[i].b) != hipSuccess) continue;
         p.total_ms += ms;
         switch (e->evs[i].family) {
-            case FAM_CONV: p.conv_ms += ms; p.conv_launches++; p.conv_flops += e->evs[i].flops; break;
+            case FAM_CONV: p.conv_ms += ms; p.conv_launches++; p.conv_flops += e->evs[i].flops; p.conv_bytes += e->evs[i].bytes; break;
             case FAM_STEM: p.stem_ms += ms; break;
             case FAM_TCONV: p.tconv_ms += ms; break;
             case FAM_HEAD: p.head_ms += ms; break;
@@ -502,7 +505,7 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
             p.chunks = L.chunks; p.ksteps = L.ksteps; p.packing = L.packing;
             p.tile_d = FNN_TILE_D;
-            Scope sc(e, st, FAM_CONV, L.flops * nb);
+            Scope sc(e, st, FAM_CONV, L.flops * nb, L.bytes * nb);
             rc = launch_conv3d(p, st);
         } else if (L.type == Layer::POOL) {
             PoolParams p{};
@@ -1108,6 +1111,36 @@ int fnn_normalize_box(fnn_engine *e, const void *acc, const int64_t shape[4], co
     HIPCHK(e, hipMemsetAsync(e->inf_flag, 0, sizeof(int), st));
     FinalizeParams f = make_finalize(e, acc, box, out_lo, out_hi, vp, shape, *opts, opts->accum == FNN_ACC_FP32, 0, out);
     if (launch_finalize(f, st) != 0) return fail(e, FNN_E_HIP, "finalize launch failed");
+    int flag = 0;
+    HIPCHK(e, hipMemcpyAsync(&flag, e->inf_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    if (flag) return fail(e, FNN_E_INF, "Encountered inf in predicted array.");
+    return 0;
+}
+
+int fnn_labels_box(fnn_engine *e, const void *acc, const int64_t shape[4], const fnn_opts *opts,
+                   const int64_t box_lo[3], const int64_t box_hi[3], const int64_t out_lo[3], const int64_t out_hi[3],
+                   void *labels) {
+    if (!e || !opts) return FNN_E_INVALID;
+    if (!acc || !labels || !box_lo || !box_hi || !out_lo || !out_hi) return fail(e, FNN_E_INVALID, "NULL argument");
+    if (!is_device_ptr(acc) || !is_device_ptr(labels)) return fail(e, FNN_E_INVALID, "fnn_labels_box needs device pointers");
+    if (!e->label_u16 && e->label_mode == FNN_LABELS_ARGMAX && e->arch.num_heads > 256)
+        return fail(e, FNN_E_INVALID, "%d classes do not fit uint8 labels: fnn_set_label_rule(..., FNN_LABEL_U16)", e->arch.num_heads);
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)opts->stream;
+    VolPlan vp;
+    if (plan_volume(e->arch, shape + 1, opts->tile_step_size, vp) != 0) return fail(e, FNN_E_INVALID, "invalid volume shape / step size");
+    Box box;
+    for (int d = 0; d < 3; ++d) {
+        box.lo[d] = box_lo[d]; box.hi[d] = box_hi[d];
+        if (out_lo[d] < 0 || out_hi[d] > shape[1 + d] || out_lo[d] >= out_hi[d]) return fail(e, FNN_E_INVALID, "output box out of bounds");
+        if (out_lo[d] + vp.lo[d] < box.lo[d] || out_hi[d] + vp.lo[d] > box.hi[d])
+            return fail(e, FNN_E_INVALID, "output box is not covered by the accumulator box");
+    }
+    HIPCHK(e, hipMemsetAsync(e->inf_flag, 0, sizeof(int), st));
+    FinalizeParams f = make_finalize(e, acc, box, out_lo, out_hi, vp, shape, *opts, opts->accum == FNN_ACC_FP32, 0, nullptr);
+    const int *order = e->label_mode == FNN_LABELS_REGIONS ? e->label_order : nullptr;
+    if (launch_labels_from_acc(f, labels, e->label_u16, order, st) != 0) return fail(e, FNN_E_HIP, "labels launch failed");
     int flag = 0;
     HIPCHK(e, hipMemcpyAsync(&flag, e->inf_flag, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));

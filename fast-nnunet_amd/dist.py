@@ -186,11 +186,48 @@ def unpadded(box: Box, pad_lo: Sequence[int], shape_sp: Sequence[int]) -> Option
     return (lo, hi) if all(h > l for l, h in zip(lo, hi)) else None
 
 
-class ShardedPredictor:
-    """``predict_sliding_window_return_logits`` of one volume over all ranks of `group`.
+def gather_owned_boxes(full: torch.Tensor, owns: Sequence[Optional[Box]], rank: int, group=None) -> torch.Tensor:
+    """Assembles `full` ([..., X, Y, Z]; every rank has written only the box it owns, ``owns[rank]`` in un-padded
+    coordinates, None = nothing) on EVERY rank: each rank packs its box into a flat buffer of the largest box's size,
+    one ``all_gather`` moves the slabs (RCCL over xGMI on the GPUs, gloo in the CPU tests), every rank unpacks the
+    other ranks' boxes.  The owned boxes are disjoint and tile the volume, so nothing is added: the bytes that travel
+    are the volume itself, once ((world - 1) / world of it per rank), not a reduction over full-size buffers."""
+    world = len(owns)
+    lead = tuple(full.shape[:-3])
+    nlead = int(np.prod(lead)) if lead else 1
 
-    Every rank passes the same (replicated) preprocessed volume.  Returns ``(logits, owned_box)``: a full-size
-    fp16 tensor in which this rank has written the box it owns (un-padded coordinates, ``None`` if idle).
+    def nvox(b):
+        return 0 if b is None else int(np.prod([b[1][d] - b[0][d] for d in range(3)]))
+
+    cap = max(nvox(b) for b in owns) * nlead
+    if cap == 0:
+        return full
+    mine = torch.zeros(cap, dtype=full.dtype, device=full.device)
+    b = owns[rank]
+    if b is not None:
+        sl = (Ellipsis, *[slice(b[0][d], b[1][d]) for d in range(3)])
+        mine[:nvox(b) * nlead] = full[sl].reshape(-1)
+    slabs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(slabs, mine, group=group)
+    for r, br in enumerate(owns):
+        if r == rank or br is None:
+            continue
+        shape_r = lead + tuple(br[1][d] - br[0][d] for d in range(3))
+        sl = (Ellipsis, *[slice(br[0][d], br[1][d]) for d in range(3)])
+        full[sl] = slabs[r][:nvox(br) * nlead].view(shape_r)
+    return full
+
+
+class ShardedPredictor:
+    """The predictor's whole-volume entry points with the patches of ONE volume sharded over the ranks of `group`.
+
+    Every rank passes the same (replicated) preprocessed volume.
+    ``predict_sliding_window_return_logits`` returns ``(logits, owned_box)``: a full-size fp16 tensor in which this
+    rank has written the box it owns (un-padded coordinates; ``None`` on an idle rank, whose tensor holds nothing) -
+    or, with ``gather=True``, the assembled logits on every rank.  ``predict_segmentation_from_preprocessed_data``
+    labels each owned box on its owner and gathers the uint8 / uint16 slabs (128 MiB for a 512^3 volume instead of
+    15 GiB of fp16 logits for 61 classes): the assembled label map on every rank.  With several folds loaded both
+    form the ensemble mean like the single-GPU predictor.
     """
 
     def __init__(self, predictor, group=None):
@@ -199,40 +236,98 @@ class ShardedPredictor:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
-    @torch.inference_mode()
-    def predict_sliding_window_return_logits(self, input_image: torch.Tensor, out: Optional[torch.Tensor] = None):
+    def _plan(self, x):
         from . import capi
+        p = self.p
+        patch = p._spec.patch
+        padded, pad_lo, origins = capi.plan_volume(patch[3 - p._spec.spatial_dims:], x.shape[1:], p.tile_step_size)
+        steps = [sorted(set(int(v) for v in origins[:, d])) for d in range(3)]
+        dec = Decomposition.build(patch, padded, steps, self.world)
+        owns = [None if b is None else unpadded(b, pad_lo, x.shape[1:]) for b in dec.owned]
+        return dec, origins, owns
+
+    def _accumulate_fold(self, x, dec, origins, opts, fold):
+        """This rank's accumulator box with every contribution to the part it owns (its own patches + the halos)."""
+        p, eng, patch = self.p, self.p._engine, self.p._spec.patch
+        box = dec.boxes[self.rank]
+        if box is None:
+            exchange_halos(torch.empty(0), dec, self.rank, self.group)
+            return None
+        acc_dtype = torch.float32 if p.accumulate_in == 'fp32' else torch.half
+        dims = tuple(box[1][d] - box[0][d] for d in range(3))
+        acc = torch.zeros((*dims, eng.accumulator_channels), dtype=acc_dtype, device=p.device)
+        # patches that feed another rank's box first; their halos travel over xGMI while the interior computes
+        boundary, interior = dec.split_patches(self.rank, patch, origins)
+        hx = HaloExchange(acc, dec, self.rank, self.group)
+        if boundary:
+            eng.accumulate_patches(x.data_ptr(), x.shape, opts, boundary, box[0], box[1], acc.data_ptr(), fold=fold)
+        hx.start()
+        if interior:
+            eng.accumulate_patches(x.data_ptr(), x.shape, opts, interior, box[0], box[1], acc.data_ptr(), fold=fold)
+        hx.finish()
+        return acc
+
+    @torch.inference_mode()
+    def predict_sliding_window_return_logits(self, input_image: torch.Tensor, out: Optional[torch.Tensor] = None,
+                                             gather: bool = False, folds: Optional[Sequence[int]] = None):
         p = self.p
         p._check_input(input_image)
         eng = p._engine
-        patch = p._spec.patch
+        folds = [p._active_fold] if folds is None else list(folds)
         with torch.cuda.device(p.device):
             x = input_image.to(device=p.device, dtype=torch.float32).contiguous()
-            padded, pad_lo, origins = capi.plan_volume(patch[3 - p._spec.spatial_dims:], x.shape[1:], p.tile_step_size)
-            steps = [sorted(set(int(v) for v in origins[:, d])) for d in range(3)]
-            dec = Decomposition.build(patch, padded, steps, self.world)
+            dec, origins, owns = self._plan(x)
             opts = p._opts()                                  # accumulator dtype follows predictor.accumulate_in
-            acc_dtype = torch.float32 if p.accumulate_in == 'fp32' else torch.half
             if out is None:
                 out = torch.empty((p._spec.num_heads, *x.shape[1:]), dtype=torch.half, device=p.device)
-            box = dec.boxes[self.rank]
-            if box is None:
-                exchange_halos(torch.empty(0), dec, self.rank, self.group)
-                return out, None
-            dims = tuple(box[1][d] - box[0][d] for d in range(3))
-            acc = torch.zeros((*dims, eng.accumulator_channels), dtype=acc_dtype, device=p.device)
-            # patches that feed another rank's box first; their halos travel over xGMI while the interior computes
-            boundary, interior = dec.split_patches(self.rank, patch, origins)
-            hx = HaloExchange(acc, dec, self.rank, self.group)
-            if boundary:
-                eng.accumulate_patches(x.data_ptr(), x.shape, opts, boundary, box[0], box[1], acc.data_ptr(),
-                                       fold=p._active_fold)
-            hx.start()
-            if interior:
-                eng.accumulate_patches(x.data_ptr(), x.shape, opts, interior, box[0], box[1], acc.data_ptr(),
-                                       fold=p._active_fold)
-            hx.finish()
-            own = unpadded(dec.owned[self.rank], pad_lo, x.shape[1:])
-            if own is not None:
+            box, own = dec.boxes[self.rank], owns[self.rank]
+            part = None
+            for i, f in enumerate(folds):
+                acc = self._accumulate_fold(x, dec, origins, opts, f)
+                if own is None:
+                    continue
                 eng.normalize_box(acc.data_ptr(), x.shape, opts, box[0], box[1], own[0], own[1], out.data_ptr())
+                if len(folds) > 1:                            # fp16 sum over the folds, then / n (:494-500)
+                    sl = (slice(None), *[slice(own[0][d], own[1][d]) for d in range(3)])
+                    part = out[sl].clone() if i == 0 else part.add_(out[sl])
+            if part is not None:
+                out[(slice(None), *[slice(own[0][d], own[1][d]) for d in range(3)])] = part.div_(len(folds))
+            if gather:
+                return gather_owned_boxes(out, owns, self.rank, self.group)
         return out, own
+
+    @torch.inference_mode()
+    def predict_logits_from_preprocessed_data(self, data: torch.Tensor) -> torch.Tensor:
+        """Ensemble mean over the loaded folds, assembled on every rank (device tensor)."""
+        return self.predict_sliding_window_return_logits(data, gather=True, folds=range(self.p._n_folds))
+
+    @torch.inference_mode()
+    def predict_segmentation_from_preprocessed_data(self, data: torch.Tensor, gather: bool = True) -> torch.Tensor:
+        """Label map [X, Y, Z] on every rank: the owner labels its box straight from its accumulators
+        (``fnn_labels_box``), the slabs are gathered.  Several folds: ensemble logits of the owned box first."""
+        p = self.p
+        p._check_input(data)
+        eng = p._engine
+        order, u16 = p._label_rule()
+        with torch.cuda.device(p.device):
+            x = data.to(device=p.device, dtype=torch.float32).contiguous()
+            eng.set_label_rule(order, uint16=u16)
+            labels = torch.zeros(x.shape[1:], dtype=torch.int16 if u16 else torch.uint8, device=p.device)
+            if p._n_folds > 1:
+                logits, own = self.predict_sliding_window_return_logits(x, folds=range(p._n_folds))
+                if own is not None:
+                    sl = tuple(slice(own[0][d], own[1][d]) for d in range(3))
+                    labels[sl] = p.convert_logits_to_segmentation(logits[(slice(None), *sl)].contiguous()).to(labels.dtype)
+                dec, origins, owns = self._plan(x)
+            else:
+                dec, origins, owns = self._plan(x)
+                opts = p._opts()
+                acc = self._accumulate_fold(x, dec, origins, opts, p._active_fold)
+                box, own = dec.boxes[self.rank], owns[self.rank]
+                if own is not None:
+                    eng.labels_box(acc.data_ptr(), x.shape, opts, box[0], box[1], own[0], own[1], labels.data_ptr())
+            if gather:
+                gather_owned_boxes(labels, owns, self.rank, self.group)
+            if u16:
+                labels = labels.to(torch.int32) & 0xffff
+        return labels

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import capi
-from .arch import ArchSpec, check_against_plans, spec_from_state_dict, weight_blob
+from .arch import ArchSpec, check_against_plans, ops_from_plans, spec_from_state_dict, weight_blob
 from .plans import ConfigurationManager, PlansManager, determine_num_input_channels
 from .sliding_window import compute_gaussian, compute_steps_for_sliding_window
 
@@ -156,8 +156,8 @@ class nnUNetPredictor(object):
             kw = self.configuration_manager.network_arch_init_kwargs or {}
         except (KeyError, TypeError):
             kw = {}
-        eps = float((kw.get('norm_op_kwargs') or {}).get('eps', 1e-5)) if kw else 1e-5
-        spec = spec_from_state_dict(sds[0], patch, eps=eps)
+        eps, slope = ops_from_plans(kw) if kw else (1e-5, 0.01)
+        spec = spec_from_state_dict(sds[0], patch, eps=eps, slope=slope)
         if kw and 'n_stages' in kw and 'strides' in kw:
             check_against_plans(spec, kw, self._reduction)
         heads = self.label_manager.num_segmentation_heads

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define FNN_MAX_STAGES 8
-#define FNN_ABI_VERSION 1
+#define FNN_ABI_VERSION 2
 
 enum {
     FNN_OK = 0,
@@ -72,7 +72,9 @@ typedef struct fnn_arch_desc {
 
 /* Knobs of nnUNetPredictor.__init__ (:40-65) + engine-side choices. */
 typedef struct fnn_opts {
-    float tile_step_size;                       /* 0 < s <= 1                                 */
+    double tile_step_size;                      /* 0 < s <= 1; a double like the reference's Python float:
+                                                 * ceil((image - patch) / (patch * step)) of a float-rounded
+                                                 * 0.3 or 0.7 gives another patch count (sliding_window_prediction.py:38-41) */
     int32_t use_gaussian;
     int32_t n_mirror_axes;                      /* 0 = no test-time mirroring                 */
     int32_t mirror_axes[3];                     /* spatial axes 0..2                          */
@@ -174,6 +176,15 @@ int fnn_normalize_box(fnn_engine *e, const void *acc, const int64_t shape[4], co
                       const int64_t box_lo[3], const int64_t box_hi[3],
                       const int64_t out_lo[3], const int64_t out_hi[3], void *out_logits);
 
+/* fnn_normalize_box's label-map twin: divide, round to fp16, apply the engine's label rule
+ * (fnn_set_label_rule) and write the un-padded box [out_lo, out_hi) into `labels`, the full
+ * [X][Y][Z] uint8 / uint16 map - what convert_logits_to_segmentation (label_handling.py:144-195)
+ * would produce from that box's logits.  A rank of the sharded predictor labels the box it owns
+ * and only the label slabs (not the logits) travel between the GPUs. */
+int fnn_labels_box(fnn_engine *e, const void *acc, const int64_t shape[4], const fnn_opts *opts,
+                   const int64_t box_lo[3], const int64_t box_hi[3],
+                   const int64_t out_lo[3], const int64_t out_hi[3], void *labels);
+
 /* LabelManager.convert_logits_to_segmentation on resident logits with the
  * engine's label rule: logits [heads, n_vox] f16/f32 -> labels uint8/uint16. */
 int fnn_argmax_labels(fnn_engine *e, const void *logits, int dtype, int heads, int64_t n_vox,
@@ -265,6 +276,8 @@ typedef struct fnn_profile {
     int64_t conv_launches;
     double conv_flops;                           /* algorithmic 2*MACs of the timed convs     */
     int64_t n_patches;
+    double conv_bytes;                           /* algorithmic HBM bytes of the timed convs: every input
+                                                  * element read once, every output element written once */
 } fnn_profile;
 int fnn_set_profiling(fnn_engine *e, int enabled);
 int fnn_get_profile(const fnn_engine *e, fnn_profile *out);

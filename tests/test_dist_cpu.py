@@ -134,14 +134,15 @@ def _worker(rank, world, port, shape, patch, step, heads, q):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        from fast_nnunet_amd.dist import Decomposition, HaloExchange, exchange_halos, unpadded
+        from fast_nnunet_amd.dist import Decomposition, HaloExchange, exchange_halos, gather_owned_boxes, unpadded
         padded, pad_lo, steps = _geometry(shape, patch, step)
         origins = [(x, y, z) for x in steps[0] for y in steps[1] for z in steps[2]]
         hp = (heads + 1 + 7) // 8 * 8
         gauss = osw.gaussian_weight(patch).float()
         dec = Decomposition.build(patch, padded, steps, world)
         box = dec.boxes[rank]
-        out = torch.zeros((heads, *shape))
+        out = torch.full((heads, *shape), float('nan'))       # what no rank owns or gathers would stay NaN
+        labels = torch.full(shape, 255, dtype=torch.uint8)
         if box is not None:
             # the order ShardedPredictor uses: boundary patches, sends leave, interior patches, receives are added
             boundary, interior = dec.split_patches(rank, patch, origins)
@@ -157,16 +158,20 @@ def _worker(rank, world, port, shape, patch, step, heads, q):
                 part = acc[sl_acc]
                 sl_out = tuple(slice(own[0][d], own[1][d]) for d in range(3))
                 out[(slice(None), *sl_out)] = (part[..., :heads] / part[..., heads:heads + 1]).permute(3, 0, 1, 2)
+                labels[sl_out] = out[(slice(None), *sl_out)].argmax(0).to(torch.uint8)
         else:
             exchange_halos(torch.empty(0), dec, rank, None)
-        dist.all_reduce(out)                         # owned boxes are disjoint: the sum assembles the volume
-        if rank == 0:
-            q.put(out.numpy())
+        # the assembly step of ShardedPredictor: every rank ends up with the whole volume (logits: leading head axis;
+        # labels: none), although ranks own boxes of different sizes and some may own nothing
+        owns = [None if b is None else unpadded(b, pad_lo, shape) for b in dec.owned]
+        gather_owned_boxes(out, owns, rank, None)
+        gather_owned_boxes(labels, owns, rank, None)
+        q.put((rank, out.numpy(), labels.numpy()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 7])
 def test_halo_exchange_matches_single_process_gloo(world):
     shape, patch, step, heads = (30, 41, 26), (16, 16, 16), 0.5, 3
     ctx = mp.get_context('spawn')
@@ -175,10 +180,15 @@ def test_halo_exchange_matches_single_process_gloo(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, shape, patch, step, heads, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=240)
+    results = [q.get(timeout=240) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    assert sorted(r for r, _, _ in results) == list(range(world))
+    got = results[0][1]
+    for _, o, l in results[1:]:                               # every rank holds the same assembled volume
+        assert np.array_equal(o, got) and np.array_equal(l, results[0][2])
+    assert np.array_equal(results[0][2], got.argmax(0).astype(np.uint8))
     # single-process reference
     padded, pad_lo, steps = _geometry(shape, patch, step)
     origins = [(x, y, z) for x in steps[0] for y in steps[1] for z in steps[2]]

@@ -33,3 +33,24 @@ def test_bench_json_line_contract():
 def _patches(j):
     import re
     return int(re.search(r'(\d+) patches/volume', j['config']['workload']).group(1))
+
+
+def test_bench_force_sharded_single_rank_runs_the_multi_gpu_path():
+    """`--gpus 1 --force-sharded`: the rank-sharded code path (RCCL process group, halo exchange, labels on the owner,
+    all_gather of the label slabs) on one GPU - the line the driver would get from every rank 0 at N > 1."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--volume', '192', '--steps', '1', '--warmup', '1',
+                          '--gpus', '1', '--force-sharded'], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 1 and 'patch-sharded x1' in j['config']['parallelism'] and 'all_gather' in j['config']['step_output']
+    assert j['value'] > 0 and j['ms_per_step_compute_and_halo_only'] <= j['ms_per_step'] * 1.25
+    assert 'roofline' not in j and 'cpu_baseline' not in j
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'], capture_output=True,
+                         text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and 'WORLD_SIZE=1' in (out.stderr + out.stdout)

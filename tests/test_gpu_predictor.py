@@ -153,6 +153,10 @@ DRIVER_CASES = [
     dict(shape=(24, 33, 40), mirror=[0], step=0.5, gaussian=True, folds=1),
     dict(shape=(20, 18, 47), mirror=[0, 1, 2], step=0.5, gaussian=True, folds=1),
     dict(shape=(33, 20, 37), mirror=[1, 2], step=0.3, gaussian=True, folds=3),
+    # (image - patch) / (patch * step) lands on an integer: ceil() of the quotient formed with a float-rounded step
+    # gives one tile position more (72: 6 instead of 5; 44 and 88: 6 instead of 5) - fnn_opts carries a double
+    dict(shape=(72, 20, 40), mirror=None, step=0.7, gaussian=True, folds=1),
+    dict(shape=(44, 16, 88), mirror=None, step=0.35, gaussian=True, folds=1),
 ]
 
 
@@ -422,20 +426,35 @@ def test_sharded_boxes_through_c_abi_match_single_gpu(world, acc_mode):
 
 
 def test_sharded_predictor_single_rank_process_group():
-    """ShardedPredictor end to end with a one-rank process group on the GPU."""
+    """ShardedPredictor end to end with a one-rank RCCL process group on the GPU: owned box, gathered logits,
+    gathered labels (fnn_labels_box + all_gather) and the fold ensemble must equal the single-GPU predictor's."""
     import torch.distributed as dist
     from fast_nnunet_amd.dist import ShardedPredictor
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29533')
-    dist.init_process_group('gloo', rank=0, world_size=1)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     try:
         spec, patch = SPECS['toy3']
-        p = _predictor(spec, patch, [synthetic_state_dict(spec, 22)], accumulate_in='fp32')
-        image = torch.randn(1, 20, 40, 33, generator=torch.Generator().manual_seed(7))
-        want = p.predict_sliding_window_return_logits(image)
-        got, own = ShardedPredictor(p).predict_sliding_window_return_logits(image)
-        assert own == ((0, 0, 0), (20, 40, 33))
-        assert torch.equal(got, want)
+        sds = [synthetic_state_dict(spec, 22 + f) for f in range(2)]
+        for accum in ('fp32', 'fp16'):
+            p = _predictor(spec, patch, sds[:1], accumulate_in=accum)
+            image = torch.randn(1, 20, 40, 33, generator=torch.Generator().manual_seed(7))
+            want = p.predict_sliding_window_return_logits(image)
+            sp = ShardedPredictor(p)
+            got, own = sp.predict_sliding_window_return_logits(image)
+            assert own == ((0, 0, 0), (20, 40, 33))
+            assert torch.equal(got, want)                     # one rank: the reference's visiting order, bit for bit
+            assert torch.equal(sp.predict_sliding_window_return_logits(image, gather=True), want)
+            labels = sp.predict_segmentation_from_preprocessed_data(image)
+            assert labels.dtype == torch.uint8 and torch.equal(labels, p.predict_segmentation_from_preprocessed_data(image))
+            assert torch.equal(labels.long(), want.float().argmax(0))
+        p2 = _predictor(spec, patch, sds)
+        sp2 = ShardedPredictor(p2)
+        assert torch.equal(sp2.predict_logits_from_preprocessed_data(image).cpu(), p2.predict_logits_from_preprocessed_data(image))
+        assert torch.equal(sp2.predict_segmentation_from_preprocessed_data(image),
+                           p2.predict_segmentation_from_preprocessed_data(image))
     finally:
         dist.destroy_process_group()
 

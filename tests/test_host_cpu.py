@@ -34,7 +34,18 @@ def test_library_exports_every_symbol_in_header(capi):
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/fnn.h but not exported'
     assert declared == set(capi.EXPORTS)
-    assert lib.fnn_abi_version() == 1
+    assert lib.fnn_abi_version() == 2
+
+
+def test_opts_carry_the_step_size_as_a_double(capi):
+    """The patch grid is ceil((image - patch) / (patch * step)) with the reference's Python float
+    (sliding_window_prediction.py:38-41); a float32 step gives another count on e.g. step 0.7, patch 16, image 72."""
+    assert capi.Opts.tile_step_size.size == 8
+    header = open(os.path.join(ROOT, 'include', 'fnn.h')).read()
+    assert re.search(r'double\s+tile_step_size', header)
+    import math
+    assert len(capi.compute_steps(72, 16, 0.7)) == math.ceil((72 - 16) / (16 * 0.7)) + 1 == 6
+    assert capi.plan_volume((16, 16, 32), (72, 20, 40), 0.7)[2].shape[0] == 6 * 2 * 2
 
 
 def test_compute_steps_matches_reference_golden(capi, golden_dir):
@@ -149,6 +160,30 @@ def test_spec_from_state_dict_roundtrip_and_aliases():
     assert np.array_equal(a, b)
     n_params = sum(v.numel() for k, v in sd.items() if 'seg_layers.0' not in k)
     assert a.size == n_params
+
+
+def test_checkpoints_with_other_operators_are_refused():
+    """A BatchNorm / ReLU network must not load silently: the engine hard-wires affine InstanceNorm + LeakyReLU and
+    takes eps and the slope from the plans (the reference builds whatever the plans name, get_network_from_plans.py:9-43)."""
+    from fast_nnunet_amd.arch import ops_from_plans, spec_from_state_dict, weight_blob
+    ok = {'norm_op': 'torch.nn.modules.instancenorm.InstanceNorm3d', 'norm_op_kwargs': {'eps': 1e-4, 'affine': True},
+          'nonlin': 'torch.nn.LeakyReLU', 'nonlin_kwargs': {'inplace': True, 'negative_slope': 0.2},
+          'dropout_op': None, 'dropout_op_kwargs': None}
+    assert ops_from_plans(ok) == (1e-4, 0.2)
+    assert ops_from_plans({}) == (1e-5, 0.01)
+    assert ops_from_plans({'norm_op': torch.nn.InstanceNorm2d, 'nonlin': torch.nn.LeakyReLU}) == (1e-5, 0.01)
+    for bad in ({'norm_op': 'torch.nn.modules.batchnorm.BatchNorm3d'}, {'nonlin': 'torch.nn.ReLU'},
+                {'norm_op': 'torch.nn.InstanceNorm3d', 'norm_op_kwargs': {'affine': False}},
+                {'nonlin': 'torch.nn.LeakyReLU', 'nonlin_kwargs': {'negative_slope': 1.5}}):
+        with pytest.raises(NotImplementedError):
+            ops_from_plans({**ok, **bad})
+    ospec = toy_unet_spec(1, 2)
+    sd = dict(synthetic_state_dict(ospec, 5))
+    spec = spec_from_state_dict(sd, (16, 16, 32))
+    weight_blob(spec, sd)
+    sd['encoder.stages.0.0.convs.0.norm.running_mean'] = torch.zeros(ospec.features[0])
+    with pytest.raises(NotImplementedError, match='running_mean'):
+        weight_blob(spec, sd)
 
 
 def test_resenc_checkpoint_topology_and_blob():
@@ -288,3 +323,22 @@ def test_engine_front_end_call_order():
         e.set_workspace('/nonexistent')
     with pytest.raises(RuntimeError, match='set_workspace'):
         e.infer(np.zeros((4, 4, 4), np.float32), (1, 1, 1))
+
+
+def test_bench_gpus_n_spawns_one_rank_per_gpu_and_propagates_failure():
+    """`python bench.py --gpus 2` without a launcher starts two ranks before touching a GPU; on this CPU-only box both
+    fail (no device), and the parent must report that instead of printing a 1-GPU line."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip('two GPUs are visible: this is the CPU-box check')
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith('{')]
+    # with WORLD_SIZE set by a launcher the script must not spawn again, and must refuse a contradicting --gpus
+    env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    out2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'],
+                          capture_output=True, text=True, timeout=300, env=env2, cwd=ROOT)
+    assert out2.returncode != 0 and 'WORLD_SIZE=1' in (out2.stderr + out2.stdout)
