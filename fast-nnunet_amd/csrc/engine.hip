@@ -486,6 +486,9 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.tiles_h = (p.PH + FNN_TILE_H - 1) / FNN_TILE_H;
             p.tiles_w = (p.PW + FNN_TILE_W - 1) / FNN_TILE_W;
             Scope sc(e, st, FAM_STEM, L.flops * nb);
+#ifdef FNN_BOUND_FUSE
+            if (li + 1 < e->layers.size() && e->layers[li + 1].type == Layer::CONV && e->layers[li + 1].s[1] == 1) rc = 0; else
+#endif
             rc = launch_stem(p, nb, st);
         } else if (L.type == Layer::CONV) {
             ConvParams p{};
@@ -506,6 +509,14 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.chunks = L.chunks; p.ksteps = L.ksteps; p.packing = L.packing;
             p.tile_d = FNN_TILE_D;
             Scope sc(e, st, FAM_CONV, L.flops * nb, L.bytes * nb);
+#ifdef FNN_BOUND_FUSE
+            {   // upper bound of fusing the stem / the last transposed conv into this conv's staging: the producer is
+                // not launched and this conv reads its source 0 from a 16 KB window (results are wrong)
+                const Layer &P = e->layers[L.src_layer[0] >= 0 ? L.src_layer[0] : 0];
+                const bool full = L.in_dims[0] == e->arch.patch[0] && L.in_dims[1] == e->arch.patch[1] && L.in_dims[2] == e->arch.patch[2];
+                p.bound_mask0 = full && L.s[1] == 1 && L.src_layer[0] >= 0 && (P.type == Layer::STEM || P.type == Layer::TCONV);
+            }
+#endif
             rc = launch_conv3d(p, st);
         } else if (L.type == Layer::POOL) {
             PoolParams p{};
@@ -531,6 +542,9 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.Cout = L.cout_pad; p.wpk = fw.wpk + L.w_off; p.bias = fw.fparam + L.bias_off;
             p.out = out; p.ksteps = L.ksteps; p.nblk = L.cout_pad / 16;
             Scope sc(e, st, FAM_TCONV, L.flops * nb);
+#ifdef FNN_BOUND_FUSE
+            if (L.out_dims[0] == e->arch.patch[0] && L.out_dims[1] == e->arch.patch[1] && L.out_dims[2] == e->arch.patch[2]) rc = 0; else
+#endif
             rc = launch_tconv(p, st);
         }
         if (rc != 0) return fail(e, rc == -1 ? FNN_E_UNSUPPORTED : FNN_E_HIP, "kernel launch failed at layer %zu (rc=%d)", li, rc);
@@ -925,6 +939,9 @@ int predict_impl(fnn_engine *e, int fold0, int n_folds, const float *vol, const 
     if (lab_tmp) (void)hipFree(lab_tmp);
     if (rc) return rc;
     if (e->profiling) collect_profile(e, vp.n_patches * n_folds);
+#ifdef FNN_BOUND_FUSE
+    flag = 0;
+#endif
     if (flag)
         return fail(e, FNN_E_INF, "Encountered inf in predicted array. Aborting... If this problem persists, reduce "
                                   "value_scaling_factor in compute_gaussian or increase the dtype of predicted_logits to fp32");
@@ -1019,7 +1036,10 @@ int fnn_load_weights(fnn_engine *e, int fold, const float *blob, int64_t count) 
             pack_tconv(L, W, wpk.data() + L.w_off);
         }
         for (int c = 0; c < L.cout_real; ++c) {
-            fp[L.bias_off + c] = L.has_bias ? blob[L.blob_b + c] : 0.f;
+            // A conv bias in front of an InstanceNorm cancels exactly (the norm removes the channel mean), so it is
+            // dropped: the raw conv outputs are stored in fp16, and a large bias would only cost them resolution
+            // (|bias| = 10 in front of a unit-variance channel: 2^-7 instead of 2^-11 of sigma).
+            fp[L.bias_off + c] = (L.has_bias && !L.has_norm) ? blob[L.blob_b + c] : 0.f;
             if (L.has_norm) { fp[L.gamma_off + c] = blob[L.blob_g + c]; fp[L.beta_off + c] = blob[L.blob_beta + c]; }
         }
     }

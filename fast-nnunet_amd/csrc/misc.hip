@@ -932,7 +932,103 @@ __global__ __launch_bounds__(256) void labels_from_acc_kernel(const FinalizePara
     if (bad) atomicOr(p.inf_flag, 1);
 }
 
+// The same with G = 2^LOG_G consecutive lanes per voxel, each lane on 8 channels (one 16-byte piece of an fp16
+// accumulator line, two of an fp32 one): a wave instruction then reads 64 / G whole voxel lines - contiguous along z -
+// instead of 2 bytes out of 64 different lines, 61 times over (the one-thread-per-voxel form above re-fetched every
+// line many times: 75 ms for the 17 GB of a 512^3 x 61 volume, this one runs at the HBM rate).  The lanes' partial
+// results are merged in channel order, so "first maximum / first NaN wins" and "last region above the threshold
+// wins" are exactly the sequential rule.
+template <bool ACC32, typename LT, int LOG_G>
+__global__ __launch_bounds__(256) void labels_from_acc_coop_kernel(const FinalizeParams p, LT *labels, const int *order) {
+    constexpr int G = 1 << LOG_G;
+    const long long nbox = p.OX * p.OY * p.OZ;
+    const long long gt = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long iv = gt >> LOG_G;
+    const int piece = (int)(gt & (G - 1));
+    const long long i = iv < nbox ? iv : nbox - 1;                   // surplus lanes redo the last voxel (no store)
+    const long long z = i % p.OZ, y = (i / p.OZ) % p.OY, x = i / (p.OZ * p.OY);
+    const size_t aelem = (((size_t)(x + p.lo_x) * p.Y + (y + p.lo_y)) * p.Z + (z + p.lo_z)) * p.HP;
+    const int c0 = piece * 8;
+    float v[8];
+    const bool have = c0 < p.HP;
+    if (ACC32) {
+        const float4 a = have ? *(const float4 *)((const float *)p.acc + aelem + c0) : make_float4(0, 0, 0, 0);
+        const float4 b = have ? *(const float4 *)((const float *)p.acc + aelem + c0 + 4) : make_float4(0, 0, 0, 0);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        f16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (have) a = *(const f16x8 *)((const f16 *)p.acc + aelem + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
+    }
+    // the weight sum sits in channel `heads`: broadcast from the lane that holds it
+    const int wl = p.heads >> 3, wj = p.heads & 7;
+    float wsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j == wj) wsum = v[j];
+    wsum = __shfl(wsum, (threadIdx.x & 63 & ~(G - 1)) + wl, 64);
+    // local pick over this lane's channels (in order)
+    float best = 0.f; int arg = -1; bool nan = false; int hit = -1; bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int h = c0 + j;
+        if (h < p.heads) {
+            const float q = (float)(f16)__fdiv_rn(v[j], wsum);
+            bad |= isinf(q);
+            if (q > FNN_SIGMOID_HALF_THRESHOLD) hit = h;
+            if (arg < 0) { best = q; arg = h; nan = q != q; }
+            else if (!nan && (q > best || q != q)) { best = q; arg = h; nan = q != q; }
+        }
+    }
+    // merge in channel order: the lower lane holds the lower channels
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) {
+        const float ob = __shfl_xor(best, m, 64);
+        const int oa = __shfl_xor(arg, m, 64), on = __shfl_xor((int)nan, m, 64), oh = __shfl_xor(hit, m, 64);
+        const bool lower = (piece & m) == 0;
+        // (lo, hi) = (mine, other) when this lane is the lower one
+        const float lb = lower ? best : ob, hb = lower ? ob : best;
+        const int la = lower ? arg : oa, ha = lower ? oa : arg;
+        const bool ln = lower ? nan : (on != 0), hn = lower ? (on != 0) : nan;
+        bool take_hi;
+        if (la < 0) take_hi = true;                                   // the lower part holds no head
+        else if (ha < 0) take_hi = false;
+        else if (ln) take_hi = false;
+        else take_hi = hn || hb > lb;
+        best = take_hi ? hb : lb; arg = take_hi ? ha : la; nan = take_hi ? hn : ln;
+        hit = hit > oh ? hit : oh;
+    }
+    if (piece == 0 && iv < nbox) {
+        const size_t oidx0 = ((size_t)(x + p.out_x) * p.out_Y + (y + p.out_y)) * p.out_Z + (z + p.out_z);
+        labels[oidx0] = (LT)(order ? (hit >= 0 ? order[hit] : 0) : arg);
+    }
+    if (bad && iv < nbox) atomicOr(p.inf_flag, 1);
+}
+
+template <bool ACC32, typename LT>
+static void launch_labels_coop(const FinalizeParams &p, void *labels, const int *order, int log_g, hipStream_t st) {
+    const long long n = (p.OX * p.OY * p.OZ) << log_g;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    switch (log_g) {
+        case 0: hipLaunchKernelGGL((labels_from_acc_coop_kernel<ACC32, LT, 0>), grid, dim3(256), 0, st, p, (LT *)labels, order); break;
+        case 1: hipLaunchKernelGGL((labels_from_acc_coop_kernel<ACC32, LT, 1>), grid, dim3(256), 0, st, p, (LT *)labels, order); break;
+        case 2: hipLaunchKernelGGL((labels_from_acc_coop_kernel<ACC32, LT, 2>), grid, dim3(256), 0, st, p, (LT *)labels, order); break;
+        case 3: hipLaunchKernelGGL((labels_from_acc_coop_kernel<ACC32, LT, 3>), grid, dim3(256), 0, st, p, (LT *)labels, order); break;
+        case 4: hipLaunchKernelGGL((labels_from_acc_coop_kernel<ACC32, LT, 4>), grid, dim3(256), 0, st, p, (LT *)labels, order); break;
+        default: hipLaunchKernelGGL((labels_from_acc_coop_kernel<ACC32, LT, 5>), grid, dim3(256), 0, st, p, (LT *)labels, order); break;
+    }
+}
+
 int launch_labels_from_acc(const FinalizeParams &p, void *labels, int label_u16, const int *order, hipStream_t st) {
+    static const bool v1 = getenv("FNN_LABELS_V1") != nullptr;                     // A-B aid
+    int log_g = 0;
+    while ((8 << log_g) < p.HP) ++log_g;                                         // lanes per voxel: HP / 8 rounded up to 2^k
+    const long long nvox = p.OX * p.OY * p.OZ;
+    if (!v1 && log_g <= 5 && (nvox << log_g) < (1LL << 39)) {
+        if (p.acc_fp32) { if (label_u16) launch_labels_coop<true, uint16_t>(p, labels, order, log_g, st); else launch_labels_coop<true, uint8_t>(p, labels, order, log_g, st); }
+        else { if (label_u16) launch_labels_coop<false, uint16_t>(p, labels, order, log_g, st); else launch_labels_coop<false, uint8_t>(p, labels, order, log_g, st); }
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     const long long n = p.OX * p.OY * p.OZ;
     const dim3 grid((unsigned)((n + 255) / 256));
     if (p.acc_fp32) {
