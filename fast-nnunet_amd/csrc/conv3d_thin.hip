@@ -1,0 +1,646 @@
+// conv3d_thin.hip - the full-resolution end of the network without its two largest HBM round trips (gfx950).
+//
+// At full resolution the U-Net has 16 channels: its layers are bound by HBM, not by the matrix cores (47 MB per
+// tensor and patch of the benchmark network).  Two of those tensors exist only to be read once by the next kernel:
+//   * the stem's output (first conv, 1 input channel), read by the second conv of stage 0;
+//   * the last ConvTranspose3d's output ("up"), read - next to the skip - by the first conv of the last decoder stage.
+// Both producers are tiny GEMMs per voxel (stem: K = taps <= 32; transposed conv with kernel = stride: one input voxel
+// per output voxel, K = 32 input channels), so the consumer recomputes them while it stages its halo tile:
+//   conv_thin_kernel<KD, 1, FUSE_STEM>   image of the 16-channel chunk = LeakyReLU(norm(stem(x))) computed with one
+//                                         MFMA per 16 halo voxels from a raw fp32 window of the volume kept in LDS;
+//   conv_thin_kernel<KD, 2, FUSE_TCONV>  chunk 0 ("up") = transposed conv of the normalised low-resolution voxels
+//                                         (one load of 16 B per lane = a ready MFMA operand, one MFMA per stride
+//                                         phase), chunk 1 (skip) staged as in conv3d_persist_kernel.
+// The stem's InstanceNorm statistics need the whole patch before any voxel can be normalised: stem_mfma_kernel
+// computes them in a pass of its own over the 1-channel volume (6 MB per patch instead of writing 47 MB); with
+// `out` set it is also the stand-alone stem (same arithmetic, so fused and unfused engines agree bit for bit).
+//
+// Arithmetic of the stem: x and the weights rounded to fp16, products exact, fp32 accumulation in the MFMA's order,
+// one rounding to fp16 - the same contract as every other conv of the engine.
+//
+// Replaces (with conv3d.hip / misc.hip) the ConvDropoutNormReLU stacks and the transpconvs of the reference's
+// PlainConvUNet decoder, nnUNetDistillationTrainer.py:141-173; patch slicing predict_from_raw_data.py:560-566.
+#include "fnn_device.h"
+#include "conv_common.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int TH_PW = 12;                                    // LDS row pitch of the halo image (voxels), 4 mod 8
+
+// fp16 affine + LeakyReLU of 4 values exactly as conv3d_persist_kernel::commit() does it for 8
+static __device__ __forceinline__ f16x4 norm_act4(f16x4 h, const float (&sc)[4], const float (&sh)[4], f16 slope_h) {
+#ifdef FNN_NORM_FP32
+    f16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (f16)fmaf((float)h[j], sc[j], sh[j]);
+#else
+    f16x4 sc_h, sh_h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sc_h[j] = (f16)sc[j]; sh_h[j] = (f16)sh[j]; }
+    f16x4 o = h * sc_h + sh_h;
+#endif
+    return __builtin_elementwise_max(o, o * slope_h);
+}
+
+// One stem GEMM: D[16 couts, 16 voxels] from the raw fp32 window in LDS.  Lane (r = voxel, q = k-group): element j
+// of the B operand is tap k = 8 q + j of voxel r (k >= taps: any finite value, its weights are zero).
+static __device__ __forceinline__ f16x4 stem_block(const float *sRaw, int rawbase, const int (&tapoff)[8], f16x8 wf,
+                                                   const float4 &bias) {
+    f16x8 xb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xb[j] = (f16)sRaw[rawbase + tapoff[j]];
+    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xb, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    f16x4 h;
+    h[0] = (f16)(d[0] + bias.x); h[1] = (f16)(d[1] + bias.y); h[2] = (f16)(d[2] + bias.z); h[3] = (f16)(d[3] + bias.w);
+    return h;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------
+// stem: statistics pass (+ optional output)
+// ----------------------------------------------------------------------------
+// Workgroup = 16 x 8 x 8 output voxels (64 column blocks, 16 per wave), 16 output channels; raw window of the patch
+// in LDS ((16 + kd - 1) x 10 x 10 floats); zero padding at the PATCH border; mirroring flips the window read.
+#define STEMM_TD 16
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, const f16 *wfrag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    int t = blockIdx.x;
+    const int tw = t % p.tiles_w; t /= p.tiles_w;
+    const int th = t % p.tiles_h; t /= p.tiles_h;
+    const int td = t % p.tiles_d;
+    const int n = t / p.tiles_d;
+    const int pd = (p.kd - 1) / 2;
+    const int RD = STEMM_TD - 1 + p.kd, RVOX = RD * 100, T = p.kd * 9;
+    float *sRaw = (float *)smem;                                         // [RD][10][10]
+    float *sRed = sRaw + ((RVOX + 3) & ~3);                              // [4 waves][16][2]
+
+    const int ox = p.origins[n * 3 + 0], oy = p.origins[n * 3 + 1], oz = p.origins[n * 3 + 2];
+    const int d0 = td * STEMM_TD - pd, h0 = th * 8 - 1, w0 = tw * 8 - 1;
+    const float *voln = p.vol + (size_t)n * p.vol_batch_stride;
+    for (int v = tid; v < RVOX; v += 256) {
+        const int zd = v / 100, rem = v - zd * 100, zh = rem / 10, zw = rem - zh * 10;
+        int d = d0 + zd, h = h0 + zh, w = w0 + zw;
+        const bool ok = d >= 0 && d < p.PD && h >= 0 && h < p.PH && w >= 0 && w < p.PW;
+        if (p.flip_d) d = p.PD - 1 - d;
+        if (p.flip_h) h = p.PH - 1 - h;
+        if (p.flip_w) w = p.PW - 1 - w;
+        const float val = voln[((size_t)(ox + (ok ? d : 0)) * p.Y + (oy + (ok ? h : 0))) * p.Z + (oz + (ok ? w : 0))];
+        sRaw[v] = ok ? val : 0.f;
+    }
+    const f16x8 wf = *(const f16x8 *)(wfrag + lane * 8);
+    const float4 bias = *(const float4 *)(p.bias + q * 4);
+    int tapoff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * q + j, tap = k < T ? k : 0;
+        tapoff[j] = ((tap / 9) * 10 + (tap / 3) % 3) * 10 + tap % 3;
+    }
+    __syncthreads();
+
+    float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+    const f16x2 ones = {(f16)1.f, (f16)1.f};
+    const int oh = th * 8 + (r >> 3), ow = tw * 8 + (r & 7);
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {                                       // column block = (depth slice, pair of h rows)
+        const int dl = wave * 4 + (j >> 2), hp = j & 3;
+        const int od = td * STEMM_TD + dl, ohh = oh + 2 * hp;
+        f16x4 h = stem_block(sRaw, (dl * 10 + 2 * hp + (r >> 3)) * 10 + (r & 7), tapoff, wf, bias);
+        const bool ok = od < p.PD && ohh < p.PH && ow < p.PW;
+        if (ok && p.out) *(f16x4 *)(p.out + ((((size_t)n * p.PD + od) * p.PH + ohh) * p.PW + ow) * p.Cout + q * 4) = h;
+        if (!ok) h = (f16x4){0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f16x2 pr = {h[c], (f16)0.f};
+            t1[c] = __builtin_amdgcn_fdot2(pr, ones, t1[c], false);
+            t2[c] = __builtin_amdgcn_fdot2(pr, pr, t2[c], false);
+        }
+    }
+    if (p.stats_out) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float a = row16_sum(t1[c]), b = row16_sum(t2[c]);
+            if (r == 0) { sRed[(wave * 16 + q * 4 + c) * 2] = a; sRed[(wave * 16 + q * 4 + c) * 2 + 1] = b; }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int c = tid >> 1, which = tid & 1;
+            double v = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += (double)sRed[(w * 16 + c) * 2 + which];
+            const int slot = (td * p.tiles_h + th) * p.tiles_w + tw;
+            p.stats_out[(((size_t)n * (p.tiles_d * p.tiles_h * p.tiles_w) + slot) * p.Cout + c) * 2 + which] = v;
+        }
+    }
+}
+
+bool stem_mfma_ok(int C, int kd, int kh, int kw, int cout_pad) {
+    return C == 1 && kh == 3 && kw == 3 && (kd == 1 || kd == 3) && cout_pad == 16;
+}
+
+int stem_mfma_stats_slots(int PD, int PH, int PW) { return ((PD + STEMM_TD - 1) / STEMM_TD) * ((PH + 7) / 8) * ((PW + 7) / 8); }
+
+// `wfrag`: the stem weights as one MFMA "A" fragment (fnn_pack_stem_frag); p.out == nullptr: statistics only.
+int launch_stem_mfma(const StemParams &p_in, const f16 *wfrag, int N, hipStream_t st) {
+    StemParams p = p_in;
+    if (!stem_mfma_ok(p.C, p.kd, p.kh, p.kw, p.Cout)) return -1;
+    p.tiles_d = (p.PD + STEMM_TD - 1) / STEMM_TD;
+    p.tiles_h = (p.PH + 7) / 8;
+    p.tiles_w = (p.PW + 7) / 8;
+    const int RVOX = (STEMM_TD - 1 + p.kd) * 100;
+    const size_t lds = (size_t)((RVOX + 3) & ~3) * 4 + 4 * 16 * 2 * 4;
+    hipLaunchKernelGGL(stem_mfma_kernel, dim3(N * p.tiles_d * p.tiles_h * p.tiles_w), dim3(256), lds, st, p, wfrag);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ----------------------------------------------------------------------------
+// thin full-resolution conv with a fused producer
+// ----------------------------------------------------------------------------
+// Persistent like conv3d_persist_kernel<1, 4, true, KS, CH, PF>: 16 output channels, tile 4 x 8 x 8, (KD, 3, 3)
+// taps, all weight fragments resident in LDS, halo image double buffered, one barrier per work item
+// (tile, 16-channel chunk), the next item's global loads in flight during the MFMAs of the current one.
+template <int KD, int CH, int FUSE, int NCLS, int WPS>
+__global__ __launch_bounds__(256, WPS) void conv_thin_kernel(const ThinParams tp, const int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ConvParams &p = tp.c;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    constexpr int TD = 4, ID = TD + KD - 1, IH = 10, IW = 10, IVOX = ID * IH * IW, T = 9 * KD;
+    constexpr int KS = (T + 1) / 2, TS = CH * KS;
+    constexpr int PF = (IVOX * 2 + 255) / 256;
+    constexpr int ABYTES = (ID * IH * TH_PW * 32 + 1023) & ~1023;
+    constexpr int NCB = (IVOX + 15) / 16, NCBW = (NCB + 3) / 4;          // stem: halo column blocks (per wave)
+    constexpr int RD = ID + KD - 1, RVOX = RD * 144, RPF = (RVOX + 255) / 256;   // stem: raw window [RD][12][12]
+    constexpr int NLBW = 3;                                              // tconv: low-resolution column blocks per wave
+
+    char *sA0 = smem;
+    char *sW = smem + 2 * ABYTES;                                        // [TS][64][16 B]
+    char *sF = sW + TS * 1024;                                           // fused producer's weight fragments
+    constexpr int nfw = FUSE == FUSE_STEM ? 1 : NCLS;
+    float *sRaw = (float *)(sF + nfw * 1024);                            // stem: 2 x [RD][12][12]
+    int *sTap = (int *)(sRaw + (FUSE == FUSE_STEM ? 2 * RVOX : 0));
+    double *sRed = (double *)(sTap + 64);                                // [4 waves][16][2]
+
+    int t_begin, t_end;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        const int g = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+        t_begin = (int)((long long)total_tiles * g / nwg);
+        t_end = (int)((long long)total_tiles * (g + 1) / nwg);
+    }
+    if (t_begin >= t_end) return;
+
+    // ---- one-time set-up
+    for (int idx = tid; idx < TS * 64; idx += 256) ((uint4 *)sW)[idx] = ((const uint4 *)p.wpk)[idx];
+    for (int idx = tid; idx < nfw * 64; idx += 256) ((uint4 *)sF)[idx] = ((const uint4 *)tp.fw)[idx];
+    if (tid < 2 * KS) {
+        int off = 0, par = 0;
+        if (tid < T) {
+            const int a = tid / 9, b = (tid / 3) % 3, c = tid % 3;
+            off = ((a * IH + b) * TH_PW + c) * 32;
+            par = b & 1;
+        }
+        sTap[tid * 2] = off + 16 * par;
+        sTap[tid * 2 + 1] = off + 16 * (1 - par);
+    }
+    for (int i = tid; i < 4 * 16 * 2; i += 256) sRed[i] = 0.0;
+    const int cg = tid & 1;
+    int rel[PF];                                                         // regular staging: packed halo coords
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int idx = tid + u * 256, v = idx >> 1;
+        const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
+        rel[u] = idx < IVOX * 2 ? (zd << 16) | (zh << 8) | zw : -1;
+    }
+    int base[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        int od_l, oh_l, ow_l;
+        mb_coords<4>(wave, mb, r, od_l, oh_l, ow_l);
+        base[mb] = ((od_l * IH + oh_l) * TH_PW + ow_l) * 32;
+    }
+    const int kgp = ((lane >> 4) & 1) ^ ((lane & 15) >> 3);
+    const float4 bv4 = *(const float4 *)(p.bias + q * 4);
+    float4 bv[1] = {bv4};
+    double dsum[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dsum[j][0] = 0.0; dsum[j][1] = 0.0; }
+    f32x4 acc[4][1];
+
+    // ---- fused producer: per-lane constants
+    // stem: column blocks cb = wave + 4 j of the halo's IVOX voxels
+    int s_rawbase[NCBW], s_img[NCBW], s_zp[NCBW];
+    int tapoff[8];
+    f16x8 fwf = {0, 0, 0, 0, 0, 0, 0, 0};
+    float4 fbias = make_float4(0.f, 0.f, 0.f, 0.f);
+    int rrel[RPF];
+    if (FUSE == FUSE_STEM) {
+#pragma unroll
+        for (int j = 0; j < NCBW; ++j) {
+            const int v = (wave + 4 * j) * 16 + r;
+            const int vc = v < IVOX ? v : IVOX - 1;
+            const int zd = vc / 100, rem = vc - zd * 100, zh = rem / 10, zw = rem - zh * 10;
+            s_rawbase[j] = (zd * 12 + zh) * 12 + zw;
+            s_img[j] = ((zd * IH + zh) * TH_PW + zw) * 32 + (((q >> 1) ^ (zh & 1)) * 16) + (q & 1) * 8;
+            s_zp[j] = v < IVOX ? (zd << 16) | (zh << 8) | zw : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * q + j, tap = k < T ? k : 0;
+            tapoff[j] = ((tap / 9) * 12 + (tap / 3) % 3) * 12 + tap % 3;
+        }
+#pragma unroll
+        for (int u = 0; u < RPF; ++u) {
+            const int e = tid + u * 256;
+            const int rd = e / 144, rem = e - rd * 144, rh = rem / 12, rw = rem - rh * 12;
+            rrel[u] = e < RVOX ? (rd << 16) | (rh << 8) | rw : -1;
+        }
+        fbias = *(const float4 *)(tp.fbias + q * 4);
+    } else {
+        fbias = *(const float4 *)(tp.fbias + q * 4);
+    }
+    // tconv: low-resolution halo voxels, LD x LH x LW per tile
+    const int LH = tp.tsh == 2 ? 6 : IH, LW = tp.tsw == 2 ? 6 : IW;
+    const int LD = tp.tsd == 2 ? (ID + 2) / 2 : ID;                      // KD = 3: ID = 6 -> 4; KD = 1: ID = 4 -> 3 (od0 is a multiple of 4)
+    const int LV = LD * LH * LW;
+    // The halo origin is odd in-plane and od0 is a multiple of 4, so where a (low voxel, stride phase) pair lands in
+    // the halo image does not depend on the tile: per block j the image offset of phase 0 and a mask of the phases that
+    // fall inside the halo, per phase a lane-constant offset (with the row swizzle: the parity of zh is the phase's).
+    int l_zp[NLBW], l_img[NLBW], l_in[NLBW], c_off[NCLS];
+    if (FUSE == FUSE_TCONV) {
+        const float rlw = 1.0f / (float)LW, rlh = 1.0f / (float)LH;
+        const int dd = tp.tsd == 2 ? ((KD - 1) / 2) & 1 : 0, dh = tp.tsh == 2 ? 1 : 0, dw = tp.tsw == 2 ? 1 : 0;   // id0 - s * lo
+#pragma unroll
+        for (int j = 0; j < NLBW; ++j) {
+            const int l = (wave + 4 * j) * 16 + r;
+            const int lc = l < LV ? l : LV - 1;
+            const int row = small_div(lc, LW, rlw), lw = lc - row * LW;
+            const int ld = small_div(row, LH, rlh), lh = row - ld * LH;
+            l_zp[j] = l < LV ? (ld << 16) | (lh << 8) | lw : -1;
+            const int zd0 = ld * tp.tsd - dd, zh0 = lh * tp.tsh - dh, zw0 = lw * tp.tsw - dw;
+            l_img[j] = ((zd0 * IH + zh0) * TH_PW + zw0) * 32 + (q & 1) * 8;
+            int m = 0;
+#pragma unroll
+            for (int cls = 0; cls < NCLS; ++cls) {
+                const int jd = cls / (tp.tsh * tp.tsw), jh = (cls / tp.tsw) % tp.tsh, jw = cls % tp.tsw;
+                const unsigned zd = (unsigned)(zd0 + jd), zh = (unsigned)(zh0 + jh), zw = (unsigned)(zw0 + jw);
+                m |= (l < LV && zd < (unsigned)ID && zh < (unsigned)IH && zw < (unsigned)IW) ? 1 << cls : 0;
+            }
+            l_in[j] = m;
+        }
+#pragma unroll
+        for (int cls = 0; cls < NCLS; ++cls) {
+            const int jd = cls / (tp.tsh * tp.tsw), jh = (cls / tp.tsw) % tp.tsh, jw = cls % tp.tsw;
+            c_off[cls] = ((jd * IH + jh) * TH_PW + jw) * 32 + (((q >> 1) ^ ((jh - dh) & 1)) * 16);
+        }
+    }
+    __syncthreads();
+    if (FUSE == FUSE_STEM) fwf = *(const f16x8 *)(sF + lane * 16);
+    int toffs[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) toffs[ks] = sTap[(2 * ks + (lane >> 5)) * 2 + kgp];
+
+    auto tile_coords = [&](int t, int &n, int &od0, int &oh0, int &ow0) {
+        const int tw = t % p.tiles_w; t /= p.tiles_w;
+        const int th = t % p.tiles_h; t /= p.tiles_h;
+        const int td = t % p.tiles_d;
+        n = t / p.tiles_d;
+        od0 = td * TD; oh0 = th * 8; ow0 = tw * 8;
+    };
+    auto next_tile = [&](int &n, int &od0, int &oh0, int &ow0) {
+        ow0 += 8;
+        if (ow0 >= p.tiles_w * 8) {
+            ow0 = 0; oh0 += 8;
+            if (oh0 >= p.tiles_h * 8) {
+                oh0 = 0; od0 += TD;
+                if (od0 >= p.tiles_d * TD) { od0 = 0; ++n; }
+            }
+        }
+    };
+
+    // ---- regular staging (chunk CH - 1 = the consumer's last source: loads + normalise + LDS image)
+    int offv[PF];
+    f16x8 xr[PF];
+    float4 scr[2], shr[2];
+    float slope_next = 1.f;
+    auto set_offsets = [&](int od0, int oh0, int ow0) {
+        const int id0 = od0 - (KD - 1) / 2, ih0 = oh0 - 1, iw0 = ow0 - 1;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const unsigned gd = (unsigned)(id0 + (rel[u] >> 16)), gh = (unsigned)(ih0 + ((rel[u] >> 8) & 255)),
+                           gw = (unsigned)(iw0 + (rel[u] & 255));
+            const bool ok = rel[u] >= 0 && gd < (unsigned)p.Di && gh < (unsigned)p.Hi && gw < (unsigned)p.Wi;
+            offv[u] = ok ? (int)(__umul24(__umul24(gd, (unsigned)p.Hi) + gh, (unsigned)p.Wi) + gw) : -1;
+        }
+    };
+    auto issue_reg = [&](int n) {
+        const SrcDesc &S = p.src[1];
+        const int c_loc = cg * 8, sC = S.C;
+        const char *sp = (const char *)(S.ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + c_loc);
+        slope_next = S.slope;
+        const float *qs = S.ss ? S.ss + (size_t)(2 * n) * sC + c_loc : p.ident_ss + c_loc;
+        const float *qh = S.ss ? qs + sC : p.ident_ss + 512 + c_loc;
+        scr[0] = *(const float4 *)qs; scr[1] = *(const float4 *)(qs + 4);
+        shr[0] = *(const float4 *)qh; shr[1] = *(const float4 *)(qh + 4);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) xr[u] = *(const f16x8 *)(sp + (unsigned)((offv[u] >= 0 ? offv[u] : 0) * sC * 2));
+    };
+    auto commit_reg = [&](char *dst) {
+        const f16 slope_h = (f16)slope_next;
+        const float sc[8] = {scr[0].x, scr[0].y, scr[0].z, scr[0].w, scr[1].x, scr[1].y, scr[1].z, scr[1].w};
+        const float sh[8] = {shr[0].x, shr[0].y, shr[0].z, shr[0].w, shr[1].x, shr[1].y, shr[1].z, shr[1].w};
+#ifndef FNN_NORM_FP32
+        f16x8 sc_h, sh_h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc_h[j] = (f16)sc[j]; sh_h[j] = (f16)sh[j]; }
+#endif
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+#ifdef FNN_NORM_FP32
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)xr[u][j], sc[j], sh[j]);
+#else
+            f16x8 o = xr[u] * sc_h + sh_h;
+#endif
+            o = __builtin_elementwise_max(o, o * slope_h);
+            if (offv[u] < 0) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            const int zd = rel[u] >> 16, zh = (rel[u] >> 8) & 255, zw = rel[u] & 255;
+            if (rel[u] >= 0) *(f16x8 *)(dst + ((zd * IH + zh) * TH_PW + zw) * 32 + ((cg ^ (zh & 1)) * 16)) = o;
+        }
+    };
+
+    // ---- fused stem: raw window of tile (n, od0, oh0, ow0) -> registers -> sRaw[slot]; sRaw[slot] -> image
+    float rawv[RPF];
+    float ssc[4], ssh[4];                                                // stem InstanceNorm of this lane's 4 channels
+    auto issue_raw = [&](int n, int od0, int oh0, int ow0) {
+        const int ox = tp.origins[n * 3 + 0], oy = tp.origins[n * 3 + 1], oz = tp.origins[n * 3 + 2];
+        const float *voln = tp.vol + (size_t)n * tp.vol_batch_stride;
+        const int d0 = od0 - (KD - 1), h0 = oh0 - 2, w0 = ow0 - 2;
+#pragma unroll
+        for (int u = 0; u < RPF; ++u) {
+            int d = d0 + (rrel[u] >> 16), h = h0 + ((rrel[u] >> 8) & 255), w = w0 + (rrel[u] & 255);
+            const bool ok = rrel[u] >= 0 && (unsigned)d < (unsigned)p.Di && (unsigned)h < (unsigned)p.Hi && (unsigned)w < (unsigned)p.Wi;
+            if (tp.flip_d) d = p.Di - 1 - d;
+            if (tp.flip_h) h = p.Hi - 1 - h;
+            if (tp.flip_w) w = p.Wi - 1 - w;
+            const float val = voln[((size_t)(ox + (ok ? d : 0)) * tp.Y + (oy + (ok ? h : 0))) * tp.Z + (oz + (ok ? w : 0))];
+            rawv[u] = ok ? val : 0.f;
+        }
+    };
+    auto store_raw = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < RPF; ++u)
+            if (rrel[u] >= 0) sRaw[slot * RVOX + tid + u * 256] = rawv[u];
+    };
+    auto load_stem_ss = [&](int n) {
+        const float4 a = *(const float4 *)(tp.fss + (size_t)(2 * n) * 16 + q * 4);
+        const float4 b = *(const float4 *)(tp.fss + (size_t)(2 * n + 1) * 16 + q * 4);
+        ssc[0] = a.x; ssc[1] = a.y; ssc[2] = a.z; ssc[3] = a.w;
+        ssh[0] = b.x; ssh[1] = b.y; ssh[2] = b.z; ssh[3] = b.w;
+    };
+    auto stem_to_image = [&](int slot, char *dst, int od0, int oh0, int ow0) {
+        const int id0 = od0 - (KD - 1) / 2, ih0 = oh0 - 1, iw0 = ow0 - 1;
+        const f16 slope_h = (f16)tp.fslope;
+        const float *raw = sRaw + slot * RVOX;
+#pragma unroll
+        for (int j = 0; j < NCBW; ++j) {                                 // no branch per block: the chains interleave; a block
+            const f16x4 h = stem_block(raw, s_rawbase[j], tapoff, fwf, fbias);   // past the halo recomputes its last voxel and stores nothing
+            f16x4 o = norm_act4(h, ssc, ssh, slope_h);
+            const unsigned gd = (unsigned)(id0 + (s_zp[j] >> 16)), gh = (unsigned)(ih0 + ((s_zp[j] >> 8) & 255)),
+                           gw = (unsigned)(iw0 + (s_zp[j] & 255));
+            if (!(gd < (unsigned)p.Di && gh < (unsigned)p.Hi && gw < (unsigned)p.Wi)) o = (f16x4){0, 0, 0, 0};   // conv zero padding
+            if (s_zp[j] >= 0) *(f16x4 *)(dst + s_img[j]) = o;
+        }
+    };
+
+    // ---- fused transposed conv: low-resolution voxels of the tile's halo -> xr[0 .. NLBW) -> image of chunk 0
+    int l_ok[NLBW];
+    int lo_d = 0, lo_h = 0, lo_w = 0;                                    // first low-resolution index of the halo per axis
+    auto issue_low = [&](int n, int od0, int oh0, int ow0) {
+        const SrcDesc &S = tp.low;
+        const int id0 = od0 - (KD - 1) / 2, ih0 = oh0 - 1, iw0 = ow0 - 1;
+        lo_d = tp.tsd == 2 ? (id0 >> 1) : id0;                           // arithmetic shift = floor (id0 may be -1)
+        lo_h = tp.tsh == 2 ? (ih0 >> 1) : ih0;
+        lo_w = tp.tsw == 2 ? (iw0 >> 1) : iw0;
+        const int c0 = q * 8, sC = S.C;
+        const int cc = c0 < sC ? c0 : 0;
+        const char *sp = (const char *)(S.ptr + (size_t)n * tp.Dl * tp.Hl * tp.Wl * sC + cc);
+        const float *qs = S.ss ? S.ss + (size_t)(2 * n) * sC + cc : p.ident_ss + cc;
+        const float *qh = S.ss ? qs + sC : p.ident_ss + 512 + cc;
+        scr[0] = *(const float4 *)qs; scr[1] = *(const float4 *)(qs + 4);
+        shr[0] = *(const float4 *)qh; shr[1] = *(const float4 *)(qh + 4);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NLBW; ++j) {
+            const unsigned gd = (unsigned)(lo_d + (l_zp[j] >> 16)), gh = (unsigned)(lo_h + ((l_zp[j] >> 8) & 255)),
+                           gw = (unsigned)(lo_w + (l_zp[j] & 255));
+            const bool ok = l_zp[j] >= 0 && gd < (unsigned)tp.Dl && gh < (unsigned)tp.Hl && gw < (unsigned)tp.Wl;
+            l_ok[j] = (ok && c0 < sC ? 1 : 0) | (ok ? 2 : 0);
+            const unsigned off = ok ? __umul24(__umul24(gd, (unsigned)tp.Hl) + gh, (unsigned)tp.Wl) + gw : 0u;
+            xr[j] = *(const f16x8 *)(sp + off * (unsigned)(sC * 2));
+        }
+    };
+    auto low_to_image = [&](char *dst) {
+        const f16 slope_h = (f16)tp.low.slope;
+        const float sc[8] = {scr[0].x, scr[0].y, scr[0].z, scr[0].w, scr[1].x, scr[1].y, scr[1].z, scr[1].w};
+        const float sh[8] = {shr[0].x, shr[0].y, shr[0].z, shr[0].w, shr[1].x, shr[1].y, shr[1].z, shr[1].w};
+#pragma unroll
+        for (int j = 0; j < NLBW; ++j) {                                 // no branch per block (see stem_to_image)
+            f16x8 o;                                                     // load_act_frag's arithmetic (misc.hip)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (f16)fmaf((float)xr[j][k], sc[k], sh[k]);
+            o = __builtin_elementwise_max(o, o * slope_h);
+            if (!(l_ok[j] & 1)) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int cls = 0; cls < NCLS; ++cls) {
+                const f16x8 wf = *(const f16x8 *)(sF + (cls * 64 + lane) * 16);
+                const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, o, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                f16x4 h;
+                h[0] = (f16)(d[0] + fbias.x); h[1] = (f16)(d[1] + fbias.y); h[2] = (f16)(d[2] + fbias.z); h[3] = (f16)(d[3] + fbias.w);
+                // a low-resolution voxel outside its tensor <=> its full-resolution voxels outside the patch: zero padding
+                if (!(l_ok[j] & 2)) h = (f16x4){0, 0, 0, 0};
+                if ((l_in[j] >> cls) & 1) *(f16x4 *)(dst + l_img[j] + c_off[cls]) = h;
+            }
+        }
+    };
+
+    auto kloop = [&](const char *sA, int ch) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            f16x8 xf[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) xf[mb] = *(const f16x8 *)(sA + base[mb] + toffs[ks]);
+            const f16x8 wf = *(const f16x8 *)(sW + ((size_t)(ch * KS + ks) * 64 + lane) * 16);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[mb], acc[mb][0], 0, 0, 0);
+        }
+    };
+    auto epilogue = [&](int n, int od0, int oh0, int ow0) {
+        float t1[1][4], t2[1][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { t1[0][j] = 0.f; t2[0][j] = 0.f; }
+        tile_epilogue<1, 4>(p, acc, bv, n, od0, oh0, ow0, 0, wave, lane, t1, t2);
+        if (p.stats_out) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dsum[j][0] += (double)t1[0][j]; dsum[j][1] += (double)t2[0][j]; }
+        }
+    };
+    auto flush_stats = [&](int n) {
+        if (!p.stats_out) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double a = row16_sum_f64(dsum[j][0]), b = row16_sum_f64(dsum[j][1]);
+            if (r == 0) { double *slot = sRed + (wave * 16 + q * 4 + j) * 2; slot[0] = a; slot[1] = b; }
+            dsum[j][0] = 0.0; dsum[j][1] = 0.0;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int c = tid >> 1, which = tid & 1;
+            double v = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { v += sRed[(w * 16 + c) * 2 + which]; sRed[(w * 16 + c) * 2 + which] = 0.0; }
+            unsafeAtomicAdd(p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout + c) * 2 + which, v);
+        }
+        __syncthreads();
+    };
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[mb][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+
+    int n_cur, od0, oh0, ow0;
+    tile_coords(t_begin, n_cur, od0, oh0, ow0);
+    int buf = 0;
+
+    if (FUSE == FUSE_STEM) {
+        // raw windows run two tiles ahead (registers, then sRaw[t & 1]); the image one tile ahead
+        int n1 = n_cur, d1 = od0, h1 = oh0, w1 = ow0;                   // tile t + 1
+        issue_raw(n_cur, od0, oh0, ow0);
+        load_stem_ss(n_cur);
+        store_raw(0);
+        if (t_begin + 1 < t_end) next_tile(n1, d1, h1, w1);
+        issue_raw(n1, d1, h1, w1);
+        __syncthreads();
+        stem_to_image(0, sA0, od0, oh0, ow0);
+        store_raw(1);
+        __syncthreads();
+        for (int t = t_begin; t < t_end; ++t) {
+            int n2 = n1, d2 = d1, h2 = h1, w2 = w1;                      // tile t + 2
+            if (t + 2 < t_end) next_tile(n2, d2, h2, w2);
+            issue_raw(n2, d2, h2, w2);
+            load_stem_ss(n1);                                            // the next tile's batch item (unconditional: see conv3d.hip on waits)
+            zero_acc();
+            kloop(sA0 + buf * ABYTES, 0);
+            epilogue(n_cur, od0, oh0, ow0);
+            stem_to_image((t + 1 - t_begin) & 1, sA0 + (buf ^ 1) * ABYTES, d1, h1, w1);
+            store_raw((t - t_begin) & 1);
+            __syncthreads();
+            buf ^= 1;
+            if (n1 != n_cur || t + 1 == t_end) flush_stats(n_cur);
+            n_cur = n1; od0 = d1; oh0 = h1; ow0 = w1;
+            n1 = n2; d1 = d2; h1 = h2; w1 = w2;
+        }
+    } else {
+        issue_low(n_cur, od0, oh0, ow0);
+        low_to_image(sA0);
+        __syncthreads();
+        for (int t = t_begin; t < t_end; ++t) {
+            // item (t, 0): "up" chunk; prefetch the skip chunk of the same tile
+            set_offsets(od0, oh0, ow0);
+            issue_reg(n_cur);
+            zero_acc();
+            kloop(sA0 + buf * ABYTES, 0);
+            commit_reg(sA0 + (buf ^ 1) * ABYTES);
+            __syncthreads();
+            buf ^= 1;
+            // item (t, 1): skip chunk; prefetch the next tile's low-resolution voxels
+            int n1 = n_cur, d1 = od0, h1 = oh0, w1 = ow0;
+            if (t + 1 < t_end) next_tile(n1, d1, h1, w1);
+            issue_low(n1, d1, h1, w1);
+            kloop(sA0 + buf * ABYTES, 1);
+            epilogue(n_cur, od0, oh0, ow0);
+            low_to_image(sA0 + (buf ^ 1) * ABYTES);
+            __syncthreads();
+            buf ^= 1;
+            if (n1 != n_cur || t + 1 == t_end) flush_stats(n_cur);
+            n_cur = n1; od0 = d1; oh0 = h1; ow0 = w1;
+        }
+    }
+}
+
+static size_t thin_lds_bytes(int kd, int ch, int fuse, int ncls) {
+    const int ID = 4 + kd - 1, T = 9 * kd, KS = (T + 1) / 2;
+    const size_t ab = (size_t)((ID * 10 * TH_PW * 32 + 1023) & ~1023);
+    const int RVOX = (ID + kd - 1) * 144;
+    return 2 * ab + (size_t)ch * KS * 1024 + (size_t)(fuse == FUSE_STEM ? 1 : ncls) * 1024 +
+           (fuse == FUSE_STEM ? (size_t)2 * RVOX * 4 : 0) + 256 + 4 * 16 * 2 * 8;
+}
+
+// Can launch_conv_thin run this layer?  (engine.hip asks before it plans the fusion)
+bool conv_thin_ok(const ThinParams &tp) {
+    const ConvParams &p = tp.c;
+    if (p.Cout != 16 || p.kh != 3 || p.kw != 3 || (p.kd != 1 && p.kd != 3) || p.sd != 1 || p.sh != 1 || p.sw != 1) return false;
+    if (p.Di != p.Do || p.Hi != p.Ho || p.Wi != p.Wo) return false;
+    const unsigned long long item = 2ull * p.Do * p.Ho * p.Wo * 16;
+    if (item >= (1ull << 31) || (long long)p.Di * p.Hi >= (1 << 24)) return false;
+    const int ID = 4 + p.kd - 1;
+    if (tp.fuse == FUSE_STEM) {
+        if (p.n_src != 1 || p.chunks != 1) return false;
+    } else if (tp.fuse == FUSE_TCONV) {
+        if (p.n_src != 2 || p.chunks != 2 || p.src[1].C != 16 || tp.low.C > 32 || tp.low.C % 16) return false;
+        const int LD = tp.tsd == 2 ? (ID + 2) / 2 : ID, LH = tp.tsh == 2 ? 6 : 10, LW = tp.tsw == 2 ? 6 : 10;
+        if (LD * LH * LW > 3 * 4 * 16) return false;
+        const int ncls = tp.tsd * tp.tsh * tp.tsw;
+        if (ncls != 2 && ncls != 4 && ncls != 8) return false;
+        if (tp.Dl * tp.tsd != p.Di || tp.Hl * tp.tsh != p.Hi || tp.Wl * tp.tsw != p.Wi) return false;
+        if ((long long)tp.Dl * tp.Hl >= (1 << 24)) return false;
+    } else {
+        return false;
+    }
+    return thin_lds_bytes(p.kd, p.chunks, tp.fuse, tp.tsd * tp.tsh * tp.tsw) * 2 <= 160 * 1024;
+}
+
+template <int KD, int CH, int FUSE, int NCLS, int WPS>
+static int launch_thin_w(ThinParams tp, hipStream_t st) {
+    ConvParams &p = tp.c;
+    p.tile_d = 4;
+    p.tiles_d = (p.Do + 3) / 4; p.tiles_h = (p.Ho + 7) / 8; p.tiles_w = (p.Wo + 7) / 8;
+    const int total = p.N * p.tiles_d * p.tiles_h * p.tiles_w;
+    p.ident_ss = conv3d_identity_ss();
+    if (!p.ident_ss) return -2;
+    const size_t lds = thin_lds_bytes(KD, CH, FUSE, tp.tsd * tp.tsh * tp.tsw);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)conv_thin_kernel<KD, CH, FUSE, NCLS, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > WPS) per_cu = WPS;
+    int gx = 256 * per_cu;
+    if (gx > total) gx = total;
+    hipLaunchKernelGGL((conv_thin_kernel<KD, CH, FUSE, NCLS, WPS>), dim3(gx), dim3(256), lds, st, tp, total);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int KD, int CH, int FUSE, int NCLS>
+static int launch_thin_t(const ThinParams &tp, hipStream_t st) {
+    static const int wps = getenv("FNN_THIN_WPS") ? atoi(getenv("FNN_THIN_WPS")) : 3;       // A-B aid
+    if (KD == 1 && wps == 3) return launch_thin_w<KD, CH, FUSE, NCLS, KD == 1 ? 3 : 2>(tp, st);
+    return launch_thin_w<KD, CH, FUSE, NCLS, 2>(tp, st);
+}
+
+int launch_conv_thin(const ThinParams &tp, hipStream_t st) {
+    if (!conv_thin_ok(tp)) return -1;
+    const int kd = tp.c.kd;
+    if (tp.fuse == FUSE_STEM) return kd == 1 ? launch_thin_t<1, 1, FUSE_STEM, 1>(tp, st) : launch_thin_t<3, 1, FUSE_STEM, 1>(tp, st);
+    switch (tp.tsd * tp.tsh * tp.tsw) {
+        case 2: return kd == 1 ? launch_thin_t<1, 2, FUSE_TCONV, 2>(tp, st) : launch_thin_t<3, 2, FUSE_TCONV, 2>(tp, st);
+        case 4: return kd == 1 ? launch_thin_t<1, 2, FUSE_TCONV, 4>(tp, st) : launch_thin_t<3, 2, FUSE_TCONV, 4>(tp, st);
+        case 8: return kd == 1 ? launch_thin_t<1, 2, FUSE_TCONV, 8>(tp, st) : launch_thin_t<3, 2, FUSE_TCONV, 8>(tp, st);
+    }
+    return -1;
+}

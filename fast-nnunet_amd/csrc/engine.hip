@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -42,6 +43,11 @@ struct Layer {
     int64_t blob_w = 0, blob_b = 0, blob_g = 0, blob_beta = 0;
     int chunks = 0, ksteps = 0, packing = 0;
     int stats_slots = FNN_STAT_REPL;  // rows per item in the stats buffer: atomics' replicas, or one row per tile
+    // conv3d_thin.hip: the stem as one MFMA per 16 voxels (w_off2 = its weight fragment in wpk); a CONV that recomputes
+    // its producer while staging (fuse = FUSE_STEM / FUSE_TCONV); a producer whose output is never written (virtual)
+    bool mfma_stem = false, virtual_out = false;
+    int fuse = 0;
+    size_t w_off2 = 0;
     double flops = 0;                 // 2*MACs per patch
     double bytes = 0;                 // algorithmic HBM bytes per patch: every input read once + the output written once (fp16)
 };
@@ -63,6 +69,7 @@ struct fnn_engine {
     int device = 0;
     int max_batch = 1;
     std::string err;
+    bool fuse_enabled = true;               // FNN_NO_FUSE (read when the engine is created) keeps every layer a kernel of its own
     std::vector<Layer> layers;
     int head_src = -1;                      // layer feeding the seg head
     int hblocks = 0, head_ksteps = 0;
@@ -96,6 +103,11 @@ struct fnn_engine {
     float *vol_pad = nullptr; size_t vol_pad_bytes = 0;
     void *out_tmp = nullptr; size_t out_tmp_bytes = 0;
     float *patch_buf = nullptr; size_t patch_buf_bytes = 0;
+    // gather path (gather.hip): the last conv's raw output and InstanceNorm of every patch of the volume
+    void *feat = nullptr; size_t feat_bytes = 0;
+    void *featss = nullptr; size_t featss_bytes = 0;
+    int *steps_dev = nullptr; size_t steps_cap = 0;
+    bool gather_enabled = true;             // FNN_NO_GATHER (read when the engine is created): always accumulate in HBM
     double head_flops = 0, patch_flops = 0, patch_act_bytes = 0;
     // profiling
     bool profiling = false;
@@ -289,6 +301,43 @@ int build_plan(fnn_engine *e) {
     e->blob_head_b = blob; blob += a.num_heads;
     e->blob_count = blob;
 
+    // ---- producers recomputed inside their consumer's staging (conv3d_thin.hip)
+    auto thin_probe = [&](const Layer &L, int fuse, const Layer *T) {
+        ThinParams tp{};
+        ConvParams &q = tp.c;
+        q.n_src = L.n_src; q.chunks = (L.cin_pad[0] + (L.n_src > 1 ? L.cin_pad[1] : 0)) / 16;
+        q.src[0].C = L.cin_pad[0]; q.src[1].C = L.n_src > 1 ? L.cin_pad[1] : 0;
+        q.Di = L.in_dims[0]; q.Hi = L.in_dims[1]; q.Wi = L.in_dims[2];
+        q.Do = L.out_dims[0]; q.Ho = L.out_dims[1]; q.Wo = L.out_dims[2];
+        q.Cout = L.cout_pad; q.kd = L.k[0]; q.kh = L.k[1]; q.kw = L.k[2]; q.sd = L.s[0]; q.sh = L.s[1]; q.sw = L.s[2];
+        tp.fuse = fuse;
+        if (T) {
+            tp.low.C = T->cin_pad[0];
+            tp.Dl = T->in_dims[0]; tp.Hl = T->in_dims[1]; tp.Wl = T->in_dims[2];
+            tp.tsd = T->s[0]; tp.tsh = T->s[1]; tp.tsw = T->s[2];
+        } else { tp.tsd = tp.tsh = tp.tsw = 1; }
+        return conv_thin_ok(tp);
+    };
+    if (a.spatial_dims != 2) {
+        std::vector<int> consumers(e->layers.size(), 0);
+        for (const Layer &L : e->layers)
+            for (int i = 0; i < L.n_src; ++i) if (L.src_layer[i] >= 0) consumers[L.src_layer[i]]++;
+        for (size_t li = 0; li < e->layers.size(); ++li) {
+            Layer &L = e->layers[li];
+            if (L.type == Layer::STEM && stem_mfma_ok(L.cin_real[0], L.k[0], L.k[1], L.k[2], L.cout_pad)) L.mfma_stem = true;
+            if (!e->fuse_enabled || L.type != Layer::CONV) continue;
+            const int s0 = L.src_layer[0];
+            if (s0 < 0) continue;
+            Layer &P = e->layers[s0];
+            if (L.n_src == 1 && P.type == Layer::STEM && P.mfma_stem && consumers[s0] == 1 && P.k[0] == L.k[0] &&
+                thin_probe(L, FUSE_STEM, nullptr)) {
+                L.fuse = FUSE_STEM; P.virtual_out = true;
+            } else if (L.n_src == 2 && P.type == Layer::TCONV && consumers[s0] == 1 && P.cout_pad == 16 && thin_probe(L, FUSE_TCONV, &P)) {
+                L.fuse = FUSE_TCONV; P.virtual_out = true;
+            }
+        }
+    }
+
     // device offsets
     size_t wpk = 0, fp = 0, st = 0, act = 0, ssn = 0;
     double flops = 0, bytes = 0;
@@ -297,6 +346,7 @@ int build_plan(fnn_engine *e) {
         if (L.type == Layer::STEM) {
             const int T = L.k[0] * L.k[1] * L.k[2];
             L.w_off = fp; fp += (size_t)L.cin_real[0] * T * L.cout_pad;
+            if (L.mfma_stem) { L.w_off2 = wpk; wpk += 512; }
         } else if (L.type == Layer::CONV) {
             const int T = L.k[0] * L.k[1] * L.k[2];
             L.chunks = (L.cin_pad[0] + (L.n_src > 1 ? L.cin_pad[1] : 0)) / 16;
@@ -305,7 +355,7 @@ int build_plan(fnn_engine *e) {
                 q.plan_N = e->max_batch; q.N = e->max_batch; q.Cout = L.cout_pad;
                 q.Do = L.out_dims[0]; q.Ho = L.out_dims[1]; q.Wo = L.out_dims[2];
                 q.kd = L.k[0]; q.kh = L.k[1]; q.kw = L.k[2]; q.sd = L.s[0]; q.sh = L.s[1]; q.sw = L.s[2];
-                L.packing = conv3d_packing(q);
+                L.packing = L.fuse ? FNN_PACK_LINEAR : conv3d_packing(q);
             }
             L.ksteps = conv3d_ksteps(L.packing, T);
             L.w_off = wpk; wpk += (size_t)(L.cout_pad / 16) * L.chunks * L.ksteps * 512;
@@ -317,7 +367,9 @@ int build_plan(fnn_engine *e) {
         L.bias_off = fp; fp += L.cout_pad;
         if (L.has_norm) { L.gamma_off = fp; fp += L.cout_pad; L.beta_off = fp; fp += L.cout_pad; }
         L.stats_slots = FNN_STAT_REPL;
-        if (L.type == Layer::STEM) L.stats_slots = stem_stats_slots(L.out_dims[0], L.out_dims[1], L.out_dims[2]);
+        if (L.type == Layer::STEM) L.stats_slots = L.mfma_stem ? stem_mfma_stats_slots(L.out_dims[0], L.out_dims[1], L.out_dims[2])
+                                                                 : stem_stats_slots(L.out_dims[0], L.out_dims[1], L.out_dims[2]);
+        else if (L.type == Layer::CONV && L.fuse) L.stats_slots = FNN_STAT_REPL;
         else if (L.type == Layer::CONV) {
             ConvParams q{};
             q.plan_N = e->max_batch; q.N = e->max_batch; q.Cout = L.cout_pad;
@@ -462,13 +514,17 @@ SrcDesc make_src(fnn_engine *e, const FoldWeights &fw, int layer, int nb) {
     return s;
 }
 
+// head_out / head_ss: where the network's last layer writes its raw output and its (scale, shift) rows instead of the
+// arena (the gather path keeps them per patch)
 int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch_stride, const long long vdim[3],
-                  const int *origins_dev, int nb, const int flip[3], hipStream_t st) {
+                  const int *origins_dev, int nb, const int flip[3], hipStream_t st, f16 *head_out = nullptr,
+                  float *head_ss = nullptr) {
     const FoldWeights &fw = e->folds[fold];
     HIPCHK(e, hipMemsetAsync(e->stats, 0, e->stats_doubles * e->max_batch * sizeof(double), st));
     for (size_t li = 0; li < e->layers.size(); ++li) {
         const Layer &L = e->layers[li];
         f16 *out = e->act + L.out_off * e->max_batch;
+        if (head_out && (int)li == e->head_src) out = head_out;
         double *stats_out = L.has_norm ? e->stats + L.stats_off * e->max_batch : nullptr;
         int rc = 0;
         if (L.type == Layer::STEM) {
@@ -489,6 +545,10 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
 #ifdef FNN_BOUND_FUSE
             if (li + 1 < e->layers.size() && e->layers[li + 1].type == Layer::CONV && e->layers[li + 1].s[1] == 1) rc = 0; else
 #endif
+            if (L.mfma_stem) {
+                if (L.virtual_out) p.out = nullptr;                   // statistics only: the consumer recomputes the values
+                rc = launch_stem_mfma(p, fw.wpk + L.w_off2, nb, st);
+            } else
             rc = launch_stem(p, nb, st);
         } else if (L.type == Layer::CONV) {
             ConvParams p{};
@@ -517,6 +577,24 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
                 p.bound_mask0 = full && L.s[1] == 1 && L.src_layer[0] >= 0 && (P.type == Layer::STEM || P.type == Layer::TCONV);
             }
 #endif
+            if (L.fuse) {
+                ThinParams tp{};
+                tp.c = p; tp.fuse = L.fuse;
+                const Layer &P = e->layers[L.src_layer[0]];
+                tp.fbias = fw.fparam + P.bias_off;
+                if (L.fuse == FUSE_STEM) {
+                    tp.fw = fw.wpk + P.w_off2;
+                    tp.vol = vol; tp.vol_batch_stride = vol_batch_stride; tp.Y = vdim[1]; tp.Z = vdim[2];
+                    tp.origins = origins_dev; tp.flip_d = flip[0]; tp.flip_h = flip[1]; tp.flip_w = flip[2];
+                    tp.fss = e->ss + P.ss_off * e->max_batch * 2; tp.fslope = e->arch.slope;
+                } else {
+                    tp.fw = fw.wpk + P.w_off;
+                    tp.low = make_src(e, fw, P.src_layer[0], nb);
+                    tp.Dl = P.in_dims[0]; tp.Hl = P.in_dims[1]; tp.Wl = P.in_dims[2];
+                    tp.tsd = P.s[0]; tp.tsh = P.s[1]; tp.tsw = P.s[2];
+                }
+                rc = launch_conv_thin(tp, st);
+            } else
             rc = launch_conv3d(p, st);
         } else if (L.type == Layer::POOL) {
             PoolParams p{};
@@ -541,6 +619,7 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.sd = L.s[0]; p.sh = L.s[1]; p.sw = L.s[2];
             p.Cout = L.cout_pad; p.wpk = fw.wpk + L.w_off; p.bias = fw.fparam + L.bias_off;
             p.out = out; p.ksteps = L.ksteps; p.nblk = L.cout_pad / 16;
+            if (L.virtual_out) continue;                              // computed inside its consumer (conv3d_thin.hip)
             Scope sc(e, st, FAM_TCONV, L.flops * nb);
 #ifdef FNN_BOUND_FUSE
             if (L.out_dims[0] == e->arch.patch[0] && L.out_dims[1] == e->arch.patch[1] && L.out_dims[2] == e->arch.patch[2]) rc = 0; else
@@ -552,6 +631,7 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             StatsFinalizeParams q{};
             q.stats = stats_out; q.gamma = fw.fparam + L.gamma_off; q.beta = fw.fparam + L.beta_off;
             q.ss = e->ss + L.ss_off * e->max_batch * 2; q.C = L.cout_pad; q.nrep = L.stats_slots;
+            if (head_ss && (int)li == e->head_src) q.ss = head_ss;
             q.inv_count = 1.f / ((float)L.out_dims[0] * L.out_dims[1] * L.out_dims[2]); q.eps = e->arch.eps;
             if (launch_stats_finalize(q, nb, st) != 0) return fail(e, FNN_E_HIP, "stats finalize launch failed");
         }
@@ -664,9 +744,10 @@ inline int acc_hp(const fnn_arch_desc &a) { return (a.num_heads + 1 + 7) / 8 * 8
 // ([bx][by][bz][HP], channels-last, channel num_heads = weight sum).
 // `fresh`: `ids` is the volume's whole patch list in visiting order and `acc` holds nothing yet (it need not even be
 // zeroed): voxels no earlier patch has touched are then written without being read (HeadParams::fx).
+// keep_features: no head, no accumulation - patch ids[i] leaves its last activation in e->feat[i] (gather path).
 int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp, const fnn_opts &o,
                 const std::vector<int64_t> &ids, const int *ids_origins_dev, const Box &box, void *acc, int acc_fp32,
-                hipStream_t st, bool fresh = false) {
+                hipStream_t st, bool fresh = false, bool keep_features = false) {
     const fnn_arch_desc &a = e->arch;
     const long long vdim[3] = {(long long)vp.padded[0], (long long)vp.padded[1], (long long)vp.padded[2]};
     int B = o.batch > 0 ? o.batch : e->max_batch;
@@ -684,12 +765,13 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
         const int64_t nbat = (np + B - 1) / B;
         B = (int)((np + nbat - 1) / nbat);
     }
-    for (int64_t i = 0; i < np; ++i) {
+    for (int64_t i = 0; i < np && !keep_features; ++i) {
         const int *oo = &vp.origins[ids[i] * 3];
         for (int d = 0; d < 3; ++d)
             if (oo[d] < box.lo[d] || oo[d] + a.patch[d] > box.hi[d])
                 return fail(e, FNN_E_INVALID, "patch %lld lies outside the accumulator box", (long long)ids[i]);
     }
+    const size_t featC = keep_features ? (size_t)e->layers[e->head_src].cout_pad : 0;
     // ---- several batches in flight (see fnn_engine::pipe)
     static const bool no_pipe = getenv("FNN_NO_PIPELINE") != nullptr;                // A-B aid
     const bool pipelined = !no_pipe && !tta && !e->profiling && np > B;
@@ -747,6 +829,11 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
         for (size_t ci = 0; ci <= (tta ? combos.size() : 0); ++ci) {
             int flip[3] = {0, 0, 0};
             if (ci > 0) for (int ax : combos[ci - 1]) flip[ax] = 1;
+            if (keep_features) {
+                if (int rc = forward_batch(e, fold, vol_dev, 0, vdim, org, nb, flip, st, (f16 *)e->feat + (size_t)p0 * P * featC,
+                                           (float *)e->featss + (size_t)p0 * 2 * featC)) return rc;
+                continue;
+            }
             if (int rc = forward_batch(e, fold, vol_dev, 0, vdim, org, nb, flip, st)) return rc;
             if (pipelined && bi > 0) HIPCHK(e, hipStreamWaitEvent(st, e->ev_head[(bi - 1) % NP], 0));   // heads in patch order
             for (int b = 0; b < nb; ++b) {
@@ -871,6 +958,64 @@ int accumulate_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const
     return run_patches(e, fold, vol_dev, vp, o, ids, e->origins, box, e->acc, acc_fp32, st, fresh);
 }
 
+// Can this volume take the gather path (gather.hip)?  No mirroring (the flipped evaluations are summed per patch first),
+// a head the kernel holds in registers, and room for every patch's last activation next to what is already allocated.
+bool gather_applies(fnn_engine *e, const VolPlan &vp, const fnn_opts &o) {
+    if (!e->gather_enabled || o.n_mirror_axes != 0 || o.out_dtype != FNN_OUT_F16) return false;
+    const Layer &H = e->layers[e->head_src];
+    GatherParams g{};
+    g.heads = e->arch.num_heads; g.C = H.cout_pad; g.PD = e->arch.patch[0]; g.PH = e->arch.patch[1]; g.PW = e->arch.patch[2];
+    if (!H.has_norm || e->head_ksteps != 1 || !gather_ok(g)) return false;
+    const size_t P = (size_t)g.PD * g.PH * g.PW;
+    const size_t need = (size_t)vp.n_patches * P * H.cout_pad * sizeof(f16);
+    if (need <= e->feat_bytes) return true;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    static const double frac = getenv("FNN_GATHER_MEM_FRACTION") ? atof(getenv("FNN_GATHER_MEM_FRACTION")) : 0.6;
+    return (double)need <= frac * (double)(free_b + e->feat_bytes + e->acc_bytes);   // the accumulators are not needed then
+}
+
+int gather_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp, const int64_t shape[4],
+                        const fnn_opts &o, int mode, void *out, void *labels, const int *lab_order, hipStream_t st) {
+    const fnn_arch_desc &a = e->arch;
+    const Layer &H = e->layers[e->head_src];
+    const size_t P = (size_t)a.patch[0] * a.patch[1] * a.patch[2];
+    const size_t need = (size_t)vp.n_patches * P * H.cout_pad * sizeof(f16);
+    if (need > e->feat_bytes && e->acc) { (void)hipFree(e->acc); e->acc = nullptr; e->acc_bytes = 0; }
+    if (int rc = ensure(e, &e->feat, &e->feat_bytes, need)) return rc;
+    if (int rc = ensure(e, &e->featss, &e->featss_bytes, (size_t)vp.n_patches * 2 * H.cout_pad * sizeof(float))) return rc;
+    std::vector<int> steps;
+    for (int d = 0; d < 3; ++d) for (int64_t v : vp.steps[d]) steps.push_back((int)v);
+    {
+        void *t = e->steps_dev;
+        if (int rc = ensure(e, &t, &e->steps_cap, steps.size() * sizeof(int) + 64)) return rc;
+        e->steps_dev = (int *)t;
+    }
+    HIPCHK(e, hipMemcpyAsync(e->steps_dev, steps.data(), steps.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipStreamSynchronize(st));                       // `steps` is a temporary
+    Box box;
+    for (int d = 0; d < 3; ++d) { box.lo[d] = 0; box.hi[d] = vp.padded[d]; }
+    std::vector<int64_t> ids(vp.n_patches);
+    for (int64_t i = 0; i < vp.n_patches; ++i) ids[i] = i;
+    if (int rc = run_patches(e, fold, vol_dev, vp, o, ids, e->origins, box, nullptr, 0, st, false, true)) return rc;
+    const FoldWeights &fw = e->folds[fold];
+    GatherParams g{};
+    g.feat = (const f16 *)e->feat; g.fss = (const float *)e->featss; g.C = H.cout_pad;
+    g.slope = H.act ? a.slope : 1.f;
+    g.steps = e->steps_dev; g.nx = (int)vp.steps[0].size(); g.ny = (int)vp.steps[1].size(); g.nz = (int)vp.steps[2].size();
+    g.PD = a.patch[0]; g.PH = a.patch[1]; g.PW = a.patch[2];
+    g.wpk = fw.wpk + e->head_w_off; g.bias = fw.fparam + e->head_bias_off; g.heads = a.num_heads; g.hblocks = e->hblocks;
+    g.gauss = o.use_gaussian ? e->gauss : e->ones;
+    g.lo_x = (int)vp.lo[0]; g.lo_y = (int)vp.lo[1]; g.lo_z = (int)vp.lo[2];
+    g.OX = shape[1]; g.OY = shape[2]; g.OZ = shape[3];
+    g.acc_fp32 = o.accum == FNN_ACC_FP32; g.out_fp32 = o.out_dtype == FNN_OUT_F32;
+    g.out_vec = out && !g.out_fp32 && shape[3] % 8 == 0 && ((size_t)out % 16) == 0;
+    g.mode = mode; g.out = out; g.labels = labels; g.label_u16 = e->label_u16; g.order = lab_order; g.inf_flag = e->inf_flag;
+    Scope sc(e, st, FAM_HEAD, e->head_flops * (double)vp.n_patches);
+    if (launch_gather(g, st) != 0) return fail(e, FNN_E_HIP, "gather launch failed");
+    return 0;
+}
+
 int predict_impl(fnn_engine *e, int fold0, int n_folds, const float *vol, const int64_t shape[4], const fnn_opts *o,
                  void *out, void *labels) {
     for (int f = fold0; f < fold0 + n_folds; ++f)
@@ -913,7 +1058,13 @@ int predict_impl(fnn_engine *e, int fold0, int n_folds, const float *vol, const 
     const int acc_fp32 = o->accum == FNN_ACC_FP32;
     const int64_t zero3[3] = {0, 0, 0}, full3[3] = {shape[1], shape[2], shape[3]};
     int rc = 0;
+    const bool gather = gather_applies(e, vp, *o);
     for (int f = 0; f < n_folds && rc == 0; ++f) {
+        if (gather) {
+            rc = gather_whole_volume(e, fold0 + f, vol_dev, vp, shape, *o, f > 0 ? 1 : 0, labels_direct ? nullptr : out_dev,
+                                     labels_direct ? lab_dev : nullptr, lab_order, st);
+            continue;
+        }
         Box box;
         rc = accumulate_whole_volume(e, fold0 + f, vol_dev, vp, *o, box, st);
         if (rc) break;
@@ -968,6 +1119,8 @@ int fnn_create(const fnn_arch_desc *arch, int device, int max_batch, fnn_engine 
     if (device < 0 || device >= ndev) return fail(nullptr, FNN_E_INVALID, "device %d out of range (%d visible)", device, ndev);
     fnn_engine *e = new fnn_engine();
     e->arch = *arch; e->device = device; e->max_batch = max_batch;
+    e->fuse_enabled = getenv("FNN_NO_FUSE") == nullptr;
+    e->gather_enabled = getenv("FNN_NO_GATHER") == nullptr;
     if (e->arch.eps <= 0) e->arch.eps = 1e-5f;
     int rc = build_plan(e);
     if (rc != 0) { g_err = e->err; delete e; return rc; }
@@ -1003,7 +1156,7 @@ void fnn_destroy(fnn_engine *e) {
         if (k > 0) { (void)hipFree(e->actp[k]); (void)hipFree(e->statsp[k]); (void)hipFree(e->ssp[k]); }
     }
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
-    void *ptrs[] = {e->ones, e->label_order, e->act, e->stats, e->ss, e->gauss, e->inf_flag, e->origins, e->acc, e->vol_tmp, e->vol_pad, e->out_tmp, e->patch_buf};
+    void *ptrs[] = {e->feat, e->featss, e->steps_dev, e->ones, e->label_order, e->act, e->stats, e->ss, e->gauss, e->inf_flag, e->origins, e->acc, e->vol_tmp, e->vol_pad, e->out_tmp, e->patch_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ev : e->evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     delete e;
@@ -1030,6 +1183,12 @@ int fnn_load_weights(fnn_engine *e, int fold, const float *blob, int64_t count) 
                 for (int t = 0; t < T; ++t)
                     for (int co = 0; co < L.cout_real; ++co)
                         fp[L.w_off + ((size_t)c * T + t) * L.cout_pad + co] = W[((size_t)co * C + c) * T + t];
+            if (L.mfma_stem)                                          // MFMA "A" fragment: lane (cout, k-group), k = c * T + tap
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = 8 * (lane >> 4) + j, co = lane & 15;
+                        wpk[L.w_off2 + (size_t)lane * 8 + j] = f2h_bits(k < C * T && co < L.cout_real ? W[(size_t)co * C * T + k] : 0.f);
+                    }
         } else if (L.type == Layer::CONV) {
             pack_conv(L, W, wpk.data() + L.w_off);
         } else {

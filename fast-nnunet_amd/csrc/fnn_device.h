@@ -85,6 +85,28 @@ struct StemParams {
     int tiles_d, tiles_h, tiles_w;
 };
 
+// Thin full-resolution conv with a fused producer (conv3d_thin.hip)
+#define FUSE_STEM 1
+#define FUSE_TCONV 2
+struct ThinParams {
+    ConvParams c;                // the consumer conv; FUSE_TCONV: src[1] = the skip, src[0] is never read
+    int fuse;                    // FUSE_*
+    const f16 *fw;               // producer weights as MFMA "A" fragments: stem [64][8]; tconv [tap][64][8]
+    const float *fbias;          // producer bias [16]
+    // FUSE_STEM
+    const float *vol;            // [1][X][Y][Z] fp32 (the padded volume)
+    long long vol_batch_stride;
+    long long Y, Z;
+    const int *origins;          // [N][3]
+    int flip_d, flip_h, flip_w;
+    const float *fss;            // [N][2][16] scale / shift of the stem's InstanceNorm
+    float fslope;
+    // FUSE_TCONV
+    SrcDesc low;                 // input of the transposed conv with its on-load transform
+    int Dl, Hl, Wl;
+    int tsd, tsh, tsw;           // its strides (= kernel)
+};
+
 struct TconvParams {
     SrcDesc src;
     int N, Di, Hi, Wi;
@@ -132,6 +154,30 @@ struct PatchAccParams {          // patch buffer -> volume accumulators (mirrori
     int HP;
     int ox, oy, oz;
     int acc_fp32;
+};
+
+// Head + accumulate + normalise from kept patch features (gather.hip)
+struct GatherParams {
+    const f16 *feat;             // [n_patches][PD][PH][PW][C]: raw output of the network's last conv, per patch
+    const float *fss;            // [n_patches][2][C]: scale row, shift row of its InstanceNorm
+    int C;                       // padded channels (16 or 32)
+    float slope;
+    const int *steps;            // device: tile starts per axis, x then y then z (ascending)
+    int nx, ny, nz;
+    int PD, PH, PW;
+    const f16 *wpk;              // seg head [hblock][64][8] (one k-step)
+    const float *bias;           // [hblocks * 16], bias[heads] = 1 (the weight-sum channel)
+    int heads, hblocks;
+    const f16 *gauss;            // [PD][PH][PW] (all ones without Gaussian weighting)
+    int lo_x, lo_y, lo_z;        // un-padded voxel (0, 0, 0) in the padded volume
+    long long OX, OY, OZ;        // un-padded size = output size
+    int acc_fp32, out_fp32, out_vec;
+    int mode;                    // 0 write, 1 add to the existing output (fold ensembling)
+    void *out;                   // [heads][OX][OY][OZ] fp16 / fp32, or
+    void *labels;                // [OX][OY][OZ] uint8 / uint16 (then `out` is unused)
+    int label_u16;
+    const int *order;            // regions_class_order or nullptr (argmax)
+    int *inf_flag;
 };
 
 struct FinalizeParams {
@@ -206,6 +252,13 @@ int conv3d_stats_slots(const ConvParams &p);                           // rows p
 int stem_stats_slots(int PD, int PH, int PW);
 int launch_stem(const StemParams &p, int N, hipStream_t st);
 int launch_tconv(const TconvParams &p, hipStream_t st);
+bool stem_mfma_ok(int C, int kd, int kh, int kw, int cout_pad);
+int stem_mfma_stats_slots(int PD, int PH, int PW);
+int launch_stem_mfma(const StemParams &p, const f16 *wfrag, int N, hipStream_t st);    // p.out == nullptr: statistics only
+bool gather_ok(const GatherParams &p);
+int launch_gather(const GatherParams &p, hipStream_t st);
+bool conv_thin_ok(const ThinParams &tp);
+int launch_conv_thin(const ThinParams &tp, hipStream_t st);
 int launch_head(const HeadParams &p, hipStream_t st);
 bool launch_head_first_visit_ok(const HeadParams &p);   // does launch_head() honour fx / fy / fz for these parameters?
 int launch_patch_acc(const PatchAccParams &p, hipStream_t st);

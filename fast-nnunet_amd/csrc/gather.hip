@@ -1,0 +1,273 @@
+// gather.hip - seg head + Gaussian-weighted accumulation + normalisation WITHOUT volume accumulators (gfx950).
+//
+// The reference accumulates patch by patch into whole-volume buffers (predict_from_raw_data.py:602-621):
+//     pred *= gaussian;  predicted_logits[sl] += pred;  n_predictions[sl] += gaussian;  ...  predicted_logits /= n
+// Done literally on the GPU that is a read-modify-write of every accumulator line per patch visit: for 61 classes
+// 2 x 128 B per voxel and visit next to 32 B of network output - 425 MB per patch, 18 % of the benchmark's time, plus a
+// 34 GB normalisation pass.  But a voxel's value depends only on the <= 8 patches that cover it, in visiting order:
+//     acc = 0;  for p in covering patches (ascending = the reference's x-major order):  acc = fp16(acc + logit_p * g_p)
+// So the network's last activation (16 channels, 32 B per voxel) of EVERY patch of the volume is kept in HBM
+// (28 GB for 600 patches of 160 x 96 x 96 - the 288 GB make that free) and one pass over the volume does the rest:
+// a wave owns 64 consecutive z voxels; for every covering patch it loads their 32-byte feature vectors, applies the
+// producer's InstanceNorm + LeakyReLU, runs the 1x1x1 seg head on the matrix cores, multiplies by the patch's Gaussian
+// weight and adds into accumulators that live in REGISTERS, rounding to fp16 after every visit exactly like the
+// reference's half-precision buffers (or keeping fp32: FNN_ACC_FP32); then divides by the weight sum, checks for inf
+// and writes the un-padded fp16 logits (or the label map) - every byte of the result is written once, every feature
+// byte read once: 44 GB instead of ~290 GB per 512^3 volume.  Results are bit-identical to the accumulate path.
+//
+// Replaces _internal_predict_sliding_window_return_logits' accumulation and normalisation (:602-625) and, for the
+// label entry points, LabelManager.convert_logits_to_segmentation (label_handling.py:144-195).
+#include "fnn_device.h"
+#include <cstdlib>
+
+namespace {
+
+static __device__ __forceinline__ float acc_add_product_g(float a, float t, float g) {
+#pragma clang fp contract(off)
+    const float c = t * g;                                     // the reference rounds the product before the add
+    return a + c;
+}
+
+struct Pick {                                                  // LabelPick of misc.hip over this lane's heads, mergeable
+    float best; int arg; int nan; int hit;
+};
+
+}  // namespace
+
+// HB = head blocks of 16 (heads + the weight-sum channel <= 16 HB); LABELS: write the label map instead of the logits.
+template <int HB, bool ACC32, bool LABELS>
+__global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    f16 *sT = (f16 *)smem + wave * (HB * 16 * 72);             // per wave: [HB * 16 heads][64 z (+8 pad)] fp16
+
+    // wave -> (x, y, run of 64 z) of the UN-PADDED output
+    const long long zruns = (p.OZ + 63) / 64;
+    long long wid = (long long)blockIdx.x * 4 + wave;
+    const long long total = p.OX * p.OY * zruns;
+    if (wid >= total) return;
+    const int zr = (int)(wid % zruns); wid /= zruns;
+    const int y = (int)(wid % p.OY);
+    const int x = (int)(wid / p.OY);
+    const int z0 = zr * 64;
+    const int xp = x + p.lo_x, yp = y + p.lo_y, zp0 = z0 + p.lo_z;            // padded-volume coordinates
+
+    // seg head fragments: A operand per head block, bias of this lane's 4 heads per block
+    f16x8 wf[HB];
+    f32x4 bv[HB];
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb) {
+        const int hbc = hb < p.hblocks ? hb : p.hblocks - 1;     // HB = 4 with 3 blocks: the copy's rows are >= heads, ignored
+        wf[hb] = *(const f16x8 *)(p.wpk + ((size_t)hbc * 64 + lane) * 8);
+        bv[hb] = *(const f32x4 *)(p.bias + hbc * 16 + q * 4);
+    }
+    float acc[4][HB][4];                                       // [16-voxel group][head block][head]: fp16-valued unless ACC32
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[g][hb][j] = 0.f;
+
+    const int P = p.PD * p.PH * p.PW;
+    const int c0 = q * 8 < p.C ? q * 8 : 0;
+    const bool live = q * 8 < p.C;
+    const f16 slope_h = (f16)p.slope;
+    const int *sx = p.steps, *sy = p.steps + p.nx, *sz = p.steps + p.nx + p.ny;
+
+    for (int ix = 0; ix < p.nx; ++ix) {
+        const int ox = sx[ix];
+        if (xp < ox || xp >= ox + p.PD) continue;              // wave-uniform
+        for (int iy = 0; iy < p.ny; ++iy) {
+            const int oy = sy[iy];
+            if (yp < oy || yp >= oy + p.PH) continue;
+            for (int iz = 0; iz < p.nz; ++iz) {
+                const int oz = sz[iz];
+                if (zp0 + 64 <= oz || zp0 >= oz + p.PW) continue;
+                const int pid = (ix * p.ny + iy) * p.nz + iz;
+                // the patch's InstanceNorm of this lane's 8 channels
+                const float *qs = p.fss + (size_t)(2 * pid) * p.C + c0;
+                const float4 s0 = *(const float4 *)qs, s1 = *(const float4 *)(qs + 4);
+                const float4 h0 = *(const float4 *)(qs + p.C), h1 = *(const float4 *)(qs + p.C + 4);
+                const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                const int rowbase = ((xp - ox) * p.PH + (yp - oy)) * p.PW - oz;      // + zp = voxel index in the patch
+                const f16 *fp = p.feat + (size_t)pid * P * p.C + c0;
+                f16x8 xraw[4];
+                f16 graw[4];
+                bool in[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int zp = zp0 + 16 * g + r;
+                    in[g] = zp >= oz && zp < oz + p.PW;
+                    const int v = in[g] ? rowbase + zp : 0;
+                    xraw[g] = *(const f16x8 *)(fp + (size_t)v * p.C);
+                    graw[g] = p.gauss[v];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x8 o;                                   // norm_act_frag's arithmetic (misc.hip)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)xraw[g][j], sc[j], sh[j]);
+                    o = __builtin_elementwise_max(o, o * slope_h);
+                    if (!live) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    const float gw = (float)graw[g];
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb) {
+                        const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[hb], o, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        const f32x4 t = d + bv[hb];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            // channel `heads` has zero weights and bias 1: its product is the weight itself
+                            const float s = acc_add_product_g(acc[g][hb][j], t[j], gw);
+                            const float nv = ACC32 ? s : (float)(f16)s;
+                            acc[g][hb][j] = in[g] ? nv : acc[g][hb][j];
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- normalise: logits = acc / weight sum, rounded to fp16 (:619); the weight sum sits in row `heads`
+    const int wrow = p.heads, whb = wrow >> 4, wq = (wrow >> 2) & 3, wj = wrow & 3;
+    bool bad = false;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float wsum = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (hb == whb && j == wj) wsum = acc[g][hb][j];
+        wsum = __shfl(wsum, wq * 16 + r, 64);
+        const bool zok = z0 + 16 * g + r < p.OZ;
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f16 rr = (f16)__fdiv_rn(acc[g][hb][j], wsum);
+                const int head = hb * 16 + q * 4 + j;
+                bad |= zok && head < p.heads && isinf((float)rr);
+                acc[g][hb][j] = (float)rr;
+            }
+    }
+    if (bad) atomicOr(p.inf_flag, 1);
+
+    if (LABELS) {
+        // LabelPick (misc.hip) over this lane's heads in order, merged over the 4 lanes of a voxel in head order:
+        // heads of lane q, block hb are hb * 16 + 4 q + j, so per block the lanes are ordered and blocks come in order
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float best = 0.f; int arg = -1; bool nan = false; int hit = -1;
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                float b = 0.f; int a = -1; bool n = false; int h = -1;      // this lane's 4 heads of block hb
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int head = hb * 16 + q * 4 + j;
+                    const float v = acc[g][hb][j];
+                    if (head < p.heads) {
+                        if (v > 0x1.8p-24f) h = head;
+                        if (a < 0) { b = v; a = head; n = v != v; }
+                        else if (!n && (v > b || v != v)) { b = v; a = head; n = v != v; }
+                    }
+                }
+                // merge the 4 lanes of the block (xor 16, 32: lower lane = lower heads), then behind the earlier blocks
+#pragma unroll
+                for (int m = 16; m < 64; m <<= 1) {
+                    const float ob = __shfl_xor(b, m, 64);
+                    const int oa = __shfl_xor(a, m, 64), on = __shfl_xor((int)n, m, 64), oh = __shfl_xor(h, m, 64);
+                    const bool lower = (lane & m) == 0;
+                    const float lb = lower ? b : ob, hbv = lower ? ob : b;
+                    const int la = lower ? a : oa, ha = lower ? oa : a;
+                    const bool ln = lower ? n : (on != 0), hn = lower ? (on != 0) : n;
+                    const bool take_hi = la < 0 ? true : (ha < 0 ? false : (ln ? false : (hn || hbv > lb)));
+                    b = take_hi ? hbv : lb; a = take_hi ? ha : la; n = take_hi ? hn : ln;
+                    h = h > oh ? h : oh;
+                }
+                const bool take = arg < 0 ? true : (a < 0 ? false : (nan ? false : (n || b > best)));
+                if (take) { best = b; arg = a; nan = n; }
+                hit = hit > h ? hit : h;
+            }
+            const int z = z0 + 16 * g + r;
+            if (q == 0 && z < p.OZ) {
+                const int lab = p.order ? (hit >= 0 ? p.order[hit] : 0) : arg;
+                const size_t o = ((size_t)x * p.OY + y) * p.OZ + z;
+                if (p.label_u16) ((uint16_t *)p.labels)[o] = (uint16_t)lab; else ((uint8_t *)p.labels)[o] = (uint8_t)lab;
+            }
+        }
+        return;
+    }
+
+    // ---- logits: transpose through LDS so that a head's 64 z values leave as one 128-byte row
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sT[(hb * 16 + q * 4 + j) * 72 + 16 * g + r] = (f16)acc[g][hb][j];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    const size_t plane = (size_t)p.OX * p.OY * p.OZ;
+    const size_t rowoff = ((size_t)x * p.OY + y) * p.OZ + z0;
+    const int nz = (int)(p.OZ - z0 < 64 ? p.OZ - z0 : 64);
+    const bool vec = p.out_vec && nz == 64;                     // 16-byte aligned rows
+    if (!p.out_fp32 && vec) {
+        for (int h8 = 0; h8 < p.heads; h8 += 8) {
+            const int head = h8 + (lane >> 3), piece = lane & 7;
+            if (head < p.heads) {
+                f16x8 v = *(const f16x8 *)(sT + head * 72 + piece * 8);
+                f16 *o = (f16 *)p.out + (size_t)head * plane + rowoff + piece * 8;
+                if (p.mode) {
+                    const f16x8 old = *(const f16x8 *)o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (f16)((float)old[e] + (float)v[e]);
+                }
+                *(f16x8 *)o = v;
+            }
+        }
+    } else {
+        for (int head = 0; head < p.heads; ++head) {
+            if (lane < nz) {
+                const f16 v = sT[head * 72 + lane];
+                const size_t o = (size_t)head * plane + rowoff + lane;
+                if (p.out_fp32) {
+                    float *op = (float *)p.out + o;
+                    *op = p.mode ? *op + (float)v : (float)v;
+                } else {
+                    f16 *op = (f16 *)p.out + o;
+                    *op = p.mode ? (f16)((float)*op + (float)v) : v;
+                }
+            }
+        }
+    }
+}
+
+bool gather_ok(const GatherParams &p) {
+    const int hblocks = (p.heads + 1 + 15) / 16;
+    return hblocks <= 4 && p.C <= 32 && p.C % 8 == 0 && (long long)p.PD * p.PH * p.PW < (1LL << 31) / 32;
+}
+
+template <int HB>
+static int launch_gather_hb(const GatherParams &p, hipStream_t st) {
+    const long long waves = p.OX * p.OY * ((p.OZ + 63) / 64);
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    const size_t lds = (size_t)4 * HB * 16 * 72 * 2;
+    const bool labels = p.labels != nullptr;
+    if (p.acc_fp32) {
+        if (labels) hipLaunchKernelGGL((gather_head_kernel<HB, true, true>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((gather_head_kernel<HB, true, false>), grid, dim3(256), lds, st, p);
+    } else {
+        if (labels) hipLaunchKernelGGL((gather_head_kernel<HB, false, true>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((gather_head_kernel<HB, false, false>), grid, dim3(256), lds, st, p);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_gather(const GatherParams &p, hipStream_t st) {
+    if (!gather_ok(p)) return -1;
+    const int hblocks = (p.heads + 1 + 15) / 16;
+    if (hblocks == 1) return launch_gather_hb<1>(p, st);
+    if (hblocks == 2) return launch_gather_hb<2>(p, st);
+    return launch_gather_hb<4>(p, st);
+}

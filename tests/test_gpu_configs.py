@@ -245,3 +245,69 @@ def test_conv_staging_normalisation_with_large_mean_over_std(ratio):
     rel_rmse = float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
     print(f'[staging ratio {ratio}] max|err| {float(err.abs().max()):.4g} of max|ref| {float(ref.abs().max()):.4g}, rel. RMSE {rel_rmse:.3g}')
     assert rel_rmse <= RMSE_REL and float(err.abs().max()) <= MAX_REL * float(ref.abs().max())
+
+
+# ----------------------------------------------------------------------------------------------- fused stage-0 producers
+FUSE_SPECS = {
+    # bone_turbo-like stage 0: (1, 3, 3) kernels, last transposed conv with stride (1, 2, 2)
+    'aniso': (UNetSpec('plain', 1, 5, [16, 32, 64], [(1, 3, 3), (3, 3, 3), (3, 3, 3)], [(1, 1, 1), (1, 2, 2), (2, 2, 2)],
+                       [2, 2, 2], [2, 2]), (20, 40, 56)),
+    # isotropic stage 0: (3, 3, 3) kernels, stride (2, 2, 2); dims that are not multiples of the 4 x 8 x 8 tile
+    'iso': (UNetSpec('plain', 1, 3, [16, 32, 32], [(3, 3, 3)] * 3, [(1, 1, 1), (2, 2, 2), (2, 2, 2)], [2, 2, 2], [2, 2]),
+            (28, 36, 44)),
+    # three convs at stage 0 of the decoder / encoder: only the conv right behind the producer fuses
+    'three_convs': (UNetSpec('plain', 1, 2, [16, 32], [(1, 3, 3), (3, 3, 3)], [(1, 1, 1), (2, 2, 2)], [3, 2], [3]), (16, 24, 40)),
+}
+
+
+def _fused_and_plain(spec, patch, sd, batch, mirror=None):
+    os.environ.pop('FNN_NO_FUSE', None)
+    fused = _predictor(spec, patch, [sd], batch=batch, mirror=mirror)
+    os.environ['FNN_NO_FUSE'] = '1'
+    try:
+        plain = _predictor(spec, patch, [sd], batch=batch, mirror=mirror)
+    finally:
+        os.environ.pop('FNN_NO_FUSE', None)
+    return fused, plain
+
+
+@pytest.mark.parametrize('name', list(FUSE_SPECS))
+def test_fused_stage0_producers_match_the_unfused_engine_and_the_oracle(name):
+    """conv3d_thin.hip: the stem recomputed inside the second conv's staging and the last transposed conv computed
+    inside the last decoder stage's first conv, on whole volumes (ragged tiles, patch borders = the convs' zero padding,
+    mirroring) and on batches: within fp16 resolution of the layer-by-layer engine (FNN_NO_FUSE=1; small patches run
+    other kernel variants there, whose InstanceNorm statistics are summed in another order) and within the usual
+    tolerance of the fp32 oracle."""
+    spec, patch = FUSE_SPECS[name]
+    sd = synthetic_state_dict(spec, 600)
+    x = torch.randn(5, 1, *patch, generator=torch.Generator().manual_seed(60))
+    image = torch.randn(1, patch[0] + 7, patch[1] + 13, patch[2] + 22, generator=torch.Generator().manual_seed(61))
+    fused, plain = _fused_and_plain(spec, patch, sd, 3, mirror=[0, 1, 2])
+    a, b = fused.forward_patches(x).cpu(), plain.forward_patches(x).cpu()
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    with torch.inference_mode():
+        ref = build_oracle(spec, sd)(x)
+    mr, rr = _report(f'fused {name} vs oracle', a, ref)
+    assert mr <= MAX_REL and rr <= RMSE_REL
+    mr, rr = _report(f'fused {name} vs unfused', a, b)
+    assert mr <= 5e-3 and rr <= 3e-3
+    va, vb = fused.predict_sliding_window_return_logits(image).float().cpu(), plain.predict_sliding_window_return_logits(image).float().cpu()
+    inner = (slice(None), slice(8, -8), slice(8, -8), slice(8, -8))    # away from the subnormal Gaussian weights at the faces
+    mr, rr = _report(f'fused {name} volume vs unfused', va[inner], vb[inner])
+    assert mr <= 1e-2 and rr <= 3e-3
+    want = osw.sliding_window_logits(lambda t: fused.forward_patches(t).cpu(), image, patch, spec.num_heads, mirror_axes=[0, 1, 2], accum='fp16')
+    assert (_bits(fused.predict_sliding_window_return_logits(image).cpu()) == _bits(want)).all()
+
+
+def test_fused_stage0_producers_are_bit_identical_where_the_unfused_engine_runs_the_same_tiling():
+    """With >= 2048 tiles per launch the unfused engine runs the same persistent 4 x 8 x 8 kernels for the stage-0 convs
+    (same statistics order), the stand-alone stem is the same MFMA kernel and the stand-alone transposed conv the same
+    arithmetic: every bit of the logits must agree."""
+    spec, _ = FUSE_SPECS['aniso']
+    patch = (32, 64, 64)
+    sd = synthetic_state_dict(spec, 601)
+    fused, plain = _fused_and_plain(spec, patch, sd, 4)
+    x = torch.randn(4, 1, *patch, generator=torch.Generator().manual_seed(62))
+    a, b = fused.forward_patches(x), plain.forward_patches(x)
+    print('max |fused - unfused|', float((a - b).abs().max()))
+    assert torch.equal(a, b)

@@ -787,3 +787,34 @@ def test_engine_ini_front_end_rejects_a_model_that_disagrees_with_the_ini(tmp_pa
         eng.set_config(str(ini))
         with pytest.raises(RuntimeError, match=err):
             eng.set_workspace(str(folder))
+
+
+@pytest.mark.parametrize('accum', ['fp16', 'fp32'])
+@pytest.mark.parametrize('shape,heads', [((40, 36, 70), 3), ((21, 27, 50), 61), ((16, 16, 32), 3), ((11, 30, 9), 3)])
+def test_gather_path_is_bit_identical_to_the_accumulate_path(shape, heads, accum):
+    """gather.hip keeps every patch's last activation and forms each voxel's weighted sum in registers, in visiting
+    order, instead of read-modify-writing whole-volume accumulators (FNN_NO_GATHER=1): logits (fp16 and fp32
+    accumulation), the inf flag and the labels must agree bit for bit - ragged z runs, volumes smaller than the patch
+    (padding), one-patch volumes, 3 and 61 heads (1 and 4 head blocks), 2 folds (the add mode)."""
+    spec = UNetSpec('plain', 1, heads, [16, 32], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
+    patch = (16, 16, 32)
+    sds = [synthetic_state_dict(spec, 300 + f) for f in range(2)]
+    os.environ.pop('FNN_NO_GATHER', None)
+    g = _predictor(spec, patch, sds, accumulate_in=accum)
+    os.environ['FNN_NO_GATHER'] = '1'
+    try:
+        a = _predictor(spec, patch, sds, accumulate_in=accum)
+    finally:
+        os.environ.pop('FNN_NO_GATHER', None)
+    image = torch.randn(1, *shape, generator=torch.Generator().manual_seed(23))
+    for fold in (0, 1):
+        g._active_fold = a._active_fold = fold
+        assert torch.equal(g.predict_sliding_window_return_logits(image), a.predict_sliding_window_return_logits(image))
+    assert torch.equal(g.predict_logits_from_preprocessed_data(image), a.predict_logits_from_preprocessed_data(image))
+    g1, a1 = _predictor(spec, patch, sds[:1], accumulate_in=accum), None
+    os.environ['FNN_NO_GATHER'] = '1'
+    try:
+        a1 = _predictor(spec, patch, sds[:1], accumulate_in=accum)
+    finally:
+        os.environ.pop('FNN_NO_GATHER', None)
+    assert torch.equal(g1.predict_segmentation_from_preprocessed_data(image), a1.predict_segmentation_from_preprocessed_data(image))
