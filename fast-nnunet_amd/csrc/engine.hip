@@ -70,6 +70,7 @@ struct fnn_engine {
     int max_batch = 1;
     std::string err;
     bool fuse_enabled = true;               // FNN_NO_FUSE (read when the engine is created) keeps every layer a kernel of its own
+    bool fuse_stem = true, fuse_tconv = true;   // FNN_FUSE_STEM / FNN_FUSE_TCONV = 0 | 1: the two fusions separately (A-B aid)
     std::vector<Layer> layers;
     int head_src = -1;                      // layer feeding the seg head
     int hblocks = 0, head_ksteps = 0;
@@ -329,10 +330,10 @@ int build_plan(fnn_engine *e) {
             const int s0 = L.src_layer[0];
             if (s0 < 0) continue;
             Layer &P = e->layers[s0];
-            if (L.n_src == 1 && P.type == Layer::STEM && P.mfma_stem && consumers[s0] == 1 && P.k[0] == L.k[0] &&
+            if (e->fuse_stem && L.n_src == 1 && P.type == Layer::STEM && P.mfma_stem && consumers[s0] == 1 && P.k[0] == L.k[0] &&
                 thin_probe(L, FUSE_STEM, nullptr)) {
                 L.fuse = FUSE_STEM; P.virtual_out = true;
-            } else if (L.n_src == 2 && P.type == Layer::TCONV && consumers[s0] == 1 && P.cout_pad == 16 && thin_probe(L, FUSE_TCONV, &P)) {
+            } else if (e->fuse_tconv && L.n_src == 2 && P.type == Layer::TCONV && consumers[s0] == 1 && P.cout_pad == 16 && thin_probe(L, FUSE_TCONV, &P)) {
                 L.fuse = FUSE_TCONV; P.virtual_out = true;
             }
         }
@@ -1120,6 +1121,8 @@ int fnn_create(const fnn_arch_desc *arch, int device, int max_batch, fnn_engine 
     fnn_engine *e = new fnn_engine();
     e->arch = *arch; e->device = device; e->max_batch = max_batch;
     e->fuse_enabled = getenv("FNN_NO_FUSE") == nullptr;
+    if (const char *v = getenv("FNN_FUSE_STEM")) e->fuse_stem = atoi(v) != 0;
+    if (const char *v = getenv("FNN_FUSE_TCONV")) e->fuse_tconv = atoi(v) != 0;
     e->gather_enabled = getenv("FNN_NO_GATHER") == nullptr;
     if (e->arch.eps <= 0) e->arch.eps = 1e-5f;
     int rc = build_plan(e);

@@ -22,9 +22,9 @@
 
 namespace {
 
-static __device__ __forceinline__ float acc_add_product_g(float a, float t, float g) {
+static __device__ __forceinline__ float acc_add_product_1(float a, float t, float g) {
 #pragma clang fp contract(off)
-    const float c = t * g;                                     // the reference rounds the product before the add
+    const float c = t * g;                                     // the reference rounds the product before the add: no fma
     return a + c;
 }
 
@@ -61,13 +61,11 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
         wf[hb] = *(const f16x8 *)(p.wpk + ((size_t)hbc * 64 + lane) * 8);
         bv[hb] = *(const f32x4 *)(p.bias + hbc * 16 + q * 4);
     }
-    float acc[4][HB][4];                                       // [16-voxel group][head block][head]: fp16-valued unless ACC32
+    f32x4 acc[4][HB];                                          // [16-voxel group][head block] x 4 heads: fp16-valued unless ACC32
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int hb = 0; hb < HB; ++hb)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[g][hb][j] = 0.f;
+        for (int hb = 0; hb < HB; ++hb) acc[g][hb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int P = p.PD * p.PH * p.PW;
     const int c0 = q * 8 < p.C ? q * 8 : 0;
@@ -106,20 +104,26 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
+                    // a patch that starts or ends inside the run leaves whole 16-voxel groups untouched: skip them
+                    // (wave-uniform; 3.5 patches intersect a 64-voxel run along z, 2 cover each voxel)
+                    if (__builtin_amdgcn_ballot_w64(in[g]) == 0) continue;
                     f16x8 o;                                   // norm_act_frag's arithmetic (misc.hip)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)xraw[g][j], sc[j], sh[j]);
                     o = __builtin_elementwise_max(o, o * slope_h);
                     if (!live) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
                     const float gw = (float)graw[g];
+                    // channel `heads` has zero weights and bias 1: its product is the weight itself; the product is rounded
+                    // before the sum (no fma), one rounding to fp16 per visit; lanes outside the patch keep their sums (and
+                    // signed zeros).  Measured and dropped: packed fp32 (v_pk_add_f32 / v_pk_mul_f32 issue at well under half
+                    // the scalar rate on gfx950) and an exec-masked block per group behind all four MFMAs - both 1.6x slower
+                    // than this select-per-value form, whose MFMAs hide behind the previous block's arithmetic.
 #pragma unroll
                     for (int hb = 0; hb < HB; ++hb) {
                         const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[hb], o, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                        const f32x4 t = d + bv[hb];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            // channel `heads` has zero weights and bias 1: its product is the weight itself
-                            const float s = acc_add_product_g(acc[g][hb][j], t[j], gw);
+                            const float s = acc_add_product_1(acc[g][hb][j], d[j] + bv[hb][j], gw);
                             const float nv = ACC32 ? s : (float)(f16)s;
                             acc[g][hb][j] = in[g] ? nv : acc[g][hb][j];
                         }
