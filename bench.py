@@ -41,8 +41,12 @@ WORKLOADS = {
     'bone_turbo_r2': ((2.0, 0.9765625, 0.9765625), (160, 96, 96), 61, 2),
     'iso128_r2': ((1.0, 1.0, 1.0), (128, 128, 128), 2, 2),
     'iso128_teacher': ((1.0, 1.0, 1.0), (128, 128, 128), 2, 1),
+    # BASELINE config 5: ResidualEncoderUNet student, blocks (1, 3, 4, 6, 6, 6), decoder n_conv 1
+    # (nnUNetDistillationTrainer.py:248-266, residual_encoder_unet_planners.py:30-31); --dtype f8 for its fp8 conv path
+    'resenc160_r2': ((1.0, 1.0, 1.0), (160, 160, 160), 3, 2),
 }
-# BASELINE configs 4 (teacher, 5 folds) and 5 (ResEnc student, fp8) are parity-test topologies, not bench lines.
+RESENC_BLOCKS = (1, 3, 4, 6, 6, 6)
+# the bench line is BASELINE configs[1] (bone_turbo_r2); the other workloads are for DESIGN.md's tables.
 
 
 def plan_topology(spacing, patch, min_edge=4):
@@ -110,30 +114,79 @@ def synthetic_checkpoint(features, kernels, strides, in_ch, heads, seed=1234):
     return sd
 
 
-def build_predictor(workload, device, batch, accumulate_in):
+def synthetic_resenc_checkpoint(features, kernels, strides, blocks, in_ch, heads, seed=1234):
+    """ResidualEncoderUNet state dict in the checkpoint key schema: stem, BasicBlockD stages
+    (conv1, conv2, projected skip), UNetDecoder with one conv per stage; same initialisation as synthetic_checkpoint."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    gain = (2.0 / (1 + 0.01 ** 2)) ** 0.5
+
+    def conv(prefix, cout, cin, k, bias=True):
+        fan_in = cin * k[0] * k[1] * k[2]
+        sd[prefix + '.conv.weight'] = torch.randn(cout, cin, *k, generator=g) * (gain / fan_in ** 0.5)
+        if bias:
+            sd[prefix + '.conv.bias'] = torch.randn(cout, generator=g) * 0.05
+        sd[prefix + '.norm.weight'] = torch.rand(cout, generator=g) + 0.5
+        sd[prefix + '.norm.bias'] = torch.randn(cout, generator=g) * 0.1
+
+    n = len(features)
+    conv('encoder.stem.convs.0', features[0], in_ch, kernels[0])
+    cin = features[0]
+    for s in range(n):
+        for b in range(blocks[s]):
+            pre = f'encoder.stages.{s}.blocks.{b}'
+            conv(pre + '.conv1', features[s], cin, kernels[s])
+            conv(pre + '.conv2', features[s], features[s], kernels[s])
+            strided = b == 0 and any(v != 1 for v in strides[s])
+            if cin != features[s]:
+                conv(f'{pre}.skip.{1 if strided else 0}', features[s], cin, (1, 1, 1), bias=False)
+            cin = features[s]
+    for d in range(n - 1):
+        below, skip, st = features[-(d + 1)], features[-(d + 2)], strides[-(d + 1)]
+        fan_in = below * st[0] * st[1] * st[2]
+        sd[f'decoder.transpconvs.{d}.weight'] = torch.randn(below, skip, *st, generator=g) * (gain / fan_in ** 0.5)
+        sd[f'decoder.transpconvs.{d}.bias'] = torch.randn(skip, generator=g) * 0.05
+        conv(f'decoder.stages.{d}.convs.0', skip, 2 * skip, kernels[-(d + 2)])
+        sd[f'decoder.seg_layers.{d}.weight'] = torch.randn(heads, skip, 1, 1, 1, generator=g) * (gain / skip ** 0.5)
+        sd[f'decoder.seg_layers.{d}.bias'] = torch.randn(heads, generator=g) * 0.05
+    return sd
+
+
+def build_predictor(workload, device, batch, accumulate_in, compute_dtype='f16'):
     from fast_nnunet_amd import nnUNetPredictor
     from fast_nnunet_amd.plans import PlansManager
     spacing, patch, heads, r = WORKLOADS[workload]
     strides, kernels = plan_topology(spacing, patch)
     n = len(strides)
     features = [max(min(320, 32 * 2 ** i) // r, 8) for i in range(n)]
-    sd = synthetic_checkpoint(features, kernels, strides, 1, heads)
-    arch = {'network_class_name': 'dynamic_network_architectures.architectures.unet.PlainConvUNet',
-            'arch_kwargs': {'n_stages': n, 'features_per_stage': [min(320, 32 * 2 ** i) for i in range(n)],
-                            'kernel_sizes': kernels, 'strides': strides, 'n_conv_per_stage': [2] * n,
-                            'n_conv_per_stage_decoder': [2] * (n - 1), 'conv_bias': True,
-                            'norm_op_kwargs': {'eps': 1e-5, 'affine': True}},
-            '_kw_requires_import': []}
+    resenc = workload.startswith('resenc')
+    if resenc:
+        sd = synthetic_resenc_checkpoint(features, kernels, strides, RESENC_BLOCKS[:n], 1, heads)
+        arch = {'network_class_name': 'dynamic_network_architectures.architectures.unet.ResidualEncoderUNet',
+                'arch_kwargs': {'n_stages': n, 'features_per_stage': [min(320, 32 * 2 ** i) for i in range(n)],
+                                'kernel_sizes': kernels, 'strides': strides, 'n_blocks_per_stage': list(RESENC_BLOCKS[:n]),
+                                'n_conv_per_stage_decoder': [1] * (n - 1), 'conv_bias': True,
+                                'norm_op_kwargs': {'eps': 1e-5, 'affine': True}},
+                '_kw_requires_import': []}
+    else:
+        sd = synthetic_checkpoint(features, kernels, strides, 1, heads)
+        arch = {'network_class_name': 'dynamic_network_architectures.architectures.unet.PlainConvUNet',
+                'arch_kwargs': {'n_stages': n, 'features_per_stage': [min(320, 32 * 2 ** i) for i in range(n)],
+                                'kernel_sizes': kernels, 'strides': strides, 'n_conv_per_stage': [2] * n,
+                                'n_conv_per_stage_decoder': [2] * (n - 1), 'conv_bias': True,
+                                'norm_op_kwargs': {'eps': 1e-5, 'affine': True}},
+                '_kw_requires_import': []}
     pm = PlansManager({'dataset_name': 'Dataset000_Synthetic', 'plans_name': 'nnUNetPlans',
                        'configurations': {'3d_fullres': {'patch_size': list(patch), 'spacing': list(spacing),
                                                          'architecture': arch}}})
     dj = {'labels': {('background' if i == 0 else f'class_{i}'): i for i in range(heads)},
           'channel_names': {'0': 'CT'}, 'file_ending': '.nii.gz'}
     p = nnUNetPredictor(tile_step_size=0.5, use_gaussian=True, use_mirroring=False, perform_everything_on_device=True,
-                        device=device, allow_tqdm=False, accumulate_in=accumulate_in, patches_per_forward=batch)
+                        device=device, allow_tqdm=False, accumulate_in=accumulate_in, patches_per_forward=batch,
+                        compute_dtype=compute_dtype)
     p._reduction = None
     p.manual_initialization(None, pm, pm.get_configuration('3d_fullres'), [sd], dj, 'nnUNetDistillationTrainer', None)
-    return p, sd, dict(features=features, kernels=kernels, strides=strides, patch=patch, heads=heads, r=r)
+    return p, sd, dict(features=features, kernels=kernels, strides=strides, patch=patch, heads=heads, r=r, resenc=resenc)
 
 
 def synthetic_volume(size, device):
@@ -222,6 +275,8 @@ def main():
     ap.add_argument('--volume', type=int, default=512)
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--accum', default='fp16', choices=['fp16', 'fp32'])
+    ap.add_argument('--dtype', default='f16', choices=['f16', 'f8'],
+                    help='operand format of the 3x3x3 stride-1 convolutions (f8: OCP e4m3, BASELINE config 5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-sharded', action='store_true', help='run the multi-GPU code path even with one rank')
@@ -252,7 +307,7 @@ def main():
     torch.cuda.set_device(device)
 
     accumulate_in = args.accum                                  # halo sums travel in the accumulator dtype
-    predictor, sd, info = build_predictor(args.workload, device, args.batch, accumulate_in)
+    predictor, sd, info = build_predictor(args.workload, device, args.batch, accumulate_in, args.dtype)
     vol = synthetic_volume(args.volume, device)
     from fast_nnunet_amd import capi
     n_patches = capi.plan_volume(info['patch'], vol.shape[1:], 0.5)[2].shape[0]
@@ -310,9 +365,10 @@ def main():
         'higher_is_better': True,
         'scaling': 'strong',
         'vs_baseline': None,
-        'dtype': 'f16',
+        'dtype': args.dtype,
         'data': 'synthetic',
-        'config': {'workload': f'{args.workload}: PlainConvUNet {"student" if info["r"] > 1 else "teacher"} r={info["r"]}, '
+        'config': {'workload': f'{args.workload}: {"ResidualEncoderUNet" if info["resenc"] else "PlainConvUNet"} '
+                               f'{"student" if info["r"] > 1 else "teacher"} r={info["r"]}, '
                                f'features {info["features"]}, '
                                f'patch {"x".join(map(str, info["patch"]))}, {info["heads"]} classes, '
                                f'{args.volume}^3 volume, tile_step_size 0.5, Gaussian on, mirroring off, '
@@ -366,7 +422,7 @@ def main():
                               'finalize': round(pr.finalize_ms, 2)},
             'whole_net_tflops': round(flops_patch * n_patches / (dt / args.steps) / 1e12, 2),
         }
-    if rank == 0 and not distributed and not args.no_cpu_baseline:
+    if rank == 0 and not distributed and not args.no_cpu_baseline and not info['resenc']:
         result['cpu_baseline'] = cpu_baseline(sd, info)
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -41,6 +41,7 @@ class ArchSpec:
     eps: float = 1e-5
     slope: float = 0.01
     spatial_dims: int = 3                      # 2: `2d` configuration, run as patch (1, py, pz) with kernels (1, k, k)
+    precision: int = 0                         # capi.FNN_PREC_*: operand format of the 3x3x3 stride-1 convs
 
     @property
     def n_stages(self) -> int:
@@ -63,6 +64,7 @@ class ArchSpec:
             d.patch[a] = int(self.patch[a])
         d.eps, d.slope = self.eps, self.slope
         d.spatial_dims = self.spatial_dims
+        d.precision = self.precision
         return d
 
 

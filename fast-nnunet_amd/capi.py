@@ -15,6 +15,7 @@ import numpy as np
 FNN_MAX_STAGES = 8
 FNN_OK, FNN_E_INVALID, FNN_E_HIP, FNN_E_INF, FNN_E_UNSUPPORTED, FNN_E_STATE = 0, -1, -2, -3, -4, -5
 FNN_NET_PLAIN, FNN_NET_RESENC = 0, 1
+FNN_PREC_F16, FNN_PREC_F8 = 0, 1
 FNN_ACC_FP16_REFERENCE, FNN_ACC_FP32 = 0, 1
 FNN_OUT_F16, FNN_OUT_F32 = 0, 1
 FNN_LABELS_ARGMAX, FNN_LABELS_REGIONS = 0, 1
@@ -34,7 +35,7 @@ class ArchDesc(C.Structure):
                 ('n_conv_enc', C.c_int32 * FNN_MAX_STAGES),
                 ('n_conv_dec', C.c_int32 * FNN_MAX_STAGES),
                 ('patch', C.c_int32 * 3),
-                ('eps', C.c_float), ('slope', C.c_float), ('spatial_dims', C.c_int32)]
+                ('eps', C.c_float), ('slope', C.c_float), ('spatial_dims', C.c_int32), ('precision', C.c_int32)]
 
 
 class NormDesc(C.Structure):
@@ -61,7 +62,7 @@ class Profile(C.Structure):
 
 EXPORTS = ['fnn_abi_version', 'fnn_last_error', 'fnn_create', 'fnn_destroy', 'fnn_weight_count', 'fnn_load_weights',
            'fnn_set_gaussian', 'fnn_predict_volume', 'fnn_predict_volume_ensemble', 'fnn_predict_labels',
-           'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_labels_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_export_probabilities', 'fnn_resample', 'fnn_compute_steps', 'fnn_plan_volume',
+           'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_labels_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_export_probabilities', 'fnn_resample', 'fnn_compute_steps', 'fnn_plan_volume', 'fnn_fp8_e4m3_encode',
            'fnn_set_profiling', 'fnn_get_profile', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d']
 
 _lib = None
@@ -113,6 +114,7 @@ def load_library() -> C.CDLL:
     lib.fnn_compute_steps.argtypes = [i64, i64, C.c_double, C.POINTER(i64), i32]
     lib.fnn_plan_volume.argtypes = [C.POINTER(C.c_int32), C.POINTER(i64), C.c_double, C.POINTER(i64), C.POINTER(i64),
                                     C.POINTER(i64), C.POINTER(C.c_int32), i64]
+    lib.fnn_fp8_e4m3_encode.argtypes = [vp, i64, vp]
     lib.fnn_set_profiling.argtypes = [vp, i32]
     lib.fnn_get_profile.argtypes = [vp, C.POINTER(Profile)]
     lib.fnn_patch_work.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -145,6 +147,15 @@ def check(rc: int, lib, handle=None):
 
 def _f32p(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def fp8_e4m3_encode(x: np.ndarray) -> np.ndarray:
+    """float32 -> OCP e4m3 bytes with the library's host quantiser (FNN_PREC_F8 weight packing)."""
+    lib = load_library()
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty(x.shape, np.uint8)
+    check(lib.fnn_fp8_e4m3_encode(x.ctypes.data, x.size, out.ctypes.data), lib)
+    return out
 
 
 def compute_steps(image_size: int, patch_size: int, step: float):

@@ -190,11 +190,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
                 f16x8 wf[NB];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) wf[nb] = *(const f16x8 *)(sW + ((nb * KS + pr * 3 + dz) * 64 + lane) * 16);
+#ifdef FNN_ZR_SETPRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                 for (int j = 0; j < TD; ++j)
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
                         acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nb], xf[j + dz], acc[j][nb], 0, 0, 0);
+#ifdef FNN_ZR_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);                // keep the next pair's reads from being hoisted: registers
         }
@@ -256,6 +262,218 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
     FNN_STAMP_FLUSH(p.dbg);
 }
 
+// ----------------------------------------------------------------------------
+// fp8 (OCP e4m3) variant: BASELINE config 5's "fp8 MFMA conv path"
+// ----------------------------------------------------------------------------
+// Same tiling, staging and depth-shift reuse; what changes is the operand format of the matrix cores:
+//   activations  the normalised + LeakyReLU'd value times p.act_mult (8: unit-variance data sits at 2^3, e4m3 reaches
+//                448 = 56 sigma; below 2^-9 * 8 it flushes) is converted with v_cvt_pk_fp8_f32 (round to nearest even,
+//                clamped to +-448) while it is staged: 8 B per (voxel, 8 channels) in LDS instead of 16;
+//   weights      e4m3 on the host with one scale per output channel (max |w| -> 448), packed in the same fragment
+//                order at 8 B per lane;
+//   MFMA         v_mfma_f32_16x16x32_fp8_fp8, fp32 accumulation; the epilogue multiplies by w_scale[cout] / act_mult
+//                (p.oscale) before the bias, the fp16 store and the statistics, which stay as in the fp16 kernel.
+// The non-scaled fp8 MFMA issues at the f16 rate on gfx950 (MI355X_MICROARCH.md, Matrix cores): this path halves the
+// LDS and weight traffic, not the matrix time; the 2x rate needs the MX-scaled K = 128 form.
+// LDS image: [plane][row][8-channel half][24 slots of 8 B] - sub-row pitch 192 B puts the four 64-byte segments a
+// 32-lane ds_read_b64 group touches (2 rows x 2 halves) into four different bank quarters: conflict free.
+typedef long fnn_i64;
+typedef unsigned fnn_u32x4 __attribute__((ext_vector_type(4)));      // (HIP's uint4 struct arrays go to scratch)
+template <int NB, int TD>
+__global__ __launch_bounds__(256, 2) void conv3d_zr8_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int IH = 10, IW = 10, ID = TD + 2;
+    constexpr int SUB = 192, PS = IH * 2 * SUB;               // sub-row pitch, bytes per halo plane
+    constexpr int ABYTES = (ID * PS + 1023) & ~1023;
+    constexpr int KS = 15;
+    constexpr int IELEM = ID * IH * IW * 2;
+    constexpr int PF = (IELEM + 255) / 256;
+    constexpr int WTOT = NB * KS * 32;                        // 16-byte pieces (two lanes' fragments) per chunk
+    constexpr int WPF = (WTOT + 255) / 256;
+
+    int t;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
+    const int tw = t % p.tiles_w; t /= p.tiles_w;
+    const int th = t % p.tiles_h; t /= p.tiles_h;
+    const int td = t % p.tiles_d;
+    const int n = t / p.tiles_d;
+    const int cb0 = blockIdx.y * NB;
+    const int od0 = td * TD, oh0 = th * 8, ow0 = tw * 8;
+
+    char *sA = smem;
+    char *sW = smem + ABYTES;                                 // [NB][15][64 lanes][8 B]
+    float *sBias = (float *)(sW + NB * KS * 512);             // [NB * 16] bias, then [NB * 16] output scales
+
+    int toff[5];
+    f32x4 acc[TD][NB];
+    const int cg = tid & 1;
+    int offv[PF], ldso[PF];
+    {
+        const int id0 = od0 - 1, ih0 = oh0 - 1, iw0 = ow0 - 1;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int idx = tid + u * 256;
+            const int v = idx >> 1;
+            const int zd = v / (IH * IW), rem = v - zd * (IH * IW), zh = rem / IW, zw = rem - zh * IW;
+            const int gd = id0 + zd, gh = ih0 + zh, gw = iw0 + zw;
+            const bool ok = gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 && gw < p.Wi;
+            offv[u] = idx < IELEM ? (ok ? (gd * p.Hi + gh) * p.Wi + gw : -1) : -2;
+            ldso[u] = zd * PS + (zh * 2 + cg) * SUB + zw * 8;
+        }
+    }
+    int wofs[WPF];
+#pragma unroll
+    for (int u = 0; u < WPF; ++u) {
+        const int idx = tid + u * 256;
+        const int idc = idx < WTOT ? idx : WTOT - 1;
+        const int nb = idc >= KS * 32 ? 1 : 0;                // NB <= 2
+        wofs[u] = (cb0 + nb) * p.chunks * (KS * 32) + idc - nb * (KS * 32);
+    }
+    f16x8 xr[PF];
+    fnn_u32x4 wr[WPF];
+    float4 scr[2], shr[2];
+    float slope_next = 1.f;
+
+    auto issue = [&](int ch) {
+        const int c_glob = ch * 16;
+        const int s = (c_glob < p.src[0].C) ? 0 : 1;
+        const int c_uni = c_glob - (s ? p.src[0].C : 0);
+        const int c_loc = c_uni + cg * 8;
+        const int sC = p.src[s].C;
+        const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + c_uni);
+        slope_next = p.src[s].slope;
+        const float *qs = p.src[s].ss ? p.src[s].ss + (size_t)(2 * n) * sC + c_loc : p.ident_ss + c_loc;
+        const float *qh = p.src[s].ss ? qs + sC : p.ident_ss + 512 + c_loc;
+        scr[0] = *(const float4 *)qs; scr[1] = *(const float4 *)(qs + 4);
+        shr[0] = *(const float4 *)qh; shr[1] = *(const float4 *)(qh + 4);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * sC + cg * 8) * 2));
+#pragma unroll
+        for (int u = 0; u < WPF; ++u) wr[u] = *(const fnn_u32x4 *)((const char *)p.wpk + (unsigned)((wofs[u] + ch * (KS * 32)) * 16));
+    };
+    auto commit = [&]() {
+        const float am = p.act_mult, slope = slope_next;
+        // LeakyReLU commutes with a positive factor: the fp8 multiplier goes into scale and shift
+        const float sc[8] = {scr[0].x * am, scr[0].y * am, scr[0].z * am, scr[0].w * am, scr[1].x * am, scr[1].y * am, scr[1].z * am, scr[1].w * am};
+        const float sh[8] = {shr[0].x * am, shr[0].y * am, shr[0].z * am, shr[0].w * am, shr[1].x * am, shr[1].y * am, shr[1].z * am, shr[1].w * am};
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if ((u + 1) * 256 > IELEM && offv[u] == -2) continue;
+            auto q = [&](int j) {
+                const float v = fmaf((float)xr[u][j], sc[j], sh[j]);
+                return __builtin_amdgcn_fmed3f(fmaxf(v, v * slope), -448.f, 448.f);
+            };
+            int lo = 0, hi = 0;
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(q(0), q(1), lo, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(q(2), q(3), lo, true);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(q(4), q(5), hi, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(q(6), q(7), hi, true);
+            if (offv[u] < 0) { lo = 0; hi = 0; }               // the conv's zero padding
+            *(int2 *)(sA + ldso[u]) = make_int2(lo, hi);
+        }
+#pragma unroll
+        for (int u = 0; u < WPF; ++u) {
+            const int idx = tid + u * 256;
+            if ((u + 1) * 256 <= WTOT || idx < WTOT) ((fnn_u32x4 *)sW)[idx] = wr[u];
+        }
+    };
+    auto kloop = [&]() {
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const char *bp = sA + toff[pr];
+            fnn_i64 xf[ID];
+#pragma unroll
+            for (int pl = 0; pl < ID; ++pl) xf[pl] = *(const fnn_i64 *)(bp + pl * PS);
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                fnn_i64 wf[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wf[nb] = *(const fnn_i64 *)(sW + ((nb * KS + pr * 3 + dz) * 64 + lane) * 8);
+#pragma unroll
+                for (int j = 0; j < TD; ++j)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wf[nb], xf[j + dz], acc[j][nb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    issue(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < NB * 16) { sBias[tid] = p.bias[cb0 * 16 + tid]; sBias[NB * 16 + tid] = p.oscale[cb0 * 16 + tid]; }
+    {
+        const int r = lane & 15, hl = lane >> 5, kh = (lane >> 4) & 1;
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const int tp = 2 * pr + hl < 9 ? 2 * pr + hl : 8;
+            const int row = 2 * wave + (r >> 3) + tp / 3, col = (r & 7) + tp % 3;
+            toff[pr] = (row * 2 + kh) * SUB + col * 8;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TD; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[j][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    commit();
+    __syncthreads();
+    for (int ch = 0; ch + 1 < p.chunks; ++ch) {
+        issue(ch + 1);
+        kloop();
+        __syncthreads();
+        commit();
+        __syncthreads();
+    }
+    kloop();
+    __syncthreads();
+    {
+        float4 bv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            bv[nb] = *(const float4 *)(sBias + nb * 16 + (lane >> 4) * 4);
+            const float4 sv = *(const float4 *)(sBias + NB * 16 + nb * 16 + (lane >> 4) * 4);
+#pragma unroll
+            for (int j = 0; j < TD; ++j) {
+                acc[j][nb][0] *= sv.x; acc[j][nb][1] *= sv.y; acc[j][nb][2] *= sv.z; acc[j][nb][3] *= sv.w;
+            }
+        }
+        float t1[NB][4], t2[NB][4];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
+        tile_epilogue<NB, TD, true>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
+        if (p.stats_out) stats_to_global<NB, true>(p, t1, t2, (float *)smem, n, cb0, wave, lane, tid, (td * p.tiles_h + th) * p.tiles_w + tw);
+    }
+}
+
+template <int NB, int TD>
+static int launch_zr8(ConvParams p, hipStream_t st) {
+    p.tile_d = TD;
+    p.tiles_d = (p.Do + TD - 1) / TD;
+    p.tiles_h = (p.Ho + 7) / 8;
+    p.tiles_w = (p.Wo + 7) / 8;
+    const size_t lds = (size_t)(((TD + 2) * 10 * 2 * 192 + 1023) & ~1023) + (size_t)NB * 15 * 512 + (size_t)NB * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)conv3d_zr8_kernel<NB, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    p.ident_ss = conv3d_identity_ss();
+    if (!p.ident_ss || !p.oscale) return -2;
+    dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
+    hipLaunchKernelGGL((conv3d_zr8_kernel<NB, TD>), grid, dim3(256), lds, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 template <int NB, int TD>
 static int launch_zr(ConvParams p, hipStream_t st) {
     p.tile_d = TD;
@@ -282,6 +500,10 @@ static int launch_zr(ConvParams p, hipStream_t st) {
 int launch_conv3d_zr(const ConvParams &p, hipStream_t st) {
     int nb, td;
     if (p.packing != FNN_PACK_ZR || p.ksteps != 15 || !zr_pick(p, nb, td)) return -1;
+    if (p.fp8) {
+        if (nb == 2) return td == 8 ? launch_zr8<2, 8>(p, st) : launch_zr8<2, 4>(p, st);
+        return td == 8 ? launch_zr8<1, 8>(p, st) : launch_zr8<1, 4>(p, st);
+    }
     if (nb == 2) return td == 8 ? launch_zr<2, 8>(p, st) : launch_zr<2, 4>(p, st);
     return td == 8 ? launch_zr<1, 8>(p, st) : launch_zr<1, 4>(p, st);
 }

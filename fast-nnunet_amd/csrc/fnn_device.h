@@ -56,6 +56,9 @@ struct ConvParams {
     int ksteps;                  // MFMA k-steps per chunk: conv3d_ksteps(packing, taps)
     const float *ident_ss;       // conv3d_identity_ss(): ones[512] then zeros[512] (set by the launchers that need it)
     int packing;                 // FNN_PACK_*: which taps share a k-step (fixed per layer when the weights are packed)
+    int fp8;                     // conv3d_zr8_kernel: e4m3 operands (weights packed at 8 B per lane)
+    const float *oscale;         // fp8: [Cout] w_scale[cout] / act_mult, applied to the accumulators before the bias
+    float act_mult;              // fp8: activations are quantised as e4m3(value * act_mult)
     int bound_mask0;             // timing-only builds (-DFNN_BOUND_FUSE): source 0 is read from a few KB (its producer is skipped)
     int stats_slots;             // rows per batch item in stats_out (conv3d_stats_slots): FNN_STAT_REPL replicas filled by
                                  // atomics, or one row per tile written with plain stores (ZR kernel)

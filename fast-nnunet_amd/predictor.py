@@ -46,12 +46,15 @@ class nnUNetPredictor(object):
                  verbose_preprocessing: bool = False,
                  allow_tqdm: bool = True,
                  accumulate_in: str = 'fp16',
-                 patches_per_forward: int = 4):
+                 patches_per_forward: int = 4,
+                 compute_dtype: str = 'f16'):
         """Same knobs as the reference (:40-65) plus two engine choices:
 
         accumulate_in  'fp16' reproduces the reference's half accumulators and
                        their rounding per patch visit; 'fp32' is the exact blend.
         patches_per_forward  how many patches one network forward batches.
+        compute_dtype  'f16' (default: the mode every parity statement is for) or 'f8': OCP e4m3 operands in
+                       the 3x3x3 stride-1 convolutions (BASELINE config 5; budget in DESIGN.md).
         """
         self.verbose = verbose
         self.verbose_preprocessing = verbose_preprocessing
@@ -71,6 +74,9 @@ class nnUNetPredictor(object):
             raise ValueError("accumulate_in must be 'fp16' or 'fp32'")
         self.accumulate_in = accumulate_in
         self.patches_per_forward = int(patches_per_forward)
+        if compute_dtype not in ('f16', 'f8'):
+            raise ValueError("compute_dtype must be 'f16' or 'f8'")
+        self.compute_dtype = compute_dtype
         self._engine: Optional[capi.Engine] = None
         self._spec: Optional[ArchSpec] = None
         self._active_fold = 0
@@ -160,6 +166,7 @@ class nnUNetPredictor(object):
         spec = spec_from_state_dict(sds[0], patch, eps=eps, slope=slope)
         if kw and 'n_stages' in kw and 'strides' in kw:
             check_against_plans(spec, kw, self._reduction)
+        spec.precision = capi.FNN_PREC_F8 if self.compute_dtype == 'f8' else capi.FNN_PREC_F16
         heads = self.label_manager.num_segmentation_heads
         if heads != spec.num_heads:
             raise RuntimeError(f'checkpoint has {spec.num_heads} segmentation heads, dataset.json implies {heads}')

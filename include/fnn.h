@@ -44,6 +44,14 @@ enum {
 };
 
 enum { FNN_NET_PLAIN = 0, FNN_NET_RESENC = 1 };
+/* fnn_arch_desc.precision - the operand format of the matrix cores in the 3x3x3 stride-1 convolutions
+ * (BASELINE config 5 asks for an fp8 conv path; the reference has no fp8 semantics):
+ *   FNN_PREC_F16  fp16 operands everywhere (default; every parity statement in DESIGN.md is for this mode);
+ *   FNN_PREC_F8   OCP e4m3 operands in those convolutions: weights quantised per output channel when they are
+ *                 loaded, activations while they are staged (after InstanceNorm + LeakyReLU, x 8); fp32
+ *                 accumulation; everything else (storage, statistics, strided / 1x1x1 / transposed convs, seg
+ *                 head, accumulation) as in fp16.  Budget against the fp32 oracle: DESIGN.md, "fp8". */
+enum { FNN_PREC_F16 = 0, FNN_PREC_F8 = 1 };
 enum { FNN_ACC_FP16_REFERENCE = 0, FNN_ACC_FP32 = 1 };
 enum { FNN_OUT_F16 = 0, FNN_OUT_F32 = 1 };
 
@@ -68,6 +76,7 @@ typedef struct fnn_arch_desc {
                                                  * kernels[s][0] and strides[s][0] are 1 and EVERY slice of
                                                  * the first image axis is a tile position
                                                  * (predict_from_raw_data.py:508-524)               */
+    int32_t precision;                          /* FNN_PREC_*                                  */
 } fnn_arch_desc;
 
 /* Knobs of nnUNetPredictor.__init__ (:40-65) + engine-side choices. */
@@ -266,6 +275,11 @@ int fnn_compute_steps(int64_t image_size, int64_t patch_size, double step, int64
 /* patch[0] == 0 denotes a 2-D configuration (patch = {0, py, pz}): every slice of the first axis. */
 int fnn_plan_volume(const int32_t patch[3], const int64_t shape_sp[3], double step, int64_t padded[3],
                     int64_t pad_lo[3], int64_t *n_patches, int32_t *origins, int64_t origins_cap);
+
+/* The weight quantiser of FNN_PREC_F8: float32 -> OCP e4m3 ("fn": +-448 saturating, 0x7f = NaN), round to nearest
+ * even - the encoding v_mfma_f32_16x16x32_fp8_fp8 reads on gfx950 (not MI300's fnuz).  Exposed so that the host-side
+ * packing can be checked against another implementation without a GPU. */
+int fnn_fp8_e4m3_encode(const float *in, int64_t n, uint8_t *out);
 
 /* ---- timing / introspection ----------------------------------------------- */
 /* Per-kernel-family device time of the last fnn_predict_volume call, measured

@@ -342,3 +342,18 @@ def test_bench_gpus_n_spawns_one_rank_per_gpu_and_propagates_failure():
     out2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'],
                           capture_output=True, text=True, timeout=300, env=env2, cwd=ROOT)
     assert out2.returncode != 0 and 'WORLD_SIZE=1' in (out2.stderr + out2.stdout)
+
+
+def test_fp8_weight_quantiser_matches_torch_e4m3fn(capi):
+    """FNN_PREC_F8 packs weights as OCP e4m3 on the host: the encoder must agree with torch's float8_e4m3fn (round to
+    nearest even, subnormals down to 2^-9, saturation at +-448) on every value class."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.cat([torch.randn(200000, generator=g) * 100, torch.randn(200000, generator=g), torch.randn(100000, generator=g) * 0.01,
+                   torch.tensor([0.0, -0.0, 448.0, -448.0, 447.9, 464.0, 1e9, -1e9, 2.0 ** -6, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -10,
+                                 0.0175, 0.0146484375, 240.0, 232.0, 1.0625, 1.1875])])
+    # every e4m3 value and every midpoint between neighbours (ties go to the even mantissa)
+    allv = torch.arange(0, 127, dtype=torch.uint8).view(torch.float8_e4m3fn).float()
+    x = torch.cat([x, allv, -allv, (allv[:-1] + allv[1:]) / 2, -(allv[:-1] + allv[1:]) / 2])
+    want = x.clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    got = capi.fp8_e4m3_encode(x.numpy())
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
