@@ -190,17 +190,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
                 f16x8 wf[NB];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) wf[nb] = *(const f16x8 *)(sW + ((nb * KS + pr * 3 + dz) * 64 + lane) * 16);
-#ifdef FNN_ZR_SETPRIO
-                __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
                 for (int j = 0; j < TD; ++j)
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
                         acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nb], xf[j + dz], acc[j][nb], 0, 0, 0);
-#ifdef FNN_ZR_SETPRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);                // keep the next pair's reads from being hoisted: registers
         }
@@ -496,6 +490,11 @@ static int launch_zr(ConvParams p, hipStream_t st) {
 // A persistent form of this kernel (tile ranges per workgroup, cross-tile prefetch, like conv3d_persist_kernel) was
 // built and measured: 5-20 % SLOWER on every layer of the benchmark net - <2, 8> does not fit 256 VGPRs next to the
 // prefetch registers, <2, 4> loses the operand reuse - so one tile per workgroup it stays.
+// Round 2, also measured and dropped: (1) two tiles per 512-thread workgroup forced half a period apart (one half in its
+// k-loop while the other stages, shared barriers; same registers and LDS per tile, bit-identical results): 6 % slower
+// end to end than two independent workgroups per CU - a chunk's staging (load issue + normalise + LDS writes) takes
+// longer than its k-loop, so the forced alternation idles the matrix cores where independent workgroups drift;
+// (2) s_setprio(1) around the MFMA clusters: -0.6 %.
 // Runs the layer on the ZR kernel; the weights must have been packed as FNN_PACK_ZR (p.packing).
 int launch_conv3d_zr(const ConvParams &p, hipStream_t st) {
     int nb, td;
