@@ -152,7 +152,7 @@ def synthetic_resenc_checkpoint(features, kernels, strides, blocks, in_ch, heads
     return sd
 
 
-def build_predictor(workload, device, batch, accumulate_in, compute_dtype='f16'):
+def build_predictor(workload, device, batch, accumulate_in, compute_dtype='f16', mirror=False):
     from fast_nnunet_amd import nnUNetPredictor
     from fast_nnunet_amd.plans import PlansManager
     spacing, patch, heads, r = WORKLOADS[workload]
@@ -181,11 +181,12 @@ def build_predictor(workload, device, batch, accumulate_in, compute_dtype='f16')
                                                          'architecture': arch}}})
     dj = {'labels': {('background' if i == 0 else f'class_{i}'): i for i in range(heads)},
           'channel_names': {'0': 'CT'}, 'file_ending': '.nii.gz'}
-    p = nnUNetPredictor(tile_step_size=0.5, use_gaussian=True, use_mirroring=False, perform_everything_on_device=True,
+    p = nnUNetPredictor(tile_step_size=0.5, use_gaussian=True, use_mirroring=mirror, perform_everything_on_device=True,
                         device=device, allow_tqdm=False, accumulate_in=accumulate_in, patches_per_forward=batch,
                         compute_dtype=compute_dtype)
     p._reduction = None
-    p.manual_initialization(None, pm, pm.get_configuration('3d_fullres'), [sd], dj, 'nnUNetDistillationTrainer', None)
+    p.manual_initialization(None, pm, pm.get_configuration('3d_fullres'), [sd], dj, 'nnUNetDistillationTrainer',
+                            (0, 1, 2) if mirror else None)
     return p, sd, dict(features=features, kernels=kernels, strides=strides, patch=patch, heads=heads, r=r, resenc=resenc)
 
 
@@ -277,6 +278,9 @@ def main():
     ap.add_argument('--accum', default='fp16', choices=['fp16', 'fp32'])
     ap.add_argument('--dtype', default='f16', choices=['f16', 'f8'],
                     help='operand format of the 3x3x3 stride-1 convolutions (f8: OCP e4m3, BASELINE config 5)')
+    ap.add_argument('--mirror', action='store_true',
+                    help='test-time mirroring over all three axes (8 evaluations per patch; the reference default, off in the '
+                         'bone_turbo .ini and in the bench line)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-sharded', action='store_true', help='run the multi-GPU code path even with one rank')
@@ -307,7 +311,7 @@ def main():
     torch.cuda.set_device(device)
 
     accumulate_in = args.accum                                  # halo sums travel in the accumulator dtype
-    predictor, sd, info = build_predictor(args.workload, device, args.batch, accumulate_in, args.dtype)
+    predictor, sd, info = build_predictor(args.workload, device, args.batch, accumulate_in, args.dtype, args.mirror)
     vol = synthetic_volume(args.volume, device)
     from fast_nnunet_amd import capi
     n_patches = capi.plan_volume(info['patch'], vol.shape[1:], 0.5)[2].shape[0]
@@ -371,7 +375,7 @@ def main():
                                f'{"student" if info["r"] > 1 else "teacher"} r={info["r"]}, '
                                f'features {info["features"]}, '
                                f'patch {"x".join(map(str, info["patch"]))}, {info["heads"]} classes, '
-                               f'{args.volume}^3 volume, tile_step_size 0.5, Gaussian on, mirroring off, '
+                               f'{args.volume}^3 volume, tile_step_size 0.5, Gaussian on, mirroring {"(0, 1, 2)" if args.mirror else "off"}, '
                                f'{n_patches} patches/volume',
                    'patches_per_forward': args.batch,
                    'accumulators': accumulate_in,

@@ -810,7 +810,7 @@ inline int acc_hp(const fnn_arch_desc &a) { return (a.num_heads + 1 + 7) / 8 * 8
 // keep_features: no head, no accumulation - patch ids[i] leaves its last activation in e->feat[i] (gather path).
 int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp, const fnn_opts &o,
                 const std::vector<int64_t> &ids, const int *ids_origins_dev, const Box &box, void *acc, int acc_fp32,
-                hipStream_t st, bool fresh = false, bool keep_features = false) {
+                hipStream_t st, bool fresh = false, bool keep_features = false, int64_t slot0 = 0, int64_t n_slots = 0) {
     const fnn_arch_desc &a = e->arch;
     const long long vdim[3] = {(long long)vp.padded[0], (long long)vp.padded[1], (long long)vp.padded[2]};
     int B = o.batch > 0 ? o.batch : e->max_batch;
@@ -818,7 +818,7 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
     const auto combos = mirror_combos(o);
     const bool tta = !combos.empty();
     const size_t P = (size_t)a.patch[0] * a.patch[1] * a.patch[2];
-    if (tta) {
+    if (tta && !keep_features) {
         void *pbuf = e->patch_buf;
         if (int rc = ensure(e, &pbuf, &e->patch_buf_bytes, (size_t)B * a.num_heads * P * sizeof(float))) return rc;
         e->patch_buf = (float *)pbuf;
@@ -837,7 +837,7 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
     const size_t featC = keep_features ? (size_t)e->layers[e->head_src].cout_pad : 0;
     // ---- several batches in flight (see fnn_engine::pipe)
     static const bool no_pipe = getenv("FNN_NO_PIPELINE") != nullptr;                // A-B aid
-    const bool pipelined = !no_pipe && !tta && !e->profiling && np > B;
+    const bool pipelined = !no_pipe && (!tta || keep_features) && !e->profiling && np > B;
     f16 *const act0 = e->act; double *const stats0 = e->stats; float *const ss0 = e->ss;
     static const int want_pipes = getenv("FNN_PIPES") ? atoi(getenv("FNN_PIPES")) : 3;
     const int NP = want_pipes < 2 ? 2 : (want_pipes > fnn_engine::MAXP ? fnn_engine::MAXP : want_pipes);
@@ -892,9 +892,10 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
         for (size_t ci = 0; ci <= (tta ? combos.size() : 0); ++ci) {
             int flip[3] = {0, 0, 0};
             if (ci > 0) for (int ax : combos[ci - 1]) flip[ax] = 1;
-            if (keep_features) {
-                if (int rc = forward_batch(e, fold, vol_dev, 0, vdim, org, nb, flip, st, (f16 *)e->feat + (size_t)p0 * P * featC,
-                                           (float *)e->featss + (size_t)p0 * 2 * featC)) return rc;
+            if (keep_features) {                              // [evaluation][slot]: the batch's items stay contiguous
+                const size_t item = (size_t)ci * n_slots + slot0 + p0;
+                if (int rc = forward_batch(e, fold, vol_dev, 0, vdim, org, nb, flip, st, (f16 *)e->feat + item * P * featC,
+                                           (float *)e->featss + item * 2 * featC)) return rc;
                 continue;
             }
             if (int rc = forward_batch(e, fold, vol_dev, 0, vdim, org, nb, flip, st)) return rc;
@@ -915,7 +916,7 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
             }
             if (pipelined) HIPCHK(e, hipEventRecord(e->ev_head[k], st));
         }
-        if (tta) {
+        if (tta && !keep_features) {
             for (int b = 0; b < nb; ++b) {
                 const int *oo = &vp.origins[ids[p0 + b] * 3];
                 PatchAccParams q{};
@@ -1021,32 +1022,55 @@ int accumulate_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const
     return run_patches(e, fold, vol_dev, vp, o, ids, e->origins, box, e->acc, acc_fp32, st, fresh);
 }
 
-// Can this volume take the gather path (gather.hip)?  No mirroring (the flipped evaluations are summed per patch first),
-// a head the kernel holds in registers, and room for every patch's last activation next to what is already allocated.
-bool gather_applies(fnn_engine *e, const VolPlan &vp, const fnn_opts &o) {
-    if (!e->gather_enabled || o.n_mirror_axes != 0 || o.out_dtype != FNN_OUT_F16) return false;
+// Plan of the gather path (gather.hip) for a volume: how many x layers of patches are kept at a time.
+struct GatherPlan { bool ok = false; int n_eval = 1, ring = 0, cover = 1; size_t layer_items = 0, feat_bytes = 0; };
+
+// No gather when the head does not fit the kernel's registers or when not even the layers that cover one output slab fit
+// next to what is already allocated; otherwise the whole volume's patches when they fit (one launch at the end), else
+// a ring of `cover` layers with one launch per output slab.
+GatherPlan gather_plan(fnn_engine *e, const VolPlan &vp, const fnn_opts &o) {
+    GatherPlan gp;
+    if (!e->gather_enabled || o.out_dtype != FNN_OUT_F16) return gp;
     const Layer &H = e->layers[e->head_src];
     GatherParams g{};
     g.heads = e->arch.num_heads; g.C = H.cout_pad; g.PD = e->arch.patch[0]; g.PH = e->arch.patch[1]; g.PW = e->arch.patch[2];
-    if (!H.has_norm || e->head_ksteps != 1 || !gather_ok(g)) return false;
+    gp.n_eval = 1 + (int)mirror_combos(o).size();
+    g.n_eval = gp.n_eval;
+    if (!H.has_norm || e->head_ksteps != 1 || !gather_ok(g)) return gp;
+    const auto &sx = vp.steps[0];
+    const int nx = (int)sx.size();
+    gp.cover = 1;
+    for (int i = 0; i < nx; ++i) {                            // layers still needed when layer i has just been produced
+        int c = 0;
+        for (int j = 0; j <= i; ++j) c += sx[j] + g.PD > sx[i];
+        gp.cover = std::max(gp.cover, c);
+    }
     const size_t P = (size_t)g.PD * g.PH * g.PW;
-    const size_t need = (size_t)vp.n_patches * P * H.cout_pad * sizeof(f16);
-    if (need <= e->feat_bytes) return true;
+    gp.layer_items = (size_t)vp.steps[1].size() * vp.steps[2].size();
+    const size_t layer_bytes = gp.layer_items * gp.n_eval * P * H.cout_pad * sizeof(f16);
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
-    static const double frac = getenv("FNN_GATHER_MEM_FRACTION") ? atof(getenv("FNN_GATHER_MEM_FRACTION")) : 0.6;
-    return (double)need <= frac * (double)(free_b + e->feat_bytes + e->acc_bytes);   // the accumulators are not needed then
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return gp;
+    const double frac = getenv("FNN_GATHER_MEM_FRACTION") ? atof(getenv("FNN_GATHER_MEM_FRACTION")) : 0.6;
+    const int force_ring = getenv("FNN_GATHER_RING") ? atoi(getenv("FNN_GATHER_RING")) : 0;     // tests: a ring although all fits
+    const double budget = frac * (double)(free_b + e->feat_bytes + e->acc_bytes);       // the accumulators are not needed then
+    if (!force_ring && (double)layer_bytes * nx <= budget) gp.ring = nx;
+    else if ((double)layer_bytes * gp.cover <= budget) gp.ring = std::min(nx, std::max(gp.cover, force_ring));
+    else return gp;
+    gp.feat_bytes = layer_bytes * gp.ring;
+    gp.ok = true;
+    return gp;
 }
 
 int gather_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp, const int64_t shape[4],
-                        const fnn_opts &o, int mode, void *out, void *labels, const int *lab_order, hipStream_t st) {
+                        const fnn_opts &o, const GatherPlan &gp, int mode, void *out, void *labels, const int *lab_order,
+                        hipStream_t st) {
     const fnn_arch_desc &a = e->arch;
     const Layer &H = e->layers[e->head_src];
     const size_t P = (size_t)a.patch[0] * a.patch[1] * a.patch[2];
-    const size_t need = (size_t)vp.n_patches * P * H.cout_pad * sizeof(f16);
-    if (need > e->feat_bytes && e->acc) { (void)hipFree(e->acc); e->acc = nullptr; e->acc_bytes = 0; }
-    if (int rc = ensure(e, &e->feat, &e->feat_bytes, need)) return rc;
-    if (int rc = ensure(e, &e->featss, &e->featss_bytes, (size_t)vp.n_patches * 2 * H.cout_pad * sizeof(float))) return rc;
+    if (gp.feat_bytes > e->feat_bytes && e->acc) { (void)hipFree(e->acc); e->acc = nullptr; e->acc_bytes = 0; }
+    if (int rc = ensure(e, &e->feat, &e->feat_bytes, gp.feat_bytes)) return rc;
+    const int64_t n_slots = (int64_t)gp.layer_items * gp.ring;
+    if (int rc = ensure(e, &e->featss, &e->featss_bytes, (size_t)n_slots * gp.n_eval * 2 * H.cout_pad * sizeof(float))) return rc;
     std::vector<int> steps;
     for (int d = 0; d < 3; ++d) for (int64_t v : vp.steps[d]) steps.push_back((int)v);
     {
@@ -1058,12 +1082,19 @@ int gather_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const Vol
     HIPCHK(e, hipStreamSynchronize(st));                       // `steps` is a temporary
     Box box;
     for (int d = 0; d < 3; ++d) { box.lo[d] = 0; box.hi[d] = vp.padded[d]; }
-    std::vector<int64_t> ids(vp.n_patches);
-    for (int64_t i = 0; i < vp.n_patches; ++i) ids[i] = i;
-    if (int rc = run_patches(e, fold, vol_dev, vp, o, ids, e->origins, box, nullptr, 0, st, false, true)) return rc;
     const FoldWeights &fw = e->folds[fold];
     GatherParams g{};
     g.feat = (const f16 *)e->feat; g.fss = (const float *)e->featss; g.C = H.cout_pad;
+    g.n_eval = gp.n_eval; g.n_slots = (int)n_slots; g.ring = gp.ring;
+    {
+        const auto combos = mirror_combos(o);
+        g.flipmask[0] = 0;
+        for (size_t ci = 0; ci < combos.size() && ci + 1 < 8; ++ci) {
+            int m = 0;
+            for (int ax : combos[ci]) m |= 1 << ax;
+            g.flipmask[ci + 1] = m;
+        }
+    }
     g.slope = H.act ? a.slope : 1.f;
     g.steps = e->steps_dev; g.nx = (int)vp.steps[0].size(); g.ny = (int)vp.steps[1].size(); g.nz = (int)vp.steps[2].size();
     g.PD = a.patch[0]; g.PH = a.patch[1]; g.PW = a.patch[2];
@@ -1071,11 +1102,32 @@ int gather_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const Vol
     g.gauss = o.use_gaussian ? e->gauss : e->ones;
     g.lo_x = (int)vp.lo[0]; g.lo_y = (int)vp.lo[1]; g.lo_z = (int)vp.lo[2];
     g.OX = shape[1]; g.OY = shape[2]; g.OZ = shape[3];
-    g.acc_fp32 = o.accum == FNN_ACC_FP32; g.out_fp32 = o.out_dtype == FNN_OUT_F32;
-    g.out_vec = out && !g.out_fp32 && shape[3] % 8 == 0 && ((size_t)out % 16) == 0;
+    g.acc_fp32 = o.accum == FNN_ACC_FP32; g.out_fp32 = 0;
+    g.out_vec = out && shape[3] % 8 == 0 && ((size_t)out % 16) == 0;
     g.mode = mode; g.out = out; g.labels = labels; g.label_u16 = e->label_u16; g.order = lab_order; g.inf_flag = e->inf_flag;
-    Scope sc(e, st, FAM_HEAD, e->head_flops * (double)vp.n_patches);
-    if (launch_gather(g, st) != 0) return fail(e, FNN_E_HIP, "gather launch failed");
+    auto launch = [&](int x_lo, int x_hi, double n_patches) {
+        g.x_lo = x_lo; g.x_hi = x_hi;
+        Scope sc(e, st, FAM_HEAD, e->head_flops * n_patches * gp.n_eval);
+        return launch_gather(g, st) == 0 ? 0 : fail(e, FNN_E_HIP, "gather launch failed");
+    };
+    if (gp.ring == g.nx) {                                     // every patch of the volume is kept: one pass at the end
+        std::vector<int64_t> ids(vp.n_patches);
+        for (int64_t i = 0; i < vp.n_patches; ++i) ids[i] = i;
+        if (int rc = run_patches(e, fold, vol_dev, vp, o, ids, e->origins, box, nullptr, 0, st, false, true, 0, n_slots)) return rc;
+        return launch(0, (int)shape[1], (double)vp.n_patches);
+    }
+    // ring: after x layer ix the output slab up to the next layer's first voxel is complete (padded coordinates
+    // [steps[ix], steps[ix + 1]); the un-padded range is clamped); the next layer then overwrites the oldest slot
+    const int64_t L = (int64_t)gp.layer_items;
+    for (int ix = 0; ix < g.nx; ++ix) {
+        std::vector<int64_t> ids(L);
+        for (int64_t i = 0; i < L; ++i) ids[i] = ix * L + i;
+        if (int rc = run_patches(e, fold, vol_dev, vp, o, ids, e->origins + ix * L * 3, box, nullptr, 0, st, false, true,
+                                 (ix % gp.ring) * L, n_slots)) return rc;
+        const int64_t p_lo = ix == 0 ? 0 : vp.steps[0][ix], p_hi = ix + 1 < g.nx ? vp.steps[0][ix + 1] : vp.padded[0];
+        const int x_lo = (int)std::max<int64_t>(0, p_lo - vp.lo[0]), x_hi = (int)std::min<int64_t>(shape[1], p_hi - vp.lo[0]);
+        if (x_hi > x_lo) if (int rc = launch(x_lo, x_hi, (double)L)) return rc;
+    }
     return 0;
 }
 
@@ -1121,10 +1173,10 @@ int predict_impl(fnn_engine *e, int fold0, int n_folds, const float *vol, const 
     const int acc_fp32 = o->accum == FNN_ACC_FP32;
     const int64_t zero3[3] = {0, 0, 0}, full3[3] = {shape[1], shape[2], shape[3]};
     int rc = 0;
-    const bool gather = gather_applies(e, vp, *o);
+    const GatherPlan gp = gather_plan(e, vp, *o);
     for (int f = 0; f < n_folds && rc == 0; ++f) {
-        if (gather) {
-            rc = gather_whole_volume(e, fold0 + f, vol_dev, vp, shape, *o, f > 0 ? 1 : 0, labels_direct ? nullptr : out_dev,
+        if (gp.ok) {
+            rc = gather_whole_volume(e, fold0 + f, vol_dev, vp, shape, *o, gp, f > 0 ? 1 : 0, labels_direct ? nullptr : out_dev,
                                      labels_direct ? lab_dev : nullptr, lab_order, st);
             continue;
         }

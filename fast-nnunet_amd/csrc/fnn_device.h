@@ -161,8 +161,13 @@ struct PatchAccParams {          // patch buffer -> volume accumulators (mirrori
 
 // Head + accumulate + normalise from kept patch features (gather.hip)
 struct GatherParams {
-    const f16 *feat;             // [n_patches][PD][PH][PW][C]: raw output of the network's last conv, per patch
-    const float *fss;            // [n_patches][2][C]: scale row, shift row of its InstanceNorm
+    const f16 *feat;             // [n_eval][n_slots][PD][PH][PW][C]: raw output of the network's last conv per (mirrored
+                                 // evaluation, patch slot); patch (ix, iy, iz) sits in slot ((ix % ring) * ny + iy) * nz + iz
+    const float *fss;            // [n_eval][n_slots][2][C]: scale row, shift row of its InstanceNorm
+    int n_eval;                  // 1, or 1 + the number of mirror-axis subsets (test-time mirroring)
+    int flipmask[8];             // per evaluation: bit 0 / 1 / 2 = the network input was flipped along d / h / w
+    int n_slots, ring;           // ring = x layers of patches kept (nx: the whole volume)
+    int x_lo, x_hi;              // un-padded x range this launch writes
     int C;                       // padded channels (16 or 32)
     float slope;
     const int *steps;            // device: tile starts per axis, x then y then z (ascending)

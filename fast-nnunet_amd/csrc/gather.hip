@@ -14,6 +14,10 @@
 // reference's half-precision buffers (or keeping fp32: FNN_ACC_FP32); then divides by the weight sum, checks for inf
 // and writes the un-padded fp16 logits (or the label map) - every byte of the result is written once, every feature
 // byte read once: 44 GB instead of ~290 GB per 512^3 volume.  Results are bit-identical to the accumulate path.
+// Test-time mirroring (:541-557): the activations of all 2^k mirrored evaluations are kept and their logits summed in
+// fp32 per patch visit (read at the flipped voxel), divided by 2^k, then weighted - again the reference's order.
+// Memory: patches are produced x layer by x layer; a layer is needed until the output slab behind it is written, so a
+// RING of layers bounds the footprint (the whole volume when it fits: one launch at the end).
 //
 // Replaces _internal_predict_sliding_window_return_logits' accumulation and normalisation (:602-625) and, for the
 // label entry points, LabelManager.convert_logits_to_segmentation (label_handling.py:144-195).
@@ -35,7 +39,7 @@ struct Pick {                                                  // LabelPick of m
 }  // namespace
 
 // HB = head blocks of 16 (heads + the weight-sum channel <= 16 HB); LABELS: write the label map instead of the logits.
-template <int HB, bool ACC32, bool LABELS>
+template <int HB, bool ACC32, bool LABELS, bool TTA>
 __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
@@ -44,11 +48,11 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
     // wave -> (x, y, run of 64 z) of the UN-PADDED output
     const long long zruns = (p.OZ + 63) / 64;
     long long wid = (long long)blockIdx.x * 4 + wave;
-    const long long total = p.OX * p.OY * zruns;
+    const long long total = (long long)(p.x_hi - p.x_lo) * p.OY * zruns;
     if (wid >= total) return;
     const int zr = (int)(wid % zruns); wid /= zruns;
     const int y = (int)(wid % p.OY);
-    const int x = (int)(wid / p.OY);
+    const int x = p.x_lo + (int)(wid / p.OY);
     const int z0 = zr * 64;
     const int xp = x + p.lo_x, yp = y + p.lo_y, zp0 = z0 + p.lo_z;            // padded-volume coordinates
 
@@ -82,51 +86,87 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
             for (int iz = 0; iz < p.nz; ++iz) {
                 const int oz = sz[iz];
                 if (zp0 + 64 <= oz || zp0 >= oz + p.PW) continue;
-                const int pid = (ix * p.ny + iy) * p.nz + iz;
-                // the patch's InstanceNorm of this lane's 8 channels
-                const float *qs = p.fss + (size_t)(2 * pid) * p.C + c0;
-                const float4 s0 = *(const float4 *)qs, s1 = *(const float4 *)(qs + 4);
-                const float4 h0 = *(const float4 *)(qs + p.C), h1 = *(const float4 *)(qs + p.C + 4);
-                const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-                const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-                const int rowbase = ((xp - ox) * p.PH + (yp - oy)) * p.PW - oz;      // + zp = voxel index in the patch
-                const f16 *fp = p.feat + (size_t)pid * P * p.C + c0;
-                f16x8 xraw[4];
-                f16 graw[4];
+                const int slot = ((ix % p.ring) * p.ny + iy) * p.nz + iz;
+                const int dx = xp - ox, dy = yp - oy;
                 bool in[4];
+                f16 graw[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int zp = zp0 + 16 * g + r;
                     in[g] = zp >= oz && zp < oz + p.PW;
-                    const int v = in[g] ? rowbase + zp : 0;
-                    xraw[g] = *(const f16x8 *)(fp + (size_t)v * p.C);
-                    graw[g] = p.gauss[v];
+                    graw[g] = p.gauss[in[g] ? (dx * p.PH + dy) * p.PW + zp - oz : 0];
                 }
+                f32x4 tsum[TTA ? 4 : 1][HB];                  // mirrored evaluations: running fp32 sum of the logits
+                for (int f = 0; f < (TTA ? p.n_eval : 1); ++f) {
+                    const int fm = TTA ? p.flipmask[f] : 0;
+                    // the patch-space voxel (dx, dy, dz) is output voxel (PD-1-dx, ...) of an evaluation whose input was flipped
+                    const int fx = (fm & 1) ? p.PD - 1 - dx : dx, fy = (fm & 2) ? p.PH - 1 - dy : dy;
+                    const size_t ev = (size_t)f * p.n_slots + slot;
+                    // the evaluation's InstanceNorm of this lane's 8 channels
+                    const float *qs = p.fss + ev * 2 * p.C + c0;
+                    const float4 s0 = *(const float4 *)qs, s1 = *(const float4 *)(qs + 4);
+                    const float4 h0 = *(const float4 *)(qs + p.C), h1 = *(const float4 *)(qs + p.C + 4);
+                    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                    const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                    const int rowbase = (fx * p.PH + fy) * p.PW;
+                    const f16 *fp = p.feat + ev * P * p.C + c0;
+                    f16x8 xraw[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    // a patch that starts or ends inside the run leaves whole 16-voxel groups untouched: skip them
-                    // (wave-uniform; 3.5 patches intersect a 64-voxel run along z, 2 cover each voxel)
-                    if (__builtin_amdgcn_ballot_w64(in[g]) == 0) continue;
-                    f16x8 o;                                   // norm_act_frag's arithmetic (misc.hip)
+                    for (int g = 0; g < 4; ++g) {
+                        const int dz = zp0 + 16 * g + r - oz;
+                        const int v = in[g] ? rowbase + ((fm & 4) ? p.PW - 1 - dz : dz) : 0;
+                        xraw[g] = *(const f16x8 *)(fp + (size_t)v * p.C);
+                    }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)xraw[g][j], sc[j], sh[j]);
-                    o = __builtin_elementwise_max(o, o * slope_h);
-                    if (!live) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                    const float gw = (float)graw[g];
-                    // channel `heads` has zero weights and bias 1: its product is the weight itself; the product is rounded
-                    // before the sum (no fma), one rounding to fp16 per visit; lanes outside the patch keep their sums (and
-                    // signed zeros).  Measured and dropped: packed fp32 (v_pk_add_f32 / v_pk_mul_f32 issue at well under half
-                    // the scalar rate on gfx950) and an exec-masked block per group behind all four MFMAs - both 1.6x slower
-                    // than this select-per-value form, whose MFMAs hide behind the previous block's arithmetic.
+                    for (int g = 0; g < 4; ++g) {
+                        // a patch that starts or ends inside the run leaves whole 16-voxel groups untouched: skip them
+                        // (wave-uniform; 3.5 patches intersect a 64-voxel run along z, 2 cover each voxel)
+                        if (__builtin_amdgcn_ballot_w64(in[g]) == 0) continue;
+                        f16x8 o;                               // norm_act_frag's arithmetic (misc.hip)
 #pragma unroll
-                    for (int hb = 0; hb < HB; ++hb) {
-                        const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[hb], o, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)xraw[g][j], sc[j], sh[j]);
+                        o = __builtin_elementwise_max(o, o * slope_h);
+                        if (!live) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                        const float gw = (float)graw[g];
+                        // channel `heads` has zero weights and bias 1: its product is the weight itself; the product is
+                        // rounded before the sum (no fma), one rounding to fp16 per visit; lanes outside the patch keep their
+                        // sums (and signed zeros).  Measured and dropped: packed fp32 (v_pk_add_f32 / v_pk_mul_f32 issue at well
+                        // under half the scalar rate on gfx950) and an exec-masked block per group behind all four MFMAs -
+                        // both 1.6x slower than this select-per-value form, whose MFMAs hide behind the previous block's
+                        // arithmetic.
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float s = acc_add_product_1(acc[g][hb][j], d[j] + bv[hb][j], gw);
-                            const float nv = ACC32 ? s : (float)(f16)s;
-                            acc[g][hb][j] = in[g] ? nv : acc[g][hb][j];
+                        for (int hb = 0; hb < HB; ++hb) {
+                            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[hb], o, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            if (TTA) {
+                                // predict_from_raw_data.py:541-557: net(x) + sum over the mirror subsets, in their order (fp32)
+                                const f32x4 t = d + bv[hb];
+                                tsum[TTA ? g : 0][hb] = f == 0 ? t : tsum[TTA ? g : 0][hb] + t;
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const float sv = acc_add_product_1(acc[g][hb][j], d[j] + bv[hb][j], gw);
+                                    const float nv = ACC32 ? sv : (float)(f16)sv;
+                                    acc[g][hb][j] = in[g] ? nv : acc[g][hb][j];
+                                }
+                            }
                         }
+                    }
+                }
+                if (TTA) {
+                    const float nf = (float)p.n_eval;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (__builtin_amdgcn_ballot_w64(in[g]) == 0) continue;
+                        const float gw = (float)graw[g];
+#pragma unroll
+                        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float t = __fdiv_rn(tsum[TTA ? g : 0][hb][j], nf);         // prediction /= (len(axes_combinations) + 1)
+                                const float sv = acc_add_product_1(acc[g][hb][j], t, gw);
+                                const float nv = ACC32 ? sv : (float)(f16)sv;
+                                acc[g][hb][j] = in[g] ? nv : acc[g][hb][j];
+                            }
                     }
                 }
             }
@@ -249,21 +289,22 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
 
 bool gather_ok(const GatherParams &p) {
     const int hblocks = (p.heads + 1 + 15) / 16;
-    return hblocks <= 4 && p.C <= 32 && p.C % 8 == 0 && (long long)p.PD * p.PH * p.PW < (1LL << 31) / 32;
+    return hblocks <= 4 && p.C <= 32 && p.C % 8 == 0 && (long long)p.PD * p.PH * p.PW < (1LL << 31) / 32 && p.n_eval <= 8;
 }
 
-template <int HB>
+template <int HB, bool TTA>
 static int launch_gather_hb(const GatherParams &p, hipStream_t st) {
-    const long long waves = p.OX * p.OY * ((p.OZ + 63) / 64);
+    const long long waves = (long long)(p.x_hi - p.x_lo) * p.OY * ((p.OZ + 63) / 64);
+    if (waves <= 0) return 0;
     const dim3 grid((unsigned)((waves + 3) / 4));
     const size_t lds = (size_t)4 * HB * 16 * 72 * 2;
     const bool labels = p.labels != nullptr;
     if (p.acc_fp32) {
-        if (labels) hipLaunchKernelGGL((gather_head_kernel<HB, true, true>), grid, dim3(256), lds, st, p);
-        else hipLaunchKernelGGL((gather_head_kernel<HB, true, false>), grid, dim3(256), lds, st, p);
+        if (labels) hipLaunchKernelGGL((gather_head_kernel<HB, true, true, TTA>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((gather_head_kernel<HB, true, false, TTA>), grid, dim3(256), lds, st, p);
     } else {
-        if (labels) hipLaunchKernelGGL((gather_head_kernel<HB, false, true>), grid, dim3(256), lds, st, p);
-        else hipLaunchKernelGGL((gather_head_kernel<HB, false, false>), grid, dim3(256), lds, st, p);
+        if (labels) hipLaunchKernelGGL((gather_head_kernel<HB, false, true, TTA>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((gather_head_kernel<HB, false, false, TTA>), grid, dim3(256), lds, st, p);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -271,7 +312,12 @@ static int launch_gather_hb(const GatherParams &p, hipStream_t st) {
 int launch_gather(const GatherParams &p, hipStream_t st) {
     if (!gather_ok(p)) return -1;
     const int hblocks = (p.heads + 1 + 15) / 16;
-    if (hblocks == 1) return launch_gather_hb<1>(p, st);
-    if (hblocks == 2) return launch_gather_hb<2>(p, st);
-    return launch_gather_hb<4>(p, st);
+    if (p.n_eval > 1) {
+        if (hblocks == 1) return launch_gather_hb<1, true>(p, st);
+        if (hblocks == 2) return launch_gather_hb<2, true>(p, st);
+        return launch_gather_hb<4, true>(p, st);
+    }
+    if (hblocks == 1) return launch_gather_hb<1, false>(p, st);
+    if (hblocks == 2) return launch_gather_hb<2, false>(p, st);
+    return launch_gather_hb<4, false>(p, st);
 }

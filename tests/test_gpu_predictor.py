@@ -818,3 +818,27 @@ def test_gather_path_is_bit_identical_to_the_accumulate_path(shape, heads, accum
     finally:
         os.environ.pop('FNN_NO_GATHER', None)
     assert torch.equal(g1.predict_segmentation_from_preprocessed_data(image), a1.predict_segmentation_from_preprocessed_data(image))
+
+
+@pytest.mark.parametrize('mirror', [None, (0, 1, 2), (1,)])
+def test_gather_ring_and_mirroring_are_bit_identical_to_the_accumulate_path(mirror):
+    """The gather path with test-time mirroring (the 2^k evaluations' logits summed per visit, predict_from_raw_data.py:
+    541-557) and with a RING of x layers instead of every patch of the volume (FNN_GATHER_RING: what a volume whose
+    patch activations exceed the memory budget gets) against the accumulate path with its per-patch fp32 buffers."""
+    spec, patch = SPECS['toy3']
+    sd = synthetic_state_dict(spec, 77)
+    image = torch.randn(1, 50, 37, 70, generator=torch.Generator().manual_seed(29))       # 6 x 4 x 4 tile positions
+    os.environ['FNN_NO_GATHER'] = '1'
+    try:
+        want = _predictor(spec, patch, [sd], mirror=mirror).predict_sliding_window_return_logits(image)
+    finally:
+        os.environ.pop('FNN_NO_GATHER', None)
+    p = _predictor(spec, patch, [sd], mirror=mirror)
+    assert torch.equal(p.predict_sliding_window_return_logits(image), want)
+    for ring in (2, 3):
+        os.environ['FNN_GATHER_RING'] = str(ring)
+        try:
+            assert torch.equal(p.predict_sliding_window_return_logits(image), want)
+            assert torch.equal(p.predict_segmentation_from_preprocessed_data(image).long(), want.float().argmax(0))
+        finally:
+            os.environ.pop('FNN_GATHER_RING', None)
