@@ -257,16 +257,24 @@ class nnUNetPredictor(object):
         ``save_or_return_probabilities=True`` returns ``(labels, float32 probabilities [heads, s0, s1, s2])`` like the
         reference (softmax / sigmoid, background probability 1 outside the crop box)."""
         from .preprocess import DevicePreprocessor
-        if segmentation_previous_stage is not None:
-            raise NotImplementedError('cascade input (one-hot previous-stage segmentation) is not implemented on the device')
         if output_file_truncated is not None:
             raise NotImplementedError('image file export is the caller\'s side (SURVEY.md 8: image I/O out of scope)')
         pp = DevicePreprocessor(self.device, verbose=self.verbose)
         props = dict(image_properties)
         if self.verbose:
             print('preprocessing')
-        data, _, props = pp.run_case_npy(input_image, None, props, self.plans_manager, self.configuration_manager,
-                                         self.dataset_json)
+        data, seg, props = pp.run_case_npy(input_image, segmentation_previous_stage, props, self.plans_manager,
+                                           self.configuration_manager, self.dataset_json)
+        if segmentation_previous_stage is not None:
+            # cascade: the previous stage's labels as one-hot channels behind the image (convert_labelmap_to_one_hot,
+            # label_handling.py:259-292; data_iterators.py:202-204) - the network was built with that many inputs
+            # (determine_num_input_channels, label_handling.py:305-310)
+            fg = torch.as_tensor(list(self.label_manager.foreground_labels), device=seg.device, dtype=seg.dtype)
+            onehot = (seg[0][None] == fg.view(-1, 1, 1, 1)).to(data.dtype)
+            data = torch.cat((data, onehot), 0).contiguous()
+            if data.shape[0] != self._spec.in_channels:
+                raise RuntimeError(f'cascade input has {data.shape[0]} channels (image + {len(fg)} foreground labels), '
+                                   f'the network expects {self._spec.in_channels}')
         if self.verbose:
             print('predicting')
         u16 = len(self.label_manager.foreground_labels) >= 255

@@ -75,10 +75,13 @@ class DevicePreprocessor:
 
     @torch.inference_mode()
     def run_case_npy(self, data: Union[np.ndarray, torch.Tensor], seg, properties: dict, plans_manager,
-                     configuration_manager, dataset_json=None) -> Tuple[torch.Tensor, None, dict]:
-        """-> (float32 ``[C, x, y, z]`` on the device, None, properties) - the ``data`` the predictor consumes."""
-        if seg is not None:
-            raise NotImplementedError('inference-time preprocessing only (seg=None)')
+                     configuration_manager, dataset_json=None) -> Tuple[torch.Tensor, Optional[torch.Tensor], dict]:
+        """-> (float32 ``[C, x, y, z]`` on the device, seg, properties) - the ``data`` the predictor consumes.
+        ``seg`` (the previous stage's segmentation of a cascade, ``[1, s0, s1, s2]``) travels with the image: transposed,
+        cropped to the same box and resampled with ``resampling_fn_seg`` (int16 on the device), so that it stays aligned
+        (inference/data_iterators.py:195-201); the -1 the reference writes outside the non-zero mask (cropping.py:36) is
+        not produced - it only ever meets ``convert_labelmap_to_one_hot`` over the foreground labels."""
+        seg_in = seg
         with torch.cuda.device(self.device):
             raw = torch.as_tensor(data).to(device=self.device, dtype=torch.float32).contiguous()   # :49 astype(float32)
             assert raw.ndim == 4, 'data must have shape (C, X, Y, Z)'
@@ -113,14 +116,47 @@ class DevicePreprocessor:
             out = self.resample(out, new_shape, original_spacing, target_spacing,
                                 getattr(configuration_manager, 'resampling_fn_data_kwargs', None) or
                                 {'is_seg': False, 'order': 3, 'order_z': 0, 'force_separate_z': None})
-        return out, None, properties
+            seg_out = None
+            if seg_in is not None:
+                sg = torch.as_tensor(seg_in).to(self.device)
+                assert sg.ndim == 4 and tuple(sg.shape[1:]) == tuple(raw.shape[1:]), 'seg must have shape (1, X, Y, Z) of the image'
+                sg = sg.permute(0, *[1 + i for i in tf])
+                sg = sg[(slice(None), *[slice(lo, hi) for lo, hi in bbox])].to(torch.int16).contiguous()
+                seg_out = self.resample_seg(sg, new_shape, original_spacing, target_spacing,
+                                            getattr(configuration_manager, 'resampling_fn_seg_kwargs', None) or
+                                            {'is_seg': True, 'order': 1, 'order_z': 0, 'force_separate_z': None})
+        return out, seg_out, properties
+
+    @torch.inference_mode()
+    def resample_seg(self, seg: torch.Tensor, new_shape, current_spacing, new_spacing, kwargs: dict) -> torch.Tensor:
+        """``resample_data_or_seg_to_shape(seg, ..., is_seg=True, order, order_z=0)`` (default_resampling.py:113-196)
+        with ``resize_segmentation`` (batchgenerators): order 0 resizes the label image; otherwise every label's mask
+        is resized (``fnn_resample``, the images' kernel) and the voxels where it reaches 0.5 take the label, labels
+        ascending.  Thresholding commutes with the nearest-neighbour pass along an anisotropic axis, so the per-slice
+        path is the same call with ``separate_axis``.  ``[C, x, y, z]`` integer tensor -> int16 on the device."""
+        if int(kwargs.get('order_z', 0)) != 0:
+            raise NotImplementedError('order_z != 0 for segmentations (the reference\'s plans use 0)')
+        new_shape = [int(i) for i in new_shape]
+        with torch.cuda.device(self.device):
+            sg = seg.to(self.device)
+            if [int(i) for i in sg.shape[1:]] == new_shape:
+                return sg.to(torch.int16)
+            order = int(kwargs.get('order', 1))
+            kw = dict(kwargs, is_seg=False)
+            if order == 0:
+                return self.resample(sg.float(), new_shape, current_spacing, new_spacing, kw).round().to(torch.int16)
+            out = torch.zeros((sg.shape[0], *new_shape), dtype=torch.int16, device=self.device)
+            for c in torch.unique(sg).tolist():                              # ascending, like np.unique
+                m = self.resample((sg == c).float(), new_shape, current_spacing, new_spacing, kw)
+                out[m >= 0.5] = int(c)
+        return out
 
     @torch.inference_mode()
     def resample(self, data: torch.Tensor, new_shape, current_spacing, new_spacing, kwargs: dict) -> torch.Tensor:
         """``resample_data_or_seg_to_shape(data, new_shape, current_spacing, new_spacing, **kwargs)`` for images /
         logits (``is_seg`` False): fp32 or fp16 ``[C, x, y, z]`` on the device."""
         if kwargs.get('is_seg', False):
-            raise NotImplementedError('segmentation resampling (resize_segmentation) is not implemented on the device')
+            raise ValueError('is_seg=True: call resample_seg')
         do_sep, axis = determine_do_sep_z_and_axis(kwargs.get('force_separate_z', None), current_spacing, new_spacing,
                                                    kwargs.get('separate_z_anisotropy_threshold', ANISO_THRESHOLD))
         with torch.cuda.device(self.device):

@@ -101,3 +101,54 @@ def resample_data(data: np.ndarray, new_shape: Sequence[int], axis: Optional[int
         for c in range(data.shape[0]):
             out[c] = skimage_resize(data[c], new_shape, order)
     return out
+
+
+def resize_segmentation(segmentation: np.ndarray, new_shape: Sequence[int], order: int = 3) -> np.ndarray:
+    """``batchgenerators.augmentations.utils.resize_segmentation`` (third-party, un-vendored, absent here: published
+    algorithm restated; the reference calls it at default_resampling.py:143-146 for ``is_seg=True``): order 0 resizes the
+    label image itself; otherwise every label's mask is resized with `order` and the voxels where it reaches 0.5 take
+    the label, labels in ascending order (a later label overwrites an earlier one; voxels no mask claims stay 0)."""
+    tpe = segmentation.dtype
+    assert len(segmentation.shape) == len(new_shape)
+    if order == 0:
+        return skimage_resize(segmentation.astype(float), new_shape, 0).astype(tpe)
+    out = np.zeros(tuple(new_shape), dtype=tpe)
+    for c in np.unique(segmentation):
+        out[skimage_resize((segmentation == c).astype(float), new_shape, order) >= 0.5] = c
+    return out
+
+
+def resample_seg(seg: np.ndarray, new_shape: Sequence[int], axis: Optional[int] = None, order: int = 1,
+                 do_separate_z: bool = False, order_z: int = 0) -> np.ndarray:
+    """``resample_data_or_seg(seg, new_shape, is_seg=True, ...)`` (default_resampling.py:113-196) for ``order_z == 0``
+    (the only value the reference's plans use, default_experiment_planner.py:170-181): per-slice
+    ``resize_segmentation`` + nearest-neighbour along the anisotropic axis, or one 3-D ``resize_segmentation``."""
+    assert seg.ndim == 4 and len(new_shape) == 3 and order_z == 0
+    shape = np.array(seg[0].shape)
+    new_shape = np.array(new_shape)
+    if not np.any(shape != new_shape):
+        return seg
+    out = np.zeros((seg.shape[0], *new_shape), dtype=seg.dtype)
+    data = seg.astype(float, copy=False)
+    for c in range(seg.shape[0]):
+        if do_separate_z:
+            new_shape_2d = [new_shape[i] for i in range(3) if i != axis]
+            tmp = list(new_shape)
+            tmp[axis] = shape[axis]
+            here = np.zeros(tmp)
+            for s in range(shape[axis]):
+                sl = [slice(None)] * 3
+                sl[axis] = s
+                here[tuple(sl)] = resize_segmentation(data[c][tuple(sl)], new_shape_2d, order)
+            if shape[axis] != new_shape[axis]:
+                rows, cols, dim = new_shape
+                orows, ocols, odim = here.shape
+                mr, mc, md = np.mgrid[:rows, :cols, :dim]
+                coords = np.array([float(orows) / rows * (mr + 0.5) - 0.5, float(ocols) / cols * (mc + 0.5) - 0.5,
+                                   float(odim) / dim * (md + 0.5) - 0.5])
+                out[c] = ndi.map_coordinates(here, coords, order=0, mode='nearest')
+            else:
+                out[c] = here
+        else:
+            out[c] = resize_segmentation(data[c], new_shape, order)
+    return out

@@ -255,3 +255,92 @@ def test_export_probabilities_rejects_bad_arguments():
     with pytest.raises(AssertionError, match='device pointers'):
         capi.export_probabilities(np.zeros(128, np.float16).ctypes.data, True, 2, None, [[0, 4], [0, 4], [0, 4]], (6, 6, 6),
                                   (0, 1, 2), probs.data_ptr(), labels.data_ptr(), False, st)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# segmentation resampling + cascade input (f-2 / f-4): resample_data_or_seg(is_seg=True) with batchgenerators'
+# resize_segmentation (third-party, absent: oracle/resample.py restates its published algorithm - parity unpinned)
+# ---------------------------------------------------------------------------------------------------------------
+def _blobs(shape, n_labels, seed):
+    """A label image of smooth random regions (argmax of smoothed noise fields)."""
+    from scipy import ndimage as ndi
+    rng = np.random.default_rng(seed)
+    fields = np.stack([ndi.gaussian_filter(rng.standard_normal(shape), 2.5) for _ in range(n_labels + 1)])
+    return fields.argmax(0).astype(np.int16)
+
+
+@pytest.mark.parametrize('shape,new_shape,order,axis', [((20, 24, 18), (31, 20, 27), 1, None), ((9, 26, 22), (14, 40, 17), 1, 0),
+                                                        ((16, 16, 12), (24, 11, 19), 0, None), ((12, 20, 7), (18, 30, 7), 3, 2)])
+def test_segmentation_resampling_matches_the_restatement(shape, new_shape, order, axis):
+    from fast_nnunet_amd.preprocess import DevicePreprocessor
+    from oracle import resample as ores
+    seg = _blobs(shape, 4, hash((shape, order)) % 1000)[None]
+    want = ores.resample_seg(seg, new_shape, axis=axis, order=order, do_separate_z=axis is not None)
+    pp = DevicePreprocessor(torch.device('cuda', 0))
+    # spacings that make determine_do_sep_z_and_axis choose the wanted path
+    cur = [1.0, 1.0, 1.0]
+    if axis is not None:
+        cur[axis] = 4.0
+    got = pp.resample_seg(torch.from_numpy(seg).cuda(), new_shape, cur, cur,
+                          {'is_seg': True, 'order': order, 'order_z': 0, 'force_separate_z': None}).cpu().numpy()
+    assert got.shape == want.shape and got.dtype == np.int16
+    # both sides resize in fp64 and threshold at 0.5.  A linearly interpolated binary mask lands on 0.5 at whole families
+    # of rational positions; there the two summation orders round to either side (the device also stores the resized mask
+    # in fp32 first): a few voxels per ten thousand may differ, nowhere else
+    assert (got != want).mean() <= 1e-3, (got != want).mean()
+    assert set(np.unique(got)) <= set(np.unique(seg))
+
+
+def test_cascade_input_one_hot_channels_through_the_predictor():
+    """predict_single_npy_array(image, props, segmentation_previous_stage): the previous stage's labels are cropped and
+    resampled with the image and enter the network as one-hot channels (data_iterators.py:195-204); the result must equal
+    running the predictor on the hand-built [image, one-hot] input."""
+    from fast_nnunet_amd import nnUNetPredictor
+    from fast_nnunet_amd.plans import PlansManager
+    from fast_nnunet_amd.preprocess import DevicePreprocessor
+    from oracle import resample as ores
+    from oracle.topology import UNetSpec
+    from oracle.unet import synthetic_state_dict
+    n_fg = 3
+    spec = UNetSpec('plain', 1 + n_fg, n_fg + 1, [16, 32], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
+    patch = (16, 16, 32)
+    pm = PlansManager({'dataset_name': 'Dataset998_Cascade', 'plans_name': 'nnUNetPlans', 'transpose_forward': [0, 1, 2],
+                       'transpose_backward': [0, 1, 2],
+                       'foreground_intensity_properties_per_channel': {'0': {'mean': 0.0, 'std': 1.0, 'percentile_00_5': -5.0,
+                                                                             'percentile_99_5': 5.0}},
+                       'configurations': {'3d_lowres': {'patch_size': list(patch), 'spacing': [2.0, 2.0, 2.0]},
+                                          '3d_cascade_fullres': {'patch_size': list(patch), 'spacing': [1.0, 1.0, 1.5],
+                                                                 'previous_stage': '3d_lowres',
+                                                                 'normalization_schemes': ['CTNormalization'],
+                                                                 'use_mask_for_norm': [False],
+                                                                 'resampling_fn_data_kwargs': {'is_seg': False, 'order': 3, 'order_z': 0, 'force_separate_z': None},
+                                                                 'resampling_fn_seg_kwargs': {'is_seg': True, 'order': 1, 'order_z': 0, 'force_separate_z': None},
+                                                                 'resampling_fn_probabilities_kwargs': {'is_seg': False, 'order': 1, 'order_z': 0, 'force_separate_z': None},
+                                                                 'architecture': {'network_class_name': 'PlainConvUNet', 'arch_kwargs': {},
+                                                                                  '_kw_requires_import': []}}}})
+    cm = pm.get_configuration('3d_cascade_fullres')
+    dj = {'labels': {'background': 0, 'a': 1, 'b': 2, 'c': 3}, 'channel_names': {'0': 'CT'}, 'file_ending': '.nii.gz'}
+    p = nnUNetPredictor(tile_step_size=0.5, use_gaussian=True, use_mirroring=False, device=torch.device('cuda', 0),
+                        allow_tqdm=False, patches_per_forward=2)
+    p.manual_initialization(None, pm, cm, [synthetic_state_dict(spec, 12)], dj, 'nnUNetTrainer', None)
+    rng = np.random.default_rng(5)
+    image = rng.standard_normal((1, 30, 34, 40)).astype(np.float32)
+    image[:, :3] = 0
+    prev = _blobs(image.shape[1:], n_fg, 9)[None]
+    props = {'spacing': [1.0, 1.0, 1.0]}
+    labels = p.predict_single_npy_array(image, dict(props), prev)
+    assert labels.shape == image.shape[1:] and labels.dtype == np.uint8
+    # by hand: the same preprocessing, then the one-hot channels from the ORACLE's segmentation resampler
+    pp = DevicePreprocessor(torch.device('cuda', 0))
+    data, seg, pr = pp.run_case_npy(image, prev, dict(props), pm, cm, dj)
+    bbox = pr['bbox_used_for_cropping']
+    crop = prev[(slice(None), *[slice(lo, hi) for lo, hi in bbox])]
+    want_seg = ores.resample_seg(crop, data.shape[1:], order=1)
+    assert (seg.cpu().numpy() != want_seg).mean() <= 1e-3
+    onehot = torch.stack([(seg[0] == l) for l in (1, 2, 3)]).float()
+    logits = p.predict_logits_from_preprocessed_data(torch.cat((data, onehot), 0))
+    want = pp.convert_predicted_logits_to_segmentation_with_correct_shape(logits.cuda(), p, pm, cm, pr).cpu().numpy()
+    assert np.array_equal(labels, want)
+    # and the image-only call on a cascade network fails loudly instead of feeding one channel into a four-channel stem
+    with pytest.raises((RuntimeError, AssertionError)):
+        p.predict_single_npy_array(image, dict(props))
