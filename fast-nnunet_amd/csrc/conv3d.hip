@@ -882,11 +882,7 @@ __global__ __launch_bounds__(256, (NB == 1 && MB == 4 && WRES && PF == 4) ? 3 : 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < PF; ++u)                        // unconditional: branches around loads make hipcc drain vmcnt
-#ifdef FNN_BOUND_FUSE
-            xr[u] = *(const f16x8 *)(sp + ((unsigned)((offv[u] >= 0 ? offv[u] : 0) * sC * 2) & ((p.bound_mask0 && s == 0) ? 0x3FFFu : 0xFFFFFFFFu)));
-#else
             xr[u] = *(const f16x8 *)(sp + (unsigned)((offv[u] >= 0 ? offv[u] : 0) * sC * 2));
-#endif
         if (!WRES) {
 #pragma unroll
             for (int u = 0; u < WPF; ++u) wr[u] = ((const f16x8 *)p.wpk)[wofs[u] + ch * per_nb];

@@ -59,12 +59,15 @@ static __device__ __forceinline__ f16x4 stem_block(const float *sRaw, int rawbas
 }  // namespace
 
 // ----------------------------------------------------------------------------
-// stem: statistics pass (+ optional output)
+// stem: first conv of the network (+ statistics; output optional)
 // ----------------------------------------------------------------------------
-// Workgroup = 16 x 8 x 8 output voxels (64 column blocks, 16 per wave), 16 output channels; raw window of the patch
-// in LDS ((16 + kd - 1) x 10 x 10 floats); zero padding at the PATCH border; mirroring flips the window read.
+// Workgroup = 16 x 8 x 8 output voxels (64 column blocks, 16 per wave), 16 output channels (blockIdx.y picks the block);
+// raw window of the patch in LDS (C x (15 + kd) x (7 + kh) x (7 + kw) floats); zero padding at the PATCH border; mirroring
+// flips the window read.  GEMM K = C * taps in k-steps of 32 (one for a single-channel CT): element k of the im2col
+// column is input channel k / taps, tap k % taps; the per-k LDS offsets come from a table.
 #define STEMM_TD 16
-__global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, const f16 *wfrag) {
+template <bool ONE>                                                  // ONE: a single k-step (C * taps <= 32): offsets and weights in registers
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, const f16 *wfrag, const int ksteps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     int t = blockIdx.x;
@@ -72,33 +75,41 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, cons
     const int th = t % p.tiles_h; t /= p.tiles_h;
     const int td = t % p.tiles_d;
     const int n = t / p.tiles_d;
-    const int pd = (p.kd - 1) / 2;
-    const int RD = STEMM_TD - 1 + p.kd, RVOX = RD * 100, T = p.kd * 9;
-    float *sRaw = (float *)smem;                                         // [RD][10][10]
-    float *sRed = sRaw + ((RVOX + 3) & ~3);                              // [4 waves][16][2]
+    const int cb = blockIdx.y;
+    const int pd = (p.kd - 1) / 2, ph = (p.kh - 1) / 2, pw = (p.kw - 1) / 2;
+    const int RD = STEMM_TD - 1 + p.kd, RH = 7 + p.kh, RW = 7 + p.kw, RVOX = RD * RH * RW, T = p.kd * p.kh * p.kw, K = p.C * T;
+    float *sRaw = (float *)smem;                                         // [C][RD][RH][RW]
+    int *sTab = (int *)(sRaw + ((p.C * RVOX + 3) & ~3));                 // [ksteps * 32] LDS offset of im2col element k
+    float *sRed = (float *)(sTab + ksteps * 32);                         // [4 waves][16][2]
 
     const int ox = p.origins[n * 3 + 0], oy = p.origins[n * 3 + 1], oz = p.origins[n * 3 + 2];
-    const int d0 = td * STEMM_TD - pd, h0 = th * 8 - 1, w0 = tw * 8 - 1;
+    const int d0 = td * STEMM_TD - pd, h0 = th * 8 - ph, w0 = tw * 8 - pw;
     const float *voln = p.vol + (size_t)n * p.vol_batch_stride;
-    for (int v = tid; v < RVOX; v += 256) {
-        const int zd = v / 100, rem = v - zd * 100, zh = rem / 10, zw = rem - zh * 10;
-        int d = d0 + zd, h = h0 + zh, w = w0 + zw;
-        const bool ok = d >= 0 && d < p.PD && h >= 0 && h < p.PH && w >= 0 && w < p.PW;
-        if (p.flip_d) d = p.PD - 1 - d;
-        if (p.flip_h) h = p.PH - 1 - h;
-        if (p.flip_w) w = p.PW - 1 - w;
-        const float val = voln[((size_t)(ox + (ok ? d : 0)) * p.Y + (oy + (ok ? h : 0))) * p.Z + (oz + (ok ? w : 0))];
-        sRaw[v] = ok ? val : 0.f;
+    for (int c = 0; c < p.C; ++c)
+        for (int v = tid; v < RVOX; v += 256) {
+            const int zd = v / (RH * RW), rem = v - zd * (RH * RW), zh = rem / RW, zw = rem - zh * RW;
+            int d = d0 + zd, h = h0 + zh, w = w0 + zw;
+            const bool ok = d >= 0 && d < p.PD && h >= 0 && h < p.PH && w >= 0 && w < p.PW;
+            if (p.flip_d) d = p.PD - 1 - d;
+            if (p.flip_h) h = p.PH - 1 - h;
+            if (p.flip_w) w = p.PW - 1 - w;
+            const float val = voln[(((size_t)c * p.X + (ox + (ok ? d : 0))) * p.Y + (oy + (ok ? h : 0))) * p.Z + (oz + (ok ? w : 0))];
+            sRaw[c * RVOX + v] = ok ? val : 0.f;
+        }
+    for (int k = tid; k < ksteps * 32; k += 256) {
+        const int kk = k < K ? k : 0;                                    // padding elements: any finite value, their weights are zero
+        const int c = kk / T, tap = kk - c * T;
+        sTab[k] = c * RVOX + ((tap / (p.kh * p.kw)) * RH + (tap / p.kw) % p.kh) * RW + tap % p.kw;
     }
-    const f16x8 wf = *(const f16x8 *)(wfrag + lane * 8);
-    const float4 bias = *(const float4 *)(p.bias + q * 4);
-    int tapoff[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = 8 * q + j, tap = k < T ? k : 0;
-        tapoff[j] = ((tap / 9) * 10 + (tap / 3) % 3) * 10 + tap % 3;
-    }
+    const float4 bias = *(const float4 *)(p.bias + cb * 16 + q * 4);
     __syncthreads();
+    int tapoff[8];
+    f16x8 wf1 = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ONE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tapoff[e] = sTab[8 * q + e];
+        wf1 = *(const f16x8 *)(wfrag + ((size_t)cb * 64 + lane) * 8);
+    }
 
     float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
     const f16x2 ones = {(f16)1.f, (f16)1.f};
@@ -107,9 +118,26 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, cons
     for (int j = 0; j < 16; ++j) {                                       // column block = (depth slice, pair of h rows)
         const int dl = wave * 4 + (j >> 2), hp = j & 3;
         const int od = td * STEMM_TD + dl, ohh = oh + 2 * hp;
-        f16x4 h = stem_block(sRaw, (dl * 10 + 2 * hp + (r >> 3)) * 10 + (r & 7), tapoff, wf, bias);
+        const int rawbase = (dl * RH + 2 * hp + (r >> 3)) * RW + (r & 7);
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        if (ONE) {
+            f16x8 xb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xb[e] = (f16)sRaw[rawbase + tapoff[e]];
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1, xb, d, 0, 0, 0);
+        } else {
+            for (int ks = 0; ks < ksteps; ++ks) {
+                const f16x8 wf = *(const f16x8 *)(wfrag + ((size_t)(cb * ksteps + ks) * 64 + lane) * 8);
+                f16x8 xb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xb[e] = (f16)sRaw[rawbase + sTab[ks * 32 + 8 * q + e]];
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xb, d, 0, 0, 0);
+            }
+        }
+        f16x4 h;
+        h[0] = (f16)(d[0] + bias.x); h[1] = (f16)(d[1] + bias.y); h[2] = (f16)(d[2] + bias.z); h[3] = (f16)(d[3] + bias.w);
         const bool ok = od < p.PD && ohh < p.PH && ow < p.PW;
-        if (ok && p.out) *(f16x4 *)(p.out + ((((size_t)n * p.PD + od) * p.PH + ohh) * p.PW + ow) * p.Cout + q * 4) = h;
+        if (ok && p.out) *(f16x4 *)(p.out + ((((size_t)n * p.PD + od) * p.PH + ohh) * p.PW + ow) * p.Cout + cb * 16 + q * 4) = h;
         if (!ok) h = (f16x4){0, 0, 0, 0};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -131,27 +159,38 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, cons
 #pragma unroll
             for (int w = 0; w < 4; ++w) v += (double)sRed[(w * 16 + c) * 2 + which];
             const int slot = (td * p.tiles_h + th) * p.tiles_w + tw;
-            p.stats_out[(((size_t)n * (p.tiles_d * p.tiles_h * p.tiles_w) + slot) * p.Cout + c) * 2 + which] = v;
+            p.stats_out[(((size_t)n * (p.tiles_d * p.tiles_h * p.tiles_w) + slot) * p.Cout + cb * 16 + c) * 2 + which] = v;
         }
     }
 }
 
+// every stem the engine accepts: 1..8 input channels, per-axis kernel 1 | 3
 bool stem_mfma_ok(int C, int kd, int kh, int kw, int cout_pad) {
-    return C == 1 && kh == 3 && kw == 3 && (kd == 1 || kd == 3) && cout_pad == 16;
+    auto k13 = [](int k) { return k == 1 || k == 3; };
+    return C >= 1 && C <= 8 && k13(kd) && k13(kh) && k13(kw) && cout_pad % 16 == 0;
 }
+int stem_mfma_ksteps(int C, int taps) { return (C * taps + 31) / 32; }
 
 int stem_mfma_stats_slots(int PD, int PH, int PW) { return ((PD + STEMM_TD - 1) / STEMM_TD) * ((PH + 7) / 8) * ((PW + 7) / 8); }
 
-// `wfrag`: the stem weights as one MFMA "A" fragment (fnn_pack_stem_frag); p.out == nullptr: statistics only.
+// `wfrag`: the stem weights as MFMA "A" fragments [cout block][k-step][64][8]; p.out == nullptr: statistics only.
 int launch_stem_mfma(const StemParams &p_in, const f16 *wfrag, int N, hipStream_t st) {
     StemParams p = p_in;
     if (!stem_mfma_ok(p.C, p.kd, p.kh, p.kw, p.Cout)) return -1;
     p.tiles_d = (p.PD + STEMM_TD - 1) / STEMM_TD;
     p.tiles_h = (p.PH + 7) / 8;
     p.tiles_w = (p.PW + 7) / 8;
-    const int RVOX = (STEMM_TD - 1 + p.kd) * 100;
-    const size_t lds = (size_t)((RVOX + 3) & ~3) * 4 + 4 * 16 * 2 * 4;
-    hipLaunchKernelGGL(stem_mfma_kernel, dim3(N * p.tiles_d * p.tiles_h * p.tiles_w), dim3(256), lds, st, p, wfrag);
+    const int ks = stem_mfma_ksteps(p.C, p.kd * p.kh * p.kw);
+    const int RVOX = (STEMM_TD - 1 + p.kd) * (7 + p.kh) * (7 + p.kw);
+    const size_t lds = (size_t)((p.C * RVOX + 3) & ~3) * 4 + (size_t)ks * 32 * 4 + 4 * 16 * 2 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)stem_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const dim3 grid(N * p.tiles_d * p.tiles_h * p.tiles_w, p.Cout / 16);
+    if (ks == 1) hipLaunchKernelGGL(stem_mfma_kernel<true>, grid, dim3(256), lds, st, p, wfrag, ks);
+    else hipLaunchKernelGGL(stem_mfma_kernel<false>, grid, dim3(256), lds, st, p, wfrag, ks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

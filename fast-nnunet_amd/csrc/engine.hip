@@ -324,18 +324,23 @@ int build_plan(fnn_engine *e) {
         } else { tp.tsd = tp.tsh = tp.tsw = 1; }
         return conv_thin_ok(tp);
     };
+    for (Layer &L : e->layers)
+        if (L.type == Layer::STEM) {
+            if (!stem_mfma_ok(L.cin_real[0], L.k[0], L.k[1], L.k[2], L.cout_pad)) return fail(e, FNN_E_UNSUPPORTED, "stem conv shape");
+            L.mfma_stem = true;
+        }
     if (a.spatial_dims != 2) {
         std::vector<int> consumers(e->layers.size(), 0);
         for (const Layer &L : e->layers)
             for (int i = 0; i < L.n_src; ++i) if (L.src_layer[i] >= 0) consumers[L.src_layer[i]]++;
         for (size_t li = 0; li < e->layers.size(); ++li) {
             Layer &L = e->layers[li];
-            if (L.type == Layer::STEM && stem_mfma_ok(L.cin_real[0], L.k[0], L.k[1], L.k[2], L.cout_pad)) L.mfma_stem = true;
             if (!e->fuse_enabled || L.type != Layer::CONV) continue;
             const int s0 = L.src_layer[0];
             if (s0 < 0) continue;
             Layer &P = e->layers[s0];
-            if (e->fuse_stem && L.n_src == 1 && P.type == Layer::STEM && P.mfma_stem && consumers[s0] == 1 && P.k[0] == L.k[0] &&
+            if (e->fuse_stem && L.n_src == 1 && P.type == Layer::STEM && P.mfma_stem && P.cin_real[0] == 1 && P.cout_pad == 16 &&
+                consumers[s0] == 1 && P.k[0] == L.k[0] &&
                 thin_probe(L, FUSE_STEM, nullptr)) {
                 L.fuse = FUSE_STEM; P.virtual_out = true;
             } else if (e->fuse_tconv && L.n_src == 2 && P.type == Layer::TCONV && consumers[s0] == 1 && P.cout_pad == 16 && thin_probe(L, FUSE_TCONV, &P)) {
@@ -352,7 +357,7 @@ int build_plan(fnn_engine *e) {
         if (L.type == Layer::STEM) {
             const int T = L.k[0] * L.k[1] * L.k[2];
             L.w_off = fp; fp += (size_t)L.cin_real[0] * T * L.cout_pad;
-            if (L.mfma_stem) { L.w_off2 = wpk; wpk += 512; }
+            if (L.mfma_stem) { L.w_off2 = wpk; wpk += (size_t)(L.cout_pad / 16) * stem_mfma_ksteps(L.cin_real[0], L.k[0] * L.k[1] * L.k[2]) * 512; }
         } else if (L.type == Layer::CONV) {
             const int T = L.k[0] * L.k[1] * L.k[2];
             L.chunks = (L.cin_pad[0] + (L.n_src > 1 ? L.cin_pad[1] : 0)) / 16;
@@ -375,8 +380,7 @@ int build_plan(fnn_engine *e) {
         if (L.fp8) { L.oscale_off = fp; fp += L.cout_pad; }
         if (L.has_norm) { L.gamma_off = fp; fp += L.cout_pad; L.beta_off = fp; fp += L.cout_pad; }
         L.stats_slots = FNN_STAT_REPL;
-        if (L.type == Layer::STEM) L.stats_slots = L.mfma_stem ? stem_mfma_stats_slots(L.out_dims[0], L.out_dims[1], L.out_dims[2])
-                                                                 : stem_stats_slots(L.out_dims[0], L.out_dims[1], L.out_dims[2]);
+        if (L.type == Layer::STEM) L.stats_slots = stem_mfma_stats_slots(L.out_dims[0], L.out_dims[1], L.out_dims[2]);
         else if (L.type == Layer::CONV && L.fuse) L.stats_slots = FNN_STAT_REPL;
         else if (L.type == Layer::CONV) {
             ConvParams q{};
@@ -604,14 +608,8 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.tiles_h = (p.PH + FNN_TILE_H - 1) / FNN_TILE_H;
             p.tiles_w = (p.PW + FNN_TILE_W - 1) / FNN_TILE_W;
             Scope sc(e, st, FAM_STEM, L.flops * nb);
-#ifdef FNN_BOUND_FUSE
-            if (li + 1 < e->layers.size() && e->layers[li + 1].type == Layer::CONV && e->layers[li + 1].s[1] == 1) rc = 0; else
-#endif
-            if (L.mfma_stem) {
-                if (L.virtual_out) p.out = nullptr;                   // statistics only: the consumer recomputes the values
-                rc = launch_stem_mfma(p, fw.wpk + L.w_off2, nb, st);
-            } else
-            rc = launch_stem(p, nb, st);
+            if (L.virtual_out) p.out = nullptr;                       // statistics only: the consumer recomputes the values
+            rc = launch_stem_mfma(p, fw.wpk + L.w_off2, nb, st);
         } else if (L.type == Layer::CONV) {
             ConvParams p{};
             p.n_src = L.n_src;
@@ -632,14 +630,6 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.fp8 = L.fp8; p.oscale = L.fp8 ? fw.fparam + L.oscale_off : nullptr; p.act_mult = FNN_FP8_ACT_MULT;
             p.tile_d = FNN_TILE_D;
             Scope sc(e, st, FAM_CONV, L.flops * nb, L.bytes * nb);
-#ifdef FNN_BOUND_FUSE
-            {   // upper bound of fusing the stem / the last transposed conv into this conv's staging: the producer is
-                // not launched and this conv reads its source 0 from a 16 KB window (results are wrong)
-                const Layer &P = e->layers[L.src_layer[0] >= 0 ? L.src_layer[0] : 0];
-                const bool full = L.in_dims[0] == e->arch.patch[0] && L.in_dims[1] == e->arch.patch[1] && L.in_dims[2] == e->arch.patch[2];
-                p.bound_mask0 = full && L.s[1] == 1 && L.src_layer[0] >= 0 && (P.type == Layer::STEM || P.type == Layer::TCONV);
-            }
-#endif
             if (L.fuse) {
                 ThinParams tp{};
                 tp.c = p; tp.fuse = L.fuse;
@@ -684,9 +674,6 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.out = out; p.ksteps = L.ksteps; p.nblk = L.cout_pad / 16;
             if (L.virtual_out) continue;                              // computed inside its consumer (conv3d_thin.hip)
             Scope sc(e, st, FAM_TCONV, L.flops * nb);
-#ifdef FNN_BOUND_FUSE
-            if (L.out_dims[0] == e->arch.patch[0] && L.out_dims[1] == e->arch.patch[1] && L.out_dims[2] == e->arch.patch[2]) rc = 0; else
-#endif
             rc = launch_tconv(p, st);
         }
         if (rc != 0) return fail(e, rc == -1 ? FNN_E_UNSUPPORTED : FNN_E_HIP, "kernel launch failed at layer %zu (rc=%d)", li, rc);
@@ -1205,9 +1192,6 @@ int predict_impl(fnn_engine *e, int fold0, int n_folds, const float *vol, const 
     if (lab_tmp) (void)hipFree(lab_tmp);
     if (rc) return rc;
     if (e->profiling) collect_profile(e, vp.n_patches * n_folds);
-#ifdef FNN_BOUND_FUSE
-    flag = 0;
-#endif
     if (flag)
         return fail(e, FNN_E_INF, "Encountered inf in predicted array. Aborting... If this problem persists, reduce "
                                   "value_scaling_factor in compute_gaussian or increase the dtype of predicted_logits to fp32");
@@ -1300,12 +1284,17 @@ int fnn_load_weights(fnn_engine *e, int fold, const float *blob, int64_t count) 
                 for (int t = 0; t < T; ++t)
                     for (int co = 0; co < L.cout_real; ++co)
                         fp[L.w_off + ((size_t)c * T + t) * L.cout_pad + co] = W[((size_t)co * C + c) * T + t];
-            if (L.mfma_stem)                                          // MFMA "A" fragment: lane (cout, k-group), k = c * T + tap
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int k = 8 * (lane >> 4) + j, co = lane & 15;
-                        wpk[L.w_off2 + (size_t)lane * 8 + j] = f2h_bits(k < C * T && co < L.cout_real ? W[(size_t)co * C * T + k] : 0.f);
-                    }
+            if (L.mfma_stem) {                                        // MFMA "A" fragments [cout block][k-step]: lane (cout, k-group), k = c * T + tap
+                const int KST = stem_mfma_ksteps(C, T);
+                for (int cb = 0; cb < L.cout_pad / 16; ++cb)
+                    for (int ks = 0; ks < KST; ++ks)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int k = ks * 32 + 8 * (lane >> 4) + j, co = cb * 16 + (lane & 15);
+                                wpk[L.w_off2 + ((size_t)(cb * KST + ks) * 64 + lane) * 8 + j] =
+                                    f2h_bits(k < C * T && co < L.cout_real ? W[(size_t)co * C * T + k] : 0.f);
+                            }
+            }
         } else if (L.type == Layer::CONV) {
             if (L.fp8) pack_conv_fp8(L, W, (uint8_t *)(wpk.data() + L.w_off), fp.data() + L.oscale_off);
             else pack_conv(L, W, wpk.data() + L.w_off);

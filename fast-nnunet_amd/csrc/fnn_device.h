@@ -59,7 +59,6 @@ struct ConvParams {
     int fp8;                     // conv3d_zr8_kernel: e4m3 operands (weights packed at 8 B per lane)
     const float *oscale;         // fp8: [Cout] w_scale[cout] / act_mult, applied to the accumulators before the bias
     float act_mult;              // fp8: activations are quantised as e4m3(value * act_mult)
-    int bound_mask0;             // timing-only builds (-DFNN_BOUND_FUSE): source 0 is read from a few KB (its producer is skipped)
     int stats_slots;             // rows per batch item in stats_out (conv3d_stats_slots): FNN_STAT_REPL replicas filled by
                                  // atomics, or one row per tile written with plain stores (ZR kernel)
 };
@@ -257,11 +256,10 @@ int conv3d_ksteps(int packing, int taps);
 int conv3d_kstep_tap(int packing, int ks, int half, int taps);     // linear tap index, or -1 = zero padding
 int launch_conv3d_zr(const ConvParams &p, hipStream_t st);
 int conv3d_stats_slots(const ConvParams &p);                           // rows per item the layer's kernel writes into stats_out
-int stem_stats_slots(int PD, int PH, int PW);
-int launch_stem(const StemParams &p, int N, hipStream_t st);
 int launch_tconv(const TconvParams &p, hipStream_t st);
 bool stem_mfma_ok(int C, int kd, int kh, int kw, int cout_pad);
 int stem_mfma_stats_slots(int PD, int PH, int PW);
+int stem_mfma_ksteps(int C, int taps);
 int launch_stem_mfma(const StemParams &p, const f16 *wfrag, int N, hipStream_t st);    // p.out == nullptr: statistics only
 bool gather_ok(const GatherParams &p);
 int launch_gather(const GatherParams &p, hipStream_t st);
