@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools_ab.sh libA.so libB.so [rounds]
+# usage (on the GPU box, from the repo root): bash tools/ab.sh libA.so libB.so [rounds]
 # Alternates two builds of libfnn_hip.so (paths relative to fast-nnunet_amd/csrc) inside one session: boxes of the pool
 # differ by +-3 %, so two builds can only be compared back to back on the same box.
 root=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -1,5 +1,5 @@
 """Diagnostic: run one conv layer shape through fnn_op_conv3d of a -DFNN_STAMPS build (prints s_memtime segment means).
-usage: python tools_stamps.py N CIN COUT D H W [kd kh kw] [cin2]"""
+usage: python tools/stamps.py N CIN COUT D H W [kd kh kw] [cin2]"""
 import sys
 import numpy as np
 sys.path.insert(0, '.')

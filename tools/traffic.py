@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic per kernel family from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
-    python tools_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json]
+    python tools/traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json]
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads
 (MI355X_MICROARCH.md, HBM section), so reads are doubled; WRITE_SIZE is exact for 16-byte-per-lane stores and
@@ -12,7 +12,7 @@ import csv
 import json
 import sys
 
-FAMILIES = {'conv3d_': 'conv3d_mfma', 'stem_conv': 'stem', 'tconv_mfma': 'tconv', 'seg_head': 'seg_head_accumulate',
+FAMILIES = {'conv3d_': 'conv3d_mfma', 'conv_thin': 'conv3d_mfma', 'stem_mfma': 'stem', 'gather_head': 'seg_head_accumulate', 'tconv_mfma': 'tconv', 'seg_head': 'seg_head_accumulate',
             'finalize': 'finalize', 'stats_finalize': 'stats_finalize'}
 
 
