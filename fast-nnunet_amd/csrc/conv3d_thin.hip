@@ -18,6 +18,12 @@
 // Arithmetic of the stem: x and the weights rounded to fp16, products exact, fp32 accumulation in the MFMA's order,
 // one rounding to fp16 - the same contract as every other conv of the engine.
 //
+// Measured and dropped (round 2): the single-channel (1, 3, 3) stem as ONE v_mfma_f32_32x32x16_f16 per 32 voxels (K = 16
+// holds the 9 taps, raw window kept in fp16, eight ds_read_u16 at constant offsets, A rows permuted so that a lane ends
+// up with 8 consecutive channels = one 16-byte store): 2.25x fewer instructions on paper, SLOWER on the GPU - stem pass
+// 568 us against 337 us per batch, fused consumer 1417 us against 1020 us (the d16 loads chain through their destination
+// registers and the 32x32 MFMA's result arrives 64 cycles late).  The 16x16x32 form below stays.
+//
 // Replaces (with conv3d.hip / misc.hip) the ConvDropoutNormReLU stacks and the transpconvs of the reference's
 // PlainConvUNet decoder, nnUNetDistillationTrainer.py:141-173; patch slicing predict_from_raw_data.py:560-566.
 #include "fnn_device.h"
