@@ -254,207 +254,9 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
 static int lds_pitch(int IW) { return (IW & 7) ? ((IW + 3) & ~7) + 4 : IW; }
 
 // ----------------------------------------------------------------------------
-// pipelined MFMA conv (stride 1): the hot kernel
-// ----------------------------------------------------------------------------
-// Same GEMM view as conv3d_mfma_kernel, restructured around what rocprof showed
-// on the first version (latency-bound staging, weights re-staged through LDS):
-//   * activations: halo tile of a 16-channel chunk in LDS, DOUBLE BUFFERED; the
-//     global loads of chunk c+1 are issued before the MFMAs of chunk c and
-//     normalised + written to the other buffer afterwards (one barrier per chunk);
-//   * weights: never touch LDS - each wave streams its 1-KiB fragments straight
-//     from L2/L1 into registers, two k-steps ahead (every workgroup of a layer
-//     reads the same <= 2.8 MB, so they stay cache resident);
-//   * MB = 4 or 8 column blocks per wave (tile 4x8x8 or 8x8x8 voxels): thin
-//     layers get twice the work per staged halo voxel and per weight fragment;
-//   * workgroup ids are remapped so that every XCD (private L2) walks a
-//     contiguous range of tiles and neighbouring halos hit the same L2.
-template <int NB, int MB>
-__global__ __launch_bounds__(256) void conv3d_pipe_kernel(const ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int TD = MB;                                 // 4 waves x (MB / 4) depth slices
-    constexpr int PF = 8;                                  // halo elements (16 B) prefetched per thread
-
-    // XCD-aware, bijective remap (blocks b and b + 8 share an XCD)
-    int t;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
-    }
-    const int tw = t % p.tiles_w; t /= p.tiles_w;
-    const int th = t % p.tiles_h; t /= p.tiles_h;
-    const int td = t % p.tiles_d;
-    const int n = t / p.tiles_d;
-    const int cb0 = blockIdx.y * NB;
-
-    const int od0 = td * TD, oh0 = th * FNN_TILE_H, ow0 = tw * FNN_TILE_W;
-    const int ID = TD - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
-    const int IVOX = ID * IH * IW;
-    const int T = p.kd * p.kh * p.kw;
-    const int cin_total = p.chunks * 16;
-    // LDS image of the halo tile: row pitch PWp voxels, and the two 16-byte channel halves of a voxel are
-    // swapped on odd rows (swz) - with PWp = 4 (mod 8) every ds_read_b128 of an MFMA operand is then
-    // bank-conflict free (the dense 10-voxel pitch was 2-way conflicted on every read)
-    const int swz = (IW & 7) != 0;
-    const int PWp = swz ? ((IW + 3) & ~7) + 4 : IW;
-    const int abytes = (ID * IH * PWp * 32 + 1023) & ~1023;
-
-    char *sA0 = smem;
-    float2 *sSS = (float2 *)(smem + 2 * abytes);
-    int *sTap = (int *)(sSS + cin_total);
-
-    {
-        if (tid < 2 * p.ksteps) {
-            int off = 0, par = 0;
-            if (tid < T) {
-                const int a = tid / (p.kh * p.kw), b = (tid / p.kw) % p.kh, c = tid % p.kw;
-                off = ((a * IH + b) * PWp + c) * 32;
-                par = swz & b & 1;
-            }
-            sTap[tid * 2] = off + 16 * par;                  // column for lanes with kgp = 0
-            sTap[tid * 2 + 1] = off + 16 * (1 - par);        // kgp = 1
-        }
-        for (int c = tid; c < cin_total; c += 256) {
-            const int s = (c < p.src[0].C) ? 0 : 1;
-            const int cl = c - (s ? p.src[0].C : 0);
-            sSS[c] = p.src[s].ss ? make_float2(p.src[s].ss[(size_t)(2 * n) * p.src[s].C + cl], p.src[s].ss[(size_t)(2 * n + 1) * p.src[s].C + cl])
-                                 : make_float2(1.f, 0.f);
-        }
-    }
-
-    int base[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        const int r = lane & 15;
-        const int od_l = wave + 4 * (mb >> 2), oh_l = 2 * (mb & 3) + (r >> 3), ow_l = r & 7;
-        base[mb] = ((od_l * IH + oh_l) * PWp + ow_l) * 32;
-    }
-    const int kgp = ((lane >> 4) & 1) ^ (swz & ((lane & 15) >> 3));     // channel half after the row swizzle
-
-    f32x4 acc[MB][NB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 bv[NB];                                           // bias of this lane's 4 channels per cout block
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const float4 *)(p.bias + (cb0 + nb) * 16 + (lane >> 4) * 4);
-
-    // weight stream: fragment of global k-step ts (= chunk * ksteps + ks) of cout block nb
-    const int TS = p.chunks * p.ksteps;
-    const f16 *wbase[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) wbase[nb] = p.wpk + (size_t)(cb0 + nb) * TS * 512 + lane * 8;
-    f16x8 w0[NB], w1[NB], w2[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        w0[nb] = *(const f16x8 *)(wbase[nb]);
-        w1[nb] = *(const f16x8 *)(wbase[nb] + (size_t)(TS > 1 ? 1 : 0) * 512);
-    }
-
-    __syncthreads();
-
-    const int cg = tid & 1;
-    int offv[PF];                                           // global voxel index of this thread's halo elements
-    int ldso[PF];                                           // and where they go in the LDS image
-    {
-        const int id0 = od0 - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int idx = tid + u * 256;
-            const int v = idx >> 1;
-            const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
-            const int gd = id0 + zd, gh = ih0 + zh, gw = iw0 + zw;
-            const bool ok = gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 && gw < p.Wi;
-            offv[u] = idx < IVOX * 2 ? (ok ? ((n * p.Di + gd) * p.Hi + gh) * p.Wi + gw : -1) : -2;
-            ldso[u] = ((zd * IH + zh) * PWp + zw) * 32 + ((cg ^ (swz & zh & 1)) * 16);
-        }
-    }
-    f16x8 xr[PF];
-
-    auto issue = [&](int ch) {
-        const int c_glob = ch * 16;
-        const int s = (c_glob < p.src[0].C) ? 0 : 1;
-        const f16 *sp = p.src[s].ptr + (c_glob - (s ? p.src[0].C : 0) + cg * 8);
-        const int sC = p.src[s].C;
-#pragma unroll
-        for (int u = 0; u < PF; ++u)
-            if (u * 256 < IVOX * 2)                        // workgroup-uniform: skip rounds past the tile
-                xr[u] = *(const f16x8 *)(sp + (size_t)(offv[u] >= 0 ? offv[u] : 0) * sC);
-    };
-    auto commit = [&](int ch, char *dst) {
-        const int c_glob = ch * 16;
-        const int s = (c_glob < p.src[0].C) ? 0 : 1;
-        const f16 slope_h = (f16)p.src[s].slope;
-        float sc[8], sh[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float2 v = sSS[c_glob + cg * 8 + j];
-            sc[j] = v.x; sh[j] = v.y;
-        }
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            if (u * 256 >= IVOX * 2 || offv[u] == -2) continue;
-            f16x8 o;
-            if (offv[u] >= 0) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)xr[u][j], sc[j], sh[j]);
-                o = __builtin_elementwise_max(o, o * slope_h);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
-            }
-            *(f16x8 *)(dst + ldso[u]) = o;
-        }
-    };
-
-    issue(0);
-    commit(0, sA0);
-    __syncthreads();
-
-    int ts = 0;
-    for (int ch = 0; ch < p.chunks; ++ch) {
-        const char *sA = sA0 + (ch & 1) * abytes;
-        const bool more = ch + 1 < p.chunks;
-        if (more) issue(ch + 1);
-        for (int ks = 0; ks < p.ksteps; ++ks, ++ts) {
-            const int tn = ts + 2 < TS ? ts + 2 : TS - 1;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) w2[nb] = *(const f16x8 *)(wbase[nb] + (size_t)tn * 512);
-            const int toff = sTap[(2 * ks + (lane >> 5)) * 2 + kgp];
-            f16x8 xf[MB];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) xf[mb] = *(const f16x8 *)(sA + base[mb] + toff);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nb], xf[mb], acc[mb][nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) { w0[nb] = w1[nb]; w1[nb] = w2[nb]; }
-        }
-        if (more) commit(ch + 1, sA0 + ((ch + 1) & 1) * abytes);
-        __syncthreads();
-    }
-
-    // ---- epilogue: bias, fp16 store, statistics
-    {
-        float t1[NB][4], t2[NB][4];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
-        tile_epilogue<NB, MB>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
-        if (p.stats_out) stats_to_global<NB>(p, t1, t2, (float *)smem, n, cb0, wave, lane, tid);
-    }
-}
-
-
-// ----------------------------------------------------------------------------
 // pipelined MFMA conv, weights through LDS per chunk (stride 1)
 // ----------------------------------------------------------------------------
-// Variant of conv3d_pipe_kernel without any global load inside the k-loop: vmcnt is an in-order
+// No global load inside the k-loop: vmcnt is an in-order
 // counter, so a weight fragment requested after the halo prefetch could not be consumed before the
 // whole prefetch had landed, and every chunk stalled on it.  Here the prefetch of chunk c+1 covers the
 // halo elements AND the chunk's weight fragments (registers), the k-loop reads both from LDS, and the
@@ -693,30 +495,6 @@ static int launch_ldsk(ConvParams p, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-static size_t pipe_lds_bytes(const ConvParams &p, int mb) {
-    const int ID = mb - 1 + p.kd, IH = FNN_TILE_H - 1 + p.kh, IW = FNN_TILE_W - 1 + p.kw;
-    size_t b = 2 * (size_t)((ID * IH * lds_pitch(IW) * 32 + 1023) & ~1023);
-    b += (size_t)p.chunks * 16 * 8 + 4 * p.ksteps * 4 + 64;
-    return b < 4096 ? 4096 : b;
-}
-
-template <int NB, int MB>
-static int launch_pipe(ConvParams p, hipStream_t st) {
-    p.tile_d = MB;
-    p.tiles_d = (p.Do + MB - 1) / MB;
-    p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
-    p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
-    const size_t lds = pipe_lds_bytes(p, MB);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)conv3d_pipe_kernel<NB, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
-    hipLaunchKernelGGL((conv3d_pipe_kernel<NB, MB>), grid, dim3(256), lds, st, p);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
-}
-
 // ----------------------------------------------------------------------------
 // persistent MFMA conv (stride 1) for layers with many tiles
 // ----------------------------------------------------------------------------
@@ -741,7 +519,7 @@ __global__ __launch_bounds__(256, (NB == 1 && MB == 4 && WRES && PF == 4) ? 3 : 
     const int IVOX = ID * IH * IW;
     const int T = p.kd * p.kh * p.kw;
     const int TS = p.chunks * p.ksteps;
-    const int swz = p.sw == 1 && (IW & 7) != 0;                       // LDS image: see conv3d_pipe_kernel
+    const int swz = p.sw == 1 && (IW & 7) != 0;                       // LDS image: see conv3d_lds_kernel
     const int PWp = swz ? ((IW + 3) & ~7) + 4 : IW;
     const int abytes = (ID * IH * PWp * 32 + 1023) & ~1023;
     const int cb0 = blockIdx.y * NB;
@@ -796,14 +574,22 @@ __global__ __launch_bounds__(256, (NB == 1 && MB == 4 && WRES && PF == 4) ? 3 : 
         sTap[tid * 2 + 1] = off + 16 * (1 - par);
     }
     const int cg = tid & 1;
-    int rel[PF];                                                      // packed halo coords of this thread's elements
+    // packed halo coords of this thread's elements: registers, or - for the 12-element prefetch of the strided kernels,
+    // which otherwise spill - a table in LDS behind the statistics scratch
+    // (tried for the strided kernels' 12-element prefetch, which spills 20-48 B per lane: the table's 12 KB push the
+    // 32 -> 64 strided conv over 80 KB, one workgroup per CU: -6 % end to end; the spill stays)
+    constexpr bool REL_LDS = false && PF >= 12;
+    int *sRel = (int *)(sRed + 4 * NB * 16 * 2) + tid;
+    int relr[REL_LDS ? 1 : PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const int idx = tid + u * 256;
         const int v = idx >> 1;
         const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
-        rel[u] = idx < IVOX * 2 ? (zd << 16) | (zh << 8) | zw : -1;
+        const int rv = idx < IVOX * 2 ? (zd << 16) | (zh << 8) | zw : -1;
+        if (REL_LDS) sRel[u * 256] = rv; else relr[REL_LDS ? 0 : u] = rv;
     }
+#define FNN_REL(u) (REL_LDS ? sRel[(u) * 256] : relr[REL_LDS ? 0 : (u)])
     int base[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
@@ -859,9 +645,10 @@ __global__ __launch_bounds__(256, (NB == 1 && MB == 4 && WRES && PF == 4) ? 3 : 
         const int id0 = od0 * p.sd - p.pd, ih0 = oh0 * p.sh - p.ph, iw0 = ow0 * p.sw - p.pw;
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const unsigned gd = (unsigned)(id0 + (rel[u] >> 16)), gh = (unsigned)(ih0 + ((rel[u] >> 8) & 255)),
-                           gw = (unsigned)(iw0 + (rel[u] & 255));
-            const bool ok = rel[u] >= 0 && gd < (unsigned)p.Di && gh < (unsigned)p.Hi && gw < (unsigned)p.Wi;
+            const int rel_u = FNN_REL(u);
+            const unsigned gd = (unsigned)(id0 + (rel_u >> 16)), gh = (unsigned)(ih0 + ((rel_u >> 8) & 255)),
+                           gw = (unsigned)(iw0 + (rel_u & 255));
+            const bool ok = rel_u >= 0 && gd < (unsigned)p.Di && gh < (unsigned)p.Hi && gw < (unsigned)p.Wi;
             // two 24-bit mads (full rate; v_mul_lo_u32 is quarter rate) instead of a held offset: Di * Hi < 2^24 (launcher)
             offv[u] = ok ? (int)(__umul24(__umul24(gd, (unsigned)p.Hi) + gh, (unsigned)p.Wi) + gw) : -1;
         }
@@ -915,8 +702,9 @@ __global__ __launch_bounds__(256, (NB == 1 && MB == 4 && WRES && PF == 4) ? 3 : 
 #endif
             o = __builtin_elementwise_max(o, o * slope_h);
             if (offv[u] < 0) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};             // the conv's zero padding
-            const int zd = rel[u] >> 16, zh = (rel[u] >> 8) & 255, zw = rel[u] & 255;
-            if (rel[u] >= 0) *(f16x8 *)(dst + ((zd * IH + zh) * PWp + zw) * 32 + ((cg ^ (swz & zh & 1)) * 16)) = o;
+            const int rel_u = FNN_REL(u);
+            const int zd = rel_u >> 16, zh = (rel_u >> 8) & 255, zw = rel_u & 255;
+            if (rel_u >= 0) *(f16x8 *)(dst + ((zd * IH + zh) * PWp + zw) * 32 + ((cg ^ (swz & zh & 1)) * 16)) = o;
         }
         if (!WRES) {
 #pragma unroll
@@ -1050,12 +838,14 @@ __global__ __launch_bounds__(256, (NB == 1 && MB == 4 && WRES && PF == 4) ? 3 : 
         n_cur = n_next; od0 = nod0; oh0 = noh0; ow0 = now0;
     }
     FNN_STAMP_FLUSH(p.dbg);
+#undef FNN_REL
 }
 
-static size_t persist_lds_bytes(const ConvParams &p, int nb, int mb, bool wres, bool sbuf = false) {
+static size_t persist_lds_bytes(const ConvParams &p, int nb, int mb, bool wres, bool sbuf = false, int pf = 8) {
     const int ID = (mb - 1) * p.sd + p.kd, IH = (FNN_TILE_H - 1) * p.sh + p.kh, IW = (FNN_TILE_W - 1) * p.sw + p.kw;
     const size_t ab = (size_t)((ID * IH * (p.sw == 1 ? lds_pitch(IW) : IW) * 32 + 1023) & ~1023);
-    return (wres && !sbuf ? 2 : 1) * ab + (size_t)nb * (wres ? p.chunks : 1) * p.ksteps * 1024 + 256 + (size_t)4 * nb * 16 * 2 * 8;
+    return (wres && !sbuf ? 2 : 1) * ab + (size_t)nb * (wres ? p.chunks : 1) * p.ksteps * 1024 + 256 + (size_t)4 * nb * 16 * 2 * 8 +
+           (false && pf >= 12 ? (size_t)pf * 256 * 4 : 0);
 }
 
 template <int NB, int MB, bool WRES, int KS, int CH = 0, int PF = 8, bool SBUF = false>
@@ -1067,7 +857,7 @@ static int launch_persist_ks(ConvParams p, int wgs_per_cu, hipStream_t st, int g
     const int total = p.N * p.tiles_d * p.tiles_h * p.tiles_w;
     p.ident_ss = conv3d_identity_ss();
     if (!p.ident_ss) return -2;
-    const size_t lds = persist_lds_bytes(p, NB, MB, WRES, SBUF);
+    const size_t lds = persist_lds_bytes(p, NB, MB, WRES, SBUF, PF);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)conv3d_persist_kernel<NB, MB, WRES, KS, CH, PF, SBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1191,8 +981,8 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
         nb = cand[pick][0];
         const int mbsel = cand[pick][1];
         static const bool no_persist = getenv("FNN_CONV_NO_PERSIST") != nullptr;
-        static const int persist_max_nb = getenv("FNN_PERSIST_MAX_NB") ? atoi(getenv("FNN_PERSIST_MAX_NB")) : 1;   // A-B aid
-        if (!no_persist && p.ksteps <= 14 && nb <= persist_max_nb) {
+        // one cout block only: the NB = 2 / 4 forms need 272-644 B of scratch per lane next to their accumulators
+        if (!no_persist && p.ksteps <= 14 && nb == 1) {
             // persistent variants: a workgroup walks a range of tiles and prefetches across tile boundaries.
             // Weights resident in LDS when the whole cout group fits next to a double-buffered halo tile with
             // 2 workgroups per CU, otherwise they travel with the prefetch chunk by chunk.
@@ -1208,22 +998,16 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
                     if (per_cu < 2) continue;
                     const int wpc = per_cu > persist_wpc ? persist_wpc : per_cu;
 #define FNN_PERSIST(NBv, MBv) (wres ? launch_persist<NBv, MBv, true>(p, wpc, st) : launch_persist<NBv, MBv, false>(p, wpc, st))
-                    if (nb == 1) return mb == 8 ? FNN_PERSIST(1, 8) : FNN_PERSIST(1, 4);
-                    if (nb == 2) return mb == 8 ? FNN_PERSIST(2, 8) : FNN_PERSIST(2, 4);
-                    if (mb == 4) return FNN_PERSIST(4, 4);
+                    return mb == 8 ? FNN_PERSIST(1, 8) : FNN_PERSIST(1, 4);
 #undef FNN_PERSIST
                 }
             }
         }
-        static const bool stream_w = getenv("FNN_CONV_STREAMW") != nullptr;   // A-B aid: weights streamed from L2
-        if (!stream_w && p.ksteps <= 14) {
+        if (p.ksteps <= 14) {
             if (nb == 1) return mbsel == 8 ? launch_ldsk<1, 8>(p, st) : launch_ldsk<1, 4>(p, st);
             if (nb == 2) return mbsel == 8 ? launch_ldsk<2, 8>(p, st) : launch_ldsk<2, 4>(p, st);
             return launch_ldsk<4, 4>(p, st);
         }
-        if (nb == 1) return mbsel == 8 ? launch_pipe<1, 8>(p, st) : launch_pipe<1, 4>(p, st);
-        if (nb == 2) return mbsel == 8 ? launch_pipe<2, 8>(p, st) : launch_pipe<2, 4>(p, st);
-        return launch_pipe<4, 4>(p, st);
     }
     static const bool strided_v1 = getenv("FNN_CONV_STRIDED_V1") != nullptr;   // A-B aid
     if (!force_v1 && !strided_v1 && p.ksteps <= 14) {
@@ -1237,14 +1021,14 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
             const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;
             const long long tiles = (long long)plan_n * ((p.Do + 1) / 2) * p.tiles_h * p.tiles_w;
             const int groups = (p.Cout / 16) / nbs;
-            if (!no_sp && nbs == 2 && ID * IH * IW * 2 <= 12 * 256 && persist_lds_bytes(p, 2, 2, false) <= 80 * 1024 &&
+            if (!no_sp && nbs == 2 && ID * IH * IW * 2 <= 12 * 256 && persist_lds_bytes(p, 2, 2, false, false, 12) <= 80 * 1024 &&
                 tiles >= 8LL * (512 / groups) && 512 / groups >= 8) {
                 const int gx = 512 / groups;                       // 2 resident workgroups per CU over all cout groups
                 if (p.chunks == 1) {
                     // weights resident next to a single halo buffer: the 28 KB of weight fragments no longer travel with
                     // every 37 KB halo tile (+1 % on the benchmark)
                     static const bool wres = getenv("FNN_STRIDED_NO_WRES") == nullptr;              // A-B aid
-                    if (wres && persist_lds_bytes(p, 2, 2, true, true) <= 80 * 1024)
+                    if (wres && persist_lds_bytes(p, 2, 2, true, true, 12) <= 80 * 1024)
                         return launch_persist_ks<2, 2, true, 0, 1, 12, true>(p, 2, st, gx);
                     return launch_persist_ks<2, 2, false, 0, 1, 12>(p, 2, st, gx);
                 }
