@@ -18,7 +18,7 @@ FAMILIES = {'conv3d_': 'conv3d_mfma', 'conv_thin': 'conv3d_mfma', 'stem_mfma': '
 
 def family(name):
     for k, v in FAMILIES.items():
-        if name.startswith(k) or name.startswith('void ' + k):
+        if k in name:
             return v
     return 'other'
 
