@@ -11,7 +11,7 @@ Gaussian blending: 600 patches per volume.  Synthetic data, random-init weights
 (seed 1234).  One step = one whole volume through
 ``nnUNetPredictor.predict_sliding_window_return_logits`` with the volume already
 resident in HBM.  N > 1 shards the patches of the SAME volume over the ranks
-(strong scaling) with a halo exchange over RCCL and ends with every rank holding
+(strong scaling) with an exchange of patch activations over RCCL and ends with every rank holding
 the assembled label map (``--gather``); without a launcher ``--gpus N`` starts
 the N ranks itself.
 
@@ -381,7 +381,7 @@ def main():
                    'accumulators': accumulate_in,
                    'gflop_per_patch': round(flops_patch / 1e9, 2),
                    'step_output': assembly,
-                   'parallelism': f'patch-sharded x{world}, halo exchange + gather over RCCL' if distributed else 'single GPU'},
+                   'parallelism': f'patch-sharded x{world}, patch-activation exchange + slab gather over RCCL' if distributed else 'single GPU'},
     }
     if dt_nogather is not None:
         result['ms_per_step_compute_and_halo_only'] = round(dt_nogather / args.steps * 1e3, 3)

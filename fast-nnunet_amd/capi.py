@@ -62,7 +62,7 @@ class Profile(C.Structure):
 
 EXPORTS = ['fnn_abi_version', 'fnn_last_error', 'fnn_create', 'fnn_destroy', 'fnn_weight_count', 'fnn_load_weights',
            'fnn_set_gaussian', 'fnn_predict_volume', 'fnn_predict_volume_ensemble', 'fnn_predict_labels',
-           'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_labels_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_export_probabilities', 'fnn_resample', 'fnn_compute_steps', 'fnn_plan_volume', 'fnn_fp8_e4m3_encode',
+           'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_labels_box', 'fnn_feature_channels', 'fnn_patch_features', 'fnn_gather_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_export_probabilities', 'fnn_resample', 'fnn_compute_steps', 'fnn_plan_volume', 'fnn_fp8_e4m3_encode',
            'fnn_set_profiling', 'fnn_get_profile', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d']
 
 _lib = None
@@ -103,6 +103,10 @@ def load_library() -> C.CDLL:
     lib.fnn_accumulate_patches.argtypes = [vp, i32, vp, P64, C.POINTER(Opts), P64, i64, P64, P64, vp]
     lib.fnn_normalize_box.argtypes = [vp, vp, P64, C.POINTER(Opts), P64, P64, P64, P64, vp]
     lib.fnn_labels_box.argtypes = [vp, vp, P64, C.POINTER(Opts), P64, P64, P64, P64, vp]
+    lib.fnn_feature_channels.argtypes = [vp]
+    lib.fnn_feature_channels.restype = i64
+    lib.fnn_patch_features.argtypes = [vp, i32, vp, P64, C.POINTER(Opts), P64, i64, vp, vp]
+    lib.fnn_gather_box.argtypes = [vp, i32, vp, vp, C.POINTER(C.c_int32), P64, C.POINTER(Opts), P64, P64, vp, vp]
     lib.fnn_forward_patches.argtypes = [vp, i32, vp, i32, vp, vp]
     lib.fnn_argmax_labels.argtypes = [vp, vp, i32, i32, i64, vp, vp]
     lib.fnn_nonzero_bbox.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64), vp]
@@ -347,6 +351,23 @@ class Engine:
         a = [(C.c_int64 * 3)(*[int(i) for i in v]) for v in (box_lo, box_hi, out_lo, out_hi)]
         check(self.lib.fnn_normalize_box(self.handle, acc_ptr, shp, C.byref(opts), a[0], a[1], a[2], a[3], out_ptr),
               self.lib, self.handle)
+
+    @property
+    def feature_channels(self) -> int:
+        return int(self.lib.fnn_feature_channels(self.handle))
+
+    def patch_features(self, vol_ptr, shape, opts, patch_ids, feat_ptr, fss_ptr, fold=0):
+        shp = (C.c_int64 * 4)(*[int(i) for i in shape])
+        ids = (C.c_int64 * max(1, len(patch_ids)))(*[int(i) for i in patch_ids])
+        check(self.lib.fnn_patch_features(self.handle, fold, vol_ptr, shp, C.byref(opts), ids, len(patch_ids), feat_ptr, fss_ptr),
+              self.lib, self.handle)
+
+    def gather_box(self, feat_ptr, fss_ptr, slot_of_patch, shape, opts, out_lo, out_hi, logits_ptr=None, labels_ptr=None, fold=0):
+        shp = (C.c_int64 * 4)(*[int(i) for i in shape])
+        tab = np.ascontiguousarray(slot_of_patch, np.int32)
+        lo, hi = (C.c_int64 * 3)(*[int(i) for i in out_lo]), (C.c_int64 * 3)(*[int(i) for i in out_hi])
+        check(self.lib.fnn_gather_box(self.handle, fold, feat_ptr, fss_ptr, tab.ctypes.data_as(C.POINTER(C.c_int32)), shp,
+                                      C.byref(opts), lo, hi, logits_ptr, labels_ptr), self.lib, self.handle)
 
     def labels_box(self, acc_ptr, shape, opts, box_lo, box_hi, out_lo, out_hi, labels_ptr):
         shp = (C.c_int64 * 4)(*[int(i) for i in shape])

@@ -797,7 +797,8 @@ inline int acc_hp(const fnn_arch_desc &a) { return (a.num_heads + 1 + 7) / 8 * 8
 // keep_features: no head, no accumulation - patch ids[i] leaves its last activation in e->feat[i] (gather path).
 int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp, const fnn_opts &o,
                 const std::vector<int64_t> &ids, const int *ids_origins_dev, const Box &box, void *acc, int acc_fp32,
-                hipStream_t st, bool fresh = false, bool keep_features = false, int64_t slot0 = 0, int64_t n_slots = 0) {
+                hipStream_t st, bool fresh = false, bool keep_features = false, int64_t slot0 = 0, int64_t n_slots = 0,
+                void *feat_ext = nullptr, float *fss_ext = nullptr) {
     const fnn_arch_desc &a = e->arch;
     const long long vdim[3] = {(long long)vp.padded[0], (long long)vp.padded[1], (long long)vp.padded[2]};
     int B = o.batch > 0 ? o.batch : e->max_batch;
@@ -881,8 +882,9 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
             if (ci > 0) for (int ax : combos[ci - 1]) flip[ax] = 1;
             if (keep_features) {                              // [evaluation][slot]: the batch's items stay contiguous
                 const size_t item = (size_t)ci * n_slots + slot0 + p0;
-                if (int rc = forward_batch(e, fold, vol_dev, 0, vdim, org, nb, flip, st, (f16 *)e->feat + item * P * featC,
-                                           (float *)e->featss + item * 2 * featC)) return rc;
+                if (int rc = forward_batch(e, fold, vol_dev, 0, vdim, org, nb, flip, st,
+                                           (f16 *)(feat_ext ? feat_ext : e->feat) + item * P * featC,
+                                           (fss_ext ? fss_ext : (float *)e->featss) + item * 2 * featC)) return rc;
                 continue;
             }
             if (int rc = forward_batch(e, fold, vol_dev, 0, vdim, org, nb, flip, st)) return rc;
@@ -1089,6 +1091,7 @@ int gather_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const Vol
     g.gauss = o.use_gaussian ? e->gauss : e->ones;
     g.lo_x = (int)vp.lo[0]; g.lo_y = (int)vp.lo[1]; g.lo_z = (int)vp.lo[2];
     g.OX = shape[1]; g.OY = shape[2]; g.OZ = shape[3];
+    g.y_lo = 0; g.y_hi = (int)shape[2]; g.z_lo = 0; g.z_hi = (int)shape[3]; g.slot_tab = nullptr;
     g.acc_fp32 = o.accum == FNN_ACC_FP32; g.out_fp32 = 0;
     g.out_vec = out && shape[3] % 8 == 0 && ((size_t)out % 16) == 0;
     g.mode = mode; g.out = out; g.labels = labels; g.label_u16 = e->label_u16; g.order = lab_order; g.inf_flag = e->inf_flag;
@@ -1427,6 +1430,100 @@ int fnn_labels_box(fnn_engine *e, const void *acc, const int64_t shape[4], const
     FinalizeParams f = make_finalize(e, acc, box, out_lo, out_hi, vp, shape, *opts, opts->accum == FNN_ACC_FP32, 0, nullptr);
     const int *order = e->label_mode == FNN_LABELS_REGIONS ? e->label_order : nullptr;
     if (launch_labels_from_acc(f, labels, e->label_u16, order, st) != 0) return fail(e, FNN_E_HIP, "labels launch failed");
+    int flag = 0;
+    HIPCHK(e, hipMemcpyAsync(&flag, e->inf_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    if (flag) return fail(e, FNN_E_INF, "Encountered inf in predicted array.");
+    return 0;
+}
+
+int64_t fnn_feature_channels(const fnn_engine *e) { return e ? e->layers[e->head_src].cout_pad : -1; }
+
+int fnn_patch_features(fnn_engine *e, int fold, const float *vol, const int64_t shape[4], const fnn_opts *opts,
+                       const int64_t *patch_ids, int64_t n_ids, void *feat, float *fss) {
+    if (int rc = check_ready(e, fold, opts)) return rc;
+    if (!vol || !feat || !fss || (n_ids > 0 && !patch_ids)) return fail(e, FNN_E_INVALID, "NULL argument");
+    if (!is_device_ptr(feat) || !is_device_ptr(fss)) return fail(e, FNN_E_INVALID, "feature buffers must be device memory");
+    if (opts->n_mirror_axes != 0) return fail(e, FNN_E_UNSUPPORTED, "fnn_patch_features does not mirror");
+    if (!e->layers[e->head_src].has_norm) return fail(e, FNN_E_UNSUPPORTED, "the network's last layer has no InstanceNorm");
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)opts->stream;
+    VolPlan vp;
+    if (plan_volume(e->arch, shape + 1, opts->tile_step_size, vp) != 0) return fail(e, FNN_E_INVALID, "invalid volume shape / step size");
+    std::vector<int64_t> ids(patch_ids, patch_ids + n_ids);
+    for (int64_t id : ids) if (id < 0 || id >= vp.n_patches) return fail(e, FNN_E_INVALID, "patch id out of range");
+    if (ids.empty()) return 0;
+    const float *vol_dev = nullptr;
+    if (int rc = stage_volume(e, vol, shape, vp, st, &vol_dev)) return rc;
+    if (int rc = upload_origins(e, vp, ids, st)) return rc;
+    Box box;
+    for (int d = 0; d < 3; ++d) { box.lo[d] = 0; box.hi[d] = vp.padded[d]; }
+    e->ev_used = 0;
+    if (int rc = run_patches(e, fold, vol_dev, vp, *opts, ids, e->origins, box, nullptr, 0, st, false, true, 0, n_ids, feat, fss)) return rc;
+    if (e->profiling) { HIPCHK(e, hipStreamSynchronize(st)); collect_profile(e, n_ids); }
+    return 0;
+}
+
+int fnn_gather_box(fnn_engine *e, int fold, const void *feat, const float *fss, const int32_t *slot_of_patch,
+                   const int64_t shape[4], const fnn_opts *opts, const int64_t out_lo[3], const int64_t out_hi[3],
+                   void *out_logits, void *labels) {
+    if (int rc = check_ready(e, fold, opts)) return rc;
+    if (!feat || !fss || !slot_of_patch || !out_lo || !out_hi || (!out_logits && !labels)) return fail(e, FNN_E_INVALID, "NULL argument");
+    if (!is_device_ptr(feat) || !is_device_ptr(fss) || (out_logits && !is_device_ptr(out_logits)) || (labels && !is_device_ptr(labels)))
+        return fail(e, FNN_E_INVALID, "fnn_gather_box needs device pointers");
+    if (opts->n_mirror_axes != 0 || opts->out_dtype != FNN_OUT_F16) return fail(e, FNN_E_UNSUPPORTED, "fnn_gather_box: no mirroring, fp16 logits");
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)opts->stream;
+    VolPlan vp;
+    if (plan_volume(e->arch, shape + 1, opts->tile_step_size, vp) != 0) return fail(e, FNN_E_INVALID, "invalid volume shape / step size");
+    for (int d = 0; d < 3; ++d)
+        if (out_lo[d] < 0 || out_hi[d] > shape[1 + d] || out_lo[d] >= out_hi[d]) return fail(e, FNN_E_INVALID, "output box out of bounds");
+    const fnn_arch_desc &a = e->arch;
+    const Layer &H = e->layers[e->head_src];
+    GatherParams g{};
+    g.heads = a.num_heads; g.C = H.cout_pad; g.PD = a.patch[0]; g.PH = a.patch[1]; g.PW = a.patch[2]; g.n_eval = 1;
+    if (!H.has_norm || e->head_ksteps != 1 || !gather_ok(g)) return fail(e, FNN_E_UNSUPPORTED, "this network's head does not fit the gather kernel");
+    // tile starts, then the slot table, in one device buffer
+    std::vector<int> tab;
+    for (int d = 0; d < 3; ++d) for (int64_t v : vp.steps[d]) tab.push_back((int)v);
+    const size_t n_steps = tab.size();
+    for (int64_t i = 0; i < vp.n_patches; ++i) tab.push_back(slot_of_patch[i]);
+    {
+        void *t = e->steps_dev;
+        if (int rc = ensure(e, &t, &e->steps_cap, tab.size() * sizeof(int) + 64)) return rc;
+        e->steps_dev = (int *)t;
+    }
+    HIPCHK(e, hipMemcpyAsync(e->steps_dev, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipStreamSynchronize(st));                       // `tab` is a temporary
+    HIPCHK(e, hipMemsetAsync(e->inf_flag, 0, sizeof(int), st));
+    const FoldWeights &fw = e->folds[fold];
+    g.feat = (const f16 *)feat; g.fss = fss;
+    g.n_slots = 0; g.ring = 1; g.flipmask[0] = 0;
+    g.slope = H.act ? a.slope : 1.f;
+    g.steps = e->steps_dev; g.slot_tab = e->steps_dev + n_steps;
+    g.nx = (int)vp.steps[0].size(); g.ny = (int)vp.steps[1].size(); g.nz = (int)vp.steps[2].size();
+    g.wpk = fw.wpk + e->head_w_off; g.bias = fw.fparam + e->head_bias_off; g.hblocks = e->hblocks;
+    g.gauss = opts->use_gaussian ? e->gauss : e->ones;
+    g.lo_x = (int)vp.lo[0]; g.lo_y = (int)vp.lo[1]; g.lo_z = (int)vp.lo[2];
+    g.OX = shape[1]; g.OY = shape[2]; g.OZ = shape[3];
+    g.x_lo = (int)out_lo[0]; g.x_hi = (int)out_hi[0]; g.y_lo = (int)out_lo[1]; g.y_hi = (int)out_hi[1];
+    g.z_lo = (int)out_lo[2]; g.z_hi = (int)out_hi[2];
+    g.acc_fp32 = opts->accum == FNN_ACC_FP32; g.out_fp32 = 0; g.mode = 0; g.inf_flag = e->inf_flag;
+    g.label_u16 = e->label_u16; g.order = e->label_mode == FNN_LABELS_REGIONS ? e->label_order : nullptr;
+    if (labels && !e->label_u16 && e->label_mode == FNN_LABELS_ARGMAX && a.num_heads > 256)
+        return fail(e, FNN_E_INVALID, "%d classes do not fit uint8 labels", a.num_heads);
+    e->ev_used = 0;
+    if (out_logits) {
+        g.out = out_logits; g.labels = nullptr;
+        g.out_vec = shape[3] % 8 == 0 && ((size_t)out_logits % 16) == 0;
+        Scope sc(e, st, FAM_HEAD, 0);
+        if (launch_gather(g, st) != 0) return fail(e, FNN_E_HIP, "gather launch failed");
+    }
+    if (labels) {
+        g.out = nullptr; g.labels = labels; g.out_vec = 0;
+        Scope sc(e, st, FAM_HEAD, 0);
+        if (launch_gather(g, st) != 0) return fail(e, FNN_E_HIP, "gather launch failed");
+    }
     int flag = 0;
     HIPCHK(e, hipMemcpyAsync(&flag, e->inf_flag, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));

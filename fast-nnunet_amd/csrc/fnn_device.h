@@ -167,6 +167,8 @@ struct GatherParams {
     int flipmask[8];             // per evaluation: bit 0 / 1 / 2 = the network input was flipped along d / h / w
     int n_slots, ring;           // ring = x layers of patches kept (nx: the whole volume)
     int x_lo, x_hi;              // un-padded x range this launch writes
+    int y_lo, y_hi, z_lo, z_hi;  // and y / z ranges (z_lo is where the 64-voxel runs start)
+    const int *slot_tab;         // patch id -> slot (or -1: not held), instead of the ring rule; nullptr = ring rule
     int C;                       // padded channels (16 or 32)
     float slope;
     const int *steps;            // device: tile starts per axis, x then y then z (ascending)

@@ -46,14 +46,15 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
     f16 *sT = (f16 *)smem + wave * (HB * 16 * 72);             // per wave: [HB * 16 heads][64 z (+8 pad)] fp16
 
     // wave -> (x, y, run of 64 z) of the UN-PADDED output
-    const long long zruns = (p.OZ + 63) / 64;
+    const int ny_box = p.y_hi - p.y_lo, nz_box = p.z_hi - p.z_lo;
+    const long long zruns = (nz_box + 63) / 64;
     long long wid = (long long)blockIdx.x * 4 + wave;
-    const long long total = (long long)(p.x_hi - p.x_lo) * p.OY * zruns;
+    const long long total = (long long)(p.x_hi - p.x_lo) * ny_box * zruns;
     if (wid >= total) return;
     const int zr = (int)(wid % zruns); wid /= zruns;
-    const int y = (int)(wid % p.OY);
-    const int x = p.x_lo + (int)(wid / p.OY);
-    const int z0 = zr * 64;
+    const int y = p.y_lo + (int)(wid % ny_box);
+    const int x = p.x_lo + (int)(wid / ny_box);
+    const int z0 = p.z_lo + zr * 64;
     const int xp = x + p.lo_x, yp = y + p.lo_y, zp0 = z0 + p.lo_z;            // padded-volume coordinates
 
     // seg head fragments: A operand per head block, bias of this lane's 4 heads per block
@@ -86,7 +87,9 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
             for (int iz = 0; iz < p.nz; ++iz) {
                 const int oz = sz[iz];
                 if (zp0 + 64 <= oz || zp0 >= oz + p.PW) continue;
-                const int slot = ((ix % p.ring) * p.ny + iy) * p.nz + iz;
+                const int pid = (ix * p.ny + iy) * p.nz + iz;
+                const int slot = p.slot_tab ? p.slot_tab[pid] : ((ix % p.ring) * p.ny + iy) * p.nz + iz;
+                if (slot < 0) continue;                        // not held here (a sharded caller's table): nothing to add
                 const int dx = xp - ox, dy = yp - oy;
                 bool in[4];
                 f16 graw[4];
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (hb == whb && j == wj) wsum = acc[g][hb][j];
         wsum = __shfl(wsum, wq * 16 + r, 64);
-        const bool zok = z0 + 16 * g + r < p.OZ;
+        const bool zok = z0 + 16 * g + r < p.z_hi;
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
                 hit = hit > h ? hit : h;
             }
             const int z = z0 + 16 * g + r;
-            if (q == 0 && z < p.OZ) {
+            if (q == 0 && z < p.z_hi) {
                 const int lab = p.order ? (hit >= 0 ? p.order[hit] : 0) : arg;
                 const size_t o = ((size_t)x * p.OY + y) * p.OZ + z;
                 if (p.label_u16) ((uint16_t *)p.labels)[o] = (uint16_t)lab; else ((uint8_t *)p.labels)[o] = (uint8_t)lab;
@@ -254,8 +257,8 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
     __builtin_amdgcn_wave_barrier();
     const size_t plane = (size_t)p.OX * p.OY * p.OZ;
     const size_t rowoff = ((size_t)x * p.OY + y) * p.OZ + z0;
-    const int nz = (int)(p.OZ - z0 < 64 ? p.OZ - z0 : 64);
-    const bool vec = p.out_vec && nz == 64;                     // 16-byte aligned rows
+    const int nz = (int)(p.z_hi - z0 < 64 ? p.z_hi - z0 : 64);
+    const bool vec = p.out_vec && nz == 64 && (p.z_lo & 7) == 0;   // 16-byte aligned rows
     if (!p.out_fp32 && vec) {
         for (int h8 = 0; h8 < p.heads; h8 += 8) {
             const int head = h8 + (lane >> 3), piece = lane & 7;
@@ -294,7 +297,7 @@ bool gather_ok(const GatherParams &p) {
 
 template <int HB, bool TTA>
 static int launch_gather_hb(const GatherParams &p, hipStream_t st) {
-    const long long waves = (long long)(p.x_hi - p.x_lo) * p.OY * ((p.OZ + 63) / 64);
+    const long long waves = (long long)(p.x_hi - p.x_lo) * (p.y_hi - p.y_lo) * ((p.z_hi - p.z_lo + 63) / 64);
     if (waves <= 0) return 0;
     const dim3 grid((unsigned)((waves + 3) / 4));
     const size_t lds = (size_t)4 * HB * 16 * 72 * 2;

@@ -117,6 +117,12 @@ class Decomposition:
                 recvs.append((peer, inc))
         return sends, recvs
 
+    def split_patches_for_features(self, rank: int, patch: Sequence[int], origins) -> Tuple[List[int], List[int]]:
+        """-> (boundary, interior) for the gather path: boundary patches reach into another rank's OWNED box."""
+        need = {i for _, i, _ in self.feature_transfers(rank, patch, origins)[0]}
+        ids = self.patch_ids[rank]
+        return [i for i in ids if i in need], [i for i in ids if i not in need]
+
     def split_patches(self, rank: int, patch: Sequence[int], origins) -> Tuple[List[int], List[int]]:
         """-> (boundary, interior) patch ids of `rank` in visiting order: a boundary patch touches a region this
         rank sends to another rank; once they are accumulated the sends can leave while the interior computes."""
@@ -130,6 +136,39 @@ class Decomposition:
 
     def halo_voxels(self, rank: int) -> int:
         return sum(int(np.prod([h - l for l, h in zip(*reg)])) for _, reg in self.transfers(rank)[0])
+
+    # ---- gather path: what travels is the part of a patch's last activation that reaches into another rank's owned box
+    def rank_of_patch(self) -> List[int]:
+        n = sum(len(i) for i in self.patch_ids)
+        out = [-1] * n
+        for r, ids in enumerate(self.patch_ids):
+            for i in ids:
+                out[i] = r
+        return out
+
+    def feature_transfers(self, rank: int, patch: Sequence[int], origins):
+        """-> (sends, recvs): lists of (peer, patch id, region) with the region in padded-volume coordinates, ordered
+        by (peer, patch id) on both sides.  A rank sends, for each of its patches, the intersection of the patch with
+        every OTHER rank's owned box; it receives the parts of foreign patches that reach into the box it owns."""
+        owner = self.rank_of_patch()
+        sends, recvs = [], []
+        if self.owned[rank] is None:
+            return sends, recvs
+        for peer in range(self.world):
+            if peer == rank or self.owned[peer] is None:
+                continue
+            for i in self.patch_ids[rank]:
+                o = [int(v) for v in origins[i]]
+                reg = _intersect((tuple(o), tuple(o[d] + patch[d] for d in range(3))), self.owned[peer])
+                if reg is not None:
+                    sends.append((peer, i, reg))
+            for i in self.patch_ids[peer]:
+                o = [int(v) for v in origins[i]]
+                reg = _intersect((tuple(o), tuple(o[d] + patch[d] for d in range(3))), self.owned[rank])
+                if reg is not None:
+                    recvs.append((peer, i, reg))
+        assert all(owner[i] == rank for _, i, _ in sends)
+        return sends, recvs
 
 
 def _view(acc: torch.Tensor, box: Box, region: Box) -> torch.Tensor:
@@ -178,6 +217,66 @@ class HaloExchange:
 def exchange_halos(acc: torch.Tensor, dec: Decomposition, rank: int, group=None) -> None:
     """Adds the other ranks' contributions to the part of `acc` this rank owns (start + finish in one go)."""
     HaloExchange(acc, dec, rank, group).start().finish()
+
+
+class FeatureExchange:
+    """Gather-path exchange (SURVEY.md 8e with csrc/gather.hip): `feat` is [n_slots, PD, PH, PW, C] (fp16 on the GPUs),
+    `fss` [n_slots, 2, C]; `slot_of[pid]` says where a patch sits.  ``start()`` sends the regions of this rank's patches
+    that other ranks' owned boxes need (call it once those patches are computed), ``finish()`` lands the foreign regions
+    in their slots.  One packed buffer per peer and direction; both sides derive the same (peer, patch, region) lists
+    from the decomposition, so no metadata travels."""
+
+    def __init__(self, feat: torch.Tensor, fss: torch.Tensor, dec: Decomposition, rank: int, patch, origins, slot_of, group=None):
+        self.feat, self.fss, self.dec, self.rank, self.patch, self.origins, self.slot_of, self.group = \
+            feat, fss, dec, rank, tuple(patch), origins, slot_of, group
+        self.sends, self.recvs = dec.feature_transfers(rank, patch, origins)
+        self.reqs, self.landing, self.keep = [], [], []
+
+    def _local(self, pid: int, region: Box):
+        o = [int(v) for v in self.origins[pid]]
+        return tuple(slice(region[0][d] - o[d], region[1][d] - o[d]) for d in range(3))
+
+    def _peers(self, items):
+        out = {}
+        for peer, pid, reg in items:
+            out.setdefault(peer, []).append((pid, reg))
+        return out
+
+    def start(self) -> 'FeatureExchange':
+        if not self.sends and not self.recvs:
+            return self
+        g = self.group
+        dst = (lambda r: dist.get_global_rank(g, r)) if g is not None else (lambda r: r)
+        ops = []
+        for peer, items in sorted(self._peers(self.sends).items()):
+            blocks = [self.feat[(self.slot_of[pid], *self._local(pid, reg))].reshape(-1) for pid, reg in items]
+            rows = torch.stack([self.fss[self.slot_of[pid]] for pid, _ in items])
+            buf = torch.cat(blocks)
+            self.keep += [buf, rows]
+            ops += [dist.P2POp(dist.isend, buf, dst(peer), g), dist.P2POp(dist.isend, rows, dst(peer), g)]
+        for peer, items in sorted(self._peers(self.recvs).items()):
+            C = self.feat.shape[-1]
+            n = sum(int(np.prod([reg[1][d] - reg[0][d] for d in range(3)])) * C for _, reg in items)
+            buf = torch.empty(n, dtype=self.feat.dtype, device=self.feat.device)
+            rows = torch.empty((len(items), 2, C), dtype=self.fss.dtype, device=self.fss.device)
+            ops += [dist.P2POp(dist.irecv, buf, dst(peer), g), dist.P2POp(dist.irecv, rows, dst(peer), g)]
+            self.landing.append((items, buf, rows))
+        self.reqs = dist.batch_isend_irecv(ops)
+        return self
+
+    def finish(self) -> None:
+        for req in self.reqs:
+            req.wait()
+        C = self.feat.shape[-1]
+        for items, buf, rows in self.landing:
+            off = 0
+            for k, (pid, reg) in enumerate(items):
+                shape = tuple(reg[1][d] - reg[0][d] for d in range(3)) + (C,)
+                n = int(np.prod(shape))
+                self.feat[(self.slot_of[pid], *self._local(pid, reg))] = buf[off:off + n].view(shape)
+                self.fss[self.slot_of[pid]] = rows[k]
+                off += n
+        self.reqs, self.landing, self.keep = [], [], []
 
 
 def unpadded(box: Box, pad_lo: Sequence[int], shape_sp: Sequence[int]) -> Optional[Box]:
@@ -230,11 +329,56 @@ class ShardedPredictor:
     form the ensemble mean like the single-GPU predictor.
     """
 
-    def __init__(self, predictor, group=None):
+    def __init__(self, predictor, group=None, mode: str = 'auto'):
+        """mode: 'gather' - ranks keep patch activations and exchange the parts that reach into a neighbour's box
+        (csrc/gather.hip: no accumulators, results bit-identical to one GPU); 'accumulate' - ranks exchange partial sums
+        of read-modify-write accumulators; 'auto' - gather where the engine's gather kernel applies (<= 63 classes, no
+        mirroring)."""
         self.p = predictor
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        assert mode in ('auto', 'gather', 'accumulate')
+        self.mode = mode
+
+    def _use_gather(self) -> bool:
+        p = self.p
+        ok = p._spec.num_heads <= 63 and not (p.use_mirroring and p.allowed_mirroring_axes) and p._spec.features[0] <= 32
+        if self.mode == 'gather' and not ok:
+            raise NotImplementedError('the gather path needs <= 63 classes, <= 32 channels at full resolution and no mirroring')
+        return ok and self.mode != 'accumulate'
+
+    def _features_fold(self, x, dec, origins, opts, fold):
+        """(feat [n_slots, PD, PH, PW, C], fss, slot table over all patches) with this rank's own patches and the
+        foreign regions its owned box needs; None on an idle rank."""
+        p, eng, patch = self.p, self.p._engine, self.p._spec.patch
+        n_patches = int(origins.shape[0])
+        table = np.full(n_patches, -1, np.int32)
+        if dec.owned[self.rank] is None:
+            FeatureExchange(torch.empty((0, *patch, 1)), torch.empty((0, 2, 1)), dec, self.rank, patch, origins, {}, self.group).start().finish()
+            return None
+        boundary, interior = dec.split_patches_for_features(self.rank, patch, origins)
+        _, recvs = dec.feature_transfers(self.rank, patch, origins)
+        local = boundary + interior
+        slot_of = {pid: i for i, pid in enumerate(local)}
+        for _, pid, _ in recvs:
+            slot_of.setdefault(pid, len(slot_of))
+        C = eng.feature_channels
+        feat = torch.zeros((len(slot_of), *patch, C), dtype=torch.half, device=p.device)
+        fss = torch.zeros((len(slot_of), 2, C), dtype=torch.float32, device=p.device)
+        P = int(np.prod(patch))
+        fx = FeatureExchange(feat, fss, dec, self.rank, patch, origins, slot_of, self.group)
+        if boundary:
+            eng.patch_features(x.data_ptr(), x.shape, opts, boundary, feat.data_ptr(), fss.data_ptr(), fold=fold)
+        fx.start()
+        if interior:
+            nb = len(boundary)
+            eng.patch_features(x.data_ptr(), x.shape, opts, interior, feat.data_ptr() + nb * P * C * 2,
+                               fss.data_ptr() + nb * 2 * C * 4, fold=fold)
+        fx.finish()
+        for pid, sl in slot_of.items():
+            table[pid] = sl
+        return feat, fss, table
 
     def _plan(self, x):
         from . import capi
@@ -282,11 +426,19 @@ class ShardedPredictor:
                 out = torch.empty((p._spec.num_heads, *x.shape[1:]), dtype=torch.half, device=p.device)
             box, own = dec.boxes[self.rank], owns[self.rank]
             part = None
+            use_gather = self._use_gather()
             for i, f in enumerate(folds):
-                acc = self._accumulate_fold(x, dec, origins, opts, f)
-                if own is None:
-                    continue
-                eng.normalize_box(acc.data_ptr(), x.shape, opts, box[0], box[1], own[0], own[1], out.data_ptr())
+                if use_gather:
+                    got = self._features_fold(x, dec, origins, opts, f)
+                    if own is None:
+                        continue
+                    eng.gather_box(got[0].data_ptr(), got[1].data_ptr(), got[2], x.shape, opts, own[0], own[1],
+                                   logits_ptr=out.data_ptr(), fold=f)
+                else:
+                    acc = self._accumulate_fold(x, dec, origins, opts, f)
+                    if own is None:
+                        continue
+                    eng.normalize_box(acc.data_ptr(), x.shape, opts, box[0], box[1], own[0], own[1], out.data_ptr())
                 if len(folds) > 1:                            # fp16 sum over the folds, then / n (:494-500)
                     sl = (slice(None), *[slice(own[0][d], own[1][d]) for d in range(3)])
                     part = out[sl].clone() if i == 0 else part.add_(out[sl])
@@ -322,10 +474,16 @@ class ShardedPredictor:
             else:
                 dec, origins, owns = self._plan(x)
                 opts = p._opts()
-                acc = self._accumulate_fold(x, dec, origins, opts, p._active_fold)
                 box, own = dec.boxes[self.rank], owns[self.rank]
-                if own is not None:
-                    eng.labels_box(acc.data_ptr(), x.shape, opts, box[0], box[1], own[0], own[1], labels.data_ptr())
+                if self._use_gather():
+                    got = self._features_fold(x, dec, origins, opts, p._active_fold)
+                    if own is not None:
+                        eng.gather_box(got[0].data_ptr(), got[1].data_ptr(), got[2], x.shape, opts, own[0], own[1],
+                                       labels_ptr=labels.data_ptr(), fold=p._active_fold)
+                else:
+                    acc = self._accumulate_fold(x, dec, origins, opts, p._active_fold)
+                    if own is not None:
+                        eng.labels_box(acc.data_ptr(), x.shape, opts, box[0], box[1], own[0], own[1], labels.data_ptr())
             if gather:
                 gather_owned_boxes(labels, owns, self.rank, self.group)
             if u16:

@@ -194,6 +194,22 @@ int fnn_labels_box(fnn_engine *e, const void *acc, const int64_t shape[4], const
                    const int64_t box_lo[3], const int64_t box_hi[3],
                    const int64_t out_lo[3], const int64_t out_hi[3], void *labels);
 
+/* The same sharding on the gather path (csrc/gather.hip; no accumulators, bit-identical to one GPU): a rank keeps the
+ * last activation of the patches it ran - fnn_patch_features writes them, [n_ids][P][C] fp16 with P = patch voxels and
+ * C = fnn_feature_channels(e), and their InstanceNorm rows [n_ids][2][C] float32, into DEVICE buffers of the caller -
+ * receives from its neighbours the parts of THEIR patches that reach into the box it owns (caller's job: plain copies
+ * of [dx][dy][dz][C] sub-blocks), and fnn_gather_box then forms every voxel of the un-padded box [out_lo, out_hi) from
+ * all patches that cover it, in the reference's visiting order: slot_of_patch[pid] (HOST array over the x-major patch
+ * list of fnn_plan_volume) = where patch pid's activation sits in feat / fss, or -1 where the caller knows the patch
+ * does not reach the box.  Writes fp16 logits [heads][X][Y][Z] and / or labels [X][Y][Z] (either may be NULL) of the
+ * full-size tensors.  Mirroring is not available on this pair (opts->n_mirror_axes must be 0). */
+int64_t fnn_feature_channels(const fnn_engine *e);
+int fnn_patch_features(fnn_engine *e, int fold, const float *vol, const int64_t shape[4], const fnn_opts *opts,
+                       const int64_t *patch_ids, int64_t n_ids, void *feat, float *fss);
+int fnn_gather_box(fnn_engine *e, int fold, const void *feat, const float *fss, const int32_t *slot_of_patch,
+                   const int64_t shape[4], const fnn_opts *opts, const int64_t out_lo[3], const int64_t out_hi[3],
+                   void *out_logits, void *labels);
+
 /* LabelManager.convert_logits_to_segmentation on resident logits with the
  * engine's label rule: logits [heads, n_vox] f16/f32 -> labels uint8/uint16. */
 int fnn_argmax_labels(fnn_engine *e, const void *logits, int dtype, int heads, int64_t n_vox,

@@ -198,3 +198,118 @@ def test_halo_exchange_matches_single_process_gloo(world):
     sl = tuple(slice(pad_lo[d], pad_lo[d] + shape[d]) for d in range(3))
     want = (acc[sl][..., :heads] / acc[sl][..., heads:heads + 1]).permute(3, 0, 1, 2).numpy()
     assert np.allclose(got, want, rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# gather path: ranks exchange the parts of their patches' last activations that reach into a neighbour's owned box
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('shape,patch,step', CASES)
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_feature_transfers_cover_every_voxel_of_every_owned_box(shape, patch, step, world):
+    """Integer geometry: with its own patches and the received regions a rank holds, for every voxel of the box it owns,
+    the activation of EVERY patch that covers the voxel; sends and receives pair up."""
+    from fast_nnunet_amd.dist import Decomposition, _intersect
+    padded, _, steps = _geometry(shape, patch, step)
+    origins = [(x, y, z) for x in steps[0] for y in steps[1] for z in steps[2]]
+    dec = Decomposition.build(patch, padded, steps, world)
+    owner = dec.rank_of_patch()
+    assert sorted(owner) == sorted(r for r, ids in enumerate(dec.patch_ids) for _ in ids) and min(owner) >= 0
+    for r in range(world):
+        sends, recvs = dec.feature_transfers(r, patch, origins)
+        for peer, pid, reg in sends:
+            assert (r, pid, reg) in dec.feature_transfers(peer, patch, origins)[1]
+        if dec.owned[r] is None:
+            assert not sends and not recvs
+            continue
+        have = {pid: [] for pid in dec.patch_ids[r]}
+        for _, pid, reg in recvs:
+            have.setdefault(pid, []).append(reg)
+        for pid, o in enumerate(origins):
+            ext = (tuple(o), tuple(o[d] + patch[d] for d in range(3)))
+            need = _intersect(ext, dec.owned[r])
+            if need is None:
+                continue
+            assert pid in have
+            if owner[pid] != r:
+                assert need in have[pid]
+        boundary, interior = dec.split_patches_for_features(r, patch, origins)
+        assert sorted(boundary + interior) == sorted(dec.patch_ids[r]) and {i for _, i, _ in sends} == set(boundary)
+
+
+def _gather_worker(rank, world, port, shape, patch, step, heads, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from fast_nnunet_amd.dist import Decomposition, FeatureExchange, gather_owned_boxes, unpadded
+        padded, pad_lo, steps = _geometry(shape, patch, step)
+        origins = [(x, y, z) for x in steps[0] for y in steps[1] for z in steps[2]]
+        gauss = osw.gaussian_weight(patch).float()
+        dec = Decomposition.build(patch, padded, steps, world)
+        out = torch.full((heads, *shape), float('nan'))
+        if dec.owned[rank] is not None:
+            boundary, interior = dec.split_patches_for_features(rank, patch, origins)
+            _, recvs = dec.feature_transfers(rank, patch, origins)
+            slot_of = {pid: i for i, pid in enumerate(boundary + interior)}
+            for _, pid, _ in recvs:
+                slot_of.setdefault(pid, len(slot_of))
+            feat = torch.full((len(slot_of), *patch, heads), float('nan'))
+            fss = torch.zeros((len(slot_of), 2, heads))
+            for pid in boundary:                                   # the order ShardedPredictor uses
+                feat[slot_of[pid]] = _toy_logits(origins[pid], patch, heads)
+                fss[slot_of[pid], 0] = float(pid)
+            fx = FeatureExchange(feat, fss, dec, rank, patch, origins, slot_of, None).start()
+            for pid in interior:
+                feat[slot_of[pid]] = _toy_logits(origins[pid], patch, heads)
+                fss[slot_of[pid], 0] = float(pid)
+            fx.finish()
+            assert all(float(fss[sl, 0, 0]) == pid for pid, sl in slot_of.items())     # every slot's rows arrived with it
+            # what gather.hip does over the owned box: every covering patch, ascending
+            ob = dec.owned[rank]
+            own = unpadded(ob, pad_lo, shape)
+            if own is not None:
+                lo = [own[0][d] + pad_lo[d] for d in range(3)]
+                hi = [own[1][d] + pad_lo[d] for d in range(3)]
+                num = torch.zeros((*[hi[d] - lo[d] for d in range(3)], heads))
+                den = torch.zeros([hi[d] - lo[d] for d in range(3)])
+                for pid, o in enumerate(origins):
+                    a = [max(lo[d], o[d]) for d in range(3)]
+                    b = [min(hi[d], o[d] + patch[d]) for d in range(3)]
+                    if any(b[d] <= a[d] for d in range(3)):
+                        continue
+                    dst = tuple(slice(a[d] - lo[d], b[d] - lo[d]) for d in range(3))
+                    src = tuple(slice(a[d] - o[d], b[d] - o[d]) for d in range(3))
+                    num[dst] += feat[(slot_of[pid], *src)] * gauss[src][..., None]
+                    den[dst] += gauss[src]
+                sl = tuple(slice(own[0][d], own[1][d]) for d in range(3))
+                out[(slice(None), *sl)] = (num / den[..., None]).permute(3, 0, 1, 2)
+        else:
+            FeatureExchange(torch.empty((0, *patch, heads)), torch.empty((0, 2, heads)), dec, rank, patch, origins, {}, None).start().finish()
+        owns = [None if b is None else unpadded(b, pad_lo, shape) for b in dec.owned]
+        gather_owned_boxes(out, owns, rank, None)
+        q.put((rank, out.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_feature_exchange_matches_single_process_gloo(world):
+    shape, patch, step, heads = (30, 41, 26), (16, 16, 16), 0.5, 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, shape, patch, step, heads, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    padded, pad_lo, steps = _geometry(shape, patch, step)
+    origins = [(x, y, z) for x in steps[0] for y in steps[1] for z in steps[2]]
+    hp = (heads + 1 + 7) // 8 * 8
+    acc = _accumulate(range(len(origins)), origins, ((0, 0, 0), tuple(padded)), patch, heads, hp, osw.gaussian_weight(patch).float())
+    sl = tuple(slice(pad_lo[d], pad_lo[d] + shape[d]) for d in range(3))
+    want = (acc[sl][..., :heads] / acc[sl][..., heads:heads + 1]).permute(3, 0, 1, 2).numpy()
+    for _, got in results:
+        assert not np.isnan(got).any() and np.allclose(got, want, rtol=1e-5, atol=1e-5)

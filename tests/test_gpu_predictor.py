@@ -442,14 +442,15 @@ def test_sharded_predictor_single_rank_process_group():
             p = _predictor(spec, patch, sds[:1], accumulate_in=accum)
             image = torch.randn(1, 20, 40, 33, generator=torch.Generator().manual_seed(7))
             want = p.predict_sliding_window_return_logits(image)
-            sp = ShardedPredictor(p)
-            got, own = sp.predict_sliding_window_return_logits(image)
-            assert own == ((0, 0, 0), (20, 40, 33))
-            assert torch.equal(got, want)                     # one rank: the reference's visiting order, bit for bit
-            assert torch.equal(sp.predict_sliding_window_return_logits(image, gather=True), want)
-            labels = sp.predict_segmentation_from_preprocessed_data(image)
-            assert labels.dtype == torch.uint8 and torch.equal(labels, p.predict_segmentation_from_preprocessed_data(image))
-            assert torch.equal(labels.long(), want.float().argmax(0))
+            for mode in ('gather', 'accumulate'):
+                sp = ShardedPredictor(p, mode=mode)
+                got, own = sp.predict_sliding_window_return_logits(image)
+                assert own == ((0, 0, 0), (20, 40, 33))
+                assert torch.equal(got, want)                 # one rank: the reference's visiting order, bit for bit
+                assert torch.equal(sp.predict_sliding_window_return_logits(image, gather=True), want)
+                labels = sp.predict_segmentation_from_preprocessed_data(image)
+                assert labels.dtype == torch.uint8 and torch.equal(labels, p.predict_segmentation_from_preprocessed_data(image))
+                assert torch.equal(labels.long(), want.float().argmax(0))
         p2 = _predictor(spec, patch, sds)
         sp2 = ShardedPredictor(p2)
         assert torch.equal(sp2.predict_logits_from_preprocessed_data(image).cpu(), p2.predict_logits_from_preprocessed_data(image))
@@ -842,3 +843,67 @@ def test_gather_ring_and_mirroring_are_bit_identical_to_the_accumulate_path(mirr
             assert torch.equal(p.predict_segmentation_from_preprocessed_data(image).long(), want.float().argmax(0))
         finally:
             os.environ.pop('FNN_GATHER_RING', None)
+
+
+@pytest.mark.parametrize('heads,world', [(3, 2), (3, 4), (61, 8)])
+def test_sharded_gather_path_through_c_abi_is_bit_identical_to_single_gpu(heads, world):
+    """fnn_patch_features / fnn_gather_box for `world` virtual ranks on one GPU, the feature exchange done with local
+    copies of exactly the regions FeatureExchange would send: logits and labels of every owned box must be the bits of
+    the single-GPU predictor (the gather kernel visits a voxel's covering patches in the reference's order whoever
+    computed them)."""
+    from fast_nnunet_amd import capi
+    from fast_nnunet_amd.dist import Decomposition, unpadded
+    spec = UNetSpec('plain', 1, heads, [16, 32], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
+    patch = (16, 16, 32)
+    p = _predictor(spec, patch, [synthetic_state_dict(spec, 33)])
+    image = torch.randn(1, 37, 30, 70, generator=torch.Generator().manual_seed(6))
+    want = p.predict_sliding_window_return_logits(image)
+    want_labels = p.predict_segmentation_from_preprocessed_data(image)
+    x = image.cuda().float().contiguous()
+    padded, pad_lo, origins = capi.plan_volume(patch, x.shape[1:], 0.5)
+    steps = [sorted(set(int(v) for v in origins[:, d])) for d in range(3)]
+    dec = Decomposition.build(patch, padded, steps, world)
+    opts, eng = p._opts(), p._engine
+    C, P = eng.feature_channels, int(np.prod(patch))
+    feats, tables = [], []
+    for r in range(world):                                           # every rank: its own patches (boundary first)
+        if dec.owned[r] is None:
+            feats.append(None); tables.append(None)
+            continue
+        boundary, interior = dec.split_patches_for_features(r, patch, origins)
+        slot_of = {pid: i for i, pid in enumerate(boundary + interior)}
+        for _, pid, _ in dec.feature_transfers(r, patch, origins)[1]:
+            slot_of.setdefault(pid, len(slot_of))
+        feat = torch.zeros((len(slot_of), *patch, C), dtype=torch.half, device='cuda')
+        fss = torch.zeros((len(slot_of), 2, C), dtype=torch.float32, device='cuda')
+        nb = len(boundary)
+        for ids, off in ((boundary, 0), (interior, nb)):
+            if ids:
+                eng.patch_features(x.data_ptr(), x.shape, opts, ids, feat.data_ptr() + off * P * C * 2, fss.data_ptr() + off * 2 * C * 4)
+        feats.append((feat, fss, slot_of))
+    torch.cuda.synchronize()
+    for r in range(world):                                           # local stand-in for FeatureExchange
+        if feats[r] is None:
+            continue
+        feat, fss, slot_of = feats[r]
+        for peer, pid, reg in dec.feature_transfers(r, patch, origins)[1]:
+            pf, ps, pslot = feats[peer]
+            o = [int(v) for v in origins[pid]]
+            loc = tuple(slice(reg[0][d] - o[d], reg[1][d] - o[d]) for d in range(3))
+            feat[(slot_of[pid], *loc)] = pf[(pslot[pid], *loc)]
+            fss[slot_of[pid]] = ps[pslot[pid]]
+    got = torch.zeros_like(want)
+    labels = torch.full_like(want_labels, 255)
+    for r in range(world):
+        if feats[r] is None:
+            continue
+        feat, fss, slot_of = feats[r]
+        table = np.full(origins.shape[0], -1, np.int32)
+        for pid, sl in slot_of.items():
+            table[pid] = sl
+        own = unpadded(dec.owned[r], pad_lo, x.shape[1:])
+        if own is not None:
+            eng.gather_box(feat.data_ptr(), fss.data_ptr(), table, x.shape, opts, own[0], own[1], logits_ptr=got.data_ptr(),
+                           labels_ptr=labels.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(got, want) and torch.equal(labels, want_labels)
