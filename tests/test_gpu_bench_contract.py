@@ -36,7 +36,7 @@ def _patches(j):
 
 
 def test_bench_force_sharded_single_rank_runs_the_multi_gpu_path():
-    """`--gpus 1 --force-sharded`: the rank-sharded code path (RCCL process group, halo exchange, labels on the owner,
+    """`--gpus 1 --force-sharded`: the rank-sharded code path (RCCL process group, patch-activation exchange, labels on the owner,
     all_gather of the label slabs) on one GPU - the line the driver would get from every rank 0 at N > 1."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--volume', '192', '--steps', '1', '--warmup', '1',
                           '--gpus', '1', '--force-sharded'], capture_output=True, text=True, timeout=600, cwd=ROOT)
