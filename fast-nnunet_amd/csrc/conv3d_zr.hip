@@ -28,6 +28,16 @@ int conv3d_kstep_tap(int packing, int ks, int half, int taps) {
     return t < taps ? t : -1;
 }
 
+// Output channel that row m of cout block cb of the packed weights computes.  The ZR kernels at two cout blocks per
+// workgroup (an even block count) interleave the two blocks' rows in groups of four: MFMA lane quarter q then holds
+// channels q * 8 .. q * 8 + 7 of a voxel (4 from each block) = ONE 16-byte store, and four lanes cover the 64 bytes of a
+// 32-channel group - half the store instructions of the 8-byte form, whole 64-byte runs (the stores of this kernel
+// delayed the next workgroup's loads in the texture-address path: a timing-only build without them ran 14 % faster).
+int conv3d_pack_cout(int packing, int nblk, int cb, int m) {
+    if (packing != FNN_PACK_ZR || nblk % 2 != 0) return cb * 16 + m;
+    return (cb >> 1) * 32 + (m >> 2) * 8 + (cb & 1) * 4 + (m & 3);
+}
+
 // (cout blocks per workgroup, tile depth) the ZR kernel would run with, or false when the layer keeps the
 // linear-tap kernels: not 3x3x3 / stride 1, or too few workgroups to fill the chip.
 static bool zr_pick(const ConvParams &p, int &nb, int &td) {
@@ -36,6 +46,7 @@ static bool zr_pick(const ConvParams &p, int &nb, int &td) {
     static const int min_cout = getenv("FNN_ZR_MIN_COUT") ? atoi(getenv("FNN_ZR_MIN_COUT")) : 0;
     if (off || p.kd != 3 || p.kh != 3 || p.kw != 3 || p.sd != 1 || p.sh != 1 || p.sw != 1) return false;
     if (p.Cout > max_cout || p.Cout < min_cout) return false;
+    if ((long long)p.Di * p.Hi * p.Wi >= (1 << 23)) return false;                 // 24-bit voxel index arithmetic in the kernels
     const int nblk = p.Cout / 16;
     nb = nblk % 2 == 0 ? 2 : 1;
     const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;
@@ -57,6 +68,53 @@ int conv3d_stats_slots(const ConvParams &p) {
 int conv3d_packing(const ConvParams &p) {
     int nb, td;
     return zr_pick(p, nb, td) ? FNN_PACK_ZR : FNN_PACK_LINEAR;
+}
+
+// Epilogue of a ZR tile at NB = 2 in the interleaved channel order of conv3d_pack_cout: bias (after `osc` for the fp8
+// form), round to fp16, one 16-byte channels-last store per (voxel, lane), statistics as in tile_epilogue (conv_common.h).
+typedef int fnn_i32x4 __attribute__((ext_vector_type(4)));
+template <int TD>
+static __device__ __forceinline__ void zr_epilogue_pair(const ConvParams &p, const f32x4 (&acc)[TD][2], const float4 (&bv)[2],
+                                                        int n, int od0, int oh0, int ow0, int cb0, int wave, int lane,
+                                                        float (&t1)[2][4], float (&t2)[2][4]) {
+    const int q = lane >> 4, r = lane & 15;
+    const unsigned item_bytes = (unsigned)p.Do * p.Ho * p.Wo * p.Cout * 2;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)n * (item_bytes >> 1), 0,
+                                                                           item_bytes, 0x00020000);
+    const unsigned coff = (unsigned)(cb0 * 16 + q * 8) * 2;
+    const int oh = oh0 + 2 * wave + (r >> 3), ow = ow0 + (r & 7);
+    const bool ok_hw = oh < p.Ho && ow < p.Wo;
+    const f16x2 ones = {(f16)1.f, (f16)1.f};
+#pragma unroll
+    for (int mb = 0; mb < TD; mb += 2) {
+        f16x8 o[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int od = od0 + mb + h;
+            const bool ok = ok_hw && od < p.Do;
+            unsigned voff = ok ? (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout) * 2 + coff : 0x80000000u;
+#ifdef FNN_TMODE
+            if (p.tmode & 4) voff = 0x80000000u;
+#endif
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                o[h][nb * 4 + 0] = (f16)(acc[mb + h][nb][0] + bv[nb].x);
+                o[h][nb * 4 + 1] = (f16)(acc[mb + h][nb][1] + bv[nb].y);
+                o[h][nb * 4 + 2] = (f16)(acc[mb + h][nb][2] + bv[nb].z);
+                o[h][nb * 4 + 3] = (f16)(acc[mb + h][nb][3] + bv[nb].w);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fnn_i32x4, o[h]), rsrc, voff, 0, 0);
+            if (!ok) o[h] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f16x2 pr = {o[0][nb * 4 + j], o[1][nb * 4 + j]};
+                t1[nb][j] = __builtin_amdgcn_fdot2(pr, ones, t1[nb][j], false);
+                t2[nb][j] = __builtin_amdgcn_fdot2(pr, pr, t2[nb][j], false);
+            }
+    }
 }
 
 template <int NB, int TD>
@@ -106,8 +164,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
             const int v = idx >> 1;
             const int zd = v / (IH * IW), rem = v - zd * (IH * IW), zh = rem / IW, zw = rem - zh * IW;
             const int gd = id0 + zd, gh = ih0 + zh, gw = iw0 + zw;
-            const bool ok = gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 && gw < p.Wi;
-            offv[u] = idx < IELEM ? (ok ? (gd * p.Hi + gh) * p.Wi + gw : -1) : -2;      // inside batch item n
+            // branch-free (one unsigned compare per axis, 24-bit multiplies: the launcher checks Di * Hi * Wi < 2^24)
+            const bool ok = ((unsigned)gd < (unsigned)p.Di) & ((unsigned)gh < (unsigned)p.Hi) & ((unsigned)gw < (unsigned)p.Wi);
+            const int lin = __mul24(__mul24(gd, p.Hi) + gh, p.Wi) + gw;
+            offv[u] = idx < IELEM ? (ok ? lin : -1) : -2;                                // inside batch item n
             ldso[u] = zd * PS + (zh * PW + zw) * 32 + ((cg ^ (zh & 1)) * 16);
         }
     }
@@ -120,36 +180,48 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
         wofs[u] = (cb0 + nb) * p.chunks * (KS * 64) + idc - nb * (KS * 64);
     }
     f16x8 xr[PF], wr[WPF];
-    float4 scr[2], shr[2];
+    float scu[16], shu[16];                                   // the chunk's scale / shift rows: wave-uniform -> scalar loads, no TA slots
     float slope_next = 1.f;
+#ifdef FNN_TMODE
+    // timing-only switches (results are wrong): 1 = every halo load reads voxel 0 (one cache line per instruction),
+    // 2 = every weight load reads element 0, 4 = output stores dropped (conv_common.h), 8 = no normalisation in commit
+    const int t_hm = (p.tmode & 1) ? 0 : 1, t_wm = (p.tmode & 2) ? 0 : 1;
+#endif
 
     auto issue = [&](int ch) {
         const int c_glob = ch * 16;
         const int s = (c_glob < p.src[0].C) ? 0 : 1;
         const int c_uni = c_glob - (s ? p.src[0].C : 0);
-        const int c_loc = c_uni + cg * 8;
         const int sC = p.src[s].C;
         // uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset: one address VGPR per load (tensors < 4 GiB)
         const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + c_uni);
-        // scale / shift FIRST and unconditionally (identity table for a source without InstanceNorm): vmcnt retires in
-        // order, so with these four loads last - and inside an `if` - commit() could not touch the first halo element
-        // before EVERY load of the chunk had landed; now it converts element u while elements u + 1.. are still in flight
+        // scale / shift of the chunk's 16 channels (identity table for a source without InstanceNorm): the address is
+        // wave-uniform, so these are s_load_dwordx8 - as four 16-byte-per-lane vector loads they took a fifth of the
+        // chunk's slots in the texture-address path, which paces this kernel
         slope_next = p.src[s].slope;
-        const float *qs = p.src[s].ss ? p.src[s].ss + (size_t)(2 * n) * sC + c_loc : p.ident_ss + c_loc;
-        const float *qh = p.src[s].ss ? qs + sC : p.ident_ss + 512 + c_loc;
-        scr[0] = *(const float4 *)qs; scr[1] = *(const float4 *)(qs + 4);
-        shr[0] = *(const float4 *)qh; shr[1] = *(const float4 *)(qh + 4);
-        __builtin_amdgcn_sched_barrier(0);
+        const float *qs = p.src[s].ss ? p.src[s].ss + (size_t)(2 * n) * sC + c_uni : p.ident_ss + c_uni;
+        const float *qh = p.src[s].ss ? qs + sC : p.ident_ss + 512 + c_uni;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { scu[j] = qs[j]; shu[j] = qh[j]; }
 #pragma unroll
         for (int u = 0; u < PF; ++u)                          // unconditional: branches around loads make hipcc drain vmcnt
+#ifdef FNN_TMODE
+            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * t_hm * sC + cg * 8) * 2));
+#else
             xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * sC + cg * 8) * 2));
+#endif
 #pragma unroll
+#ifdef FNN_TMODE
+        for (int u = 0; u < WPF; ++u) wr[u] = *(const f16x8 *)((const char *)p.wpk + (unsigned)((wofs[u] + ch * (KS * 64)) * t_wm * 16));
+#else
         for (int u = 0; u < WPF; ++u) wr[u] = *(const f16x8 *)((const char *)p.wpk + (unsigned)((wofs[u] + ch * (KS * 64)) * 16));
+#endif
     };
     auto commit = [&]() {
         const f16 slope_h = (f16)slope_next;
-        const float sc[8] = {scr[0].x, scr[0].y, scr[0].z, scr[0].w, scr[1].x, scr[1].y, scr[1].z, scr[1].w};
-        const float sh[8] = {shr[0].x, shr[0].y, shr[0].z, shr[0].w, shr[1].x, shr[1].y, shr[1].z, shr[1].w};
+        float sc[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = cg ? scu[8 + j] : scu[j]; sh[j] = cg ? shu[8 + j] : shu[j]; }
 #ifndef FNN_NORM_FP32
         // x*scale+shift with scale and shift rounded to fp16 (v_pk_fma_f16): in fp32 (convert, fma, convert back) the
         // staging's normalisation was 8 % of the benchmark's time.  Measured cost in accuracy: relative RMSE of the 64^3
@@ -170,6 +242,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
 #endif
             o = __builtin_elementwise_max(o, o * slope_h);
             if (offv[u] < 0) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};      // the conv's zero padding
+#ifdef FNN_TMODE
+            if (p.tmode & 8) o = xr[u];
+#endif
             *(f16x8 *)(sA + ldso[u]) = o;
         }
 #pragma unroll
@@ -201,10 +276,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
     };
 
     FNN_STAMP();                                              // 1: prefetch coordinates done
+    if (tid < NB * 16) sBias[tid] = p.bias[cb0 * 16 + tid];   // before the chunk's loads: vmcnt retires in order
     issue(0);
     __builtin_amdgcn_sched_barrier(0);                        // the loads leave first; the rest of the set-up runs under them
     FNN_STAMP();                                              // 2: first loads issued
-    if (tid < NB * 16) sBias[tid] = p.bias[cb0 * 16 + tid];
     // MFMA "B" operand: lane = (voxel r of the wave's two rows, k-group): k-group bit 1 picks the tap of the pair,
     // bit 0 the 8-channel half
     {
@@ -243,14 +318,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
     {
         float4 bv[NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const float4 *)(sBias + nb * 16 + (lane >> 4) * 4);
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const float4 *)(sBias + (NB == 2 ? (lane >> 4) * 8 + nb * 4 : nb * 16 + (lane >> 4) * 4));
         float t1[NB][4], t2[NB][4];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
-        tile_epilogue<NB, TD, true>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
-        if (p.stats_out) stats_to_global<NB, true>(p, t1, t2, (float *)smem, n, cb0, wave, lane, tid, (td * p.tiles_h + th) * p.tiles_w + tw);
+        if constexpr (NB == 2) zr_epilogue_pair<TD>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
+        else tile_epilogue<NB, TD, true>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
+        if (p.stats_out) stats_to_global<NB, true, NB == 2>(p, t1, t2, (float *)smem, n, cb0, wave, lane, tid, (td * p.tiles_h + th) * p.tiles_w + tw);
     }
     FNN_STAMP();                                              // epilogue done
     FNN_STAMP_FLUSH(p.dbg);
@@ -432,8 +508,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr8_kernel(const ConvParams p) 
         float4 bv[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            bv[nb] = *(const float4 *)(sBias + nb * 16 + (lane >> 4) * 4);
-            const float4 sv = *(const float4 *)(sBias + NB * 16 + nb * 16 + (lane >> 4) * 4);
+            const int co = NB == 2 ? (lane >> 4) * 8 + nb * 4 : nb * 16 + (lane >> 4) * 4;
+            bv[nb] = *(const float4 *)(sBias + co);
+            const float4 sv = *(const float4 *)(sBias + NB * 16 + co);
 #pragma unroll
             for (int j = 0; j < TD; ++j) {
                 acc[j][nb][0] *= sv.x; acc[j][nb][1] *= sv.y; acc[j][nb][2] *= sv.z; acc[j][nb][3] *= sv.w;
@@ -444,8 +521,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr8_kernel(const ConvParams p) 
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
-        tile_epilogue<NB, TD, true>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
-        if (p.stats_out) stats_to_global<NB, true>(p, t1, t2, (float *)smem, n, cb0, wave, lane, tid, (td * p.tiles_h + th) * p.tiles_w + tw);
+        if constexpr (NB == 2) zr_epilogue_pair<TD>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
+        else tile_epilogue<NB, TD, true>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
+        if (p.stats_out) stats_to_global<NB, true, NB == 2>(p, t1, t2, (float *)smem, n, cb0, wave, lane, tid, (td * p.tiles_h + th) * p.tiles_w + tw);
     }
 }
 
@@ -483,6 +561,9 @@ static int launch_zr(ConvParams p, hipStream_t st) {
     p.ident_ss = conv3d_identity_ss();
     if (!p.ident_ss) return -2;
     dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
+#ifdef FNN_TMODE
+    p.tmode = getenv("FNN_ZR_TMODE") ? atoi(getenv("FNN_ZR_TMODE")) : 0;
+#endif
     hipLaunchKernelGGL((conv3d_zr_kernel<NB, TD>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -490,6 +571,16 @@ static int launch_zr(ConvParams p, hipStream_t st) {
 // A persistent form of this kernel (tile ranges per workgroup, cross-tile prefetch, like conv3d_persist_kernel) was
 // built and measured: 5-20 % SLOWER on every layer of the benchmark net - <2, 8> does not fit 256 VGPRs next to the
 // prefetch registers, <2, 4> loses the operand reuse - so one tile per workgroup it stays.
+// Round 2 rebuilt it with what had been learnt since (scale / shift in SGPRs, tables re-derived per tile: 255 VGPRs,
+// 36 B of scratch; the next tile's first chunk requested before the last k-loop; the tiles of an XCD taken interleaved so
+// that neighbours stay concurrent - with one contiguous range per workgroup it lost 11-17 % per layer to L2 misses on the
+// shared halos): bit-identical, its stamps show 33.7 k cycles per 2-chunk tile instead of ~43 k, and it is still 3-9 %
+// slower per layer in back-to-back launches (959 vs 899 us on 32 -> 32), with or without a half-period start delay for
+// the workgroup in the odd wave slot.  Requesting one dword per 128-byte line of a later tile's halo (tile + 16 .. 256
+// of the XCD's range) to warm L2 / the Infinity Cache: 2-3 % slower at every distance.  Timing-only builds (-DFNN_TMODE,
+// tools/zr_tmode.py) say where the time of the 32 -> 32 layer is: halo loads hitting one line -23 %, weight loads
+// hitting one element -5 %, stores dropped -14 %, all three -32 %, no normalisation 0 %; MFMA work alone would be 30 %
+// of the kernel's time.
 // Round 2, also measured and dropped: (1) two tiles per 512-thread workgroup forced half a period apart (one half in its
 // k-loop while the other stages, shared barriers; same registers and LDS per tile, bit-identical results): 6 % slower
 // end to end than two independent workgroups per CU - a chunk's staging (load issue + normalise + LDS writes) takes

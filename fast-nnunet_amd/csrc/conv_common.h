@@ -80,6 +80,9 @@ static __device__ __forceinline__ void tile_epilogue(const ConvParams &p, const 
             const int od = od0 + od_l, oh = oh0 + oh_l, ow = ow0 + ow_l;
             okv[h] = od < p.Do && oh < p.Ho && ow < p.Wo;
             voff[h] = okv[h] ? (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout) * 2 + coff : 0x80000000u;
+#ifdef FNN_TMODE
+            if (p.tmode & 4) voff[h] = 0x80000000u;
+#endif
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -107,7 +110,8 @@ static __device__ __forceinline__ void tile_epilogue(const ConvParams &p, const 
 // `sRed` = 4 * NB * 32 floats of LDS that nobody else uses between the two barriers.
 // SLOT: the workgroup owns row `slot` of the item's stats rows and stores its sums there (no atomics: the double
 // atomics of one-tile-per-workgroup kernels cost 5 % of the whole benchmark - 1.5 M of them per launch).
-template <int NB, bool SLOT = false>
+// PERM: the ZR kernels' channel order at NB = 2 (conv3d_pack_cout): lane quarter q holds channels q * 8 + nb * 4 + j.
+template <int NB, bool SLOT = false, bool PERM = false>
 static __device__ __forceinline__ void stats_to_global(const ConvParams &p, float (&t1)[NB][4], float (&t2)[NB][4], float *sRed,
                                                        int n, int cb0, int wave, int lane, int tid, int slot = 0) {
     const int q = lane >> 4, r = lane & 15;
@@ -117,7 +121,7 @@ static __device__ __forceinline__ void stats_to_global(const ConvParams &p, floa
         for (int j = 0; j < 4; ++j) {
             const float a = row16_sum(t1[nb][j]), b = row16_sum(t2[nb][j]);
             if (r == 0) {
-                const int c = nb * 16 + q * 4 + j;
+                const int c = PERM ? q * 8 + nb * 4 + j : nb * 16 + q * 4 + j;
                 sRed[(wave * NB * 16 + c) * 2] = a;
                 sRed[(wave * NB * 16 + c) * 2 + 1] = b;
             }

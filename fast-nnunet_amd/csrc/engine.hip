@@ -428,7 +428,7 @@ void pack_conv(const Layer &L, const float *W, uint16_t *dst) {
                     for (int j = 0; j < 8; ++j) {
                         const int k = 8 * (lane >> 4) + j;
                         const int tap = conv3d_kstep_tap(L.packing, ks, k >> 4, T), c = ch * 16 + (k & 15);
-                        const int co = cb * 16 + (lane & 15);
+                        const int co = conv3d_pack_cout(L.packing, nblk, cb, lane & 15);
                         int src = 0, cl = c;
                         if (c >= L.cin_pad[0]) { src = 1; cl = c - L.cin_pad[0]; }
                         float v = 0.f;
@@ -482,7 +482,7 @@ void pack_conv_fp8(const Layer &L, const float *W, uint8_t *dst, float *scales) 
                     for (int j = 0; j < 8; ++j) {
                         const int k = 8 * (lane >> 4) + j;
                         const int tap = conv3d_kstep_tap(L.packing, ks, k >> 4, T), c = ch * 16 + (k & 15);
-                        const int co = cb * 16 + (lane & 15);
+                        const int co = conv3d_pack_cout(L.packing, nblk, cb, lane & 15);
                         int src = 0, cl = c;
                         if (c >= L.cin_pad[0]) { src = 1; cl = c - L.cin_pad[0]; }
                         float v = 0.f;

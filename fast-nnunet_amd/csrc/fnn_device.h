@@ -52,6 +52,7 @@ struct ConvParams {
     int tiles_d, tiles_h, tiles_w;
     int tile_d;                  // output tile depth: 4, or 8 for the pipelined kernel with 8 column blocks per wave
     unsigned long long *dbg;     // diagnostic builds only (-DFNN_STAMPS): per-workgroup s_memtime stamps
+    int tmode;                   // diagnostic builds only (-DFNN_TMODE): timing-only switches of the ZR kernel (wrong results)
     int chunks;                  // 16-channel chunks over all sources
     int ksteps;                  // MFMA k-steps per chunk: conv3d_ksteps(packing, taps)
     const float *ident_ss;       // conv3d_identity_ss(): ones[512] then zeros[512] (set by the launchers that need it)
@@ -256,6 +257,7 @@ const float *conv3d_identity_ss();
 int conv3d_packing(const ConvParams &p);
 int conv3d_ksteps(int packing, int taps);
 int conv3d_kstep_tap(int packing, int ks, int half, int taps);     // linear tap index, or -1 = zero padding
+int conv3d_pack_cout(int packing, int nblk, int cb, int m);        // output channel in row m of cout block cb of the packed weights
 int launch_conv3d_zr(const ConvParams &p, hipStream_t st);
 int conv3d_stats_slots(const ConvParams &p);                           // rows per item the layer's kernel writes into stats_out
 int launch_tconv(const TconvParams &p, hipStream_t st);

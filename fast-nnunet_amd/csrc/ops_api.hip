@@ -121,7 +121,7 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
                         const int kk = 8 * (lane >> 4) + j, tap = conv3d_kstep_tap(p.packing, ks, kk >> 4, T), c = ch * 16 + (kk & 15);
-                        const int co = cb * 16 + (lane & 15);
+                        const int co = conv3d_pack_cout(p.packing, cop / 16, cb, lane & 15);
                         int src = 0, cl = c;
                         if (c >= cp1) { src = 1; cl = c - cp1; }
                         const int creal = src ? cin2 : cin;
@@ -150,11 +150,36 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
     (void)hipDeviceSynchronize();
     (void)hipMemset(dst.p, 0, (size_t)n * slots * cop * 16);
 #endif
+    if (getenv("FNN_OP_TIME")) {                    // diagnostic: mean duration of 10 launches of this layer (after 2 warm-ups)
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        for (int i = 0; i < 2; ++i) (void)launch_conv3d(p, 0);
+        (void)hipEventRecord(e0, 0);
+        for (int i = 0; i < 10; ++i) (void)launch_conv3d(p, 0);
+        (void)hipEventRecord(e1, 0);
+        (void)hipDeviceSynchronize();
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        fprintf(stderr, "[op time] conv3d %d+%d -> %d at %dx%dx%d, N = %d: %.1f us per launch\n", cin, cin2, cout, p.Di, p.Hi, p.Wi, n, ms * 100.f);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        (void)hipMemset(dst.p, 0, (size_t)n * slots * cop * 16);
+    }
+#ifdef FNN_STAMPS
+    hipEvent_t ev0, ev1;
+    (void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
+    (void)hipEventRecord(ev0, 0);
+#endif
     const int rc = launch_conv3d(p, 0);
     if (rc != 0) return rc == -1 ? FNN_E_UNSUPPORTED : FNN_E_HIP;
+#ifdef FNN_STAMPS
+    (void)hipEventRecord(ev1, 0);
+#endif
     if (hipDeviceSynchronize() != hipSuccess) return FNN_E_HIP;
 #ifdef FNN_STAMPS
     {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev0, ev1);
+        fprintf(stderr, "[stamps] launch %.1f us; ", ms * 1000.f);
         std::vector<unsigned long long> h(dbg_n);
         (void)hipMemcpy(h.data(), ddbg.p, dbg_n * 8, hipMemcpyDeviceToHost);
         double sum[12] = {0}; long cnt = 0;
