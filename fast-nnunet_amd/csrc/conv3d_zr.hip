@@ -581,6 +581,10 @@ static int launch_zr(ConvParams p, hipStream_t st) {
 // tools/zr_tmode.py) say where the time of the 32 -> 32 layer is: halo loads hitting one line -23 %, weight loads
 // hitting one element -5 %, stores dropped -14 %, all three -32 %, no normalisation 0 %; MFMA work alone would be 30 %
 // of the kernel's time.
+// <4, 8> (four cout blocks per workgroup: the halo of a Cout >= 64 layer staged once per 64 channels instead of per 32;
+// 99 KB of LDS, one workgroup per CU, one wave per SIMD with 392-456 registers, compiler-scheduled LDS reads): per layer
+// 64 -> 64 392 -> 435 us, 128 -> 64 820 -> 765, 128 -> 128 265 -> 293, 256 -> 128 537 -> 561; +3.5 % conv time end to end.
+// One wave per SIMD has nobody to cover its commit phases and LDS latencies; it would need a hand-pipelined k-loop.
 // Round 2, also measured and dropped: (1) two tiles per 512-thread workgroup forced half a period apart (one half in its
 // k-loop while the other stages, shared barriers; same registers and LDS per tile, bit-identical results): 6 % slower
 // end to end than two independent workgroups per CU - a chunk's staging (load issue + normalise + LDS writes) takes
