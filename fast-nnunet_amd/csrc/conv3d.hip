@@ -252,6 +252,10 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
 }
 
 static int lds_pitch(int IW) { return (IW & 7) ? ((IW + 3) & ~7) + 4 : IW; }
+// Stride-2 layers keep the plain image (pitch IW): their operand reads (8 voxels 64 bytes apart, two rows) are 2-way
+// bank conflicted.  Measured and dropped (round 2): columns stored de-interleaved (even ones first) at a pitch of
+// 2 (mod 4) voxels with the channel halves swapped on rows 2, 3, 6, 7, ... - conflict-free reads, bit-identical results,
+// but 2-way conflicted ds_write_b128 and 6 % more LDS: 32 -> 64 at 160 x 48 x 48 640 -> 781 us, 64 -> 128 447 -> 514 us.
 
 // ----------------------------------------------------------------------------
 // pipelined MFMA conv, weights through LDS per chunk (stride 1)
