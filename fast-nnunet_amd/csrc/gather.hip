@@ -201,14 +201,18 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
     if (bad) atomicOr(p.inf_flag, 1);
 
     if (LABELS) {
-        // LabelPick (misc.hip) over this lane's heads in order, merged over the 4 lanes of a voxel in head order:
-        // heads of lane q, block hb are hb * 16 + 4 q + j, so per block the lanes are ordered and blocks come in order
+        // LabelPick (misc.hip): argmax with torch's rules - the first NaN wins, else the largest value, the lowest head
+        // among equals - is a maximum under a total order, so the lane picks over ITS 16 heads (ascending: a strict
+        // compare keeps the first) and the four lanes of a voxel merge once, comparing head indices on ties: 4 cross-lane
+        // moves per 16 voxels and lane instead of 32 (30.8 -> 29.3 ms per 512^3 x 61 volume; the logits form: 23.8).
+        // Measured and dropped: maximum by max3 + two cross-lane steps, then the lowest head that equals it, with this
+        // chain kept for groups that hold a NaN - 7x fewer instructions on the usual path, 35.3 ms.
+        // Regions: the highest head above the threshold - a plain maximum of indices.
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float best = 0.f; int arg = -1; bool nan = false; int hit = -1;
+            float b = 0.f; int a = -1; bool n = false; int h = -1;
 #pragma unroll
-            for (int hb = 0; hb < HB; ++hb) {
-                float b = 0.f; int a = -1; bool n = false; int h = -1;      // this lane's 4 heads of block hb
+            for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int head = hb * 16 + q * 4 + j;
@@ -219,26 +223,22 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
                         else if (!n && (v > b || v != v)) { b = v; a = head; n = v != v; }
                     }
                 }
-                // merge the 4 lanes of the block (xor 16, 32: lower lane = lower heads), then behind the earlier blocks
 #pragma unroll
-                for (int m = 16; m < 64; m <<= 1) {
-                    const float ob = __shfl_xor(b, m, 64);
-                    const int oa = __shfl_xor(a, m, 64), on = __shfl_xor((int)n, m, 64), oh = __shfl_xor(h, m, 64);
-                    const bool lower = (lane & m) == 0;
-                    const float lb = lower ? b : ob, hbv = lower ? ob : b;
-                    const int la = lower ? a : oa, ha = lower ? oa : a;
-                    const bool ln = lower ? n : (on != 0), hn = lower ? (on != 0) : n;
-                    const bool take_hi = la < 0 ? true : (ha < 0 ? false : (ln ? false : (hn || hbv > lb)));
-                    b = take_hi ? hbv : lb; a = take_hi ? ha : la; n = take_hi ? hn : ln;
-                    h = h > oh ? h : oh;
-                }
-                const bool take = arg < 0 ? true : (a < 0 ? false : (nan ? false : (n || b > best)));
-                if (take) { best = b; arg = a; nan = n; }
-                hit = hit > h ? hit : h;
+            for (int m = 16; m < 64; m <<= 1) {
+                const float ob = __shfl_xor(b, m, 64);
+                const int oa = __shfl_xor(a, m, 64);
+                const bool on = ob != ob;
+                bool take;                                     // is the other lane's pick the better one?
+                if (a < 0) take = true;
+                else if (oa < 0) take = false;
+                else if (n || on) take = on && (!n || oa < a);
+                else take = ob > b || (ob == b && oa < a);
+                if (take) { b = ob; a = oa; n = on; }
+                if (p.order) { const int oh = __shfl_xor(h, m, 64); h = h > oh ? h : oh; }
             }
             const int z = z0 + 16 * g + r;
             if (q == 0 && z < p.z_hi) {
-                const int lab = p.order ? (hit >= 0 ? p.order[hit] : 0) : arg;
+                const int lab = p.order ? (h >= 0 ? p.order[h] : 0) : a;
                 const size_t o = ((size_t)x * p.OY + y) * p.OZ + z;
                 if (p.label_u16) ((uint16_t *)p.labels)[o] = (uint16_t)lab; else ((uint8_t *)p.labels)[o] = (uint8_t)lab;
             }

@@ -364,8 +364,10 @@ class ShardedPredictor:
         for _, pid, _ in recvs:
             slot_of.setdefault(pid, len(slot_of))
         C = eng.feature_channels
-        feat = torch.zeros((len(slot_of), *patch, C), dtype=torch.half, device=p.device)
-        fss = torch.zeros((len(slot_of), 2, C), dtype=torch.float32, device=p.device)
+        # no zero fill: own slots are written whole by fnn_patch_features, a foreign slot exactly where it overlaps this
+        # rank's owned box - the only part of it fnn_gather_box reads
+        feat = torch.empty((len(slot_of), *patch, C), dtype=torch.half, device=p.device)
+        fss = torch.empty((len(slot_of), 2, C), dtype=torch.float32, device=p.device)
         P = int(np.prod(patch))
         fx = FeatureExchange(feat, fss, dec, self.rank, patch, origins, slot_of, self.group)
         if boundary:
