@@ -275,7 +275,9 @@ def main():
     ap.add_argument('--workload', default='bone_turbo_r2', choices=list(WORKLOADS))
     ap.add_argument('--volume', type=int, default=512)
     ap.add_argument('--batch', type=int, default=32)
-    ap.add_argument('--accum', default='fp16', choices=['fp16', 'fp32'])
+    ap.add_argument('--accum', default='fp16', choices=['fp16', 'fp32', 'fp16_autocast'],
+                    help="accumulation arithmetic: 'fp16' = the reference without autocast (its CPU path; the oracle's "
+                         "default and the bench line), 'fp16_autocast' = the reference on a GPU (fp16 network output)")
     ap.add_argument('--dtype', default='f16', choices=['f16', 'f8'],
                     help='operand format of the 3x3x3 stride-1 convolutions (f8: OCP e4m3, BASELINE config 5)')
     ap.add_argument('--mirror', action='store_true',

@@ -16,7 +16,7 @@ FNN_MAX_STAGES = 8
 FNN_OK, FNN_E_INVALID, FNN_E_HIP, FNN_E_INF, FNN_E_UNSUPPORTED, FNN_E_STATE = 0, -1, -2, -3, -4, -5
 FNN_NET_PLAIN, FNN_NET_RESENC = 0, 1
 FNN_PREC_F16, FNN_PREC_F8 = 0, 1
-FNN_ACC_FP16_REFERENCE, FNN_ACC_FP32 = 0, 1
+FNN_ACC_FP16_REFERENCE, FNN_ACC_FP32, FNN_ACC_FP16_AUTOCAST = 0, 1, 2
 FNN_OUT_F16, FNN_OUT_F32 = 0, 1
 FNN_LABELS_ARGMAX, FNN_LABELS_REGIONS = 0, 1
 FNN_LABEL_U8, FNN_LABEL_U16 = 0, 1

@@ -783,7 +783,13 @@ int check_ready(fnn_engine *e, int fold, const fnn_opts *o) {
     if (o->n_mirror_axes < 0 || o->n_mirror_axes > 3) return fail(e, FNN_E_INVALID, "n_mirror_axes out of range");
     for (int i = 0; i < o->n_mirror_axes; ++i)
         if (o->mirror_axes[i] < 0 || o->mirror_axes[i] > 2) return fail(e, FNN_E_INVALID, "mirror_axes does not match the dimension of the input!");
+    if (o->accum < FNN_ACC_FP16_REFERENCE || o->accum > FNN_ACC_FP16_AUTOCAST) return fail(e, FNN_E_INVALID, "accum is not a FNN_ACC_* value");
     return 0;
+}
+
+// the entry points on accumulator buffers (multi-GPU accumulate mode, > 63 classes) only know the two buffer arithmetics
+inline int no_autocast(fnn_engine *e, const fnn_opts *o, const char *who) {
+    return o->accum == FNN_ACC_FP16_AUTOCAST ? fail(e, FNN_E_UNSUPPORTED, "%s: FNN_ACC_FP16_AUTOCAST is served by the gather path only", who) : 0;
 }
 
 struct Box { int64_t lo[3], hi[3]; };
@@ -1092,7 +1098,7 @@ int gather_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const Vol
     g.lo_x = (int)vp.lo[0]; g.lo_y = (int)vp.lo[1]; g.lo_z = (int)vp.lo[2];
     g.OX = shape[1]; g.OY = shape[2]; g.OZ = shape[3];
     g.y_lo = 0; g.y_hi = (int)shape[2]; g.z_lo = 0; g.z_hi = (int)shape[3]; g.slot_tab = nullptr;
-    g.acc_fp32 = o.accum == FNN_ACC_FP32; g.out_fp32 = 0;
+    g.acc_mode = o.accum; g.out_fp32 = 0;
     g.out_vec = out && shape[3] % 8 == 0 && ((size_t)out % 16) == 0;
     g.mode = mode; g.out = out; g.labels = labels; g.label_u16 = e->label_u16; g.order = lab_order; g.inf_flag = e->inf_flag;
     auto launch = [&](int x_lo, int x_hi, double n_patches) {
@@ -1164,6 +1170,8 @@ int predict_impl(fnn_engine *e, int fold0, int n_folds, const float *vol, const 
     const int64_t zero3[3] = {0, 0, 0}, full3[3] = {shape[1], shape[2], shape[3]};
     int rc = 0;
     const GatherPlan gp = gather_plan(e, vp, *o);
+    if (!gp.ok && o->accum == FNN_ACC_FP16_AUTOCAST)
+        return fail(e, FNN_E_UNSUPPORTED, "FNN_ACC_FP16_AUTOCAST needs the gather path (<= 63 classes, a normalised last layer, FNN_NO_GATHER unset)");
     for (int f = 0; f < n_folds && rc == 0; ++f) {
         if (gp.ok) {
             rc = gather_whole_volume(e, fold0 + f, vol_dev, vp, shape, *o, gp, f > 0 ? 1 : 0, labels_direct ? nullptr : out_dev,
@@ -1357,6 +1365,7 @@ int fnn_accumulate_patches(fnn_engine *e, int fold, const float *vol, const int6
                            const int64_t *patch_ids, int64_t n_ids, const int64_t box_lo[3], const int64_t box_hi[3],
                            void *acc) {
     if (int rc = check_ready(e, fold, opts)) return rc;
+    if (int rc = no_autocast(e, opts, "fnn_accumulate_patches")) return rc;
     if (!vol || !acc || !box_lo || !box_hi || (n_ids > 0 && !patch_ids)) return fail(e, FNN_E_INVALID, "NULL argument");
     if (!is_device_ptr(acc)) return fail(e, FNN_E_INVALID, "accumulators must be device memory");
     HIPCHK(e, hipSetDevice(e->device));
@@ -1384,6 +1393,7 @@ int fnn_normalize_box(fnn_engine *e, const void *acc, const int64_t shape[4], co
                       const int64_t box_lo[3], const int64_t box_hi[3], const int64_t out_lo[3], const int64_t out_hi[3],
                       void *out) {
     if (!e || !opts) return FNN_E_INVALID;
+    if (int rc = no_autocast(e, opts, "fnn_normalize_box")) return rc;
     if (!acc || !out || !box_lo || !box_hi || !out_lo || !out_hi) return fail(e, FNN_E_INVALID, "NULL argument");
     if (!is_device_ptr(acc) || !is_device_ptr(out)) return fail(e, FNN_E_INVALID, "fnn_normalize_box needs device pointers");
     HIPCHK(e, hipSetDevice(e->device));
@@ -1411,6 +1421,7 @@ int fnn_labels_box(fnn_engine *e, const void *acc, const int64_t shape[4], const
                    const int64_t box_lo[3], const int64_t box_hi[3], const int64_t out_lo[3], const int64_t out_hi[3],
                    void *labels) {
     if (!e || !opts) return FNN_E_INVALID;
+    if (int rc = no_autocast(e, opts, "fnn_labels_box")) return rc;
     if (!acc || !labels || !box_lo || !box_hi || !out_lo || !out_hi) return fail(e, FNN_E_INVALID, "NULL argument");
     if (!is_device_ptr(acc) || !is_device_ptr(labels)) return fail(e, FNN_E_INVALID, "fnn_labels_box needs device pointers");
     if (!e->label_u16 && e->label_mode == FNN_LABELS_ARGMAX && e->arch.num_heads > 256)
@@ -1508,7 +1519,7 @@ int fnn_gather_box(fnn_engine *e, int fold, const void *feat, const float *fss, 
     g.OX = shape[1]; g.OY = shape[2]; g.OZ = shape[3];
     g.x_lo = (int)out_lo[0]; g.x_hi = (int)out_hi[0]; g.y_lo = (int)out_lo[1]; g.y_hi = (int)out_hi[1];
     g.z_lo = (int)out_lo[2]; g.z_hi = (int)out_hi[2];
-    g.acc_fp32 = opts->accum == FNN_ACC_FP32; g.out_fp32 = 0; g.mode = 0; g.inf_flag = e->inf_flag;
+    g.acc_mode = opts->accum; g.out_fp32 = 0; g.mode = 0; g.inf_flag = e->inf_flag;
     g.label_u16 = e->label_u16; g.order = e->label_mode == FNN_LABELS_REGIONS ? e->label_order : nullptr;
     if (labels && !e->label_u16 && e->label_mode == FNN_LABELS_ARGMAX && a.num_heads > 256)
         return fail(e, FNN_E_INVALID, "%d classes do not fit uint8 labels", a.num_heads);

@@ -181,7 +181,7 @@ struct GatherParams {
     const f16 *gauss;            // [PD][PH][PW] (all ones without Gaussian weighting)
     int lo_x, lo_y, lo_z;        // un-padded voxel (0, 0, 0) in the padded volume
     long long OX, OY, OZ;        // un-padded size = output size
-    int acc_fp32, out_fp32, out_vec;
+    int acc_mode, out_fp32, out_vec; // acc_mode = FNN_ACC_* (include/fnn.h)
     int mode;                    // 0 write, 1 add to the existing output (fold ensembling)
     void *out;                   // [heads][OX][OY][OZ] fp16 / fp32, or
     void *labels;                // [OX][OY][OZ] uint8 / uint16 (then `out` is unused)

@@ -32,6 +32,21 @@ static __device__ __forceinline__ float acc_add_product_1(float a, float t, floa
     return a + c;
 }
 
+// FNN_ACC_FP16_AUTOCAST: the product of two fp16 numbers rounded to fp16, then an fp16 + fp16 add rounded to fp16 -
+// torch's half arithmetic (computed in fp32, rounded once: the fp32 product of two halves is exact, and an fp32 sum of
+// two halves can only be inexact when the smaller one is below a quarter ulp of the result, where both roundings agree).
+// No contraction: v_pk_fma_f16 would skip the product's rounding.
+static __device__ __forceinline__ f16x2 acc_add_product_h2(f16x2 a, f16x2 t, f16x2 g) {
+#pragma clang fp contract(off)
+    const f16x2 c = t * g;
+    return a + c;
+}
+static __device__ __forceinline__ f16x2 add_h2(f16x2 a, f16x2 b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+static __device__ __forceinline__ f16x2 round_h2(float a, float b) { f16x2 r; r[0] = (f16)a; r[1] = (f16)b; return r; }
+
 struct Pick {                                                  // LabelPick of misc.hip over this lane's heads, mergeable
     float best; int arg; int nan; int hit;
 };
@@ -39,22 +54,32 @@ struct Pick {                                                  // LabelPick of m
 }  // namespace
 
 // HB = head blocks of 16 (heads + the weight-sum channel <= 16 HB); LABELS: write the label map instead of the logits.
-template <int HB, bool ACC32, bool LABELS, bool TTA>
-__global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) {
+// ACCM = the accumulate arithmetic (include/fnn.h): 0 FNN_ACC_FP16_REFERENCE - fp32 logits, fp32 product and sum, one
+// rounding to fp16 per visit (the reference without autocast: its CPU path); 1 FNN_ACC_FP32; 2 FNN_ACC_FP16_AUTOCAST -
+// the reference on a GPU (predict_from_raw_data.py:591-593: the network's output is fp16): logit, mirror sums, product
+// and sum each rounded to fp16 - packed fp16 arithmetic, half the instructions of mode 0.
+// The kernel is latency bound, not instruction bound: the packed fp16 arithmetic of ACCM = 2 (half the accumulate
+// instructions) changed nothing at equal occupancy, a fourth wave per SIMD (its 128 registers instead of 140, asked for
+// below) took 18 % off: 23.5 -> 19.3 ms per 512^3 x 61 volume.  ACCM = 0 holds 162 registers (fp32-valued sums): forced
+// to 128 it spills and takes 53 ms; with 32-voxel runs per wave (half the accumulators, 4 waves per SIMD without
+// scratch) it takes 26-27 ms - the per-wave set-up doubles - so it keeps 64-voxel runs and three waves per SIMD.
+template <int HB, int ACCM, bool LABELS, bool TTA>
+__global__ __launch_bounds__(256, (!TTA && ACCM == 2 && !LABELS) ? 4 : 1) void gather_head_kernel(const GatherParams p) {
+    constexpr int G = 4, ZW = 16 * G, TP = ZW + 8;             // 16-voxel groups and z voxels per wave; row pitch of the LDS transpose
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
-    f16 *sT = (f16 *)smem + wave * (HB * 16 * 72);             // per wave: [HB * 16 heads][64 z (+8 pad)] fp16
+    f16 *sT = (f16 *)smem + wave * (HB * 16 * TP);             // per wave: [HB * 16 heads][ZW z (+8 pad)] fp16
 
     // wave -> (x, y, run of 64 z) of the UN-PADDED output
     const int ny_box = p.y_hi - p.y_lo, nz_box = p.z_hi - p.z_lo;
-    const long long zruns = (nz_box + 63) / 64;
+    const long long zruns = (nz_box + ZW - 1) / ZW;
     long long wid = (long long)blockIdx.x * 4 + wave;
     const long long total = (long long)(p.x_hi - p.x_lo) * ny_box * zruns;
     if (wid >= total) return;
     const int zr = (int)(wid % zruns); wid /= zruns;
     const int y = p.y_lo + (int)(wid % ny_box);
     const int x = p.x_lo + (int)(wid / ny_box);
-    const int z0 = p.z_lo + zr * 64;
+    const int z0 = p.z_lo + zr * ZW;
     const int xp = x + p.lo_x, yp = y + p.lo_y, zp0 = z0 + p.lo_z;            // padded-volume coordinates
 
     // seg head fragments: A operand per head block, bias of this lane's 4 heads per block
@@ -66,11 +91,16 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
         wf[hb] = *(const f16x8 *)(p.wpk + ((size_t)hbc * 64 + lane) * 8);
         bv[hb] = *(const f32x4 *)(p.bias + hbc * 16 + q * 4);
     }
-    f32x4 acc[4][HB];                                          // [16-voxel group][head block] x 4 heads: fp16-valued unless ACC32
+    constexpr bool ACC32 = ACCM == 1, ACH = ACCM == 2;
+    f32x4 acc[G][HB];                                          // [16-voxel group][head block] x 4 heads: fp16-valued unless ACC32
+    f16x2 ah[ACH ? G : 1][HB][2];                              // ACH: the same sums kept as fp16 pairs (heads 4q + {0,1}, {2,3})
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int hb = 0; hb < HB; ++hb) acc[g][hb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int hb = 0; hb < HB; ++hb) {
+            acc[g][hb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (ACH) { ah[ACH ? g : 0][hb][0] = (f16x2){0, 0}; ah[ACH ? g : 0][hb][1] = (f16x2){0, 0}; }
+        }
 
     const int P = p.PD * p.PH * p.PW;
     const int c0 = q * 8 < p.C ? q * 8 : 0;
@@ -86,20 +116,21 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
             if (yp < oy || yp >= oy + p.PH) continue;
             for (int iz = 0; iz < p.nz; ++iz) {
                 const int oz = sz[iz];
-                if (zp0 + 64 <= oz || zp0 >= oz + p.PW) continue;
+                if (zp0 + ZW <= oz || zp0 >= oz + p.PW) continue;
                 const int pid = (ix * p.ny + iy) * p.nz + iz;
                 const int slot = p.slot_tab ? p.slot_tab[pid] : ((ix % p.ring) * p.ny + iy) * p.nz + iz;
                 if (slot < 0) continue;                        // not held here (a sharded caller's table): nothing to add
                 const int dx = xp - ox, dy = yp - oy;
-                bool in[4];
-                f16 graw[4];
+                bool in[G];
+                f16 graw[G];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                for (int g = 0; g < G; ++g) {
                     const int zp = zp0 + 16 * g + r;
                     in[g] = zp >= oz && zp < oz + p.PW;
                     graw[g] = p.gauss[in[g] ? (dx * p.PH + dy) * p.PW + zp - oz : 0];
                 }
-                f32x4 tsum[TTA ? 4 : 1][HB];                  // mirrored evaluations: running fp32 sum of the logits
+                f32x4 tsum[TTA ? G : 1][HB];                  // mirrored evaluations: running fp32 sum of the logits
+                f16x2 tsh[TTA && ACH ? G : 1][HB][2];         // ... or the running fp16 sum (autocast arithmetic)
                 for (int f = 0; f < (TTA ? p.n_eval : 1); ++f) {
                     const int fm = TTA ? p.flipmask[f] : 0;
                     // the patch-space voxel (dx, dy, dz) is output voxel (PD-1-dx, ...) of an evaluation whose input was flipped
@@ -113,15 +144,15 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
                     const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
                     const int rowbase = (fx * p.PH + fy) * p.PW;
                     const f16 *fp = p.feat + ev * P * p.C + c0;
-                    f16x8 xraw[4];
+                    f16x8 xraw[G];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
+                    for (int g = 0; g < G; ++g) {
                         const int dz = zp0 + 16 * g + r - oz;
                         const int v = in[g] ? rowbase + ((fm & 4) ? p.PW - 1 - dz : dz) : 0;
                         xraw[g] = *(const f16x8 *)(fp + (size_t)v * p.C);
                     }
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
+                    for (int g = 0; g < G; ++g) {
                         // a patch that starts or ends inside the run leaves whole 16-voxel groups untouched: skip them
                         // (wave-uniform; 3.5 patches intersect a 64-voxel run along z, 2 cover each voxel)
                         if (__builtin_amdgcn_ballot_w64(in[g]) == 0) continue;
@@ -140,7 +171,21 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
 #pragma unroll
                         for (int hb = 0; hb < HB; ++hb) {
                             const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[hb], o, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                            if (TTA) {
+                            if (ACH) {
+                                const f16x2 t01 = round_h2(d[0] + bv[hb][0], d[1] + bv[hb][1]);      // the network's fp16 output
+                                const f16x2 t23 = round_h2(d[2] + bv[hb][2], d[3] + bv[hb][3]);
+                                if (TTA) {
+                                    f16x2 (&ts)[2] = tsh[TTA && ACH ? g : 0][hb];
+                                    ts[0] = f == 0 ? t01 : add_h2(ts[0], t01);
+                                    ts[1] = f == 0 ? t23 : add_h2(ts[1], t23);
+                                } else {
+                                    const f16x2 gw2 = {graw[g], graw[g]};
+                                    f16x2 (&a2)[2] = ah[ACH ? g : 0][hb];
+                                    const f16x2 n01 = acc_add_product_h2(a2[0], t01, gw2), n23 = acc_add_product_h2(a2[1], t23, gw2);
+                                    a2[0] = in[g] ? n01 : a2[0];
+                                    a2[1] = in[g] ? n23 : a2[1];
+                                }
+                            } else if (TTA) {
                                 // predict_from_raw_data.py:541-557: net(x) + sum over the mirror subsets, in their order (fp32)
                                 const f32x4 t = d + bv[hb];
                                 tsum[TTA ? g : 0][hb] = f == 0 ? t : tsum[TTA ? g : 0][hb] + t;
@@ -158,9 +203,23 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
                 if (TTA) {
                     const float nf = (float)p.n_eval;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
+                    for (int g = 0; g < G; ++g) {
                         if (__builtin_amdgcn_ballot_w64(in[g]) == 0) continue;
                         const float gw = (float)graw[g];
+                        if (ACH) {
+                            const f16x2 gw2 = {graw[g], graw[g]};
+#pragma unroll
+                            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                                for (int e = 0; e < 2; ++e) {
+                                    const f16x2 ts = tsh[TTA && ACH ? g : 0][hb][e];
+                                    const f16x2 t = round_h2(__fdiv_rn((float)ts[0], nf), __fdiv_rn((float)ts[1], nf));   // half /= int
+                                    f16x2 &a2 = ah[ACH ? g : 0][hb][e];
+                                    const f16x2 nv = acc_add_product_h2(a2, t, gw2);
+                                    a2 = in[g] ? nv : a2;
+                                }
+                            continue;
+                        }
 #pragma unroll
                         for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
@@ -176,11 +235,19 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
         }
     }
 
+    if (ACH) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[g][hb][j] = (float)ah[ACH ? g : 0][hb][j >> 1][j & 1];
+    }
     // ---- normalise: logits = acc / weight sum, rounded to fp16 (:619); the weight sum sits in row `heads`
     const int wrow = p.heads, whb = wrow >> 4, wq = (wrow >> 2) & 3, wj = wrow & 3;
     bool bad = false;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < G; ++g) {
         float wsum = 0.f;
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb)
@@ -209,7 +276,7 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
         // chain kept for groups that hold a NaN - 7x fewer instructions on the usual path, 35.3 ms.
         // Regions: the highest head above the threshold - a plain maximum of indices.
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < G; ++g) {
             float b = 0.f; int a = -1; bool n = false; int h = -1;
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb)
@@ -248,22 +315,23 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
 
     // ---- logits: transpose through LDS so that a head's 64 z values leave as one 128-byte row
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sT[(hb * 16 + q * 4 + j) * 72 + 16 * g + r] = (f16)acc[g][hb][j];
+            for (int j = 0; j < 4; ++j) sT[(hb * 16 + q * 4 + j) * TP + 16 * g + r] = (f16)acc[g][hb][j];
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
     const size_t plane = (size_t)p.OX * p.OY * p.OZ;
     const size_t rowoff = ((size_t)x * p.OY + y) * p.OZ + z0;
-    const int nz = (int)(p.z_hi - z0 < 64 ? p.z_hi - z0 : 64);
-    const bool vec = p.out_vec && nz == 64 && (p.z_lo & 7) == 0;   // 16-byte aligned rows
+    const int nz = (int)(p.z_hi - z0 < ZW ? p.z_hi - z0 : ZW);
+    const bool vec = p.out_vec && nz == ZW && (p.z_lo & 7) == 0;   // 16-byte aligned rows
     if (!p.out_fp32 && vec) {
-        for (int h8 = 0; h8 < p.heads; h8 += 8) {
-            const int head = h8 + (lane >> 3), piece = lane & 7;
+        constexpr int PCS = ZW / 8, HPP = 64 / PCS;             // 16-byte pieces per row, heads per pass
+        for (int h8 = 0; h8 < p.heads; h8 += HPP) {
+            const int head = h8 + lane / PCS, piece = lane % PCS;
             if (head < p.heads) {
-                f16x8 v = *(const f16x8 *)(sT + head * 72 + piece * 8);
+                f16x8 v = *(const f16x8 *)(sT + head * TP + piece * 8);
                 f16 *o = (f16 *)p.out + (size_t)head * plane + rowoff + piece * 8;
                 if (p.mode) {
                     const f16x8 old = *(const f16x8 *)o;
@@ -276,7 +344,7 @@ __global__ __launch_bounds__(256) void gather_head_kernel(const GatherParams p) 
     } else {
         for (int head = 0; head < p.heads; ++head) {
             if (lane < nz) {
-                const f16 v = sT[head * 72 + lane];
+                const f16 v = sT[head * TP + lane];
                 const size_t o = (size_t)head * plane + rowoff + lane;
                 if (p.out_fp32) {
                     float *op = (float *)p.out + o;
@@ -302,12 +370,15 @@ static int launch_gather_hb(const GatherParams &p, hipStream_t st) {
     const dim3 grid((unsigned)((waves + 3) / 4));
     const size_t lds = (size_t)4 * HB * 16 * 72 * 2;
     const bool labels = p.labels != nullptr;
-    if (p.acc_fp32) {
-        if (labels) hipLaunchKernelGGL((gather_head_kernel<HB, true, true, TTA>), grid, dim3(256), lds, st, p);
-        else hipLaunchKernelGGL((gather_head_kernel<HB, true, false, TTA>), grid, dim3(256), lds, st, p);
+    if (p.acc_mode == 1) {
+        if (labels) hipLaunchKernelGGL((gather_head_kernel<HB, 1, true, TTA>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((gather_head_kernel<HB, 1, false, TTA>), grid, dim3(256), lds, st, p);
+    } else if (p.acc_mode == 2) {
+        if (labels) hipLaunchKernelGGL((gather_head_kernel<HB, 2, true, TTA>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((gather_head_kernel<HB, 2, false, TTA>), grid, dim3(256), lds, st, p);
     } else {
-        if (labels) hipLaunchKernelGGL((gather_head_kernel<HB, false, true, TTA>), grid, dim3(256), lds, st, p);
-        else hipLaunchKernelGGL((gather_head_kernel<HB, false, false, TTA>), grid, dim3(256), lds, st, p);
+        if (labels) hipLaunchKernelGGL((gather_head_kernel<HB, 0, true, TTA>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((gather_head_kernel<HB, 0, false, TTA>), grid, dim3(256), lds, st, p);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

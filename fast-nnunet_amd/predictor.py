@@ -50,8 +50,11 @@ class nnUNetPredictor(object):
                  compute_dtype: str = 'f16'):
         """Same knobs as the reference (:40-65) plus two engine choices:
 
-        accumulate_in  'fp16' reproduces the reference's half accumulators and
-                       their rounding per patch visit; 'fp32' is the exact blend.
+        accumulate_in  'fp16' reproduces the reference's half accumulators and their rounding per patch visit as the
+                       reference computes them WITHOUT autocast (its CPU path: fp32 logits and products, one rounding
+                       per visit); 'fp16_autocast' as it computes them on a GPU (:591-593 - the network returns fp16,
+                       so the logit, the mirror sums, the Gaussian product and the sum are each rounded to fp16);
+                       'fp32' is the exact blend.
         patches_per_forward  how many patches one network forward batches.
         compute_dtype  'f16' (default: the mode every parity statement is for) or 'f8': OCP e4m3 operands in
                        the 3x3x3 stride-1 convolutions (BASELINE config 5; budget in DESIGN.md).
@@ -70,8 +73,8 @@ class nnUNetPredictor(object):
                                f'(got device={device}). Use the reference predictor for CPU inference.')
         self.device = device
         self.perform_everything_on_device = perform_everything_on_device
-        if accumulate_in not in ('fp16', 'fp32'):
-            raise ValueError("accumulate_in must be 'fp16' or 'fp32'")
+        if accumulate_in not in ('fp16', 'fp32', 'fp16_autocast'):
+            raise ValueError("accumulate_in must be 'fp16', 'fp32' or 'fp16_autocast'")
         self.accumulate_in = accumulate_in
         self.patches_per_forward = int(patches_per_forward)
         if compute_dtype not in ('f16', 'f8'):
@@ -197,7 +200,7 @@ class nnUNetPredictor(object):
             o.n_mirror_axes = len(axes)
             for i, a in enumerate(axes):
                 o.mirror_axes[i] = int(a) + (3 - nd)           # 2-D network axes (y, z) are engine axes 1, 2
-        o.accum = capi.FNN_ACC_FP16_REFERENCE if self.accumulate_in == 'fp16' else capi.FNN_ACC_FP32
+        o.accum = {'fp16': capi.FNN_ACC_FP16_REFERENCE, 'fp32': capi.FNN_ACC_FP32, 'fp16_autocast': capi.FNN_ACC_FP16_AUTOCAST}[self.accumulate_in]
         o.out_dtype = capi.FNN_OUT_F16
         o.batch = self.patches_per_forward
         o.stream = torch.cuda.current_stream(self.device).cuda_stream

@@ -52,7 +52,17 @@ enum { FNN_NET_PLAIN = 0, FNN_NET_RESENC = 1 };
  *                 accumulation; everything else (storage, statistics, strided / 1x1x1 / transposed convs, seg
  *                 head, accumulation) as in fp16.  Budget against the fp32 oracle: DESIGN.md, "fp8". */
 enum { FNN_PREC_F16 = 0, FNN_PREC_F8 = 1 };
-enum { FNN_ACC_FP16_REFERENCE = 0, FNN_ACC_FP32 = 1 };
+/* fnn_opts.accum - the arithmetic of the Gaussian-weighted accumulation (predict_from_raw_data.py:602-621):
+ *   FNN_ACC_FP16_REFERENCE  the reference WITHOUT autocast (its CPU path, :591-593 `dummy_context`): the network's
+ *                           logits are fp32, `prediction *= gaussian` is an fp32 product, `predicted_logits += prediction`
+ *                           an fp32 sum rounded once to the fp16 accumulator.  Pinned by tests/golden/sliding_window.npz.
+ *   FNN_ACC_FP32            fp32 accumulators (what the reference's error message recommends when fp16 overflows).
+ *   FNN_ACC_FP16_AUTOCAST   the reference ON A GPU (`torch.autocast`: the network's output is fp16): the logit, every
+ *                           mirror sum, the division by the number of evaluations, the product with the Gaussian and
+ *                           the sum are each rounded to fp16.  Pinned by tests/golden/sliding_window_half.npz (made by
+ *                           the reference's own predictor through networks that return fp16).  Served by the gather
+ *                           path only (<= 63 classes; FNN_E_UNSUPPORTED otherwise and for the accumulate_* entry points). */
+enum { FNN_ACC_FP16_REFERENCE = 0, FNN_ACC_FP32 = 1, FNN_ACC_FP16_AUTOCAST = 2 };
 enum { FNN_OUT_F16 = 0, FNN_OUT_F32 = 1 };
 
 /* Network topology: what the reference builds from plans.json + checkpoint

@@ -127,6 +127,21 @@ SW_CASES = [
 ]
 
 
+# The reference's GPU numerics (network output fp16 under autocast: every step of the accumulation in half precision)
+# produced by the reference's own predictor on a CPU through networks that return fp16; fixtures in sliding_window_half.npz
+SW_CASES_HALF = [
+    _c('half_basic', 'exact', (40, 36, 44), (16, 16, 16), act='scale03', half_out=True, seed=30),
+    _c('half_nogauss', 'exact', (40, 36, 44), (16, 16, 16), gaussian=False, act='scale03', half_out=True, seed=31),
+    _c('half_step03', 'exact', (30, 36, 29), (16, 16, 16), step=0.3, act='scale03', half_out=True, seed=32, heads=4),
+    _c('half_mirror0', 'exact', (33, 30, 21), (16, 24, 16), mirror=[0], act='scale03', half_out=True, seed=33, heads=4),
+    _c('half_mirror012', 'exact', (28, 30, 33), (16, 16, 24), mirror=[0, 1, 2], act='scale03', half_out=True, seed=34,
+       heads=2, channels=2),
+    _c('half_smaller_than_patch', 'exact', (11, 30, 9), (16, 16, 16), act='scale03', half_out=True, seed=35, heads=5),
+    _c('half_3folds', 'exact', (30, 24, 27), (16, 16, 16), folds=3, act='scale03', half_out=True, seed=36, heads=3),
+    _c('half_plain_lrelu', 'exact', (24, 30, 33), (16, 16, 16), mirror=[1, 2], act='lrelu_half', half_out=True, seed=37),
+]
+
+
 # 2-D configurations (patch_size with two entries: every slice of the first axis is tiled, predict_from_raw_data.py
 # :508-524); fixtures in sliding_window_2d.npz
 SW_CASES_2D = [
@@ -141,16 +156,25 @@ SW_CASES_2D = [
 
 class ExactConvNet(nn.Module):
     """Zero-padded 3x3x3 (or 3x3) conv (+ optional LeakyReLU(1/2)) with dyadic weights:
-    every fp32 sum is exact, so results do not depend on summation order."""
+    every fp32 sum is exact, so results do not depend on summation order.
+    ``half_out``: the logits leave as fp16 - what the reference's network does under ``torch.autocast`` on a GPU
+    (predict_from_raw_data.py:591-593), so the predictor's own code then runs its half-precision arithmetic
+    (mirror sums, ``prediction *= gaussian``, ``+=``) on a CPU too.  ``scale03`` multiplies the exact sums by 0.3f
+    first (one IEEE operation: still independent of the summation order) so that the rounding to fp16 is not trivial."""
 
-    def __init__(self, cin, heads, act=None, nd=3):
+    def __init__(self, cin, heads, act=None, nd=3, half_out=False):
         super().__init__()
         self.conv = (nn.Conv3d if nd == 3 else nn.Conv2d)(cin, heads, 3, padding=1, bias=True)
         self.act = act
+        self.half_out = half_out
 
     def forward(self, x):
         y = self.conv(x)
-        return nn.functional.leaky_relu(y, 0.5) if self.act == 'lrelu_half' else y
+        if self.act == 'lrelu_half':
+            y = nn.functional.leaky_relu(y, 0.5)
+        elif self.act == 'scale03':
+            y = y * 0.3
+        return y.half() if self.half_out else y
 
 
 def exact_state_dict(cin, heads, seed, nd=3):
@@ -184,7 +208,7 @@ def make_case_networks(case):
         seed = 77 * case['seed'] + f
         nd = len(case['patch'])
         if case['kind'] == 'exact':
-            net = ExactConvNet(case['channels'], case['heads'], case['act'], nd)
+            net = ExactConvNet(case['channels'], case['heads'], case['act'], nd, case.get('half_out', False))
             sd = exact_state_dict(case['channels'], case['heads'], seed, nd)
         else:
             spec = (toy_unet_spec if nd == 3 else toy_unet_spec_2d)(case['channels'], case['heads'])

@@ -48,7 +48,7 @@ from nnunetv2.utilities.plans_handling.plans_handler import PlansManager  # noqa
 from nnunetv2.utilities.label_handling.label_handling import LabelManager, determine_num_input_channels  # noqa: E402
 from nnunetv2.experiment_planning.experiment_planners.network_topology import get_pool_and_conv_props  # noqa: E402
 
-from golden_cases import (SW_CASES, SW_CASES_2D, STEP_CASES, GAUSS_FULL, GAUSS_SUMMARY, TOPOLOGY_CASES, PLANS_NEW,  # noqa: E402
+from golden_cases import (SW_CASES, SW_CASES_2D, SW_CASES_HALF, STEP_CASES, GAUSS_FULL, GAUSS_SUMMARY, TOPOLOGY_CASES, PLANS_NEW,  # noqa: E402
                           PLANS_OLD, DATASET_JSONS, make_case_inputs, make_case_networks)
 
 
@@ -88,6 +88,10 @@ def gen_gaussian():
 
 def gen_sliding_window_2d():
     gen_sliding_window(SW_CASES_2D, 'sliding_window_2d.npz', '2d')
+
+
+def gen_sliding_window_half():
+    gen_sliding_window(SW_CASES_HALF, 'sliding_window_half.npz')
 
 
 def gen_sliding_window(cases=None, fname='sliding_window.npz', config='3d_fullres'):
@@ -273,7 +277,7 @@ def gen_resample_logic():
 if __name__ == '__main__':
     if len(sys.argv) > 1:                                   # regenerate single fixtures: labels, plans
         for what in sys.argv[1:]:
-            {'labels': gen_label_rules, 'plans': gen_plans, 'sw2d': gen_sliding_window_2d, 'prep': gen_preprocess, 'resample': gen_resample_logic, 'export': gen_export}[what]()
+            {'labels': gen_label_rules, 'plans': gen_plans, 'sw2d': gen_sliding_window_2d, 'swhalf': gen_sliding_window_half, 'prep': gen_preprocess, 'resample': gen_resample_logic, 'export': gen_export}[what]()
         sys.exit(0)
     gen_label_rules()
     gen_steps()
@@ -282,6 +286,7 @@ if __name__ == '__main__':
     gen_plans()
     gen_sliding_window()
     gen_sliding_window_2d()
+    gen_sliding_window_half()
     gen_preprocess()
     gen_resample_logic()
     gen_export()

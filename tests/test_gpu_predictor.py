@@ -160,17 +160,23 @@ DRIVER_CASES = [
 ]
 
 
+@pytest.mark.parametrize('mode', ['fp16', 'fp16_autocast'])
 @pytest.mark.parametrize('case', DRIVER_CASES, ids=lambda c: f"{c['shape']}-m{c['mirror']}-s{c['step']}-f{c['folds']}")
-def test_driver_bit_identical_to_oracle_driver_on_engine_logits(case):
+def test_driver_bit_identical_to_oracle_driver_on_engine_logits(case, mode):
+    """'fp16': the reference without autocast (fp32 logits; pinned by tests/golden/sliding_window.npz).
+    'fp16_autocast': the reference on a GPU - the network returns fp16, so the oracle's driver (the reference's own
+    torch statements, pinned for fp16-output networks by tests/golden/sliding_window_half.npz) rounds the mirror sums,
+    the Gaussian product and the accumulation to fp16; the engine's FNN_ACC_FP16_AUTOCAST must give the same bits."""
     spec, patch = SPECS['toy3']
     sds = [synthetic_state_dict(spec, 50 + f) for f in range(case['folds'])]
-    p = _predictor(spec, patch, sds, mirror=case['mirror'], step=case['step'], gaussian=case['gaussian'])
+    p = _predictor(spec, patch, sds, mirror=case['mirror'], step=case['step'], gaussian=case['gaussian'], accumulate_in=mode)
     image = torch.randn(1, *case['shape'], generator=torch.Generator().manual_seed(9))
 
     def engine_net(fold):
         def f(x):
             p._active_fold = fold
-            return p.forward_patches(x).cpu()
+            y = p.forward_patches(x).cpu()
+            return y.half() if mode == 'fp16_autocast' else y
         return f
 
     nets = [engine_net(f) for f in range(case['folds'])]
@@ -843,6 +849,51 @@ def test_gather_ring_and_mirroring_are_bit_identical_to_the_accumulate_path(mirr
             assert torch.equal(p.predict_segmentation_from_preprocessed_data(image).long(), want.float().argmax(0))
         finally:
             os.environ.pop('FNN_GATHER_RING', None)
+
+
+@pytest.mark.parametrize('heads,mirror', [(3, None), (61, None), (3, (0, 2))])
+def test_autocast_accumulation_whole_ring_labels_and_refusals(heads, mirror):
+    """FNN_ACC_FP16_AUTOCAST beyond the small driver cases: 61 heads (four head blocks), the ring of x layers, labels
+    written by the gather kernel, the fold ensemble; the accumulator entry points and a forced accumulate path refuse
+    the mode instead of silently computing the other arithmetic."""
+    spec = UNetSpec('plain', 1, heads, [16, 32], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
+    patch = (16, 16, 32)
+    sds = [synthetic_state_dict(spec, 410 + f) for f in range(2)]
+    p = _predictor(spec, patch, sds, mirror=mirror, accumulate_in='fp16_autocast')
+    image = torch.randn(1, 50, 37, 70, generator=torch.Generator().manual_seed(31))
+
+    def net(fold):
+        def f(x):
+            p._active_fold = fold
+            return p.forward_patches(x).cpu().half()
+        return f
+
+    kw = dict(step=0.5, use_gaussian=True, mirror_axes=mirror, accum='fp16')
+    want = osw.sliding_window_logits(net(0), image, patch, heads, **kw)
+    p._active_fold = 0
+    got = p.predict_sliding_window_return_logits(image)
+    assert np.array_equal(_bits(got), _bits(want))
+    p1 = _predictor(spec, patch, sds[:1], mirror=mirror, accumulate_in='fp16_autocast')      # one fold: labels of `want`
+    for ring in (2, 3):
+        os.environ['FNN_GATHER_RING'] = str(ring)
+        try:
+            assert torch.equal(p.predict_sliding_window_return_logits(image), got)
+            assert torch.equal(p1.predict_segmentation_from_preprocessed_data(image).long().cpu(), osw.logits_to_labels(want).long())
+        finally:
+            os.environ.pop('FNN_GATHER_RING', None)
+    assert torch.equal(p1.predict_segmentation_from_preprocessed_data(image).long().cpu(), osw.logits_to_labels(want).long())
+    want2 = osw.ensemble_logits([net(0), net(1)], image, patch, heads, **kw)
+    assert np.array_equal(_bits(p.predict_logits_from_preprocessed_data(image)), _bits(want2))
+    # differs from the no-autocast arithmetic (else the test above proves nothing)
+    q = _predictor(spec, patch, sds, mirror=mirror, accumulate_in='fp16')
+    assert not torch.equal(q.predict_sliding_window_return_logits(image), got)
+    os.environ['FNN_NO_GATHER'] = '1'
+    try:
+        r = _predictor(spec, patch, sds, mirror=mirror, accumulate_in='fp16_autocast')
+        with pytest.raises(NotImplementedError, match='AUTOCAST'):
+            r.predict_sliding_window_return_logits(image)
+    finally:
+        os.environ.pop('FNN_NO_GATHER', None)
 
 
 @pytest.mark.parametrize('heads,world', [(3, 2), (3, 4), (61, 8)])

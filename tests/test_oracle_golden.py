@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_cases import SW_CASES, SW_CASES_2D, DATASET_JSONS, make_case_inputs, make_case_networks
+from golden_cases import SW_CASES, SW_CASES_2D, SW_CASES_HALF, DATASET_JSONS, make_case_inputs, make_case_networks
 from oracle import sliding_window as osw
 from oracle import topology as otopo
 
@@ -79,6 +79,19 @@ def _run_case(case, accum='fp16'):
 @pytest.mark.parametrize('case', [c for c in SW_CASES if c['kind'] == 'exact'], ids=lambda c: c['name'])
 def test_sliding_window_exact_cases_bit_identical(case, golden_dir):
     z = np.load(os.path.join(golden_dir, 'sliding_window.npz'))
+    out = _run_case(case)
+    assert out.dtype == torch.half
+    assert np.array_equal(_bits(out), z[case['name']])
+    seg = osw.logits_to_labels(out).numpy().astype(np.int16)
+    assert np.array_equal(seg, z[case['name'] + '__seg'])
+
+
+@pytest.mark.parametrize('case', SW_CASES_HALF, ids=lambda c: c['name'])
+def test_sliding_window_half_logit_cases_bit_identical(case, golden_dir):
+    """The reference's GPU numerics (fp16 network output under autocast, predict_from_raw_data.py:591-593: mirror sums,
+    `prediction *= gaussian` and the accumulation all in half precision), produced by the reference's own predictor on a
+    CPU through fp16-output networks: the oracle's driver, given the same networks, matches bit for bit."""
+    z = np.load(os.path.join(golden_dir, 'sliding_window_half.npz'))
     out = _run_case(case)
     assert out.dtype == torch.half
     assert np.array_equal(_bits(out), z[case['name']])

@@ -1,5 +1,5 @@
 """Diagnostic: run one conv layer shape through fnn_op_conv3d of a -DFNN_STAMPS build (prints s_memtime segment means).
-usage: [STRIDE=2] python tools/stamps.py N CIN COUT D H W [kd kh kw] [cin2]"""
+usage: [STRIDE=2 | STRIDE=1,2,2] python tools/stamps.py N CIN COUT D H W [kd kh kw] [cin2]"""
 import os
 import sys
 import numpy as np
@@ -16,6 +16,6 @@ kw = {}
 if cin2:
     kw = dict(x2=rng.standard_normal((n, cin2, d, h, w), dtype=np.float32), gamma2=np.ones(cin2, np.float32),
               beta2=np.zeros(cin2, np.float32), slope2=0.01)
-y = capi.op_conv3d(x, wt, np.zeros(cout, np.float32), k, (int(os.environ.get('STRIDE', 1)),) * 3, gamma=np.ones(cin, np.float32),
+y = capi.op_conv3d(x, wt, np.zeros(cout, np.float32), k, (tuple(int(v) for v in os.environ['STRIDE'].split(',')) * 3)[:3] if 'STRIDE' in os.environ else (1, 1, 1), gamma=np.ones(cin, np.float32),
                    beta=np.zeros(cin, np.float32), slope=0.01, want_stats=True, **kw)
 print('ok', y[0].shape)
