@@ -64,7 +64,7 @@ struct Pick {                                                  // LabelPick of m
 // to 128 it spills and takes 53 ms; with 32-voxel runs per wave (half the accumulators, 4 waves per SIMD without
 // scratch) it takes 26-27 ms - the per-wave set-up doubles - so it keeps 64-voxel runs and three waves per SIMD.
 template <int HB, int ACCM, bool LABELS, bool TTA>
-__global__ __launch_bounds__(256, (!TTA && ACCM == 2 && !LABELS) ? 4 : 1) void gather_head_kernel(const GatherParams p) {
+__global__ __launch_bounds__(256, (!TTA && ACCM != 1 && !LABELS) ? 4 : 1) void gather_head_kernel(const GatherParams p) {
     constexpr int G = 4, ZW = 16 * G, TP = ZW + 8;             // 16-voxel groups and z voxels per wave; row pitch of the LDS transpose
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
@@ -91,15 +91,15 @@ __global__ __launch_bounds__(256, (!TTA && ACCM == 2 && !LABELS) ? 4 : 1) void g
         wf[hb] = *(const f16x8 *)(p.wpk + ((size_t)hbc * 64 + lane) * 8);
         bv[hb] = *(const f32x4 *)(p.bias + hbc * 16 + q * 4);
     }
-    constexpr bool ACC32 = ACCM == 1, ACH = ACCM == 2;
+    constexpr bool ACC32 = ACCM == 1, ACH = ACCM == 2, PKS = ACCM != 1;   // PKS: the sums are fp16 values - kept as fp16 pairs (half the registers)
     f32x4 acc[G][HB];                                          // [16-voxel group][head block] x 4 heads: fp16-valued unless ACC32
-    f16x2 ah[ACH ? G : 1][HB][2];                              // ACH: the same sums kept as fp16 pairs (heads 4q + {0,1}, {2,3})
+    f16x2 ah[PKS ? G : 1][HB][2];                              // PKS: the sums as fp16 pairs (heads 4q + {0,1}, {2,3})
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb) {
             acc[g][hb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (ACH) { ah[ACH ? g : 0][hb][0] = (f16x2){0, 0}; ah[ACH ? g : 0][hb][1] = (f16x2){0, 0}; }
+            if (PKS) { ah[PKS ? g : 0][hb][0] = (f16x2){0, 0}; ah[PKS ? g : 0][hb][1] = (f16x2){0, 0}; }
         }
 
     const int P = p.PD * p.PH * p.PW;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, (!TTA && ACCM == 2 && !LABELS) ? 4 : 1) void g
                                     ts[1] = f == 0 ? t23 : add_h2(ts[1], t23);
                                 } else {
                                     const f16x2 gw2 = {graw[g], graw[g]};
-                                    f16x2 (&a2)[2] = ah[ACH ? g : 0][hb];
+                                    f16x2 (&a2)[2] = ah[PKS ? g : 0][hb];
                                     const f16x2 n01 = acc_add_product_h2(a2[0], t01, gw2), n23 = acc_add_product_h2(a2[1], t23, gw2);
                                     a2[0] = in[g] ? n01 : a2[0];
                                     a2[1] = in[g] ? n23 : a2[1];
@@ -189,12 +189,19 @@ __global__ __launch_bounds__(256, (!TTA && ACCM == 2 && !LABELS) ? 4 : 1) void g
                                 // predict_from_raw_data.py:541-557: net(x) + sum over the mirror subsets, in their order (fp32)
                                 const f32x4 t = d + bv[hb];
                                 tsum[TTA ? g : 0][hb] = f == 0 ? t : tsum[TTA ? g : 0][hb] + t;
+                            } else if (PKS) {
+#pragma unroll
+                                for (int e = 0; e < 2; ++e) {
+                                    f16x2 &a2 = ah[PKS ? g : 0][hb][e];
+                                    const f16x2 nv = round_h2(acc_add_product_1((float)a2[0], d[2 * e] + bv[hb][2 * e], gw),
+                                                              acc_add_product_1((float)a2[1], d[2 * e + 1] + bv[hb][2 * e + 1], gw));
+                                    a2 = in[g] ? nv : a2;
+                                }
                             } else {
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
                                     const float sv = acc_add_product_1(acc[g][hb][j], d[j] + bv[hb][j], gw);
-                                    const float nv = ACC32 ? sv : (float)(f16)sv;
-                                    acc[g][hb][j] = in[g] ? nv : acc[g][hb][j];
+                                    acc[g][hb][j] = in[g] ? sv : acc[g][hb][j];
                                 }
                             }
                         }
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(256, (!TTA && ACCM == 2 && !LABELS) ? 4 : 1) void g
                                 for (int e = 0; e < 2; ++e) {
                                     const f16x2 ts = tsh[TTA && ACH ? g : 0][hb][e];
                                     const f16x2 t = round_h2(__fdiv_rn((float)ts[0], nf), __fdiv_rn((float)ts[1], nf));   // half /= int
-                                    f16x2 &a2 = ah[ACH ? g : 0][hb][e];
+                                    f16x2 &a2 = ah[PKS ? g : 0][hb][e];
                                     const f16x2 nv = acc_add_product_h2(a2, t, gw2);
                                     a2 = in[g] ? nv : a2;
                                 }
@@ -223,11 +230,18 @@ __global__ __launch_bounds__(256, (!TTA && ACCM == 2 && !LABELS) ? 4 : 1) void g
 #pragma unroll
                         for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float t = __fdiv_rn(tsum[TTA ? g : 0][hb][j], nf);         // prediction /= (len(axes_combinations) + 1)
-                                const float sv = acc_add_product_1(acc[g][hb][j], t, gw);
-                                const float nv = ACC32 ? sv : (float)(f16)sv;
-                                acc[g][hb][j] = in[g] ? nv : acc[g][hb][j];
+                            for (int e = 0; e < 2; ++e) {
+                                const float t0 = __fdiv_rn(tsum[TTA ? g : 0][hb][2 * e], nf);         // prediction /= (len(axes_combinations) + 1)
+                                const float t1 = __fdiv_rn(tsum[TTA ? g : 0][hb][2 * e + 1], nf);
+                                if (PKS) {
+                                    f16x2 &a2 = ah[PKS ? g : 0][hb][e];
+                                    const f16x2 nv = round_h2(acc_add_product_1((float)a2[0], t0, gw), acc_add_product_1((float)a2[1], t1, gw));
+                                    a2 = in[g] ? nv : a2;
+                                } else {
+                                    const float s0 = acc_add_product_1(acc[g][hb][2 * e], t0, gw), s1 = acc_add_product_1(acc[g][hb][2 * e + 1], t1, gw);
+                                    acc[g][hb][2 * e] = in[g] ? s0 : acc[g][hb][2 * e];
+                                    acc[g][hb][2 * e + 1] = in[g] ? s1 : acc[g][hb][2 * e + 1];
+                                }
                             }
                     }
                 }
@@ -235,13 +249,13 @@ __global__ __launch_bounds__(256, (!TTA && ACCM == 2 && !LABELS) ? 4 : 1) void g
         }
     }
 
-    if (ACH) {
+    if (PKS) {
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[g][hb][j] = (float)ah[ACH ? g : 0][hb][j >> 1][j & 1];
+                for (int j = 0; j < 4; ++j) acc[g][hb][j] = (float)ah[PKS ? g : 0][hb][j >> 1][j & 1];
     }
     // ---- normalise: logits = acc / weight sum, rounded to fp16 (:619); the weight sum sits in row `heads`
     const int wrow = p.heads, whb = wrow >> 4, wq = (wrow >> 2) & 3, wj = wrow & 3;
