@@ -881,7 +881,7 @@ static int launch_persist(const ConvParams &p, int wgs_per_cu, hipStream_t st) {
     if (NB == 1 && MB == 8 && WRES && p.ksteps == 5 && (p.chunks == 1 || p.chunks == 2)) {
         // 4-deep tiles with a 4-element prefetch need 138-151 VGPRs and 36 KB of LDS: three workgroups per CU instead
         // of two - more bytes in flight for these HBM-bound layers (+0.8 % on the benchmark; four would need <= 128)
-        static const bool mb8 = getenv("FNN_THIN_MB8") != nullptr;                                             // A-B aid
+        static const bool mb8 = fnn_knob("FNN_THIN_MB8") != nullptr;                                             // A-B aid
         const int ivox4 = (3 * p.sd + p.kd) * ((FNN_TILE_H - 1) * p.sh + p.kh) * ((FNN_TILE_W - 1) * p.sw + p.kw);
         if (!mb8 && ivox4 * 2 <= 4 * 256 && persist_lds_bytes(p, 1, 4, true) * 3 <= 160 * 1024) {
             if (p.chunks == 1) return launch_persist_ks<1, 4, true, 5, (NB == 1 && MB == 8 && WRES ? 1 : 0), (NB == 1 && MB == 8 && WRES ? 4 : 8)>(p, 3, st);
@@ -962,7 +962,7 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
     p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
     if (p.packing == FNN_PACK_ZR) return launch_conv3d_zr(p, st);      // weights are in that kernel's order
     int nb = conv3d_pick_nb(p.Cout / 16);
-    static const bool force_v1 = getenv("FNN_CONV_V1") != nullptr;          // debugging / A-B aid
+    static const bool force_v1 = fnn_knob("FNN_CONV_V1") != nullptr;          // debugging / A-B aid
     if (!force_v1 && p.sd == 1 && p.sh == 1 && p.sw == 1) {
         // (cout blocks per workgroup, column blocks per wave): prefer the most work per staged byte,
         // but small feature maps need workgroups first - the deep layers are latency bound otherwise
@@ -984,18 +984,18 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
         if (pick < 0) pick = best;
         nb = cand[pick][0];
         const int mbsel = cand[pick][1];
-        static const bool no_persist = getenv("FNN_CONV_NO_PERSIST") != nullptr;
+        static const bool no_persist = fnn_knob("FNN_CONV_NO_PERSIST") != nullptr;
         // one cout block only: the NB = 2 / 4 forms need 272-644 B of scratch per lane next to their accumulators
         if (!no_persist && p.ksteps <= 14 && nb == 1) {
             // persistent variants: a workgroup walks a range of tiles and prefetches across tile boundaries.
             // Weights resident in LDS when the whole cout group fits next to a double-buffered halo tile with
             // 2 workgroups per CU, otherwise they travel with the prefetch chunk by chunk.
-            static const int persist_mb = getenv("FNN_PERSIST_MB") ? atoi(getenv("FNN_PERSIST_MB")) : 8;          // A-B aids
-            static const int persist_wpc = getenv("FNN_PERSIST_WPC") ? atoi(getenv("FNN_PERSIST_WPC")) : 3;
+            static const int persist_mb = fnn_knob("FNN_PERSIST_MB") ? atoi(fnn_knob("FNN_PERSIST_MB")) : 8;          // A-B aids
+            static const int persist_wpc = fnn_knob("FNN_PERSIST_WPC") ? atoi(fnn_knob("FNN_PERSIST_WPC")) : 3;
             for (int mb = mbsel < persist_mb ? mbsel : persist_mb; mb >= 4; mb -= 4) {
                 const long long tiles = (long long)plan_n * ((p.Do + mb - 1) / mb) * p.tiles_h * p.tiles_w;
                 if (tiles < 256LL * 2 * 4) continue;
-                static const int persist_wres = getenv("FNN_PERSIST_WRES") ? atoi(getenv("FNN_PERSIST_WRES")) : 1;
+                static const int persist_wres = fnn_knob("FNN_PERSIST_WRES") ? atoi(fnn_knob("FNN_PERSIST_WRES")) : 1;
                 for (int wres = persist_wres; wres >= 0; --wres) {
                     const size_t lds = persist_lds_bytes(p, nb, mb, wres != 0);
                     const int per_cu = (int)((160 * 1024) / lds);
@@ -1013,7 +1013,7 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
             return launch_ldsk<4, 4>(p, st);
         }
     }
-    static const bool strided_v1 = getenv("FNN_CONV_STRIDED_V1") != nullptr;   // A-B aid
+    static const bool strided_v1 = fnn_knob("FNN_CONV_STRIDED_V1") != nullptr;   // A-B aid
     if (!force_v1 && !strided_v1 && p.ksteps <= 14) {
         // strided convs: 2 x 8 x 8 output tile, up to 16 halo elements per thread, <= 2 cout blocks
         const int nbs = (p.Cout / 16) % 2 == 0 ? 2 : 1;
@@ -1021,7 +1021,7 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
         {
             // persistent form (tile ranges, cross-tile prefetch) when every workgroup gets a good number of tiles:
             // with one tile per workgroup and a single 16-channel chunk nothing hides the halo round trip
-            static const bool no_sp = getenv("FNN_STRIDED_NO_PERSIST") != nullptr;            // A-B aid
+            static const bool no_sp = fnn_knob("FNN_STRIDED_NO_PERSIST") != nullptr;            // A-B aid
             const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;
             const long long tiles = (long long)plan_n * ((p.Do + 1) / 2) * p.tiles_h * p.tiles_w;
             const int groups = (p.Cout / 16) / nbs;
@@ -1031,13 +1031,13 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
                 if (p.chunks == 1) {
                     // weights resident next to a single halo buffer: the 28 KB of weight fragments no longer travel with
                     // every 37 KB halo tile (+1 % on the benchmark)
-                    static const bool wres = getenv("FNN_STRIDED_NO_WRES") == nullptr;              // A-B aid
+                    static const bool wres = fnn_knob("FNN_STRIDED_NO_WRES") == nullptr;              // A-B aid
                     if (wres && persist_lds_bytes(p, 2, 2, true, true, 12) <= 80 * 1024)
                         return launch_persist_ks<2, 2, true, 0, 1, 12, true>(p, 2, st, gx);
                     return launch_persist_ks<2, 2, false, 0, 1, 12>(p, 2, st, gx);
                 }
                 // more chunks: the generic (runtime chunk count) form; the unrolled two-chunk variant spilled and lost
-                static const bool sp_single = getenv("FNN_STRIDED_PERSIST_SINGLE") != nullptr;   // A-B aid
+                static const bool sp_single = fnn_knob("FNN_STRIDED_PERSIST_SINGLE") != nullptr;   // A-B aid
                 if (!sp_single) return launch_persist_ks<2, 2, false, 0, 0, 12>(p, 2, st, gx);
             }
         }

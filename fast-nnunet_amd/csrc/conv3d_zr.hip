@@ -41,9 +41,9 @@ int conv3d_pack_cout(int packing, int nblk, int cb, int m) {
 // (cout blocks per workgroup, tile depth) the ZR kernel would run with, or false when the layer keeps the
 // linear-tap kernels: not 3x3x3 / stride 1, or too few workgroups to fill the chip.
 static bool zr_pick(const ConvParams &p, int &nb, int &td) {
-    static const bool off = getenv("FNN_CONV_NO_ZR") != nullptr;                  // A-B aid
-    static const int max_cout = getenv("FNN_ZR_MAX_COUT") ? atoi(getenv("FNN_ZR_MAX_COUT")) : 1 << 30;
-    static const int min_cout = getenv("FNN_ZR_MIN_COUT") ? atoi(getenv("FNN_ZR_MIN_COUT")) : 0;
+    static const bool off = fnn_knob("FNN_CONV_NO_ZR") != nullptr;                  // A-B aid
+    static const int max_cout = fnn_knob("FNN_ZR_MAX_COUT") ? atoi(fnn_knob("FNN_ZR_MAX_COUT")) : 1 << 30;
+    static const int min_cout = fnn_knob("FNN_ZR_MIN_COUT") ? atoi(fnn_knob("FNN_ZR_MIN_COUT")) : 0;
     if (off || p.kd != 3 || p.kh != 3 || p.kw != 3 || p.sd != 1 || p.sh != 1 || p.sw != 1) return false;
     if (p.Cout > max_cout || p.Cout < min_cout) return false;
     if ((long long)p.Di * p.Hi * p.Wi >= (1 << 23)) return false;                 // 24-bit voxel index arithmetic in the kernels
@@ -51,7 +51,7 @@ static bool zr_pick(const ConvParams &p, int &nb, int &td) {
     nb = nblk % 2 == 0 ? 2 : 1;
     const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;
     const long long th = (p.Ho + 7) / 8, tw = (p.Wo + 7) / 8;
-    static const int td_max = getenv("FNN_ZR_TD") ? atoi(getenv("FNN_ZR_TD")) : 8;       // A-B aid
+    static const int td_max = fnn_knob("FNN_ZR_TD") ? atoi(fnn_knob("FNN_ZR_TD")) : 8;       // A-B aid
     for (td = td_max; td >= 4; td -= 4) {
         if (p.Do < td) continue;
         if ((long long)plan_n * ((p.Do + td - 1) / td) * th * tw * (nblk / nb) >= 768) return true;
@@ -562,7 +562,7 @@ static int launch_zr(ConvParams p, hipStream_t st) {
     if (!p.ident_ss) return -2;
     dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
 #ifdef FNN_TMODE
-    p.tmode = getenv("FNN_ZR_TMODE") ? atoi(getenv("FNN_ZR_TMODE")) : 0;
+    p.tmode = fnn_knob("FNN_ZR_TMODE") ? atoi(fnn_knob("FNN_ZR_TMODE")) : 0;
 #endif
     hipLaunchKernelGGL((conv3d_zr_kernel<NB, TD>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;

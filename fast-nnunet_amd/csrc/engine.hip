@@ -830,10 +830,10 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
     }
     const size_t featC = keep_features ? (size_t)e->layers[e->head_src].cout_pad : 0;
     // ---- several batches in flight (see fnn_engine::pipe)
-    static const bool no_pipe = getenv("FNN_NO_PIPELINE") != nullptr;                // A-B aid
+    static const bool no_pipe = fnn_knob("FNN_NO_PIPELINE") != nullptr;                // A-B aid
     const bool pipelined = !no_pipe && (!tta || keep_features) && !e->profiling && np > B;
     f16 *const act0 = e->act; double *const stats0 = e->stats; float *const ss0 = e->ss;
-    static const int want_pipes = getenv("FNN_PIPES") ? atoi(getenv("FNN_PIPES")) : 3;
+    static const int want_pipes = fnn_knob("FNN_PIPES") ? atoi(fnn_knob("FNN_PIPES")) : 3;
     const int NP = want_pipes < 2 ? 2 : (want_pipes > fnn_engine::MAXP ? fnn_engine::MAXP : want_pipes);
     if (pipelined) {
         if (e->n_pipe < NP) {
@@ -1008,7 +1008,7 @@ int accumulate_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const
     // The whole list in visiting order: the seg head writes every voxel's first visit without reading it, so the
     // 17 GB zero fill (and an eighth of the accumulator reads) is skipped.  Mirroring accumulates through the patch
     // buffer and the generic head kernel: those keep the zero fill.
-    static const bool no_fv = getenv("FNN_NO_FIRST_VISIT") != nullptr;            // A-B aid
+    static const bool no_fv = fnn_knob("FNN_NO_FIRST_VISIT") != nullptr;            // A-B aid
     const bool fresh = !no_fv && o.n_mirror_axes == 0 && launch_head_first_visit_ok(make_head(e, fold, 0));
     if (!fresh) HIPCHK(e, hipMemsetAsync(e->acc, 0, bytes, st));
     for (int d = 0; d < 3; ++d) { box.lo[d] = 0; box.hi[d] = vp.padded[d]; }
@@ -1045,8 +1045,8 @@ GatherPlan gather_plan(fnn_engine *e, const VolPlan &vp, const fnn_opts &o) {
     const size_t layer_bytes = gp.layer_items * gp.n_eval * P * H.cout_pad * sizeof(f16);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return gp;
-    const double frac = getenv("FNN_GATHER_MEM_FRACTION") ? atof(getenv("FNN_GATHER_MEM_FRACTION")) : 0.6;
-    const int force_ring = getenv("FNN_GATHER_RING") ? atoi(getenv("FNN_GATHER_RING")) : 0;     // tests: a ring although all fits
+    const double frac = fnn_knob("FNN_GATHER_MEM_FRACTION") ? atof(fnn_knob("FNN_GATHER_MEM_FRACTION")) : 0.6;
+    const int force_ring = fnn_knob("FNN_GATHER_RING") ? atoi(fnn_knob("FNN_GATHER_RING")) : 0;     // tests: a ring although all fits
     const double budget = frac * (double)(free_b + e->feat_bytes + e->acc_bytes);       // the accumulators are not needed then
     if (!force_ring && (double)layer_bytes * nx <= budget) gp.ring = nx;
     else if ((double)layer_bytes * gp.cover <= budget) gp.ring = std::min(nx, std::max(gp.cover, force_ring));
@@ -1229,10 +1229,10 @@ int fnn_create(const fnn_arch_desc *arch, int device, int max_batch, fnn_engine 
     if (device < 0 || device >= ndev) return fail(nullptr, FNN_E_INVALID, "device %d out of range (%d visible)", device, ndev);
     fnn_engine *e = new fnn_engine();
     e->arch = *arch; e->device = device; e->max_batch = max_batch;
-    e->fuse_enabled = getenv("FNN_NO_FUSE") == nullptr;
-    if (const char *v = getenv("FNN_FUSE_STEM")) e->fuse_stem = atoi(v) != 0;
-    if (const char *v = getenv("FNN_FUSE_TCONV")) e->fuse_tconv = atoi(v) != 0;
-    e->gather_enabled = getenv("FNN_NO_GATHER") == nullptr;
+    e->fuse_enabled = fnn_knob("FNN_NO_FUSE") == nullptr;
+    if (const char *v = fnn_knob("FNN_FUSE_STEM")) e->fuse_stem = atoi(v) != 0;
+    if (const char *v = fnn_knob("FNN_FUSE_TCONV")) e->fuse_tconv = atoi(v) != 0;
+    e->gather_enabled = fnn_knob("FNN_NO_GATHER") == nullptr;
     if (e->arch.eps <= 0) e->arch.eps = 1e-5f;
     int rc = build_plan(e);
     if (rc != 0) { g_err = e->err; delete e; return rc; }

@@ -216,6 +216,11 @@ struct FinalizeParams {
 #define FNN_STAMP_FLUSH(dbg) do {} while (0)
 #endif
 
+// Tuning / A-B switches (FNN_NO_GATHER, FNN_PIPES, FNN_ZR_TD, ...; each is documented where it is read): environment
+// variables that are honoured ONLY when FNN_KNOBS=1 is set as well - a production process does not change behaviour
+// because of a stray variable; the tests and tools/ set it.
+const char *fnn_knob(const char *name);
+
 static __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
 
 // Residual-encoder blocks (BasicBlockD): skip-path average pooling and the block's closing

@@ -7,6 +7,13 @@
 //   argmax_kernel       logits -> labels (K10)
 #include "fnn_device.h"
 #include <cstdlib>
+#include <cstring>
+
+const char *fnn_knob(const char *name) {
+    static const bool on = [] { const char *v = getenv("FNN_KNOBS"); return v && strcmp(v, "0") != 0; }();
+    return on ? getenv(name) : nullptr;
+}
+#include <cstdlib>
 #include <type_traits>
 
 // a + round(t * g): the product is rounded before the sum like the reference's `pred *= g; acc += pred`.  With the
@@ -291,7 +298,7 @@ int launch_tconv(const TconvParams &p, hipStream_t st) {
     const int nbt = (p.nblk % 2 == 0) ? 2 : 1;
     // two cout blocks x 4 taps held 128 accumulator registers (276 VGPRs: one wave per SIMD); two taps: 152, three waves
     // per SIMD, the activations are read once more - 6 % less tconv time on the benchmark net
-    static const int tg_max2 = getenv("FNN_TCONV_TG") ? atoi(getenv("FNN_TCONV_TG")) : 2;       // A-B aid
+    static const int tg_max2 = fnn_knob("FNN_TCONV_TG") ? atoi(fnn_knob("FNN_TCONV_TG")) : 2;       // A-B aid
     const int tg_cap = nbt == 2 ? tg_max2 : 4;
     const int tg = taps >= tg_cap ? tg_cap : taps;     // taps is 1, 2, 4 or 8
     dim3 grid(p.N * ((vox_in + 255) / 256), (taps / tg) * (p.nblk / nbt));
@@ -675,8 +682,8 @@ __global__ __launch_bounds__(256, MINB) void seg_head_acc1_kernel(const HeadPara
 
 // Only the vectorised accumulate kernel knows the first-visit thresholds (one k-step: <= 32 input channels).
 bool launch_head_first_visit_ok(const HeadParams &p) {
-    static const bool head_v1 = getenv("FNN_HEAD_V1") != nullptr;
-    static const bool rd1 = getenv("FNN_HEAD_RD") && atoi(getenv("FNN_HEAD_RD")) == 1;
+    static const bool head_v1 = fnn_knob("FNN_HEAD_V1") != nullptr;
+    static const bool rd1 = fnn_knob("FNN_HEAD_RD") && atoi(fnn_knob("FNN_HEAD_RD")) == 1;
     return p.mode == 0 && p.ksteps == 1 && !head_v1 && !rd1 && (long long)p.PD * p.PH * p.PW <= (1 << 24);
 }
 
@@ -690,9 +697,9 @@ int launch_head(const HeadParams &p, hipStream_t st) {
     dim3 grid((P + 255) / 256);
     if (p.mode == 0) {
         const size_t lds = (size_t)((p.src.C * 8 + 255) & ~255) + (size_t)4 * 32 * HEAD_LD * 4;
-        static const bool head_v1 = getenv("FNN_HEAD_V1") != nullptr;            // A-B aid
+        static const bool head_v1 = fnn_knob("FNN_HEAD_V1") != nullptr;            // A-B aid
         if (p.ksteps == 1 && !head_v1 && P <= (1 << 24)) {
-            static const int head_rd = getenv("FNN_HEAD_RD") ? atoi(getenv("FNN_HEAD_RD")) : 2;      // A-B aid (1: one 32-voxel round per wave - faster alone, slower next to the other stream)
+            static const int head_rd = fnn_knob("FNN_HEAD_RD") ? atoi(fnn_knob("FNN_HEAD_RD")) : 2;      // A-B aid (1: one 32-voxel round per wave - faster alone, slower next to the other stream)
             if (head_rd == 1) {
                 const dim3 g1((P + 127) / 128);
                 if (p.acc_fp32) hipLaunchKernelGGL((seg_head_acc1_kernel<true, 1>), g1, dim3(256), lds, st, p);
@@ -700,12 +707,12 @@ int launch_head(const HeadParams &p, hipStream_t st) {
             } else if (p.acc_fp32) hipLaunchKernelGGL((seg_head_acc1_kernel<true, 2>), grid, dim3(256), lds, st, p);
             else {
                 // non-temporal accumulator traffic (each line is touched once per patch): +1.3 % on the benchmark
-                static const int nt = getenv("FNN_HEAD_NT") ? atoi(getenv("FNN_HEAD_NT")) : 3;      // A-B aid
+                static const int nt = fnn_knob("FNN_HEAD_NT") ? atoi(fnn_knob("FNN_HEAD_NT")) : 3;      // A-B aid
                 if (nt == 1) hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 1>), grid, dim3(256), lds, st, p);
                 else if (nt == 2) hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 2>), grid, dim3(256), lds, st, p);
                 else if (nt == 3) {
                     // two workgroups per SIMD's worth of registers asked for: 177 VGPRs instead of 214 (three: 8 spills, slower)
-                    static const int minb = getenv("FNN_HEAD_MINB") ? atoi(getenv("FNN_HEAD_MINB")) : 2;            // A-B aid
+                    static const int minb = fnn_knob("FNN_HEAD_MINB") ? atoi(fnn_knob("FNN_HEAD_MINB")) : 2;            // A-B aid
                     if (minb == 2) hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 3, 2>), grid, dim3(256), lds, st, p);
                     else if (minb == 3) hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 3, 3>), grid, dim3(256), lds, st, p);
                     else hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 3>), grid, dim3(256), lds, st, p);
@@ -871,7 +878,7 @@ __global__ __launch_bounds__(256) void finalize_tiled_kernel(const FinalizeParam
 
 int launch_finalize(const FinalizeParams &p, hipStream_t st) {
     const long long n = p.OX * p.OY * p.OZ;
-    static const bool no_tiled = getenv("FNN_FINALIZE_V1") != nullptr;           // A-B aid
+    static const bool no_tiled = fnn_knob("FNN_FINALIZE_V1") != nullptr;           // A-B aid
     // tiled kernel: 64-channel accumulator rows, 16-byte aligned output pieces
     const int osz = p.out_fp32 ? 4 : 2;
     const bool aligned = p.HP == 64 && p.heads < 64 && (p.out_Z * osz) % 16 == 0 && (p.out_z * osz) % 16 == 0 &&
@@ -1020,7 +1027,7 @@ static void launch_labels_coop(const FinalizeParams &p, void *labels, const int 
 }
 
 int launch_labels_from_acc(const FinalizeParams &p, void *labels, int label_u16, const int *order, hipStream_t st) {
-    static const bool v1 = getenv("FNN_LABELS_V1") != nullptr;                     // A-B aid
+    static const bool v1 = fnn_knob("FNN_LABELS_V1") != nullptr;                     // A-B aid
     int log_g = 0;
     while ((8 << log_g) < p.HP) ++log_g;                                         // lanes per voxel: HP / 8 rounded up to 2^k
     const long long nvox = p.OX * p.OY * p.OZ;

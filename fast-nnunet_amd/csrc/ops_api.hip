@@ -150,7 +150,7 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
     (void)hipDeviceSynchronize();
     (void)hipMemset(dst.p, 0, (size_t)n * slots * cop * 16);
 #endif
-    if (getenv("FNN_OP_TIME")) {                    // diagnostic: mean duration of 10 launches of this layer (after 2 warm-ups)
+    if (fnn_knob("FNN_OP_TIME")) {                    // diagnostic: mean duration of 10 launches of this layer (after 2 warm-ups)
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         for (int i = 0; i < 2; ++i) (void)launch_conv3d(p, 0);

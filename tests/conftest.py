@@ -9,6 +9,8 @@ for p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+# the engine's A-B switches (FNN_NO_GATHER, FNN_GATHER_RING, FNN_NO_FUSE, ...) are only honoured next to FNN_KNOBS=1
+os.environ.setdefault('FNN_KNOBS', '1')
 
 
 def pytest_configure(config):

@@ -3,6 +3,7 @@
 # Alternates two builds of libfnn_hip.so (paths relative to fast-nnunet_amd/csrc) inside one session: boxes of the pool
 # differ by +-3 %, so two builds can only be compared back to back on the same box.
 root=${GRAFT_REPO_ROOT:-$(pwd)}
+export FNN_KNOBS=1                     # honour FNN_* A-B switches given on the command line
 a=$1; b=$2; n=${3:-3}
 for i in $(seq 1 $n); do
   for lib in $a $b; do

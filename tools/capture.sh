@@ -9,7 +9,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 # per-kernel durations and counters are taken with the two-batch pipelining off: kernels of the two internal streams
 # otherwise overlap and the trace reports their stretched durations.  The headline bench line below has it on.
-export FNN_NO_PIPELINE=1
+export FNN_KNOBS=1 FNN_NO_PIPELINE=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $out/trace.log 2>&1
 # MFMA busy / clock: SQ and GRBM counters in a pass of their own
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 --output-format csv -d $out/pmc_mfma -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $out/pmc_mfma.log 2>&1

@@ -4,7 +4,7 @@
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-export FNN_NO_PIPELINE=1
+export FNN_KNOBS=1 FNN_NO_PIPELINE=1
 i=0
 for grp in "$@"; do
   d=$root/gpurun_out/pmc_${tag}_$i

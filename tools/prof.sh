@@ -3,6 +3,7 @@
 # kernel trace of bench.py + per-kernel summary under gpurun_out/prof_<tag>*
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
+export FNN_KNOBS=1                     # honour FNN_* A-B switches given on the command line
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_$tag -- python3 $root/bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" > $root/gpurun_out/prof_$tag.log 2>&1
 cd $root

@@ -1,6 +1,7 @@
 """Diagnostic: run one conv layer shape through fnn_op_conv3d of a -DFNN_STAMPS build (prints s_memtime segment means).
 usage: [STRIDE=2 | STRIDE=1,2,2] python tools/stamps.py N CIN COUT D H W [kd kh kw] [cin2]"""
 import os
+os.environ.setdefault('FNN_KNOBS', '1')
 import sys
 import numpy as np
 sys.path.insert(0, '.')

@@ -2,6 +2,7 @@
 (`make EXP="-DFNN_STAMPS -DFNN_TMODE" libfnn_exp.so`, FNN_LIB=.../libfnn_exp.so).  Results are wrong by design.
 usage: python tools/zr_tmode.py N CIN COUT D H W [cin2] -- prints launch time + stamp segments per mode"""
 import os
+os.environ.setdefault('FNN_KNOBS', '1')
 import sys
 import numpy as np
 sys.path.insert(0, '.')
