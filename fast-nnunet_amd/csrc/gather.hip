@@ -64,7 +64,7 @@ struct Pick {                                                  // LabelPick of m
 // to 128 it spills and takes 53 ms; with 32-voxel runs per wave (half the accumulators, 4 waves per SIMD without
 // scratch) it takes 26-27 ms - the per-wave set-up doubles - so it keeps 64-voxel runs and three waves per SIMD.
 template <int HB, int ACCM, bool LABELS, bool TTA>
-__global__ __launch_bounds__(256, (!TTA && ACCM != 1 && !LABELS) ? 4 : 1) void gather_head_kernel(const GatherParams p) {
+__global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? 4 : 1) void gather_head_kernel(const GatherParams p) {
     constexpr int G = 4, ZW = 16 * G, TP = ZW + 8;             // 16-voxel groups and z voxels per wave; row pitch of the LDS transpose
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
@@ -249,55 +249,48 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1 && !LABELS) ? 4 : 1) void g
         }
     }
 
-    if (PKS) {
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int hb = 0; hb < HB; ++hb)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[g][hb][j] = (float)ah[PKS ? g : 0][hb][j >> 1][j & 1];
-    }
-    // ---- normalise: logits = acc / weight sum, rounded to fp16 (:619); the weight sum sits in row `heads`
+    // ---- per 16-voxel group (one at a time: 16 live values instead of 64): normalise - logits = sum / weight sum,
+    // rounded to fp16 (:619), the weight sum sits in row `heads` - then the label pick or the LDS transpose
     const int wrow = p.heads, whb = wrow >> 4, wq = (wrow >> 2) & 3, wj = wrow & 3;
     bool bad = false;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
+        f32x4 v4[HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v4[hb][j] = PKS ? (float)ah[PKS ? g : 0][hb][j >> 1][j & 1] : acc[g][hb][j];
         float wsum = 0.f;
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (hb == whb && j == wj) wsum = acc[g][hb][j];
+            for (int j = 0; j < 4; ++j) if (hb == whb && j == wj) wsum = v4[hb][j];
         wsum = __shfl(wsum, wq * 16 + r, 64);
         const bool zok = z0 + 16 * g + r < p.z_hi;
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f16 rr = (f16)__fdiv_rn(acc[g][hb][j], wsum);
+                const f16 rr = (f16)__fdiv_rn(v4[hb][j], wsum);
                 const int head = hb * 16 + q * 4 + j;
                 bad |= zok && head < p.heads && isinf((float)rr);
-                acc[g][hb][j] = (float)rr;
+                v4[hb][j] = (float)rr;
             }
-    }
-    if (bad) atomicOr(p.inf_flag, 1);
-
-    if (LABELS) {
-        // LabelPick (misc.hip): argmax with torch's rules - the first NaN wins, else the largest value, the lowest head
-        // among equals - is a maximum under a total order, so the lane picks over ITS 16 heads (ascending: a strict
-        // compare keeps the first) and the four lanes of a voxel merge once, comparing head indices on ties: 4 cross-lane
-        // moves per 16 voxels and lane instead of 32 (30.8 -> 29.3 ms per 512^3 x 61 volume; the logits form: 23.8).
-        // Measured and dropped: maximum by max3 + two cross-lane steps, then the lowest head that equals it, with this
-        // chain kept for groups that hold a NaN - 7x fewer instructions on the usual path, 35.3 ms.
-        // Regions: the highest head above the threshold - a plain maximum of indices.
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
+        if (LABELS) {
+            // LabelPick (misc.hip): argmax with torch's rules - the first NaN wins, else the largest value, the lowest
+            // head among equals - is a maximum under a total order, so the lane picks over ITS 16 heads (ascending: a
+            // strict compare keeps the first) and the four lanes of a voxel merge once, comparing head indices on ties:
+            // 4 cross-lane moves per 16 voxels and lane instead of 32.  Measured and dropped: maximum by max3 + two
+            // cross-lane steps, then the lowest head that equals it, with this chain kept for groups that hold a NaN -
+            // 7x fewer instructions on the usual path, 35 instead of 29 ms.
+            // Regions: the highest head above the threshold - a plain maximum of indices.
             float b = 0.f; int a = -1; bool n = false; int h = -1;
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int head = hb * 16 + q * 4 + j;
-                    const float v = acc[g][hb][j];
+                    const float v = v4[hb][j];
                     if (head < p.heads) {
                         if (v > 0x1.8p-24f) h = head;
                         if (a < 0) { b = v; a = head; n = v != v; }
@@ -323,17 +316,17 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1 && !LABELS) ? 4 : 1) void g
                 const size_t o = ((size_t)x * p.OY + y) * p.OZ + z;
                 if (p.label_u16) ((uint16_t *)p.labels)[o] = (uint16_t)lab; else ((uint8_t *)p.labels)[o] = (uint8_t)lab;
             }
+        } else {
+            // logits: transpose through LDS so that a head's 64 z values leave as one 128-byte row
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sT[(hb * 16 + q * 4 + j) * TP + 16 * g + r] = (f16)v4[hb][j];
         }
-        return;
     }
+    if (bad) atomicOr(p.inf_flag, 1);
+    if (LABELS) return;
 
-    // ---- logits: transpose through LDS so that a head's 64 z values leave as one 128-byte row
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int hb = 0; hb < HB; ++hb)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sT[(hb * 16 + q * 4 + j) * TP + 16 * g + r] = (f16)acc[g][hb][j];
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
     const size_t plane = (size_t)p.OX * p.OY * p.OZ;
