@@ -59,15 +59,18 @@ static bool zr_pick(const ConvParams &p, int &nb, int &td) {
     return false;
 }
 
+static bool zs_pick(const ConvParams &p);
+
 int conv3d_stats_slots(const ConvParams &p) {
     int nb, td;
+    if (zs_pick(p)) return ((p.Do + 7) / 8) * ((p.Ho + 3) / 4) * ((p.Wo + 7) / 8);
     if (!zr_pick(p, nb, td)) return FNN_STAT_REPL;
     return ((p.Do + td - 1) / td) * ((p.Ho + 7) / 8) * ((p.Wo + 7) / 8);
 }
 
 int conv3d_packing(const ConvParams &p) {
     int nb, td;
-    return zr_pick(p, nb, td) ? FNN_PACK_ZR : FNN_PACK_LINEAR;
+    return (zs_pick(p) || zr_pick(p, nb, td)) ? FNN_PACK_ZR : FNN_PACK_LINEAR;
 }
 
 // Epilogue of a ZR tile at NB = 2 in the interleaved channel order of conv3d_pack_cout: bias (after `osc` for the fp8
@@ -333,6 +336,255 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
 }
 
 // ----------------------------------------------------------------------------
+// in-plane stride 2, depth stride 1 (the first down-sampling conv of an anisotropic network)
+// ----------------------------------------------------------------------------
+// The linear-tap persistent kernel serves this layer with 2 x 8 x 8 output tiles: four halo planes staged per two
+// output planes (a timing-only build that staged half of them ran 21 % faster).  Here the depth-shift form: an
+// 8 x 4 x 8 output tile, halo 10 x 9 x 17 voxels = 1.25 planes per output plane (and 30 % fewer staged voxels per
+// output overall); wave = (pair of h rows, half of the depth slices): its operand of halo plane p for an in-plane tap
+// pair serves the three depth taps of its output slices p, p - 1, p - 2 - 6 activation + 6 weight reads for 24 MFMAs.
+// The operand's 8 voxels per row lie 64 bytes apart (2-way conflicted reads, like the linear-tap strided kernels; a
+// de-interleaved image was slower there).  Same weight packing (FNN_PACK_ZR, interleaved cout order), statistics row per
+// tile and epilogue as the stride-1 kernel.
+template <int NB>
+__global__ __launch_bounds__(256, 2) void conv3d_zs_kernel(const ConvParams p) {
+    static_assert(NB == 2, "two cout blocks per workgroup");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int TD = 8, TH = 4, TDW = 4;                    // output tile depth x height (x 8 wide); depth slices per wave
+    constexpr int ID = TD + 2, IH = 2 * TH + 1, IW = 17, PW = 17;
+    constexpr int PS = IH * PW * 32;
+    constexpr int ABYTES = (ID * PS + 1023) & ~1023;
+    constexpr int KS = 15;
+    constexpr int IELEM = ID * IH * IW * 2;
+    constexpr int PF = (IELEM + 255) / 256;
+    constexpr int WTOT = NB * KS * 64;
+    constexpr int WPF = (WTOT + 255) / 256;
+
+    int t;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
+    const int tw = t % p.tiles_w; t /= p.tiles_w;
+    const int th = t % p.tiles_h; t /= p.tiles_h;
+    const int td = t % p.tiles_d;
+    const int n = t / p.tiles_d;
+    const int cb0 = blockIdx.y * NB;
+    const int od0 = td * TD, oh0 = th * TH, ow0 = tw * 8;
+    const int hp = wave & 1, dh = wave >> 1;                  // this wave: output rows 2 hp, 2 hp + 1; depth slices 4 dh .. 4 dh + 3
+
+    char *sA = smem;                                          // halo image: [ID][IH][PW] voxels x 32 B
+    char *sW = smem + ABYTES;                                 // [NB][15][64 lanes][16 B]
+    float *sBias = (float *)(sW + NB * KS * 1024);
+
+    int toff[5];
+    f32x4 acc[TDW][NB];
+    const int cg = tid & 1;
+    int offv[PF], ldso[PF];
+    {
+        const int id0 = od0 - 1, ih0 = 2 * oh0 - 1, iw0 = 2 * ow0 - 1;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int idx = tid + u * 256;
+            const int v = idx >> 1;
+            const int zd = v / (IH * IW), rem = v - zd * (IH * IW), zh = rem / IW, zw = rem - zh * IW;
+            const int gd = id0 + zd, gh = ih0 + zh, gw = iw0 + zw;
+            const bool ok = ((unsigned)gd < (unsigned)p.Di) & ((unsigned)gh < (unsigned)p.Hi) & ((unsigned)gw < (unsigned)p.Wi);
+            const int lin = __mul24(__mul24(gd, p.Hi) + gh, p.Wi) + gw;
+            offv[u] = idx < IELEM ? (ok ? lin : -1) : -2;
+            ldso[u] = zd * PS + (zh * PW + zw) * 32 + cg * 16;
+        }
+    }
+    int wofs[WPF];
+#pragma unroll
+    for (int u = 0; u < WPF; ++u) {
+        const int idx = tid + u * 256;
+        const int idc = idx < WTOT ? idx : WTOT - 1;
+        const int nb = idc >= KS * 64 ? 1 : 0;
+        wofs[u] = (cb0 + nb) * p.chunks * (KS * 64) + idc - nb * (KS * 64);
+    }
+    f16x8 xr[PF], wr[WPF];
+    float scu[16], shu[16];
+    float slope_next = 1.f;
+
+    auto issue = [&](int ch) {
+        const int c_glob = ch * 16;
+        const int s = (c_glob < p.src[0].C) ? 0 : 1;
+        const int c_uni = c_glob - (s ? p.src[0].C : 0);
+        const int sC = p.src[s].C;
+        const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + c_uni);
+        slope_next = p.src[s].slope;
+        const float *qs = p.src[s].ss ? p.src[s].ss + (size_t)(2 * n) * sC + c_uni : p.ident_ss + c_uni;
+        const float *qh = p.src[s].ss ? qs + sC : p.ident_ss + 512 + c_uni;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { scu[j] = qs[j]; shu[j] = qh[j]; }
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * sC + cg * 8) * 2));
+#pragma unroll
+        for (int u = 0; u < WPF; ++u) wr[u] = *(const f16x8 *)((const char *)p.wpk + (unsigned)((wofs[u] + ch * (KS * 64)) * 16));
+    };
+    auto commit = [&]() {
+        const f16 slope_h = (f16)slope_next;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = cg ? scu[8 + j] : scu[j]; sh[j] = cg ? shu[8 + j] : shu[j]; }
+#ifndef FNN_NORM_FP32
+        f16x8 sc_h, sh_h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc_h[j] = (f16)sc[j]; sh_h[j] = (f16)sh[j]; }
+#endif
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if ((u + 1) * 256 > IELEM && offv[u] == -2) continue;
+#ifdef FNN_NORM_FP32
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)xr[u][j], sc[j], sh[j]);
+#else
+            f16x8 o = xr[u] * sc_h + sh_h;
+#endif
+            o = __builtin_elementwise_max(o, o * slope_h);
+            if (offv[u] < 0) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            *(f16x8 *)(sA + ldso[u]) = o;
+        }
+#pragma unroll
+        for (int u = 0; u < WPF; ++u) {
+            const int idx = tid + u * 256;
+            if ((u + 1) * 256 <= WTOT || idx < WTOT) ((f16x8 *)sW)[idx] = wr[u];
+        }
+    };
+    auto kloop = [&]() {
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const char *bp = sA + toff[pr];
+            f16x8 xf[TDW + 2];
+#pragma unroll
+            for (int pl = 0; pl < TDW + 2; ++pl) xf[pl] = *(const f16x8 *)(bp + pl * PS);
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                f16x8 wf[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wf[nb] = *(const f16x8 *)(sW + ((nb * KS + pr * 3 + dz) * 64 + lane) * 16);
+#pragma unroll
+                for (int j = 0; j < TDW; ++j)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nb], xf[j + dz], acc[j][nb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (tid < NB * 16) sBias[tid] = p.bias[cb0 * 16 + tid];
+    issue(0);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        // MFMA "B" operand: lane = (voxel r of the wave's two output rows, k-group): k-group bit 1 picks the tap of the
+        // pair, bit 0 the 8-channel half; the voxel's input position is twice its output position + the tap
+        const int r = lane & 15, hl = lane >> 5, kh = (lane >> 4) & 1;
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const int tp = 2 * pr + hl < 9 ? 2 * pr + hl : 8;
+            const int row = 2 * (2 * hp + (r >> 3)) + tp / 3, col = 2 * (r & 7) + tp % 3;
+            toff[pr] = (TDW * dh) * PS + (row * PW + col) * 32 + kh * 16;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TDW; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[j][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    commit();
+    __syncthreads();
+    for (int ch = 0; ch + 1 < p.chunks; ++ch) {
+        issue(ch + 1);
+        kloop();
+        __syncthreads();
+        commit();
+        __syncthreads();
+    }
+    kloop();
+    __syncthreads();
+
+    // ---- epilogue: bias, fp16 store (16 bytes per lane: the interleaved cout order), statistics
+    {
+        const int q = lane >> 4, r = lane & 15;
+        float4 bv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const float4 *)(sBias + q * 8 + nb * 4);
+        float t1[NB][4], t2[NB][4];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
+        const unsigned item_bytes = (unsigned)p.Do * p.Ho * p.Wo * p.Cout * 2;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)n * (item_bytes >> 1), 0, item_bytes, 0x00020000);
+        const unsigned coff = (unsigned)(cb0 * 16 + q * 8) * 2;
+        const int oh = oh0 + 2 * hp + (r >> 3), ow = ow0 + (r & 7);
+        const bool ok_hw = oh < p.Ho && ow < p.Wo;
+        const f16x2 ones = {(f16)1.f, (f16)1.f};
+#pragma unroll
+        for (int mb = 0; mb < TDW; mb += 2) {
+            f16x8 o[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int od = od0 + TDW * dh + mb + h;
+                const bool ok = ok_hw && od < p.Do;
+                const unsigned voff = ok ? (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout) * 2 + coff : 0x80000000u;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    o[h][nb * 4 + 0] = (f16)(acc[mb + h][nb][0] + bv[nb].x);
+                    o[h][nb * 4 + 1] = (f16)(acc[mb + h][nb][1] + bv[nb].y);
+                    o[h][nb * 4 + 2] = (f16)(acc[mb + h][nb][2] + bv[nb].z);
+                    o[h][nb * 4 + 3] = (f16)(acc[mb + h][nb][3] + bv[nb].w);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fnn_i32x4, o[h]), rsrc, voff, 0, 0);
+                if (!ok) o[h] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f16x2 pr = {o[0][nb * 4 + j], o[1][nb * 4 + j]};
+                    t1[nb][j] = __builtin_amdgcn_fdot2(pr, ones, t1[nb][j], false);
+                    t2[nb][j] = __builtin_amdgcn_fdot2(pr, pr, t2[nb][j], false);
+                }
+        }
+        if (p.stats_out) stats_to_global<NB, true, true>(p, t1, t2, (float *)smem, n, cb0, wave, lane, tid, (td * p.tiles_h + th) * p.tiles_w + tw);
+    }
+}
+
+static int launch_zs(ConvParams p, hipStream_t st) {
+    p.tile_d = 8;
+    p.tiles_d = (p.Do + 7) / 8;
+    p.tiles_h = (p.Ho + 3) / 4;
+    p.tiles_w = (p.Wo + 7) / 8;
+    const size_t lds = (size_t)((10 * 9 * 17 * 32 + 1023) & ~1023) + (size_t)2 * 15 * 1024 + (size_t)2 * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)conv3d_zs_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    p.ident_ss = conv3d_identity_ss();
+    if (!p.ident_ss) return -2;
+    dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / 2);
+    hipLaunchKernelGGL((conv3d_zs_kernel<2>), grid, dim3(256), lds, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// depth stride 1, in-plane stride 2, 3x3x3, an even number of cout blocks, enough tiles: the kernel above
+static bool zs_pick(const ConvParams &p) {
+    static const bool off = fnn_knob("FNN_CONV_NO_ZS") != nullptr;                 // A-B aid
+    if (off || p.kd != 3 || p.kh != 3 || p.kw != 3 || p.sd != 1 || p.sh != 2 || p.sw != 2 || p.fp8) return false;
+    if ((p.Cout / 16) % 2 != 0 || (long long)p.Di * p.Hi * p.Wi >= (1 << 23) || p.Do < 8) return false;
+    const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;
+    return (long long)plan_n * ((p.Do + 7) / 8) * ((p.Ho + 3) / 4) * ((p.Wo + 7) / 8) * (p.Cout / 32) >= 768;
+}
+
+// ----------------------------------------------------------------------------
 // fp8 (OCP e4m3) variant: BASELINE config 5's "fp8 MFMA conv path"
 // ----------------------------------------------------------------------------
 // Same tiling, staging and depth-shift reuse; what changes is the operand format of the matrix cores:
@@ -593,6 +845,7 @@ static int launch_zr(ConvParams p, hipStream_t st) {
 // Runs the layer on the ZR kernel; the weights must have been packed as FNN_PACK_ZR (p.packing).
 int launch_conv3d_zr(const ConvParams &p, hipStream_t st) {
     int nb, td;
+    if (p.packing == FNN_PACK_ZR && p.ksteps == 15 && zs_pick(p)) return launch_zs(p, st);
     if (p.packing != FNN_PACK_ZR || p.ksteps != 15 || !zr_pick(p, nb, td)) return -1;
     if (p.fp8) {
         if (nb == 2) return td == 8 ? launch_zr8<2, 8>(p, st) : launch_zr8<2, 4>(p, st);

@@ -369,7 +369,7 @@ int build_plan(fnn_engine *e) {
                 L.packing = L.fuse ? FNN_PACK_LINEAR : conv3d_packing(q);
             }
             L.ksteps = conv3d_ksteps(L.packing, T);
-            L.fp8 = a.precision == FNN_PREC_F8 && L.packing == FNN_PACK_ZR;
+            L.fp8 = a.precision == FNN_PREC_F8 && L.packing == FNN_PACK_ZR && L.s[0] == 1 && L.s[1] == 1 && L.s[2] == 1;   // (the strided depth-shift kernel is fp16 only)
             L.w_off = wpk; wpk += (size_t)(L.cout_pad / 16) * L.chunks * L.ksteps * 512;
         } else if (L.type == Layer::TCONV) {
             const int taps = L.s[0] * L.s[1] * L.s[2];

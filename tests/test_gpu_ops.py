@@ -38,6 +38,11 @@ CONV_CASES = [
     (1, 16, 16, (4, 8, 8), (1, 1, 1), (1, 1, 1)),
     (3, 48, 80, (4, 6, 6), (3, 1, 3), (1, 1, 1)),
     (1, 320, 160, (4, 4, 4), (3, 3, 3), (1, 1, 1)),
+    # depth stride 1, in-plane stride 2 with enough tiles for the depth-shift strided kernel (conv3d_zs_kernel): whole
+    # tiles; tiles ragged in every dimension on odd input sizes; two 16-channel chunks and 64 output channels
+    (2, 16, 32, (64, 96, 128), (3, 3, 3), (1, 2, 2)),
+    (4, 16, 32, (20, 91, 94), (3, 3, 3), (1, 2, 2)),
+    (2, 32, 64, (24, 63, 96), (3, 3, 3), (1, 2, 2)),
 ]
 
 
@@ -57,7 +62,7 @@ def test_conv3d_identity_input(n, cin, cout, dims, k, stride):
     assert np.allclose(stats[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
 
 
-@pytest.mark.parametrize('n,cin,cout,dims,k,stride', CONV_CASES[:6])
+@pytest.mark.parametrize('n,cin,cout,dims,k,stride', CONV_CASES[:6] + CONV_CASES[-2:])
 def test_conv3d_with_fused_instancenorm_lrelu_on_load(n, cin, cout, dims, k, stride):
     from fast_nnunet_amd import capi
     g = torch.Generator().manual_seed(7 + cin + cout)
