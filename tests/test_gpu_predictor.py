@@ -105,6 +105,24 @@ def test_network_forward_matches_fp32_oracle(name):
     assert (single - got[3:4]).abs().max() <= 1e-3 * float(ref.abs().max())
 
 
+def test_forward_through_the_depth_shift_strided_kernel_matches_oracle():
+    """An anisotropic net (first down-sampling (1, 2, 2), like the benchmark's) at a patch large enough for
+    conv3d_zs_kernel to take that conv (it needs >= 768 tiles; the small cases above keep the linear-tap kernels):
+    64 x 96 x 128 -> 8 x 12 x 8 tiles x batch 2, plus a ragged second patch size."""
+    spec = UNetSpec('plain', 1, 3, [16, 32], [(1, 3, 3), (3, 3, 3)], [(1, 1, 1), (1, 2, 2)], [2, 2], [2])
+    sd = synthetic_state_dict(spec, 77)
+    net = build_oracle(spec, sd)
+    torch.set_num_threads(8)
+    for patch in ((64, 96, 128), (40, 112, 184)):
+        p = _predictor(spec, patch, [sd], batch=2)
+        x = torch.randn(2, 1, *patch, generator=torch.Generator().manual_seed(3))
+        got = p.forward_patches(x).cpu()
+        with torch.inference_mode():
+            ref = net(x)
+        mr, rr = _report(f'zs_{patch}', got, ref)
+        assert mr <= MAX_REL and rr <= RMSE_REL
+
+
 def test_c1_sized_student_forward_matches_oracle():
     """BASELINE config 1 topology (PlainConv r=2, 6 stages) at a reduced 64^3 patch so the CPU oracle is quick."""
     spec = student_spec((1.0, 1.0, 1.0), (128, 128, 128), 1, 2, reduction=2)
