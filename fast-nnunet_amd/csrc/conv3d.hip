@@ -880,7 +880,10 @@ static int launch_persist(const ConvParams &p, int wgs_per_cu, hipStream_t st) {
     // for the thin single-cout-block layers that the persistent kernel is used for
     if (NB == 1 && MB == 8 && WRES && p.ksteps == 5 && (p.chunks == 1 || p.chunks == 2)) {
         // 4-deep tiles with a 4-element prefetch need 138-151 VGPRs and 36 KB of LDS: three workgroups per CU instead
-        // of two - more bytes in flight for these HBM-bound layers (+0.8 % on the benchmark; four would need <= 128)
+        // of two - more bytes in flight for these HBM-bound layers (+0.8 % on the benchmark).  Four (round 2: scale / shift
+        // through scalar loads, forced to 128 VGPRs: 44-132 B of scratch): 740 -> 895 us per launch; the scalar loads alone,
+        // at three workgroups: 817 us - SMEM shares lgkmcnt with the LDS reads of the k-loop and returns out of order, so every
+        // wait becomes a full drain
         static const bool mb8 = fnn_knob("FNN_THIN_MB8") != nullptr;                                             // A-B aid
         const int ivox4 = (3 * p.sd + p.kd) * ((FNN_TILE_H - 1) * p.sh + p.kh) * ((FNN_TILE_W - 1) * p.sw + p.kw);
         if (!mb8 && ivox4 * 2 <= 4 * 256 && persist_lds_bytes(p, 1, 4, true) * 3 <= 160 * 1024) {
