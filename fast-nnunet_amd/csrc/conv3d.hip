@@ -964,6 +964,13 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
     p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
     p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
     if (p.packing == FNN_PACK_ZR) return launch_conv3d_zr(p, st);      // weights are in that kernel's order
+    {
+        // 16-channel full-resolution (1, 3, 3) layers: the row-streaming kernel (conv3d_row.hip)
+        ThinParams tp{};
+        tp.c = p; tp.fuse = 0;
+        const int rc = launch_conv_row(tp, st);
+        if (rc != -1) return rc;
+    }
     int nb = conv3d_pick_nb(p.Cout / 16);
     static const bool force_v1 = fnn_knob("FNN_CONV_V1") != nullptr;          // debugging / A-B aid
     if (!force_v1 && p.sd == 1 && p.sh == 1 && p.sw == 1) {

@@ -1,0 +1,402 @@
+// conv3d_row.hip - the 16-channel full-resolution (1, 3, 3) convs as row streams (gfx950).
+//
+// At full resolution the U-Net of an anisotropic plan has 16 channels and (1, 3, 3) kernels: 5 MFMAs per 16 voxels and
+// chunk against 1 KB of HBM traffic - these layers are bound by HBM only if everything AROUND the MFMAs is cheap.  The
+// tile kernels (conv3d_persist_kernel, conv_thin_kernel) spend 500 - 1000 instructions per wave and 256-voxel tile
+// on halo coordinates, bounds, per-element LDS addresses, store addresses and barriers: they are bound by VALU issue at
+// 2.4 - 4 TB/s.  Here a workgroup walks DOWN a strip of one depth plane, full rows of W = 16 NBLK voxels at a time:
+//   * no halo along w (the row is complete; two zero columns in LDS are the conv's padding), none along h inside a
+//     strip (a ring of 12 LDS rows, each row staged exactly once), none along d (kd = 1);
+//   * a group of 4 input rows is ONE contiguous run of 8 W x 16 B in HBM: the loads of a thread are base + constant,
+//     the base is a scalar that moves with the step;
+//   * wave j computes output row 4 s + j of step s: NBLK column blocks of 16 consecutive voxels; every LDS operand read
+//     is lane constant + scalar row offset + immediate block offset, every output store scalar row base + lane
+//     constant + immediate;
+//   * one barrier per step; groups s + 2 (LDS write) and s + 3 (global loads) are in flight during step s.
+// LDS image: row pitch (W + 2) voxels x 32 B; the two 16-byte channel halves of a voxel are swapped where bit 2 of its
+// column is set, which makes the 16 lanes of an operand read (16 consecutive voxels, one half) hit every bank group
+// exactly twice = the full ds_read_b128 rate.
+// TCONV: chunk 0 is the last ConvTranspose3d's output, computed by this kernel from the low-resolution tensor while it
+// stages (stride (1, 2, 2), kernel = stride: two low rows give four "up" rows; one 16-byte load per lane is the MFMA
+// operand, one MFMA per stride phase) - the "up" tensor is never written or read (as conv_thin_kernel<.., FUSE_TCONV>).
+//
+// Arithmetic = the other conv kernels': packed-fp16 normalise-on-load, MFMA k-steps in the FNN_PACK_LINEAR order,
+// fp32 accumulation, bias, one rounding to fp16, statistics of the rounded values (fp32 per step, double across).
+//
+// Replaces (with conv3d.hip / conv3d_thin.hip) the ConvDropoutNormReLU stacks and the transpconv of the reference's
+// PlainConvUNet at full resolution, nnUNetDistillationTrainer.py:141-173.
+#include "fnn_device.h"
+#include "conv_common.h"
+#include <cstdlib>
+
+namespace {
+
+struct RowCur { int n, d, h0, g; };                                      // (batch item, plane, strip start, row group)
+
+template <int NBLK, int CH, bool TCONV>
+__global__ __launch_bounds__(256, CH == 1 ? 3 : 2) void conv_row_kernel(const ThinParams tp, const int total_units,
+                                                                         const int strips, const int SH) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ConvParams &p = tp.c;
+    constexpr int W = 16 * NBLK, PB = (W + 2) * 32, RINGB = 12 * PB;     // row pitch, bytes per chunk ring (3 groups x 4 rows)
+    constexpr int PF = NBLK / 2;                                         // 16-byte elements per thread and 4-row group
+    constexpr int NPL = TCONV ? 1 : CH;                                  // chunks staged from a plain source
+    constexpr int TB = TCONV ? (NBLK + 3) / 4 : 1;                       // low-resolution blocks per wave and group
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4, hl = lane >> 5, kh = q & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.Hi, D = p.Di, G = SH >> 2;
+    double *sRed = (double *)(smem + CH * RINGB);                        // [4 waves][16][2]
+
+    // ---- this workgroup's units (contiguous, XCD aware) and its group stream
+    int u_begin, u_end;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        const int g = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+        u_begin = (int)((long long)total_units * g / nwg);
+        u_end = (int)((long long)total_units * (g + 1) / nwg);
+    }
+    if (u_begin >= u_end) return;
+    const int n_groups = (u_end - u_begin) * (G + 1);
+    auto advance = [&](RowCur &c) {
+        if (++c.g > G) {
+            c.g = 0; c.h0 += SH;
+            if (c.h0 >= H) { c.h0 = 0; if (++c.d >= D) { c.d = 0; ++c.n; } }
+        }
+    };
+
+    // ---- one-time set-up
+    // zero columns 0 and W + 1 of every ring row: the conv's padding along w, never overwritten
+    if (tid < CH * 12 * 4) {
+        const int row = tid >> 2, which = (tid >> 1) & 1, half = tid & 1;
+        *(f16x8 *)(smem + row * PB + (which ? (W + 1) * 32 : 0) + half * 16) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    for (int i = tid; i < 4 * 16 * 2; i += 256) sRed[i] = 0.0;
+    // plain staging: element e = tid + 256 u of a group = (row i, column, 8-channel half); i is wave uniform
+    const int cg = tid & 1;
+    int e_row[PF], e_goff[PF], e_lds[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int e = tid + 256 * u, i = e / (2 * W), c = e - i * (2 * W), col = (c >> 1) + 1;
+        e_row[u] = __builtin_amdgcn_readfirstlane(i);
+        e_goff[u] = c * 16;                                              // bytes inside the row (C = 16: 32 B per voxel)
+        e_lds[u] = col * 32 + ((cg ^ ((col >> 2) & 1)) * 16);
+    }
+    // operand reads: k-step ks = taps (2 ks, 2 ks + 1); lane (voxel r, tap hl, half kh); column of tap (tr, tc) = r + tc
+    int lanec[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        const int t = 2 * ks + hl < 9 ? 2 * ks + hl : 8;                 // padded slot: any finite data (its weights are 0)
+        const int col = r + t % 3;
+        lanec[ks] = col * 32 + ((kh ^ ((col >> 2) & 1)) * 16);
+    }
+    // weights: all k-steps of all chunks stay in registers (FNN_PACK_LINEAR, one cout block)
+    f16x8 wf[CH][5];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) wf[ch][ks] = *(const f16x8 *)(p.wpk + ((size_t)(ch * 5 + ks) * 64 + lane) * 8);
+    const float4 bv = *(const float4 *)(p.bias + q * 4);
+    // fused transposed conv: its four phase fragments, bias and image offsets
+    f16x8 fwf[TCONV ? 4 : 1];
+    f32x4 fb = {0.f, 0.f, 0.f, 0.f};
+    int up_lds[2] = {0, 0};
+    if (TCONV) {
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) fwf[cls] = *(const f16x8 *)(tp.fw + ((size_t)cls * 64 + lane) * 8);
+        const float4 t = *(const float4 *)(tp.fbias + q * 4);
+        fb = (f32x4){t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int jw = 0; jw < 2; ++jw) {
+            const int col = 2 * r + jw + 1;                              // + 32 per low block: bit 2 unchanged
+            up_lds[jw] = col * 32 + (((q >> 1) ^ ((col >> 2) & 1)) * 16) + (q & 1) * 8;
+        }
+    }
+    const size_t plane_rows = (size_t)H;                                 // rows per (n, d) plane
+    const int Hl = tp.Hl, Wl = tp.Wl;
+
+    // ---- staging state
+    f16x8 xr[NPL][PF];
+    f16x8 xl[TB];
+    f16x8 sc_h[NPL], sh_h[NPL];
+    f16 slope_h[NPL];
+    float lsc[8], lsh[8];
+    int n_ss = -1;
+    auto load_ss = [&](int n) {                                          // wave-uniform addresses: scalar loads
+#pragma unroll
+        for (int pc = 0; pc < NPL; ++pc) {
+            const SrcDesc &S = p.src[TCONV ? 1 : pc];
+            const float *qs = S.ss ? S.ss + (size_t)(2 * n) * 16 : p.ident_ss;
+            const float *qh = S.ss ? qs + 16 : p.ident_ss + 512;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sc_h[pc][j] = (f16)(cg ? qs[8 + j] : qs[j]);
+                sh_h[pc][j] = (f16)(cg ? qh[8 + j] : qh[j]);
+            }
+            slope_h[pc] = (f16)S.slope;
+        }
+        if (TCONV) {
+            const SrcDesc &S = tp.low;
+            const float *qs = S.ss ? S.ss + (size_t)(2 * n) * 32 : p.ident_ss;
+            const float *qh = S.ss ? qs + 32 : p.ident_ss + 512;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                lsc[j] = q == 0 ? qs[j] : q == 1 ? qs[8 + j] : q == 2 ? qs[16 + j] : qs[24 + j];
+                lsh[j] = q == 0 ? qh[j] : q == 1 ? qh[8 + j] : q == 2 ? qh[16 + j] : qh[24 + j];
+            }
+        }
+    };
+    auto issue = [&](const RowCur &c) {
+        const int rbase = c.h0 - 1 + 4 * c.g;
+#pragma unroll
+        for (int pc = 0; pc < NPL; ++pc) {
+            const SrcDesc &S = p.src[TCONV ? 1 : pc];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                int row = rbase + e_row[u];
+                row = row < 0 ? 0 : (row >= H ? H - 1 : row);            // invalid rows: any valid address (zeroed in commit)
+                const char *base = (const char *)(S.ptr + (((size_t)c.n * D + c.d) * plane_rows + row) * (W * 16));
+                xr[pc][u] = *(const f16x8 *)(base + (unsigned)e_goff[u]);
+            }
+        }
+        if (TCONV) {
+            const int lbase = (c.h0 >> 1) - 1 + 2 * c.g;
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                int bb = wave + 4 * t;
+                bb = bb < NBLK ? bb : wave;                              // idle slot: a cached re-read, ignored in commit
+                const int lr = bb / (NBLK / 2), bl = bb - lr * (NBLK / 2);
+                int lrow = lbase + lr;
+                lrow = lrow < 0 ? 0 : (lrow >= Hl ? Hl - 1 : lrow);
+                const char *base = (const char *)(tp.low.ptr + (((size_t)c.n * tp.Dl + c.d) * Hl + lrow) * ((size_t)Wl * 32));
+                xl[t] = *(const f16x8 *)(base + (unsigned)((16 * bl + r) * 64 + q * 16));
+            }
+        }
+    };
+    auto commit = [&](const RowCur &c, int slot) {
+        if (c.n != n_ss) { load_ss(c.n); n_ss = c.n; }                   // uniform; scalar loads only
+        const int rbase = c.h0 - 1 + 4 * c.g;
+#pragma unroll
+        for (int pc = 0; pc < NPL; ++pc) {
+            char *ring = smem + (TCONV ? 1 : pc) * RINGB;
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int row = rbase + e_row[u];
+                f16x8 o = xr[pc][u] * sc_h[pc] + sh_h[pc];
+                o = __builtin_elementwise_max(o, o * slope_h[pc]);
+                if (row < 0 || row >= H) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};      // uniform: the conv's zero padding along h
+                *(f16x8 *)(ring + (slot * 4 + e_row[u]) * PB + e_lds[u]) = o;
+            }
+        }
+        if (TCONV) {
+            const int lbase = (c.h0 >> 1) - 1 + 2 * c.g;
+            const f16 lslope = (f16)tp.low.slope;
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                const int bb = wave + 4 * t;
+                if (bb < NBLK) {                                         // uniform
+                    const int lr = bb / (NBLK / 2), bl = bb - lr * (NBLK / 2);
+                    const int lrow = lbase + lr;
+                    const bool ok = lrow >= 0 && lrow < Hl;
+                    f16x8 o;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = (f16)fmaf((float)xl[t][k], lsc[k], lsh[k]);
+                    o = __builtin_elementwise_max(o, o * lslope);
+                    char *dst = smem + (slot * 4 + 2 * lr) * PB + bl * 1024;
+#pragma unroll
+                    for (int cls = 0; cls < 4; ++cls) {
+                        // bias added behind the MFMA like tconv_mfma_kernel: the unfused engine's bits
+                        const f32x4 dd = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwf[cls], o, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        f16x4 h;
+                        h[0] = (f16)(dd[0] + fb[0]); h[1] = (f16)(dd[1] + fb[1]); h[2] = (f16)(dd[2] + fb[2]); h[3] = (f16)(dd[3] + fb[3]);
+                        if (!ok) h = (f16x4){0, 0, 0, 0};                // rows outside the patch: the conv's zero padding
+                        *(f16x4 *)(dst + (cls >> 1) * PB + up_lds[cls & 1]) = h;
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- per-lane statistics (fp32 inside a step, double across)
+    double dsum[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dsum[j][0] = 0.0; dsum[j][1] = 0.0; }
+    auto flush_stats = [&](int n) {
+        if (!p.stats_out) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double a = row16_sum_f64(dsum[j][0]), b = row16_sum_f64(dsum[j][1]);
+            if (r == 0) { double *slot = sRed + (wave * 16 + q * 4 + j) * 2; slot[0] = a; slot[1] = b; }
+            dsum[j][0] = 0.0; dsum[j][1] = 0.0;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int c = tid >> 1, which = tid & 1;
+            double v = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { v += sRed[(w * 16 + c) * 2 + which]; sRed[(w * 16 + c) * 2 + which] = 0.0; }
+            unsafeAtomicAdd(p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout + c) * 2 + which, v);
+        }
+        __syncthreads();
+    };
+
+    // ---- one step: output row 4 s + wave of the unit, from ring groups `slot` and `slot + 1`
+    const unsigned out_lane = (unsigned)(r * 32 + q * 8);
+    const f16x2 ones = {(f16)1.f, (f16)1.f};
+    auto step = [&](const RowCur &c, int slot) {
+        const int slot1 = slot == 2 ? 0 : slot + 1;
+        f32x4 acc[NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            // window row wi = wave + tap row of this chunk's ring: the plain rings start one row above the step's first
+            // output row, the "up" ring two rows above
+            const int sh0 = (TCONV && ch == 0) ? 1 : 0;
+            int ro[3];
+#pragma unroll
+            for (int tr = 0; tr < 3; ++tr) {
+                const int wi = wave + tr + sh0;
+                ro[tr] = (wi < 4 ? slot * 4 + wi : slot1 * 4 + wi - 4) * PB;
+            }
+            const char *ring = smem + ch * RINGB;
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks) {
+                // taps (2 ks, 2 ks + 1): rows 0 0, 0 1, 1 1, 2 2, 2 (2): only k-step 1 mixes rows
+                const int vo = lanec[ks] + (ks == 1 ? (hl ? ro[1] : ro[0]) : ro[ks == 0 ? 0 : ks == 2 ? 1 : 2]);
+                f16x8 xf[NBLK];
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) xf[b] = *(const f16x8 *)(ring + vo + b * 512);
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ch][ks], xf[b], acc[b], 0, 0, 0);
+            }
+        }
+        // epilogue: bias, fp16, one 8-byte store per lane and block (512 contiguous bytes per wave instruction), statistics
+        const int orow = c.h0 + 4 * c.g + wave;
+        char *obase = (char *)(p.out + (((size_t)c.n * D + c.d) * plane_rows + orow) * (W * 16));
+        float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < NBLK; b += 2) {
+            f16x4 o[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                o[h][0] = (f16)(acc[b + h][0] + bv.x);
+                o[h][1] = (f16)(acc[b + h][1] + bv.y);
+                o[h][2] = (f16)(acc[b + h][2] + bv.z);
+                o[h][3] = (f16)(acc[b + h][3] + bv.w);
+                *(f16x4 *)(obase + out_lane + (b + h) * 512) = o[h];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f16x2 pr = {o[0][j], o[1][j]};
+                t1[j] = __builtin_amdgcn_fdot2(pr, ones, t1[j], false);
+                t2[j] = __builtin_amdgcn_fdot2(pr, pr, t2[j], false);
+            }
+        }
+        if (p.stats_out) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dsum[j][0] += (double)t1[j]; dsum[j][1] += (double)t2[j]; }
+        }
+    };
+
+    // ---- the stream
+    RowCur cc;                                                           // group gi: computed
+    {
+        const int u = u_begin, strip = u % strips, pd = u / strips;
+        cc.h0 = strip * SH; cc.d = pd % D; cc.n = pd / D; cc.g = 0;
+    }
+    RowCur cw = cc, ci = cc;                                             // groups gi + 2 (LDS write), gi + 3 (global loads)
+    int gw = 0, gl = 0;                                                  // their stream indices (clamped to the last group)
+    __syncthreads();                                                     // zero columns, sRed
+    issue(ci);
+    commit(cw, 0);
+    if (gl < n_groups - 1) { advance(ci); ++gl; }
+    if (gw < n_groups - 1) { advance(cw); ++gw; }
+    issue(ci);
+    commit(cw, 1);
+    if (gl < n_groups - 1) { advance(ci); ++gl; }
+    if (gw < n_groups - 1) { advance(cw); ++gw; }
+    issue(ci);
+    __syncthreads();
+    int slot = 0;
+    for (int gi = 0; gi < n_groups; ++gi) {
+        if (cc.g < G) step(cc, slot);
+        commit(cw, slot == 0 ? 2 : slot - 1);                            // group gi + 2 -> slot (gi + 2) % 3
+        if (gl < n_groups - 1) { advance(ci); ++gl; }
+        if (gw < n_groups - 1) { advance(cw); ++gw; }
+        issue(ci);
+        __syncthreads();
+        const int n_prev = cc.n;
+        advance(cc);
+        slot = slot == 2 ? 0 : slot + 1;
+        if (cc.n != n_prev || gi + 1 == n_groups) flush_stats(n_prev);
+    }
+}
+
+int pick_strips(int H, int &SH) {
+    for (int k = 1; k <= 8; ++k)
+        if (H % k == 0 && (H / k) % 4 == 0 && H / k <= 64) { SH = H / k; return k; }
+    SH = H;
+    return 1;
+}
+
+template <int NBLK, int CH, bool TCONV>
+int launch_row_t(ThinParams tp, hipStream_t st) {
+    ConvParams &p = tp.c;
+    p.ident_ss = conv3d_identity_ss();
+    if (!p.ident_ss) return -2;
+    int SH;
+    const int strips = pick_strips(p.Hi, SH);
+    const int total = p.N * p.Di * strips;
+    constexpr int PB = (16 * NBLK + 2) * 32;
+    const size_t lds = (size_t)CH * 12 * PB + 4 * 16 * 2 * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)conv_row_kernel<NBLK, CH, TCONV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    int per_cu = (int)((160 * 1024) / lds);
+    const int cap = CH == 1 ? 3 : 2;
+    if (per_cu > cap) per_cu = cap;
+    int gx = 256 * per_cu;
+    if (gx > total) gx = total;
+    hipLaunchKernelGGL((conv_row_kernel<NBLK, CH, TCONV>), dim3(gx), dim3(256), lds, st, tp, total, strips, SH);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int CH, bool TCONV>
+int launch_row_n(const ThinParams &tp, hipStream_t st) {
+    switch (tp.c.Wi) {
+        case 64: return launch_row_t<4, CH, TCONV>(tp, st);
+        case 96: return launch_row_t<6, CH, TCONV>(tp, st);
+        case 128: return launch_row_t<8, CH, TCONV>(tp, st);
+    }
+    return -1;
+}
+
+}  // namespace
+
+// Can the row kernel run this layer?  tp.fuse = 0 (plain sources) or FUSE_TCONV.
+bool conv_row_ok(const ThinParams &tp) {
+    static const bool off = fnn_knob("FNN_NO_ROW") != nullptr;                       // A-B aid
+    const ConvParams &p = tp.c;
+    if (off || p.Cout != 16 || p.kd != 1 || p.kh != 3 || p.kw != 3 || p.sd != 1 || p.sh != 1 || p.sw != 1 || p.fp8) return false;
+    if (p.Di != p.Do || p.Hi != p.Ho || p.Wi != p.Wo || p.packing != FNN_PACK_LINEAR || p.ksteps != 5) return false;
+    if ((p.Wi != 64 && p.Wi != 96 && p.Wi != 128) || p.Hi % 4 != 0 || p.Hi < 8) return false;
+    if (p.stats_out && p.stats_slots != FNN_STAT_REPL) return false;
+    if (tp.fuse == FUSE_TCONV) {
+        if (p.n_src != 2 || p.chunks != 2 || p.src[1].C != 16 || tp.low.C != 32) return false;
+        if (tp.tsd != 1 || tp.tsh != 2 || tp.tsw != 2 || tp.Dl != p.Di || tp.Hl * 2 != p.Hi || tp.Wl * 2 != p.Wi) return false;
+        return true;
+    }
+    if (tp.fuse != 0) return false;
+    if (p.chunks != p.n_src || p.chunks < 1 || p.chunks > 2) return false;
+    for (int i = 0; i < p.n_src; ++i) if (p.src[i].C != 16) return false;
+    return true;
+}
+
+int launch_conv_row(const ThinParams &tp, hipStream_t st) {
+    if (!conv_row_ok(tp)) return -1;
+    if (tp.fuse == FUSE_TCONV) return launch_row_n<2, true>(tp, st);
+    return tp.c.chunks == 1 ? launch_row_n<1, false>(tp, st) : launch_row_n<2, false>(tp, st);
+}

@@ -681,6 +681,10 @@ static int launch_thin_t(const ThinParams &tp, hipStream_t st) {
 
 int launch_conv_thin(const ThinParams &tp, hipStream_t st) {
     if (!conv_thin_ok(tp)) return -1;
+    if (tp.fuse == FUSE_TCONV) {                                         // stride (1, 2, 2), full rows: the row-streaming form
+        const int rc = launch_conv_row(tp, st);
+        if (rc != -1) return rc;
+    }
     const int kd = tp.c.kd;
     if (tp.fuse == FUSE_STEM) return kd == 1 ? launch_thin_t<1, 1, FUSE_STEM, 1>(tp, st) : launch_thin_t<3, 1, FUSE_STEM, 1>(tp, st);
     switch (tp.tsd * tp.tsh * tp.tsw) {

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
     FNN_STAMP();                                              // 0: entry
     constexpr int IH = 10, IW = 10, PW = 12, ID = TD + 2;    // halo tile, row pitch 12 = 4 (mod 8) voxels
     constexpr int PS = IH * PW * 32;                          // bytes per halo plane
-    constexpr int ABYTES = (ID * PS + 1023) & ~1023;
+    constexpr int ABYTES = ID * PS;                           // no rounding: at TD = 4 the workgroup is 42 LDS granules (3 per CU)
     constexpr int KS = 15;
     constexpr int IELEM = ID * IH * IW * 2;                   // 16-byte halo elements per chunk
     constexpr int PF = (IELEM + 255) / 256;
@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
 
     char *sA = smem;                                          // halo image: [ID][IH][PW] voxels x 32 B, halves swapped on odd rows
     char *sW = smem + ABYTES;                                 // [NB][15][64 lanes][16 B]
-    float *sBias = (float *)(sW + NB * KS * 1024);
+    // bias: in the two unused voxel slots behind rows 0 and 1 of halo plane 0 (pitch 12, 10 used) - 16 floats each
+    auto bias_slot = [&](int i) { return (float *)(sA + (((i >> 4) * PW + IW) * 32)) + (i & 15); };
 
     int toff[5];                                              // filled in after the first loads have left
     f32x4 acc[TD][NB];
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
     };
 
     FNN_STAMP();                                              // 1: prefetch coordinates done
-    if (tid < NB * 16) sBias[tid] = p.bias[cb0 * 16 + tid];   // before the chunk's loads: vmcnt retires in order
+    if (tid < NB * 16) *bias_slot(tid) = p.bias[cb0 * 16 + tid];   // before the chunk's loads: vmcnt retires in order
     issue(0);
     __builtin_amdgcn_sched_barrier(0);                        // the loads leave first; the rest of the set-up runs under them
     FNN_STAMP();                                              // 2: first loads issued
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
     {
         float4 bv[NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const float4 *)(sBias + (NB == 2 ? (lane >> 4) * 8 + nb * 4 : nb * 16 + (lane >> 4) * 4));
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const float4 *)bias_slot(NB == 2 ? (lane >> 4) * 8 + nb * 4 : nb * 16 + (lane >> 4) * 4);
         float t1[NB][4], t2[NB][4];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -804,7 +805,7 @@ static int launch_zr(ConvParams p, hipStream_t st) {
     p.tiles_d = (p.Do + TD - 1) / TD;
     p.tiles_h = (p.Ho + 7) / 8;
     p.tiles_w = (p.Wo + 7) / 8;
-    const size_t lds = (size_t)(((TD + 2) * 10 * 12 * 32 + 1023) & ~1023) + (size_t)NB * 15 * 1024 + (size_t)NB * 64;
+    const size_t lds = (size_t)((TD + 2) * 10 * 12 * 32) + (size_t)NB * 15 * 1024;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)conv3d_zr_kernel<NB, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -235,3 +235,58 @@ def test_conv3d_strided_persistent_variant(stride, cin, cout):
     xn = _h(F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01))
     ref = F.conv3d(xn, w, b, stride, 1)
     assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
+
+
+# ----------------------------------------------------------------------------------------------- conv3d_row.hip
+ROW_CASES = [
+    # n, sources, dims (d, h, w): (1, 3, 3) convs of 16 channels at full rows of 64 / 96 / 128 voxels
+    (3, 1, (5, 24, 64)),        # one strip of 6 steps
+    (2, 1, (7, 96, 96)),        # two strips of 48 rows (the benchmark's stage-0 geometry)
+    (2, 1, (3, 40, 128)),
+    (2, 2, (4, 48, 96)),        # two sources = torch.cat((up, skip), 1) without the fusion
+    (1, 1, (2, 8, 64)),         # a strip of two steps: the group stream is mostly prologue and tail
+]
+
+
+@pytest.mark.parametrize('n,nsrc,dims', ROW_CASES)
+def test_conv3d_row_streaming_kernel(n, nsrc, dims):
+    """conv3d_row.hip (16 -> 16 channels, (1, 3, 3), full rows): against torch on the same fp16 operands with identity
+    input, with InstanceNorm + LeakyReLU on load, and its statistics; zero padding along h at strip and plane borders."""
+    from fast_nnunet_amd import capi
+    g = torch.Generator().manual_seed(31 + dims[1] + dims[2] + nsrc)
+    k, stride = (1, 3, 3), (1, 1, 1)
+    x = _h(torch.randn(n, 16, *dims, generator=g) * 2 + 0.5)
+    x2 = _h(torch.randn(n, 16, *dims, generator=g) - 0.25) if nsrc == 2 else None
+    cin = 16 * nsrc
+    w = _h(torch.randn(16, cin, *k, generator=g) / (cin * 9) ** 0.5)
+    b = torch.randn(16, generator=g)
+    gamma, beta = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.1
+    kw = dict(x2=x2.numpy()) if nsrc == 2 else {}
+    y, stats = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), k, stride, want_stats=True, **kw)
+    xin = torch.cat((x, x2), 1) if nsrc == 2 else x
+    _check(y, F.conv3d(xin, w, b, stride, (0, 1, 1)), 'conv3d row')
+    y64 = y.astype(np.float64)
+    assert np.allclose(stats[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    assert np.allclose(stats[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    if nsrc == 2:
+        y = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), k, stride, x2=x2.numpy(), gamma2=gamma.numpy(), beta2=beta.numpy(), slope2=0.01)
+        xn = torch.cat((x, _h(F.leaky_relu(F.instance_norm(x2, weight=gamma, bias=beta, eps=1e-5), 0.01))), 1)
+    else:
+        y = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), k, stride, gamma=gamma.numpy(), beta=beta.numpy(), slope=0.01)
+        xn = _h(F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01))
+    ref = F.conv3d(xn, w, b, stride, (0, 1, 1))
+    assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_conv3d_row_operand_map_with_exact_integers():
+    """one-hot taps on integer data: a wrong tap / column block / ring row / channel half shows up as inequality"""
+    from fast_nnunet_amd import capi
+    n, c, dims = 2, 16, (3, 96, 96)
+    base = (torch.arange(dims[0] * dims[1] * dims[2]).reshape(dims) * 7 % 23).float()
+    x = torch.stack([torch.stack([base + ch + 3 * i for ch in range(c)]) for i in range(n)])
+    w = torch.zeros(c, c, 1, 3, 3)
+    for co in range(c):
+        w[co, (co * 5 + 3) % c, 0, co % 3, (co // 3) % 3] = 1.0
+        w[co, (co * 3 + 1) % c, 0, (co + 1) % 3, (co + 2) % 3] += 2.0
+    y = capi.op_conv3d(x.numpy(), w.numpy(), None, (1, 3, 3), (1, 1, 1))
+    assert np.array_equal(y, F.conv3d(x, w, None, 1, (0, 1, 1)).numpy())
