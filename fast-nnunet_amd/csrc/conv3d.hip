@@ -1024,6 +1024,11 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
         }
     }
     static const bool strided_v1 = fnn_knob("FNN_CONV_STRIDED_V1") != nullptr;   // A-B aid
+    if (!force_v1 && !strided_v1) {
+        // stride (2, 2, 2) with whole groups of 64 output channels: one staged halo per group (conv3d_s2.hip)
+        const int rc = launch_conv3d_s2(p, st);
+        if (rc != -1) return rc;
+    }
     if (!force_v1 && !strided_v1 && p.ksteps <= 14) {
         // strided convs: 2 x 8 x 8 output tile, up to 16 halo elements per thread, <= 2 cout blocks
         const int nbs = (p.Cout / 16) % 2 == 0 ? 2 : 1;

@@ -290,3 +290,27 @@ def test_conv3d_row_operand_map_with_exact_integers():
         w[co, (co * 3 + 1) % c, 0, (co + 1) % 3, (co + 2) % 3] += 2.0
     y = capi.op_conv3d(x.numpy(), w.numpy(), None, (1, 3, 3), (1, 1, 1))
     assert np.array_equal(y, F.conv3d(x, w, None, 1, (0, 1, 1)).numpy())
+
+
+@pytest.mark.parametrize('cin,cout', [(32, 64), (64, 128), (48, 192)])
+def test_conv3d_stride2_grouped_kernel(cin, cout):
+    """conv3d_s2.hip (3x3x3, stride (2,2,2), whole groups of 64 output channels per staged halo, 512-thread persistent
+    workgroups): ragged 4 x 8 x 8 tiles on every axis, 2 - 4 chunks, 1 - 3 cout groups, InstanceNorm + LeakyReLU on load,
+    statistics across units and batch items."""
+    from fast_nnunet_amd import capi
+    g = torch.Generator().manual_seed(41 + cin)
+    n, dims, stride = 8, (45, 61, 58), (2, 2, 2)
+    x = _h(torch.randn(n, cin, *dims, generator=g) * 2 + 0.5)
+    gamma = torch.rand(cin, generator=g) + 0.5
+    beta = torch.randn(cin, generator=g) * 0.1
+    w = _h(torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    y, stats = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), stride, want_stats=True)
+    _check(y, F.conv3d(x, w, b, stride, 1), 'conv3d s2')
+    y64 = y.astype(np.float64)
+    assert np.allclose(stats[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    assert np.allclose(stats[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    y = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), stride, gamma=gamma.numpy(), beta=beta.numpy(), slope=0.01)
+    xn = _h(F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01))
+    ref = F.conv3d(xn, w, b, stride, 1)
+    assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
