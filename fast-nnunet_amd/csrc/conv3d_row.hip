@@ -31,7 +31,21 @@
 
 namespace {
 
-struct RowCur { int n, d, h0, g; };                                      // (batch item, plane, strip start, row group)
+struct RowCur { int n, d, h0, g; };
+
+// Two column blocks' results (lane = voxel r, channels 4 q .. 4 q + 3 of each) -> one 16-byte store per lane:
+// v_permlane16_swap exchanges the odd 16-lane rows of block b with the even rows of block b + 1, after which lane
+// (r, q) holds channels 8 (q >> 1) .. + 7 of voxel r of block b + (q & 1) - half the store instructions of the
+// 8-byte form.  (Measured neutral on the benchmark: these kernels are not bound by store issue.)
+typedef unsigned fnn_u32x4r __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ fnn_u32x4r pair_to_b128(const f16x4 &a, const f16x4 &b) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+    const auto lo = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+    return (fnn_u32x4r){lo[0], hi[0], lo[1], hi[1]};
+}
+                                      // (batch item, plane, strip start, row group)
 
 template <int NBLK, int CH, bool TCONV>
 __global__ __launch_bounds__(256, CH == 1 ? 3 : 2) void conv_row_kernel(const ThinParams tp, const int total_units,
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(256, CH == 1 ? 3 : 2) void conv_row_kernel(const Th
     };
 
     // ---- one step: output row 4 s + wave of the unit, from ring groups `slot` and `slot + 1`
-    const unsigned out_lane = (unsigned)(r * 32 + q * 8);
+    const unsigned out_lane = (unsigned)((r + 16 * (q & 1)) * 32 + (q >> 1) * 16);     // after pair_to_b128
     const f16x2 ones = {(f16)1.f, (f16)1.f};
     auto step = [&](const RowCur &c, int slot) {
         const int slot1 = slot == 2 ? 0 : slot + 1;
@@ -284,8 +298,8 @@ __global__ __launch_bounds__(256, CH == 1 ? 3 : 2) void conv_row_kernel(const Th
                 o[h][1] = (f16)(acc[b + h][1] + bv.y);
                 o[h][2] = (f16)(acc[b + h][2] + bv.z);
                 o[h][3] = (f16)(acc[b + h][3] + bv.w);
-                *(f16x4 *)(obase + out_lane + (b + h) * 512) = o[h];
             }
+            *(fnn_u32x4r *)(obase + out_lane + b * 512) = pair_to_b128(o[0], o[1]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f16x2 pr = {o[0][j], o[1][j]};
@@ -330,6 +344,186 @@ __global__ __launch_bounds__(256, CH == 1 ? 3 : 2) void conv_row_kernel(const Th
         advance(cc);
         slot = slot == 2 ? 0 : slot + 1;
         if (cc.n != n_prev || gi + 1 == n_groups) flush_stats(n_prev);
+    }
+}
+
+// ----------------------------------------------------------------------------
+// the stem (first conv: one input channel read from the fp32 volume, (1, 3, 3)) as a row stream
+// ----------------------------------------------------------------------------
+// Same walk as conv_row_kernel.  The ring holds, per raw row and output column w, the 8-byte entry
+// (x[w - 1], x[w], x[w + 1], 0) in fp16: the im2col column of a voxel is then two aligned ds_read_b64 - k = 0 .. 7 =
+// entries of rows h - 1 and h (lane quarter 0), k = 8 .. 11 = the entry of row h + 1 (quarter 1), the remaining k
+// carry zero weights - and ONE MFMA per 16 voxels.  A raw value is written into the three entries it belongs to
+// (ds_write_b16); x[-1], x[W] and the fourth slot stay zero from the start: the conv's zero padding at the PATCH
+// border.  Arithmetic: x and the weights rounded to fp16, fp32 accumulation, bias, one rounding - as stem_mfma_kernel
+// (whose k order differs: the fp32 sums can differ in their last bit).  Statistics: one row per (plane, strip).
+template <int NBLK>
+__global__ __launch_bounds__(256, 4) void stem_row_kernel(const StemParams p, const int total_units, const int strips,
+                                                           const int SH, const int slots) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int W = 16 * NBLK, PB = W * 8, RINGB = 12 * PB;
+    constexpr int PF = (4 * W + 255) / 256;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.PH, D = p.PD, G = SH >> 2;
+    float *sRed = (float *)(smem + RINGB);                               // [4 waves][16][2]
+
+    int u_begin, u_end;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        const int g = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+        u_begin = (int)((long long)total_units * g / nwg);
+        u_end = (int)((long long)total_units * (g + 1) / nwg);
+    }
+    if (u_begin >= u_end) return;
+    const int n_groups = (u_end - u_begin) * (G + 1);
+    auto advance = [&](RowCur &c) {
+        if (++c.g > G) {
+            c.g = 0; c.h0 += SH;
+            if (c.h0 >= H) { c.h0 = 0; if (++c.d >= D) { c.d = 0; ++c.n; } }
+        }
+    };
+    for (int i = tid; i < RINGB / 16; i += 256) ((uint4 *)smem)[i] = make_uint4(0, 0, 0, 0);
+
+    // weights -> A fragment in this kernel's k order; bias of this lane's 4 channels
+    f16x8 wf = {0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        const int m = lane & 15;
+        if (q == 0) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) wf[t + t / 3] = (f16)p.w[(size_t)t * p.Cout + m];
+        } else if (q == 1) {
+#pragma unroll
+            for (int t = 6; t < 9; ++t) wf[t - 6] = (f16)p.w[(size_t)t * p.Cout + m];
+        }
+    }
+    const float4 bv = *(const float4 *)(p.bias + q * 4);
+    // staging: element e = tid + 256 u = (row i of the group, column w)
+    int e_row[PF], e_col[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int e = tid + 256 * u, i = e / W;
+        e_row[u] = i < 4 ? i : -1;
+        e_col[u] = e - i * W;
+    }
+    float xr[PF];
+    const float *voln0 = p.vol;
+    auto issue = [&](const RowCur &c) {
+        const int rbase = c.h0 - 1 + 4 * c.g;
+        const int ox = p.origins[c.n * 3 + 0], oy = p.origins[c.n * 3 + 1], oz = p.origins[c.n * 3 + 2];
+        const int dd = p.flip_d ? D - 1 - c.d : c.d;
+        const float *plane = voln0 + (size_t)c.n * p.vol_batch_stride + (size_t)(ox + dd) * p.Y * p.Z + oz;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            int row = rbase + (e_row[u] < 0 ? 0 : e_row[u]);
+            row = row < 0 ? 0 : (row >= H ? H - 1 : row);                // invalid rows: any valid address (zeroed in commit)
+            const int hh = p.flip_h ? H - 1 - row : row, ww = p.flip_w ? W - 1 - e_col[u] : e_col[u];
+            xr[u] = plane[(size_t)(oy + hh) * p.Z + ww];
+        }
+    };
+    auto commit = [&](const RowCur &c, int slot) {
+        const int rbase = c.h0 - 1 + 4 * c.g;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (e_row[u] < 0) continue;
+            const int row = rbase + e_row[u];
+            const f16 v = (row < 0 || row >= H) ? (f16)0.f : (f16)xr[u];
+            char *rowp = smem + (slot * 4 + e_row[u]) * PB;
+            const int w = e_col[u];
+            *(f16 *)(rowp + w * 8 + 2) = v;                              // x[w] of entry w
+            if (w + 1 < W) *(f16 *)(rowp + (w + 1) * 8) = v;             // x[w' - 1] of entry w' = w + 1
+            if (w > 0) *(f16 *)(rowp + (w - 1) * 8 + 4) = v;             // x[w' + 1] of entry w' = w - 1
+        }
+    };
+
+    const unsigned out_lane = (unsigned)((r + 16 * (q & 1)) * 32 + (q >> 1) * 16);     // after pair_to_b128
+    const f16x2 ones = {(f16)1.f, (f16)1.f};
+    float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};   // per-lane sums of the unit (<= 16 rows x NBLK values: fp32)
+    auto step = [&](const RowCur &c, int slot) {
+        const int slot1 = slot == 2 ? 0 : slot + 1;
+        int ro[3];
+#pragma unroll
+        for (int tr = 0; tr < 3; ++tr) {
+            const int wi = wave + tr;
+            ro[tr] = (wi < 4 ? slot * 4 + wi : slot1 * 4 + wi - 4) * PB;
+        }
+        const int va = r * 8 + (q == 1 ? ro[2] : ro[0]), vb = r * 8 + (q == 1 ? ro[2] : ro[1]);
+        const int orow = c.h0 + 4 * c.g + wave;
+        char *obase = (char *)(p.out + (((size_t)c.n * D + c.d) * H + orow) * (W * 16));
+#pragma unroll
+        for (int b = 0; b < NBLK; b += 2) {
+            f16x4 o[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f16x4 ea = *(const f16x4 *)(smem + va + (b + h) * 128), eb = *(const f16x4 *)(smem + vb + (b + h) * 128);
+                const f16x8 xb = {ea[0], ea[1], ea[2], ea[3], eb[0], eb[1], eb[2], eb[3]};
+                const f32x4 dd = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xb, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                o[h][0] = (f16)(dd[0] + bv.x); o[h][1] = (f16)(dd[1] + bv.y); o[h][2] = (f16)(dd[2] + bv.z); o[h][3] = (f16)(dd[3] + bv.w);
+            }
+            {
+                const fnn_u32x4r v = pair_to_b128(o[0], o[1]);          // (outside the branch: every lane takes part in the swap)
+                if (p.out) *(fnn_u32x4r *)(obase + out_lane + b * 512) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f16x2 pr = {o[0][j], o[1][j]};
+                t1[j] = __builtin_amdgcn_fdot2(pr, ones, t1[j], false);
+                t2[j] = __builtin_amdgcn_fdot2(pr, pr, t2[j], false);
+            }
+        }
+    };
+    auto unit_stats = [&](const RowCur &c) {                             // called by every thread at the end of a unit
+        if (p.stats_out) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = row16_sum(t1[j]), b = row16_sum(t2[j]);
+                if (r == 0) { sRed[(wave * 16 + q * 4 + j) * 2] = a; sRed[(wave * 16 + q * 4 + j) * 2 + 1] = b; }
+            }
+            __syncthreads();
+            if (tid < 32) {
+                const int ch = tid >> 1, which = tid & 1;
+                double v = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += (double)sRed[(w * 16 + ch) * 2 + which];
+                const int slot_id = c.d * strips + c.h0 / SH;
+                p.stats_out[(((size_t)c.n * slots + slot_id) * p.Cout + ch) * 2 + which] = v;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { t1[j] = 0.f; t2[j] = 0.f; }
+    };
+
+    RowCur cc;
+    {
+        const int u = u_begin, strip = u % strips, pd = u / strips;
+        cc.h0 = strip * SH; cc.d = pd % D; cc.n = pd / D; cc.g = 0;
+    }
+    RowCur cw = cc, ci = cc;
+    int gw = 0, gl = 0;
+    __syncthreads();                                                     // the zeroed ring
+    issue(ci);
+    commit(cw, 0);
+    if (gl < n_groups - 1) { advance(ci); ++gl; }
+    if (gw < n_groups - 1) { advance(cw); ++gw; }
+    issue(ci);
+    commit(cw, 1);
+    if (gl < n_groups - 1) { advance(ci); ++gl; }
+    if (gw < n_groups - 1) { advance(cw); ++gw; }
+    issue(ci);
+    __syncthreads();
+    int slot = 0;
+    for (int gi = 0; gi < n_groups; ++gi) {
+        if (cc.g < G) step(cc, slot);
+        commit(cw, slot == 0 ? 2 : slot - 1);
+        if (gl < n_groups - 1) { advance(ci); ++gl; }
+        if (gw < n_groups - 1) { advance(cw); ++gw; }
+        issue(ci);
+        __syncthreads();
+        if (cc.g == G) unit_stats(cc);                                   // the unit's tail group: its steps are done
+        advance(cc);
+        slot = slot == 2 ? 0 : slot + 1;
     }
 }
 
@@ -378,7 +572,7 @@ int launch_row_n(const ThinParams &tp, hipStream_t st) {
 
 // Can the row kernel run this layer?  tp.fuse = 0 (plain sources) or FUSE_TCONV.
 bool conv_row_ok(const ThinParams &tp) {
-    static const bool off = fnn_knob("FNN_NO_ROW") != nullptr;                       // A-B aid
+    const bool off = fnn_knob("FNN_NO_ROW") != nullptr;                              // A-B aid (read per call: tests toggle it)
     const ConvParams &p = tp.c;
     if (off || p.Cout != 16 || p.kd != 1 || p.kh != 3 || p.kw != 3 || p.sd != 1 || p.sh != 1 || p.sw != 1 || p.fp8) return false;
     if (p.Di != p.Do || p.Hi != p.Ho || p.Wi != p.Wo || p.packing != FNN_PACK_LINEAR || p.ksteps != 5) return false;
@@ -399,4 +593,31 @@ int launch_conv_row(const ThinParams &tp, hipStream_t st) {
     if (!conv_row_ok(tp)) return -1;
     if (tp.fuse == FUSE_TCONV) return launch_row_n<2, true>(tp, st);
     return tp.c.chunks == 1 ? launch_row_n<1, false>(tp, st) : launch_row_n<2, false>(tp, st);
+}
+
+// stem in row form: one input channel, (1, 3, 3), 16 output channels, rows of 64 / 96 / 128 voxels
+bool stem_row_ok(const StemParams &p) {
+    const bool off = fnn_knob("FNN_NO_ROW") != nullptr || fnn_knob("FNN_NO_STEM_ROW") != nullptr;            // A-B aids
+    if (off || p.C != 1 || p.kd != 1 || p.kh != 3 || p.kw != 3 || p.Cout != 16) return false;
+    if ((p.PW != 64 && p.PW != 96 && p.PW != 128) || p.PH % 4 != 0 || p.PH < 8) return false;
+    if (2ull * p.PD * p.PH * p.PW * 16 >= (1ull << 32)) return false;
+    int SH;
+    const int strips = pick_strips(p.PH, SH);
+    return p.PD * strips <= stem_mfma_stats_slots(p.PD, p.PH, p.PW);     // one statistics row per (plane, strip)
+}
+
+int launch_stem_row(const StemParams &p, int N, hipStream_t st) {
+    if (!stem_row_ok(p)) return -1;
+    int SH;
+    const int strips = pick_strips(p.PH, SH);
+    const int total = N * p.PD * strips, slots = stem_mfma_stats_slots(p.PD, p.PH, p.PW);
+    const size_t lds = (size_t)12 * p.PW * 8 + 4 * 16 * 2 * 4;
+    int gx = 256 * 4;
+    if (gx > total) gx = total;
+    switch (p.PW) {
+        case 64: hipLaunchKernelGGL(stem_row_kernel<4>, dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots); break;
+        case 96: hipLaunchKernelGGL(stem_row_kernel<6>, dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots); break;
+        default: hipLaunchKernelGGL(stem_row_kernel<8>, dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots); break;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }

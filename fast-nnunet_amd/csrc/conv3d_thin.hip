@@ -183,6 +183,10 @@ int stem_mfma_stats_slots(int PD, int PH, int PW) { return ((PD + STEMM_TD - 1) 
 int launch_stem_mfma(const StemParams &p_in, const f16 *wfrag, int N, hipStream_t st) {
     StemParams p = p_in;
     if (!stem_mfma_ok(p.C, p.kd, p.kh, p.kw, p.Cout)) return -1;
+    {
+        const int rc = launch_stem_row(p, N, st);                        // one channel, (1, 3, 3), full rows: conv3d_row.hip
+        if (rc != -1) return rc;
+    }
     p.tiles_d = (p.PD + STEMM_TD - 1) / STEMM_TD;
     p.tiles_h = (p.PH + 7) / 8;
     p.tiles_w = (p.PW + 7) / 8;

@@ -278,6 +278,8 @@ bool conv_thin_ok(const ThinParams &tp);
 int launch_conv_thin(const ThinParams &tp, hipStream_t st);
 bool conv_row_ok(const ThinParams &tp);                                 // conv3d_row.hip: tp.fuse = 0 or FUSE_TCONV
 int launch_conv_row(const ThinParams &tp, hipStream_t st);             // -1 = not this kernel's layer
+bool stem_row_ok(const StemParams &p);
+int launch_stem_row(const StemParams &p, int N, hipStream_t st);       // -1 = not this kernel's stem
 int launch_head(const HeadParams &p, hipStream_t st);
 bool launch_head_first_visit_ok(const HeadParams &p);   // does launch_head() honour fx / fy / fz for these parameters?
 int launch_patch_acc(const PatchAccParams &p, hipStream_t st);

@@ -373,3 +373,43 @@ def test_fp8_driver_is_bit_identical_to_the_oracle_driver_on_its_own_logits():
     image = torch.randn(1, 70, 96, 64, generator=torch.Generator().manual_seed(81))
     want = osw.sliding_window_logits(lambda t: p.forward_patches(t).cpu(), image, patch, 3, accum='fp16')
     assert (_bits(p.predict_sliding_window_return_logits(image).cpu()) == _bits(want)).all()
+
+
+# ----------------------------------------------------------------------------------------------- row-streaming kernels
+@pytest.mark.parametrize('patch', [(8, 32, 64), (6, 24, 96), (4, 16, 128)])
+def test_row_streaming_kernels_network_and_mirroring_match_the_oracle(patch):
+    """conv3d_row.hip on a whole anisotropic network: rows of 64 / 96 / 128 voxels put the stem (raw fp32 rows, flipped
+    reads for mirroring), the 16 -> 16 convs and the fused last transposed conv on the row-streaming kernels.  Forward
+    of a batch and a one-patch volume with mirroring over all axes (flipped stem reads, gather over the 8 evaluations)
+    against the fp32 oracle; the layer-by-layer tile kernels (FNN_NO_ROW=1) within fp16 resolution."""
+    spec, _ = FUSE_SPECS['aniso']
+    sd = synthetic_state_dict(spec, 640 + patch[2])
+    x = torch.randn(3, 1, *patch, generator=torch.Generator().manual_seed(64))
+    p = _predictor(spec, patch, [sd], batch=3, mirror=[0, 1, 2])
+    got = p.forward_patches(x).cpu()
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    net = build_oracle(spec, sd)
+    with torch.inference_mode():
+        ref = net(x)
+    mr, rr = _report(f'row kernels {patch} vs oracle', got, ref)
+    assert mr <= MAX_REL and rr <= RMSE_REL
+    image = x[:1, 0]
+    vol = p.predict_sliding_window_return_logits(image).float().cpu()
+    os.environ['FNN_NO_ROW'] = '1'
+    try:
+        tiles = _predictor(spec, patch, [sd], batch=3, mirror=[0, 1, 2])
+        b = tiles.forward_patches(x).cpu()
+        vol_t = tiles.predict_sliding_window_return_logits(image).float().cpu()
+    finally:
+        os.environ.pop('FNN_NO_ROW', None)
+    mr, rr = _report(f'row kernels {patch} vs tile kernels', got, b)
+    assert mr <= 5e-3 and rr <= 3e-3
+    # one-patch volume: away from the faces, where the Gaussian weights are fp16 subnormals and the reference's half
+    # accumulators quantise (logit * g) / g coarsely (both engines and the oracle's fp16 mode do; the fp32 blend does not)
+    inner = (slice(None), slice(1, -1), slice(6, -6), slice(8, -8))
+    with torch.inference_mode():
+        want = osw.sliding_window_logits(lambda t: net(t), image, patch, spec.num_heads, mirror_axes=[0, 1, 2], accum='fp32').float()
+    mr, rr = _report(f'row kernels {patch} mirrored volume vs oracle', vol[inner], want[inner])
+    assert mr <= MAX_REL and rr <= RMSE_REL
+    mr, rr = _report(f'row kernels {patch} mirrored volume vs tile kernels', vol[inner], vol_t[inner])
+    assert mr <= 5e-3 and rr <= 3e-3

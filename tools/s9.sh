@@ -1,0 +1,9 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export FNN_KNOBS=1
+timeout 900 python -m pytest tests/test_gpu_configs.py tests/test_gpu_ops.py -m gpu -x -q -k "row or fused" > gpurun_out/s9_cfg.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/s9_cfg.log
+for i in 1 2; do
+python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | grep metric | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['time_share_ms'])"
+done
+bash tools/layers.sh s9 | grep -v "stats_final" | grep "row\|stem\|sum"
