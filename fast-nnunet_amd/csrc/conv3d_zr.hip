@@ -558,6 +558,243 @@ __global__ __launch_bounds__(256, 2) void conv3d_zs_kernel(const ConvParams p) {
     }
 }
 
+// Persistent form of conv3d_zs_kernel for single-chunk layers (Cin <= 16: the first down-sampling conv).  With one
+// chunk a tile is ONE k-loop of 120 MFMAs per wave behind a serial chain - table set-up, the halo's round trip, its
+// normalisation into LDS, then the epilogue - and two workgroups per CU cannot cover that chain for each other: the
+// layer ran at a workgroup lifetime of ~8 us per tile.  Here a workgroup walks tiles (those of its XCD interleaved
+// with the other workgroups', so that the tiles in flight on an XCD stay neighbours in L2): the 30 KB of weight
+// fragments are loaded once, the per-thread LDS offsets are computed once, and the next tile's halo loads are in
+// flight during the k-loop and the epilogue of the current one.  Same tile, image, arithmetic and statistics row per
+// tile as conv3d_zs_kernel: bit-identical results.
+__global__ __launch_bounds__(256, 2) void conv3d_zsp_kernel(const ConvParams p, const int total_tiles) {
+    constexpr int NB = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int TD = 8, TH = 4, TDW = 4;
+    constexpr int ID = TD + 2, IH = 2 * TH + 1, IW = 17, PW = 17;
+    constexpr int PS = IH * PW * 32;
+    constexpr int ABYTES = (ID * PS + 1023) & ~1023;
+    constexpr int KS = 15;
+    constexpr int IELEM = ID * IH * IW * 2;
+    constexpr int PF = (IELEM + 255) / 256;
+    constexpr int WTOT = NB * KS * 64;
+    const int hp = wave & 1, dh = wave >> 1;
+
+    char *sA = smem;
+    char *sW = smem + ABYTES;                                 // [NB][15][64 lanes][16 B]: resident
+    float *sRed = (float *)(sW + NB * KS * 1024);             // [4 waves][32][2]
+
+    // this workgroup's tiles: t = first + i * stride inside its XCD's contiguous range
+    int t_first, t_stride, t_end;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        const int wg_lo = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd;      // first workgroup of the XCD
+        const int wg_n = xcd < rm ? qd + 1 : qd;
+        const int r_lo = (int)((long long)total_tiles * wg_lo / nwg), r_hi = (int)((long long)total_tiles * (wg_lo + wg_n) / nwg);
+        t_first = r_lo + idx; t_stride = wg_n; t_end = r_hi;
+    }
+    if (t_first >= t_end) return;
+    const int cb0 = blockIdx.y * NB;
+
+    // ---- one-time set-up: weights, LDS offsets, operand offsets
+    for (int idx = tid; idx < WTOT; idx += 256) {
+        const int nb = idx >= KS * 64 ? 1 : 0;
+        ((f16x8 *)sW)[idx] = ((const f16x8 *)p.wpk)[(cb0 + nb) * p.chunks * (KS * 64) + idx - nb * (KS * 64)];
+    }
+    const int cg = tid & 1;
+    unsigned relp[PF / 2];                                    // halo coordinates, two 13-bit triples (zd : 4, zh : 4, zw : 5) per register
+    static_assert(PF % 2 == 0, "pairs");
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int idx = tid + u * 256, v = (idx < IELEM ? idx : IELEM - 1) >> 1;
+        const int zd = v / (IH * IW), rem = v - zd * (IH * IW), zh = rem / IW, zw = rem - zh * IW;
+        const unsigned t = (unsigned)((zd << 9) | (zh << 5) | zw);
+        if (u & 1) relp[u >> 1] |= t << 16; else relp[u >> 1] = t;
+    }
+    const bool has_last = tid + (PF - 1) * 256 < IELEM;
+#define ZSP_REL(u) ((relp[(u) >> 1] >> (((u) & 1) * 16)) & 0x1fffu)
+    int toff[5];
+    {
+        const int r = lane & 15, hl = lane >> 5, kh = (lane >> 4) & 1;
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const int tp = 2 * pr + hl < 9 ? 2 * pr + hl : 8;
+            const int row = 2 * (2 * hp + (r >> 3)) + tp / 3, col = 2 * (r & 7) + tp % 3;
+            toff[pr] = (TDW * dh) * PS + (row * PW + col) * 32 + kh * 16;
+        }
+    }
+    const int q = lane >> 4, r = lane & 15;
+    float4 bv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const float4 *)(p.bias + cb0 * 16 + q * 8 + nb * 4);
+
+    int offv[PF];
+    f16x8 xr[PF];
+    float scu[16], shu[16];
+    auto tile_coords = [&](int t, int &n, int &od0, int &oh0, int &ow0, int &slot) {
+        const int tw = t % p.tiles_w; t /= p.tiles_w;
+        const int th = t % p.tiles_h; t /= p.tiles_h;
+        const int td = t % p.tiles_d;
+        n = t / p.tiles_d;
+        od0 = td * TD; oh0 = th * TH; ow0 = tw * 8;
+        slot = (td * p.tiles_h + th) * p.tiles_w + tw;
+    };
+    auto set_offsets = [&](int od0, int oh0, int ow0) {
+        const int id0 = od0 - 1, ih0 = 2 * oh0 - 1, iw0 = 2 * ow0 - 1;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            unsigned t = ZSP_REL(u);
+            asm volatile("" : "+v"(t));                       // keep the unpacked coordinates out of loop-invariant registers
+            const unsigned gd = (unsigned)(id0 + (int)(t >> 9)), gh = (unsigned)(ih0 + (int)((t >> 5) & 15)), gw = (unsigned)(iw0 + (int)(t & 31));
+            const bool ok = gd < (unsigned)p.Di && gh < (unsigned)p.Hi && gw < (unsigned)p.Wi;
+            offv[u] = ok ? (int)(__umul24(__umul24(gd, (unsigned)p.Hi) + gh, (unsigned)p.Wi) + gw) : -1;
+        }
+    };
+    auto issue = [&](int n) {
+        const int sC = p.src[0].C;
+        const char *sp = (const char *)(p.src[0].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC);
+        const float *qs = p.src[0].ss ? p.src[0].ss + (size_t)(2 * n) * sC : p.ident_ss;
+        const float *qh = p.src[0].ss ? qs + sC : p.ident_ss + 512;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { scu[j] = qs[j]; shu[j] = qh[j]; }
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * sC + cg * 8) * 2));
+    };
+    auto commit = [&]() {
+        const f16 slope_h = (f16)p.src[0].slope;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = cg ? scu[8 + j] : scu[j]; sh[j] = cg ? shu[8 + j] : shu[j]; }
+#ifndef FNN_NORM_FP32
+        f16x8 sc_h, sh_h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc_h[j] = (f16)sc[j]; sh_h[j] = (f16)sh[j]; }
+#endif
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+#ifdef FNN_NORM_FP32
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)xr[u][j], sc[j], sh[j]);
+#else
+            f16x8 o = xr[u] * sc_h + sh_h;
+#endif
+            o = __builtin_elementwise_max(o, o * slope_h);
+            if (offv[u] < 0) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            unsigned t = ZSP_REL(u);
+            asm volatile("" : "+v"(t));
+            const int zd = (int)(t >> 9), zh = (int)((t >> 5) & 15), zw = (int)(t & 31);
+            if (u + 1 < PF || has_last) *(f16x8 *)(sA + zd * PS + (zh * PW + zw) * 32 + cg * 16) = o;
+        }
+    };
+
+    int n_cur, od0, oh0, ow0, slot;
+    tile_coords(t_first, n_cur, od0, oh0, ow0, slot);
+    set_offsets(od0, oh0, ow0);
+    issue(n_cur);
+    commit();
+    __syncthreads();                                          // weights + first image
+    const f16x2 ones = {(f16)1.f, (f16)1.f};
+    for (int t = t_first; t < t_end; t += t_stride) {
+        // prefetch the next tile (the last one prefetches itself again: issue / commit stay unconditional)
+        int n_nx = n_cur, d_nx = od0, h_nx = oh0, w_nx = ow0, s_nx = slot;
+        if (t + t_stride < t_end) tile_coords(t + t_stride, n_nx, d_nx, h_nx, w_nx, s_nx);
+        set_offsets(d_nx, h_nx, w_nx);
+        issue(n_nx);
+        f32x4 acc[TDW][NB];
+#pragma unroll
+        for (int j = 0; j < TDW; ++j)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[j][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const char *bp = sA + toff[pr];
+            f16x8 xf[TDW + 2];
+#pragma unroll
+            for (int pl = 0; pl < TDW + 2; ++pl) xf[pl] = *(const f16x8 *)(bp + pl * PS);
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                f16x8 wf[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wf[nb] = *(const f16x8 *)(sW + ((nb * KS + pr * 3 + dz) * 64 + lane) * 16);
+#pragma unroll
+                for (int j = 0; j < TDW; ++j)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nb], xf[j + dz], acc[j][nb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- epilogue of tile t (as conv3d_zs_kernel): bias, 16-byte stores, statistics row
+        float t1[NB][4], t2[NB][4];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
+        {
+            const unsigned item_bytes = (unsigned)p.Do * p.Ho * p.Wo * p.Cout * 2;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)n_cur * (item_bytes >> 1), 0, item_bytes, 0x00020000);
+            const unsigned coff = (unsigned)(cb0 * 16 + q * 8) * 2;
+            const int oh = oh0 + 2 * hp + (r >> 3), ow = ow0 + (r & 7);
+            const bool ok_hw = oh < p.Ho && ow < p.Wo;
+#pragma unroll
+            for (int mb = 0; mb < TDW; mb += 2) {
+                f16x8 o[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int od = od0 + TDW * dh + mb + h;
+                    const bool ok = ok_hw && od < p.Do;
+                    const unsigned voff = ok ? (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout) * 2 + coff : 0x80000000u;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        o[h][nb * 4 + 0] = (f16)(acc[mb + h][nb][0] + bv[nb].x);
+                        o[h][nb * 4 + 1] = (f16)(acc[mb + h][nb][1] + bv[nb].y);
+                        o[h][nb * 4 + 2] = (f16)(acc[mb + h][nb][2] + bv[nb].z);
+                        o[h][nb * 4 + 3] = (f16)(acc[mb + h][nb][3] + bv[nb].w);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fnn_i32x4, o[h]), rsrc, voff, 0, 0);
+                    if (!ok) o[h] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f16x2 pr = {o[0][nb * 4 + j], o[1][nb * 4 + j]};
+                        t1[nb][j] = __builtin_amdgcn_fdot2(pr, ones, t1[nb][j], false);
+                        t2[nb][j] = __builtin_amdgcn_fdot2(pr, pr, t2[nb][j], false);
+                    }
+            }
+        }
+        if (p.stats_out) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = row16_sum(t1[nb][j]), b = row16_sum(t2[nb][j]);
+                    if (r == 0) {
+                        const int c = q * 8 + nb * 4 + j;              // the interleaved cout order (conv3d_pack_cout)
+                        sRed[(wave * 32 + c) * 2] = a;
+                        sRed[(wave * 32 + c) * 2 + 1] = b;
+                    }
+                }
+        }
+        __syncthreads();                                      // every wave is done reading the image; sRed complete
+        if (p.stats_out && tid < 64) {
+            const int c = tid >> 1, which = tid & 1;
+            double v = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += (double)sRed[(w * 32 + c) * 2 + which];
+            p.stats_out[(((size_t)n_cur * p.stats_slots + slot) * p.Cout + cb0 * 16 + c) * 2 + which] = v;
+        }
+        commit();
+        __syncthreads();
+        n_cur = n_nx; od0 = d_nx; oh0 = h_nx; ow0 = w_nx; slot = s_nx;
+    }
+#undef ZSP_REL
+}
+
 static int launch_zs(ConvParams p, hipStream_t st) {
     p.tile_d = 8;
     p.tiles_d = (p.Do + 7) / 8;
@@ -571,7 +808,22 @@ static int launch_zs(ConvParams p, hipStream_t st) {
     }
     p.ident_ss = conv3d_identity_ss();
     if (!p.ident_ss) return -2;
-    dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / 2);
+    const int total = p.N * p.tiles_d * p.tiles_h * p.tiles_w, groups = (p.Cout / 16) / 2;
+    static const bool no_zsp = fnn_knob("FNN_NO_ZSP") != nullptr;                  // A-B aid
+    if (!no_zsp && p.chunks == 1 && p.n_src == 1 && total >= 512 * 8) {
+        // single-chunk layers: the persistent form (two workgroups per CU over all cout groups)
+        const size_t ldsp = lds - (size_t)2 * 64 + 4 * 32 * 2 * 4;
+        static bool attr_p = false;
+        if (!attr_p) {
+            (void)hipFuncSetAttribute((const void *)conv3d_zsp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_p = true;
+        }
+        int gx = 512 / groups;
+        if (gx < 8) gx = 8;
+        hipLaunchKernelGGL(conv3d_zsp_kernel, dim3(gx, groups), dim3(256), ldsp, st, p, total);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+    dim3 grid(total, groups);
     hipLaunchKernelGGL((conv3d_zs_kernel<2>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
