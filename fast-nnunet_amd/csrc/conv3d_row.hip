@@ -37,13 +37,13 @@ struct RowCur { int n, d, h0, g; };
 // v_permlane16_swap exchanges the odd 16-lane rows of block b with the even rows of block b + 1, after which lane
 // (r, q) holds channels 8 (q >> 1) .. + 7 of voxel r of block b + (q & 1) - half the store instructions of the
 // 8-byte form.  (Measured neutral on the benchmark: these kernels are not bound by store issue.)
-typedef unsigned fnn_u32x4r __attribute__((ext_vector_type(4)));
+typedef int fnn_u32x4r __attribute__((ext_vector_type(4)));
 static __device__ __forceinline__ fnn_u32x4r pair_to_b128(const f16x4 &a, const f16x4 &b) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
     const auto lo = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
     const auto hi = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-    return (fnn_u32x4r){lo[0], hi[0], lo[1], hi[1]};
+    return (fnn_u32x4r){(int)lo[0], (int)hi[0], (int)lo[1], (int)hi[1]};
 }
                                       // (batch item, plane, strip start, row group)
 
@@ -440,7 +440,13 @@ __global__ __launch_bounds__(256, 4) void stem_row_kernel(const StemParams p, co
     const unsigned out_lane = (unsigned)((r + 16 * (q & 1)) * 32 + (q >> 1) * 16);     // after pair_to_b128
     const f16x2 ones = {(f16)1.f, (f16)1.f};
     float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};   // per-lane sums of the unit (<= 16 rows x NBLK values: fp32)
-    auto step = [&](const RowCur &c, int slot) {
+    // Branch-free: a tail group (no output rows) runs the step too, with its stores sent beyond the buffer's num_records,
+    // which the hardware drops (p.out == nullptr, the statistics-only pass: num_records 0).  With `if (has rows) step()`
+    // the number of stores in flight is unknown to hipcc's waitcnt pass and commit(), whose loads are OLDER than the
+    // step's stores, waits for vmcnt(0) - the store acknowledgements - once per step: -5 % on this kernel.  (The conv
+    // kernels above lose more to the tail group's wasted k-loop than they gain: measured, left as they are.)
+    const unsigned item_bytes = (unsigned)D * H * W * 32;
+    auto step = [&](const RowCur &c, int slot, bool valid) {
         const int slot1 = slot == 2 ? 0 : slot + 1;
         int ro[3];
 #pragma unroll
@@ -450,7 +456,9 @@ __global__ __launch_bounds__(256, 4) void stem_row_kernel(const StemParams p, co
         }
         const int va = r * 8 + (q == 1 ? ro[2] : ro[0]), vb = r * 8 + (q == 1 ? ro[2] : ro[1]);
         const int orow = c.h0 + 4 * c.g + wave;
-        char *obase = (char *)(p.out + (((size_t)c.n * D + c.d) * H + orow) * (W * 16));
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out ? p.out + (size_t)c.n * (item_bytes >> 1) : p.out, 0,
+                                                                               p.out ? item_bytes : 0u, 0x00020000);
+        const unsigned vbase = valid ? out_lane + (unsigned)((c.d * H + orow) * (W * 32)) : 0x80000000u;
 #pragma unroll
         for (int b = 0; b < NBLK; b += 2) {
             f16x4 o[2];
@@ -461,15 +469,14 @@ __global__ __launch_bounds__(256, 4) void stem_row_kernel(const StemParams p, co
                 const f32x4 dd = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xb, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 o[h][0] = (f16)(dd[0] + bv.x); o[h][1] = (f16)(dd[1] + bv.y); o[h][2] = (f16)(dd[2] + bv.z); o[h][3] = (f16)(dd[3] + bv.w);
             }
-            {
-                const fnn_u32x4r v = pair_to_b128(o[0], o[1]);          // (outside the branch: every lane takes part in the swap)
-                if (p.out) *(fnn_u32x4r *)(obase + out_lane + b * 512) = v;
-            }
+            __builtin_amdgcn_raw_buffer_store_b128(pair_to_b128(o[0], o[1]), rsrc, vbase + b * 512, 0, 0);
+            if (valid) {                                                 // uniform; no memory operation inside
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f16x2 pr = {o[0][j], o[1][j]};
-                t1[j] = __builtin_amdgcn_fdot2(pr, ones, t1[j], false);
-                t2[j] = __builtin_amdgcn_fdot2(pr, pr, t2[j], false);
+                for (int j = 0; j < 4; ++j) {
+                    const f16x2 pr = {o[0][j], o[1][j]};
+                    t1[j] = __builtin_amdgcn_fdot2(pr, ones, t1[j], false);
+                    t2[j] = __builtin_amdgcn_fdot2(pr, pr, t2[j], false);
+                }
             }
         }
     };
@@ -515,7 +522,7 @@ __global__ __launch_bounds__(256, 4) void stem_row_kernel(const StemParams p, co
     __syncthreads();
     int slot = 0;
     for (int gi = 0; gi < n_groups; ++gi) {
-        if (cc.g < G) step(cc, slot);
+        step(cc, slot, cc.g < G);
         commit(cw, slot == 0 ? 2 : slot - 1);
         if (gl < n_groups - 1) { advance(ci); ++gl; }
         if (gw < n_groups - 1) { advance(cw); ++gw; }
@@ -600,7 +607,7 @@ bool stem_row_ok(const StemParams &p) {
     const bool off = fnn_knob("FNN_NO_ROW") != nullptr || fnn_knob("FNN_NO_STEM_ROW") != nullptr;            // A-B aids
     if (off || p.C != 1 || p.kd != 1 || p.kh != 3 || p.kw != 3 || p.Cout != 16) return false;
     if ((p.PW != 64 && p.PW != 96 && p.PW != 128) || p.PH % 4 != 0 || p.PH < 8) return false;
-    if (2ull * p.PD * p.PH * p.PW * 16 >= (1ull << 32)) return false;
+    if (2ull * p.PD * p.PH * p.PW * 16 >= (1ull << 31)) return false;
     int SH;
     const int strips = pick_strips(p.PH, SH);
     return p.PD * strips <= stem_mfma_stats_slots(p.PD, p.PH, p.PW);     // one statistics row per (plane, strip)
