@@ -12,7 +12,7 @@ import csv
 import json
 import sys
 
-FAMILIES = {'conv3d_': 'conv3d_mfma', 'conv_thin': 'conv3d_mfma', 'stem_mfma': 'stem', 'gather_head': 'seg_head_accumulate', 'tconv_mfma': 'tconv', 'seg_head': 'seg_head_accumulate',
+FAMILIES = {'conv3d_': 'conv3d_mfma', 'conv_thin': 'conv3d_mfma', 'conv_row': 'conv3d_mfma', 'stem_mfma': 'stem', 'stem_row': 'stem', 'gather_head': 'seg_head_accumulate', 'tconv_mfma': 'tconv', 'seg_head': 'seg_head_accumulate',
             'finalize': 'finalize', 'stats_finalize': 'stats_finalize'}
 
 
