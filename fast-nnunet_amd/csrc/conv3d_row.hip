@@ -212,9 +212,7 @@ __global__ __launch_bounds__(256, CH == 1 ? 3 : 2) void conv_row_kernel(const Th
                     const int lr = bb / (NBLK / 2), bl = bb - lr * (NBLK / 2);
                     const int lrow = lbase + lr;
                     const bool ok = lrow >= 0 && lrow < Hl;
-                    f16x8 o;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) o[k] = (f16)fmaf((float)xl[t][k], lsc[k], lsh[k]);
+                    f16x8 o = fnn_norm8(xl[t], lsc, lsh);                // load_act_frag's arithmetic (misc.hip)
                     o = __builtin_elementwise_max(o, o * lslope);
                     char *dst = smem + (slot * 4 + 2 * lr) * PB + bl * 1024;
 #pragma unroll

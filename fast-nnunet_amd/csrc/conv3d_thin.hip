@@ -499,9 +499,7 @@ __global__ __launch_bounds__(256, WPS) void conv_thin_kernel(const ThinParams tp
         const float sh[8] = {shr[0].x, shr[0].y, shr[0].z, shr[0].w, shr[1].x, shr[1].y, shr[1].z, shr[1].w};
 #pragma unroll
         for (int j = 0; j < NLBW; ++j) {                                 // no branch per block (see stem_to_image)
-            f16x8 o;                                                     // load_act_frag's arithmetic (misc.hip)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = (f16)fmaf((float)xr[j][k], sc[k], sh[k]);
+            f16x8 o = fnn_norm8(xr[j], sc, sh);                          // load_act_frag's arithmetic (misc.hip)
             o = __builtin_elementwise_max(o, o * slope_h);
             if (!(l_ok[j] & 1)) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll

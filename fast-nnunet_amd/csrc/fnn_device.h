@@ -223,6 +223,24 @@ const char *fnn_knob(const char *name);
 
 static __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
 
+// x * scale + shift of a fragment of 8 channels, the engine's normalise-on-load: scale and shift rounded to fp16, one
+// v_pk_fma_f16 per channel pair (make NORM_FP32=1: fp32 fma, then one rounding).  Every kernel that stages or consumes a
+// raw conv output goes through this form, so that paths that must agree bit for bit (fused / unfused transposed conv,
+// gather / accumulate seg head) do.
+static __device__ __forceinline__ f16x8 fnn_norm8(const f16x8 &x, const float (&sc)[8], const float (&sh)[8]) {
+#ifdef FNN_NORM_FP32
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)x[j], sc[j], sh[j]);
+    return o;
+#else
+    f16x8 sc_h, sh_h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc_h[j] = (f16)sc[j]; sh_h[j] = (f16)sh[j]; }
+    return x * sc_h + sh_h;
+#endif
+}
+
 // Residual-encoder blocks (BasicBlockD): skip-path average pooling and the block's closing
 //   y = LeakyReLU( norm2(conv2) + skip )
 struct PoolParams {

@@ -156,9 +156,7 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? 4 : 1) void gather_head_
                         // a patch that starts or ends inside the run leaves whole 16-voxel groups untouched: skip them
                         // (wave-uniform; 3.5 patches intersect a 64-voxel run along z, 2 cover each voxel)
                         if (__builtin_amdgcn_ballot_w64(in[g]) == 0) continue;
-                        f16x8 o;                               // norm_act_frag's arithmetic (misc.hip)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)xraw[g][j], sc[j], sh[j]);
+                        f16x8 o = fnn_norm8(xraw[g], sc, sh);  // norm_act_frag's arithmetic (misc.hip)
                         o = __builtin_elementwise_max(o, o * slope_h);
                         if (!live) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
                         const float gw = (float)graw[g];
@@ -170,10 +168,10 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? 4 : 1) void gather_head_
                         // arithmetic.
 #pragma unroll
                         for (int hb = 0; hb < HB; ++hb) {
-                            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[hb], o, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[hb], o, bv[hb], 0, 0, 0);   // logit: the bias is the C operand, as in the seg-head kernels
                             if (ACH) {
-                                const f16x2 t01 = round_h2(d[0] + bv[hb][0], d[1] + bv[hb][1]);      // the network's fp16 output
-                                const f16x2 t23 = round_h2(d[2] + bv[hb][2], d[3] + bv[hb][3]);
+                                const f16x2 t01 = round_h2(d[0], d[1]);      // the network's fp16 output
+                                const f16x2 t23 = round_h2(d[2], d[3]);
                                 if (TTA) {
                                     f16x2 (&ts)[2] = tsh[TTA && ACH ? g : 0][hb];
                                     ts[0] = f == 0 ? t01 : add_h2(ts[0], t01);
@@ -187,20 +185,20 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? 4 : 1) void gather_head_
                                 }
                             } else if (TTA) {
                                 // predict_from_raw_data.py:541-557: net(x) + sum over the mirror subsets, in their order (fp32)
-                                const f32x4 t = d + bv[hb];
+                                const f32x4 t = d;
                                 tsum[TTA ? g : 0][hb] = f == 0 ? t : tsum[TTA ? g : 0][hb] + t;
                             } else if (PKS) {
 #pragma unroll
                                 for (int e = 0; e < 2; ++e) {
                                     f16x2 &a2 = ah[PKS ? g : 0][hb][e];
-                                    const f16x2 nv = round_h2(acc_add_product_1((float)a2[0], d[2 * e] + bv[hb][2 * e], gw),
-                                                              acc_add_product_1((float)a2[1], d[2 * e + 1] + bv[hb][2 * e + 1], gw));
+                                    const f16x2 nv = round_h2(acc_add_product_1((float)a2[0], d[2 * e], gw),
+                                                              acc_add_product_1((float)a2[1], d[2 * e + 1], gw));
                                     a2 = in[g] ? nv : a2;
                                 }
                             } else {
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
-                                    const float sv = acc_add_product_1(acc[g][hb][j], d[j] + bv[hb][j], gw);
+                                    const float sv = acc_add_product_1(acc[g][hb][j], d[j], gw);
                                     acc[g][hb][j] = in[g] ? sv : acc[g][hb][j];
                                 }
                             }

@@ -87,12 +87,10 @@ int launch_stats_finalize(const StatsFinalizeParams &p, int N, hipStream_t st) {
 static __device__ __forceinline__ f16x8 norm_act_frag(const SrcDesc &s, const f16x8 &x, int c0, const float2 *sSS) {
     const bool live = c0 < s.C;
     const int cc = live ? c0 : 0;
-    f16x8 o;
+    float sc[8], sh[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float2 ss = sSS[cc + j];
-        o[j] = (f16)fmaf((float)x[j], ss.x, ss.y);
-    }
+    for (int j = 0; j < 8; ++j) { const float2 ss = sSS[cc + j]; sc[j] = ss.x; sh[j] = ss.y; }
+    f16x8 o = fnn_norm8(x, sc, sh);
     o = __builtin_elementwise_max(o, o * (f16)s.slope);
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = live ? o[j] : (f16)0.f;
@@ -108,12 +106,10 @@ static __device__ __forceinline__ f16x8 load_act_frag(const SrcDesc &s, size_t v
     const bool live = vox_ok && c0 < s.C;
     const int cc = c0 < s.C ? c0 : 0;
     const f16x8 x = *(const f16x8 *)(s.ptr + (vox_ok ? vox : 0) * s.C + cc);
-    f16x8 o;
+    float sc[8], sh[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float2 ss = sSS[cc + j];
-        o[j] = (f16)fmaf((float)x[j], ss.x, ss.y);
-    }
+    for (int j = 0; j < 8; ++j) { const float2 ss = sSS[cc + j]; sc[j] = ss.x; sh[j] = ss.y; }
+    f16x8 o = fnn_norm8(x, sc, sh);
     o = __builtin_elementwise_max(o, o * (f16)s.slope);
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = live ? o[j] : (f16)0.f;
@@ -369,11 +365,15 @@ __global__ __launch_bounds__(256) void seg_head_kernel(const HeadParams p) {
 
     for (int hb0 = 0; hb0 < p.hblocks; hb0 += 4) {
         const int nhb = min(4, p.hblocks - hb0);
+        // the accumulators start from the bias (the MFMA's C operand: no add behind it) - in every seg-head kernel and
+        // in gather_head_kernel alike, whose logits must agree bit for bit
         f32x4 acc[4][4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 b4 = a < nhb ? *(const f32x4 *)(p.bias + (hb0 + a) * 16 + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < 4; ++b) acc[a][b] = b4;
+        }
         for (int ks = 0; ks < p.ksteps; ++ks) {
             f16x8 xf[4];
 #pragma unroll
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void seg_head_kernel(const HeadParams p) {
             const int nh = min(64, p.heads - hb0 * 16);
             for (int hl = 0; hl < nh; ++hl) {
                 const int head = hb0 * 16 + hl;
-                const float val = sT[hl * 65 + lane] + p.bias[head];
+                const float val = sT[hl * 65 + lane];
                 float *pb = p.patch_buf + (size_t)head * P + pv;
                 *pb = (p.mode == 1) ? val : (*pb + val);
             }
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void seg_head_acc_kernel(const HeadParams p) {
 #pragma unroll
             for (int hb = 0; hb < 4; ++hb)
 #pragma unroll
-                for (int vb = 0; vb < 2; ++vb) acc[hb][vb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int vb = 0; vb < 2; ++vb) acc[hb][vb] = bv[hb];    // bias = the MFMA's C operand (as in every head kernel)
             for (int ks = 0; ks < p.ksteps; ++ks) {
                 f16x8 xf[2], wf[4];
 #pragma unroll
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void seg_head_acc_kernel(const HeadParams p) {
             for (int hb = 0; hb < 4; ++hb)
 #pragma unroll
                 for (int vb = 0; vb < 2; ++vb) {
-                    const f32x4 t = hb_first + hb < p.hblocks ? acc[hb][vb] + bv[hb] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const f32x4 t = hb_first + hb < p.hblocks ? acc[hb][vb] : (f32x4){0.f, 0.f, 0.f, 0.f};
                     *(f32x4 *)(sT + (vb * 16 + r) * HEAD_LD + hb * 16 + q * 4) = t;
                 }
             __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -634,13 +634,13 @@ __global__ __launch_bounds__(256, MINB) void seg_head_acc1_kernel(const HeadPara
                 const f16x8 xf = norm_act_frag(p.src, xraw[rd][vb], q * 8, sSS);
 #pragma unroll
                 for (int hb = 0; hb < 4; ++hb)
-                    acc[hb][vb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[hb], xf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    acc[hb][vb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[hb], xf, bv[hb], 0, 0, 0);       // bias = C operand
             }
 #pragma unroll
             for (int hb = 0; hb < 4; ++hb)
 #pragma unroll
                 for (int vb = 0; vb < 2; ++vb) {
-                    const f32x4 t = hb_first + hb < p.hblocks ? acc[hb][vb] + bv[hb] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const f32x4 t = hb_first + hb < p.hblocks ? acc[hb][vb] : (f32x4){0.f, 0.f, 0.f, 0.f};
                     *(f32x4 *)(sT + (vb * 16 + r) * HEAD_LD + hb * 16 + q * 4) = t;
                 }
             __builtin_amdgcn_s_waitcnt(0xC07F);
