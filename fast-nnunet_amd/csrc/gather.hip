@@ -63,6 +63,10 @@ struct Pick {                                                  // LabelPick of m
 // below) took 18 % off: 23.5 -> 19.3 ms per 512^3 x 61 volume.  ACCM = 0 holds 162 registers (fp32-valued sums): forced
 // to 128 it spills and takes 53 ms; with 32-voxel runs per wave (half the accumulators, 4 waves per SIMD without
 // scratch) it takes 26-27 ms - the per-wave set-up doubles - so it keeps 64-voxel runs and three waves per SIMD.
+// Also measured and dropped: the loads of visit v + 1 issued before the arithmetic of visit v (a second set of
+// feature / weight / scale registers: 168 registers, three waves per SIMD): 20.2 -> 24.1 ms - the fourth wave hides more
+// than the prefetch does; packed-fp16 normalisation and the head bias as the MFMA's C operand (-25 % VALU work per
+// visit) changed nothing: neither instruction issue nor a single wave's round trips bound it, the number of waves does.
 template <int HB, int ACCM, bool LABELS, bool TTA>
 __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? 4 : 1) void gather_head_kernel(const GatherParams p) {
     constexpr int G = 4, ZW = 16 * G, TP = ZW + 8;             // 16-voxel groups and z voxels per wave; row pitch of the LDS transpose
