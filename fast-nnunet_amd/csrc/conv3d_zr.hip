@@ -1095,6 +1095,15 @@ static int launch_zr(ConvParams p, hipStream_t st) {
 // end to end than two independent workgroups per CU - a chunk's staging (load issue + normalise + LDS writes) takes
 // longer than its k-loop, so the forced alternation idles the matrix cores where independent workgroups drift;
 // (2) s_setprio(1) around the MFMA clusters: -0.6 %.
+// Round 2, second session, the persistent form once more with what conv3d_zsp_kernel had taught (no hoisted tables: LDS
+// offsets packed two per register and decoded per tile, weight addresses rebuilt per chunk; last chunk peeled so that its
+// stores are unconditional; tiles of an XCD interleaved; first chunk of the next tile requested before the last k-loop;
+// a plane-outer k-loop with 32 live operand registers; 255 VGPRs, one 8-byte scratch reload per tile; bit-identical):
+// 32 -> 32 733 -> 783 us, 64 -> 64 348 -> 416, 128 -> 64 647 -> 757, 64 -> 32 1270 -> 1447 - 7-14 % SLOWER per layer, most
+// on the layers with the most chunks, where the walk saves the least: what it loses is in the chunk loop itself.  With
+// one tile per workgroup the dispatcher starts a workgroup whenever one ends, and the two workgroups of a CU drift into
+// complementary phases; two walkers that start together stay together.  The single-chunk strided layer is the
+// exception (conv3d_zsp_kernel, +25 %): there the serial chain IS the tile.
 // Runs the layer on the ZR kernel; the weights must have been packed as FNN_PACK_ZR (p.packing).
 int launch_conv3d_zr(const ConvParams &p, hipStream_t st) {
     int nb, td;
