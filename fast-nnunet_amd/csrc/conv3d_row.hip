@@ -33,20 +33,6 @@ namespace {
 
 struct RowCur { int n, d, h0, g; };
 
-// Two column blocks' results (lane = voxel r, channels 4 q .. 4 q + 3 of each) -> one 16-byte store per lane:
-// v_permlane16_swap exchanges the odd 16-lane rows of block b with the even rows of block b + 1, after which lane
-// (r, q) holds channels 8 (q >> 1) .. + 7 of voxel r of block b + (q & 1) - half the store instructions of the
-// 8-byte form.  (Measured neutral on the benchmark: these kernels are not bound by store issue.)
-typedef int fnn_u32x4r __attribute__((ext_vector_type(4)));
-static __device__ __forceinline__ fnn_u32x4r pair_to_b128(const f16x4 &a, const f16x4 &b) {
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
-    const auto lo = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-    return (fnn_u32x4r){(int)lo[0], (int)hi[0], (int)lo[1], (int)hi[1]};
-}
-                                      // (batch item, plane, strip start, row group)
-
 template <int NBLK, int CH, bool TCONV>
 __global__ __launch_bounds__(256, CH == 1 ? 3 : 2) void conv_row_kernel(const ThinParams tp, const int total_units,
                                                                          const int strips, const int SH) {

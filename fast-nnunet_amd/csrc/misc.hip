@@ -272,14 +272,20 @@ __global__ __launch_bounds__(256, 2) void tconv_mfma_kernel(const TconvParams p)
 #pragma unroll
         for (int tg = 0; tg < TG; ++tg) {
             const unsigned ov = ob + toff[tg];
+            f16x4 o[NBT];
 #pragma unroll
             for (int nb = 0; nb < NBT; ++nb) {
-                f16x4 o;
-                o[0] = (f16)(acc[mb][tg][nb][0] + bv[nb].x);
-                o[1] = (f16)(acc[mb][tg][nb][1] + bv[nb].y);
-                o[2] = (f16)(acc[mb][tg][nb][2] + bv[nb].z);
-                o[3] = (f16)(acc[mb][tg][nb][3] + bv[nb].w);
-                *(f16x4 *)(outn + ov + nb * 16) = o;
+                o[nb][0] = (f16)(acc[mb][tg][nb][0] + bv[nb].x);
+                o[nb][1] = (f16)(acc[mb][tg][nb][1] + bv[nb].y);
+                o[nb][2] = (f16)(acc[mb][tg][nb][2] + bv[nb].z);
+                o[nb][3] = (f16)(acc[mb][tg][nb][3] + bv[nb].w);
+            }
+            if constexpr (NBT == 2) {
+                // the two cout blocks of a voxel as ONE 16-byte store per lane (pair_to_b128: lane (r, q) then holds channels
+                // 8 (q >> 1) .. + 7 of block q & 1): 64 contiguous bytes per voxel and instruction instead of 2 x 32
+                *(fnn_u32x4r *)(p.out + (size_t)n * p.Di * p.sd * Ho * Wo * p.Cout + cb0 * 16 + ov + (q & 1) * 16 + (q >> 1) * 8) = pair_to_b128(o[0], o[1]);
+            } else {
+                *(f16x4 *)(outn + ov) = o[0];
             }
         }
     }
