@@ -201,15 +201,16 @@ int launch_combine(const CombineParams &p, hipStream_t st) {
 // the activation fragments are loaded (and normalised) once and reused for every tap of the group.
 // grid.x = N * ceil(vox / 256), grid.y = (taps / TG) * (nblk / NBT).
 // ----------------------------------------------------------------------------
-template <int NBT, int TG>
+template <int NBT, int TG, int MB = 4>                                  // MB: column blocks (16 input voxels each) per wave
 __global__ __launch_bounds__(256, 2) void tconv_mfma_kernel(const TconvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *sSS = (float2 *)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int vox_in = p.Di * p.Hi * p.Wi;
-    const int wg_per_n = (vox_in + 255) / 256;
+    constexpr int WGV = 64 * MB;                                          // input voxels per workgroup
+    const int wg_per_n = (vox_in + WGV - 1) / WGV;
     const int n = blockIdx.x / wg_per_n;
-    const int v0 = (blockIdx.x - n * wg_per_n) * 256 + wave * 64;
+    const int v0 = (blockIdx.x - n * wg_per_n) * WGV + wave * (16 * MB);
     const int groups = p.nblk / NBT;
     const int tap0 = (blockIdx.y / groups) * TG;
     const int cb0 = (blockIdx.y - (blockIdx.y / groups) * groups) * NBT;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void tconv_mfma_kernel(const TconvParams p)
     __syncthreads();
     if (v0 >= vox_in) return;
 
-    f32x4 acc[4][TG][NBT];
+    f32x4 acc[MB][TG][NBT];
     const int r = lane & 15, q = lane >> 4;
     // the first k-step starts from the zero constant (no accumulator initialisation), the rest accumulate
     auto kstep = [&](int ks, auto first_c) {
@@ -229,9 +230,9 @@ __global__ __launch_bounds__(256, 2) void tconv_mfma_kernel(const TconvParams p)
 #pragma unroll
             for (int nb = 0; nb < NBT; ++nb)
                 wf[tg][nb] = *(const f16x8 *)(p.wpk + ((((size_t)(tap0 + tg) * p.nblk + cb0 + nb) * p.ksteps + ks) * 64 + lane) * 8);
-        f16x8 xf[4];
+        f16x8 xf[MB];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
+        for (int mb = 0; mb < MB; ++mb) {
             const int v = v0 + mb * 16 + r;
             xf[mb] = load_act_frag(p.src, (size_t)n * vox_in + (v < vox_in ? v : vox_in - 1), true, ks * 32 + q * 8, sSS);
         }
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void tconv_mfma_kernel(const TconvParams p)
 #pragma unroll
             for (int nb = 0; nb < NBT; ++nb)
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
+                for (int mb = 0; mb < MB; ++mb)
                     acc[mb][tg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tg][nb], xf[mb],
                                           FIRST ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mb][tg][nb], 0, 0, 0);
     };
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void tconv_mfma_kernel(const TconvParams p)
     }
     const float rcp_wi = 1.0f / (float)p.Wi, rcp_hi = 1.0f / (float)p.Hi;
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
+    for (int mb = 0; mb < MB; ++mb) {
         const int v = v0 + mb * 16 + r;
         if (v >= vox_in) continue;
         const int row = recip_div(v, p.Wi, rcp_wi), iw = v - (int)__umul24(row, p.Wi);
@@ -300,9 +301,11 @@ int launch_tconv(const TconvParams &p, hipStream_t st) {
     const int nbt = (p.nblk % 2 == 0) ? 2 : 1;
     // two cout blocks x 4 taps held 128 accumulator registers (276 VGPRs: one wave per SIMD); two taps: 152, three waves
     // per SIMD, the activations are read once more - 6 % less tconv time on the benchmark net
-    static const int tg_max2 = fnn_knob("FNN_TCONV_TG") ? atoi(fnn_knob("FNN_TCONV_TG")) : 2;       // A-B aid
+    // (round 2, late: with the 16-byte stores four taps per wave win - 9.3 -> 7.9 ms per volume; eight taps on two column
+    // blocks per wave - every activation read once - measured the same as four: not kept)
+    static const int tg_max2 = fnn_knob("FNN_TCONV_TG") ? atoi(fnn_knob("FNN_TCONV_TG")) : 4;       // A-B aid
     const int tg_cap = nbt == 2 ? tg_max2 : 4;
-    const int tg = taps >= tg_cap ? tg_cap : taps;     // taps is 1, 2, 4 or 8
+    const int tg = taps >= tg_cap ? (tg_cap > 4 ? 4 : tg_cap) : taps;     // taps is 1, 2, 4 or 8
     dim3 grid(p.N * ((vox_in + 255) / 256), (taps / tg) * (p.nblk / nbt));
 #define FNN_TCONV(NBTv, TGv) hipLaunchKernelGGL((tconv_mfma_kernel<NBTv, TGv>), grid, dim3(256), lds, st, p)
     if (nbt == 2) { if (tg == 4) FNN_TCONV(2, 4); else if (tg == 2) FNN_TCONV(2, 2); else FNN_TCONV(2, 1); }
