@@ -52,9 +52,10 @@ static bool zr_pick(const ConvParams &p, int &nb, int &td) {
     const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;
     const long long th = (p.Ho + 7) / 8, tw = (p.Wo + 7) / 8;
     static const int td_max = fnn_knob("FNN_ZR_TD") ? atoi(fnn_knob("FNN_ZR_TD")) : 8;       // A-B aid
+    static const int min_wgs = fnn_knob("FNN_ZR_MIN_WGS") ? atoi(fnn_knob("FNN_ZR_MIN_WGS")) : 480;   // one round of 512 slots at TD = 8 beats two of 768 at TD = 4 (stage 4: 70 -> 64 us)
     for (td = td_max; td >= 4; td -= 4) {
         if (p.Do < td) continue;
-        if ((long long)plan_n * ((p.Do + td - 1) / td) * th * tw * (nblk / nb) >= 768) return true;
+        if ((long long)plan_n * ((p.Do + td - 1) / td) * th * tw * (nblk / nb) >= min_wgs) return true;
     }
     return false;
 }
