@@ -314,3 +314,25 @@ def test_conv3d_stride2_grouped_kernel(cin, cout):
     xn = _h(F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01))
     ref = F.conv3d(xn, w, b, stride, 1)
     assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_conv3d_persistent_depth_shift_kernel_with_two_cout_groups():
+    """conv3d_zsp_kernel (single 16-channel chunk, stride (1, 2, 2), >= 4096 tiles) with 64 output channels: two cout
+    groups walk the same tiles (grid.y = 2); ragged tiles, fused InstanceNorm + LeakyReLU on load, statistics rows."""
+    from fast_nnunet_amd import capi
+    g = torch.Generator().manual_seed(77)
+    n, cin, cout, dims, stride = 8, 16, 64, (61, 93, 90), (1, 2, 2)
+    x = _h(torch.randn(n, cin, *dims, generator=g) * 2 + 0.5)
+    gamma = torch.rand(cin, generator=g) + 0.5
+    beta = torch.randn(cin, generator=g) * 0.1
+    w = _h(torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    y, stats = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), stride, want_stats=True)
+    _check(y, F.conv3d(x, w, b, stride, 1), 'conv3d zsp two groups')
+    y64 = y.astype(np.float64)
+    assert np.allclose(stats[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    assert np.allclose(stats[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    y = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), stride, gamma=gamma.numpy(), beta=beta.numpy(), slope=0.01)
+    xn = _h(F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01))
+    ref = F.conv3d(xn, w, b, stride, 1)
+    assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
