@@ -811,7 +811,8 @@ static int launch_zs(ConvParams p, hipStream_t st) {
     if (!p.ident_ss) return -2;
     const int total = p.N * p.tiles_d * p.tiles_h * p.tiles_w, groups = (p.Cout / 16) / 2;
     static const bool no_zsp = fnn_knob("FNN_NO_ZSP") != nullptr;                  // A-B aid
-    if (!no_zsp && p.chunks == 1 && p.n_src == 1 && total >= 512 * 8) {
+    const int plan_total = (p.plan_N > 0 ? p.plan_N : p.N) * p.tiles_d * p.tiles_h * p.tiles_w;   // the variant is a property of the layer, not of the batch
+    if (!no_zsp && p.chunks == 1 && p.n_src == 1 && plan_total >= 512 * 8) {
         // single-chunk layers: the persistent form (two workgroups per CU over all cout groups)
         const size_t ldsp = lds - (size_t)2 * 64 + 4 * 32 * 2 * 4;
         static bool attr_p = false;
