@@ -4,7 +4,8 @@
 // chunk against 1 KB of HBM traffic - these layers are bound by HBM only if everything AROUND the MFMAs is cheap.  The
 // tile kernels (conv3d_persist_kernel, conv_thin_kernel) spend 500 - 1000 instructions per wave and 256-voxel tile
 // on halo coordinates, bounds, per-element LDS addresses, store addresses and barriers: they are bound by VALU issue at
-// 2.4 - 4 TB/s.  Here a workgroup walks DOWN a strip of one depth plane, full rows of W = 16 NBLK voxels at a time:
+// 2.4 - 4 TB/s.  Here a workgroup walks DOWN a strip of one depth plane, full rows of W = 16 NBLK voxels at a time
+// (W = 64 ... 192; beyond 128 the k-loop takes a row's column blocks in two halves and one workgroup fills a CU):
 //   * no halo along w (the row is complete; two zero columns in LDS are the conv's padding), none along h inside a
 //     strip (a ring of 12 LDS rows, each row staged exactly once), none along d (kd = 1);
 //   * a group of 4 input rows is ONE contiguous run of 8 W x 16 B in HBM: the loads of a thread are base + constant,
@@ -34,7 +35,7 @@ namespace {
 struct RowCur { int n, d, h0, g; };
 
 template <int NBLK, int CH, bool TCONV>
-__global__ __launch_bounds__(256, CH == 1 ? 3 : 2) void conv_row_kernel(const ThinParams tp, const int total_units,
+__global__ __launch_bounds__(256, CH == 1 ? (NBLK <= 8 ? 3 : 2) : (NBLK <= 8 ? 2 : 1)) void conv_row_kernel(const ThinParams tp, const int total_units,
                                                                          const int strips, const int SH) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvParams &p = tp.c;
@@ -262,11 +263,15 @@ __global__ __launch_bounds__(256, CH == 1 ? 3 : 2) void conv_row_kernel(const Th
             for (int ks = 0; ks < 5; ++ks) {
                 // taps (2 ks, 2 ks + 1): rows 0 0, 0 1, 1 1, 2 2, 2 (2): only k-step 1 mixes rows
                 const int vo = lanec[ks] + (ks == 1 ? (hl ? ro[1] : ro[0]) : ro[ks == 0 ? 0 : ks == 2 ? 1 : 2]);
-                f16x8 xf[NBLK];
+                constexpr int BG = NBLK <= 8 ? NBLK : NBLK / 2;          // wide rows: two halves (operand registers)
 #pragma unroll
-                for (int b = 0; b < NBLK; ++b) xf[b] = *(const f16x8 *)(ring + vo + b * 512);
+                for (int b0 = 0; b0 < NBLK; b0 += BG) {
+                    f16x8 xf[BG];
 #pragma unroll
-                for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ch][ks], xf[b], acc[b], 0, 0, 0);
+                    for (int b = 0; b < BG; ++b) xf[b] = *(const f16x8 *)(ring + vo + (b0 + b) * 512);
+#pragma unroll
+                    for (int b = 0; b < BG; ++b) acc[b0 + b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ch][ks], xf[b], acc[b0 + b], 0, 0, 0);
+                }
             }
         }
         // epilogue: bias, fp16, one 8-byte store per lane and block (512 contiguous bytes per wave instruction), statistics
@@ -541,7 +546,7 @@ int launch_row_t(ThinParams tp, hipStream_t st) {
         attr_set = true;
     }
     int per_cu = (int)((160 * 1024) / lds);
-    const int cap = CH == 1 ? 3 : 2;
+    const int cap = CH == 1 ? (NBLK <= 8 ? 3 : 2) : (NBLK <= 8 ? 2 : 1);
     if (per_cu > cap) per_cu = cap;
     int gx = 256 * per_cu;
     if (gx > total) gx = total;
@@ -555,6 +560,8 @@ int launch_row_n(const ThinParams &tp, hipStream_t st) {
         case 64: return launch_row_t<4, CH, TCONV>(tp, st);
         case 96: return launch_row_t<6, CH, TCONV>(tp, st);
         case 128: return launch_row_t<8, CH, TCONV>(tp, st);
+        case 160: return launch_row_t<10, CH, TCONV>(tp, st);
+        case 192: return launch_row_t<12, CH, TCONV>(tp, st);
     }
     return -1;
 }
@@ -567,7 +574,7 @@ bool conv_row_ok(const ThinParams &tp) {
     const ConvParams &p = tp.c;
     if (off || p.Cout != 16 || p.kd != 1 || p.kh != 3 || p.kw != 3 || p.sd != 1 || p.sh != 1 || p.sw != 1 || p.fp8) return false;
     if (p.Di != p.Do || p.Hi != p.Ho || p.Wi != p.Wo || p.packing != FNN_PACK_LINEAR || p.ksteps != 5) return false;
-    if ((p.Wi != 64 && p.Wi != 96 && p.Wi != 128) || p.Hi % 4 != 0 || p.Hi < 8) return false;
+    if ((p.Wi != 64 && p.Wi != 96 && p.Wi != 128 && p.Wi != 160 && p.Wi != 192) || p.Hi % 4 != 0 || p.Hi < 8) return false;
     if (p.stats_out && p.stats_slots != FNN_STAT_REPL) return false;
     if (tp.fuse == FUSE_TCONV) {
         if (p.n_src != 2 || p.chunks != 2 || p.src[1].C != 16 || tp.low.C != 32) return false;
@@ -590,7 +597,7 @@ int launch_conv_row(const ThinParams &tp, hipStream_t st) {
 bool stem_row_ok(const StemParams &p) {
     const bool off = fnn_knob("FNN_NO_ROW") != nullptr || fnn_knob("FNN_NO_STEM_ROW") != nullptr;            // A-B aids
     if (off || p.C != 1 || p.kd != 1 || p.kh != 3 || p.kw != 3 || p.Cout != 16) return false;
-    if ((p.PW != 64 && p.PW != 96 && p.PW != 128) || p.PH % 4 != 0 || p.PH < 8) return false;
+    if ((p.PW != 64 && p.PW != 96 && p.PW != 128 && p.PW != 160 && p.PW != 192) || p.PH % 4 != 0 || p.PH < 8) return false;
     if (2ull * p.PD * p.PH * p.PW * 16 >= (1ull << 31)) return false;
     int SH;
     const int strips = pick_strips(p.PH, SH);
@@ -608,7 +615,9 @@ int launch_stem_row(const StemParams &p, int N, hipStream_t st) {
     switch (p.PW) {
         case 64: hipLaunchKernelGGL(stem_row_kernel<4>, dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots); break;
         case 96: hipLaunchKernelGGL(stem_row_kernel<6>, dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots); break;
-        default: hipLaunchKernelGGL(stem_row_kernel<8>, dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots); break;
+        case 128: hipLaunchKernelGGL(stem_row_kernel<8>, dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots); break;
+        case 160: hipLaunchKernelGGL(stem_row_kernel<10>, dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots); break;
+        default: hipLaunchKernelGGL(stem_row_kernel<12>, dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots); break;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

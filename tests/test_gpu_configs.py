@@ -376,7 +376,7 @@ def test_fp8_driver_is_bit_identical_to_the_oracle_driver_on_its_own_logits():
 
 
 # ----------------------------------------------------------------------------------------------- row-streaming kernels
-@pytest.mark.parametrize('patch', [(8, 32, 64), (6, 24, 96), (4, 16, 128)])
+@pytest.mark.parametrize('patch', [(8, 32, 64), (6, 24, 96), (4, 16, 128), (4, 16, 160), (4, 24, 192)])
 def test_row_streaming_kernels_network_and_mirroring_match_the_oracle(patch):
     """conv3d_row.hip on a whole anisotropic network: rows of 64 / 96 / 128 voxels put the stem (raw fp32 rows, flipped
     reads for mirroring), the 16 -> 16 convs and the fused last transposed conv on the row-streaming kernels.  Forward

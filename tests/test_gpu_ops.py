@@ -245,6 +245,8 @@ ROW_CASES = [
     (2, 1, (3, 40, 128)),
     (2, 2, (4, 48, 96)),        # two sources = torch.cat((up, skip), 1) without the fusion
     (1, 1, (2, 8, 64)),         # a strip of two steps: the group stream is mostly prologue and tail
+    (2, 1, (3, 24, 160)),       # wide rows: the k-loop runs in two halves of the row's column blocks
+    (1, 2, (2, 16, 192)),
 ]
 
 
