@@ -338,6 +338,247 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
 }
 
 // ----------------------------------------------------------------------------
+// whole 12 x 12 planes per tile (the 128-channel stage of a 96 x 96 in-plane patch)
+// ----------------------------------------------------------------------------
+// 8 x 8 in-plane tiles cover a 12 x 12 plane with four tiles that are filled to 56 %: the MFMAs of the empty columns are
+// wasted and a 10 x 10 x 10 halo is staged for 288 outputs (3.5 halo voxels per output; with 128 output channels once per
+// 32 of them).  Here the tile is TD x 12 x 12: nine waves (576 threads), each the owner of one 4 x 4 column block in
+// every depth slice - the depth-shift reuse of conv3d_zr_kernel unchanged (0.33 LDS reads per MFMA) - over a halo of
+// (TD + 2) x 14 x 14 voxels: 1.7 halo voxels per output, every MFMA column a real voxel, and the chunk's 30 KB of weight
+// fragments serve 1152 outputs instead of 288.  LDS image: row pitch 20 voxels (4 mod 8) with the channel halves
+// swapped on odd rows: the 16 lanes of a ds_read_b128 group hold rows 0 and 3 of the block in one half and rows 1 and 2
+// in the other - 16 different slots.  One workgroup per CU (120 KB of LDS); a SIMD holds two or three of its waves.
+// Same weights (FNN_PACK_ZR, interleaved cout order), arithmetic and statistics rows (one per tile) as
+// conv3d_zr_kernel; the sums of a statistics row are formed over other voxel groups: fp16-resolution differences.
+template <int TD>
+__global__ __launch_bounds__(576, 1) void conv3d_zr12_kernel(const ConvParams p) {
+    constexpr int NB = 2, NT = 576;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int IH = 14, IW = 14, PW = 20, ID = TD + 2;
+    constexpr int PS = IH * PW * 32;
+    constexpr int ABYTES = ID * PS;
+    constexpr int KS = 15;
+    constexpr int IELEM = ID * IH * IW * 2;
+    constexpr int PF = (IELEM + NT - 1) / NT;
+    constexpr int WTOT = NB * KS * 64;
+    constexpr int WPF = (WTOT + NT - 1) / NT;
+
+    const int td = blockIdx.x % p.tiles_d, n = blockIdx.x / p.tiles_d;
+    const int cb0 = blockIdx.y * NB;
+    const int od0 = td * TD;
+    const int bh = wave / 3, bw = wave - bh * 3;                      // this wave's 4 x 4 block of the plane
+
+    char *sA = smem;
+    char *sW = smem + ABYTES;
+    float *sRed = (float *)(sW + NB * KS * 1024);             // [9 waves][32][2]
+
+    const int cg = tid & 1;
+    int offv[PF], ldso[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int idx = tid + u * NT;
+        const int v = idx >> 1;
+        const int zd = v / (IH * IW), rem = v - zd * (IH * IW), zh = rem / IW, zw = rem - zh * IW;
+        const int gd = od0 - 1 + zd, gh = zh - 1, gw = zw - 1;
+        const bool ok = ((unsigned)gd < (unsigned)p.Di) & ((unsigned)gh < (unsigned)p.Hi) & ((unsigned)gw < (unsigned)p.Wi);
+        offv[u] = idx < IELEM ? (ok ? __mul24(__mul24(gd, p.Hi) + gh, p.Wi) + gw : -1) : -2;
+        ldso[u] = zd * PS + (zh * PW + zw) * 32 + ((cg ^ (zh & 1)) * 16);
+    }
+    const int wbase = cb0 * p.chunks * (KS * 64), wskip = (p.chunks - 1) * (KS * 64);
+    f16x8 xr[PF], wr[WPF];
+    float scu[16], shu[16];
+    float slope_next = 1.f;
+    auto issue = [&](int ch) {
+        const int c_glob = ch * 16;
+        const int s = (c_glob < p.src[0].C) ? 0 : 1;
+        const int c_uni = c_glob - (s ? p.src[0].C : 0);
+        const int sC = p.src[s].C;
+        const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + c_uni);
+        slope_next = p.src[s].slope;
+        const float *qs = p.src[s].ss ? p.src[s].ss + (size_t)(2 * n) * sC + c_uni : p.ident_ss + c_uni;
+        const float *qh = p.src[s].ss ? qs + sC : p.ident_ss + 512 + c_uni;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { scu[j] = qs[j]; shu[j] = qh[j]; }
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * sC + cg * 8) * 2));
+#pragma unroll
+        for (int u = 0; u < WPF; ++u) {
+            const int idx = tid + u * NT, idc = idx < WTOT ? idx : WTOT - 1;
+            int e = idc + (idc >= KS * 64 ? wskip : 0);
+            asm volatile("" : "+v"(e));                       // (a hoisted 64-bit address per element costs registers)
+            wr[u] = *(const f16x8 *)((const char *)p.wpk + (unsigned)((wbase + e + ch * (KS * 64)) * 16));
+        }
+    };
+    auto commit = [&]() {
+        const f16 slope_h = (f16)slope_next;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = cg ? scu[8 + j] : scu[j]; sh[j] = cg ? shu[8 + j] : shu[j]; }
+#ifndef FNN_NORM_FP32
+        f16x8 sc_h, sh_h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc_h[j] = (f16)sc[j]; sh_h[j] = (f16)sh[j]; }
+#endif
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if ((u + 1) * NT > IELEM && offv[u] == -2) continue;
+#ifdef FNN_NORM_FP32
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)xr[u][j], sc[j], sh[j]);
+#else
+            f16x8 o = xr[u] * sc_h + sh_h;
+#endif
+            o = __builtin_elementwise_max(o, o * slope_h);
+            if (offv[u] < 0) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};      // the conv's zero padding
+            *(f16x8 *)(sA + ldso[u]) = o;
+        }
+#pragma unroll
+        for (int u = 0; u < WPF; ++u) {
+            const int idx = tid + u * NT;
+            if ((u + 1) * NT <= WTOT || idx < WTOT) ((f16x8 *)sW)[idx] = wr[u];
+        }
+    };
+    int toff[5];
+    f32x4 acc[TD][NB];
+    auto kloop = [&]() {
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const char *bp = sA + toff[pr];
+            f16x8 xf[ID];
+#pragma unroll
+            for (int pl = 0; pl < ID; ++pl) xf[pl] = *(const f16x8 *)(bp + pl * PS);
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                f16x8 wf[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wf[nb] = *(const f16x8 *)(sW + ((nb * KS + pr * 3 + dz) * 64 + lane) * 16);
+#pragma unroll
+                for (int j = 0; j < TD; ++j)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nb], xf[j + dz], acc[j][nb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    issue(0);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        // MFMA "B" operand: lane = (voxel r of the wave's 4 x 4 block, k-group): bit 1 of the k-group picks the tap of the
+        // pair, bit 0 the 8-channel half
+        const int r = lane & 15, hl = lane >> 5, kh = (lane >> 4) & 1;
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const int tp = 2 * pr + hl < 9 ? 2 * pr + hl : 8;
+            const int row = 4 * bh + (r >> 2) + tp / 3, col = 4 * bw + (r & 3) + tp % 3;
+            toff[pr] = (row * PW + col) * 32 + ((kh ^ (row & 1)) * 16);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TD; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[j][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    commit();
+    __syncthreads();
+    for (int ch = 0; ch + 1 < p.chunks; ++ch) {
+        issue(ch + 1);
+        kloop();
+        __syncthreads();
+        commit();
+        __syncthreads();
+    }
+    kloop();
+
+    // ---- epilogue: bias, 16-byte stores (the interleaved cout order: lane quarter q holds channels q * 8 .. + 7), statistics
+    {
+        const int q = lane >> 4, r = lane & 15;
+        float4 bv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const float4 *)(p.bias + cb0 * 16 + q * 8 + nb * 4);
+        float t1[NB][4], t2[NB][4];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
+        const unsigned item_bytes = (unsigned)p.Do * p.Ho * p.Wo * p.Cout * 2;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)n * (item_bytes >> 1), 0, item_bytes, 0x00020000);
+        const unsigned coff = (unsigned)(cb0 * 16 + q * 8) * 2;
+        const int oh = 4 * bh + (r >> 2), ow = 4 * bw + (r & 3);
+        const bool ok_hw = oh < p.Ho && ow < p.Wo;
+        const f16x2 ones = {(f16)1.f, (f16)1.f};
+#pragma unroll
+        for (int mb = 0; mb < TD; mb += 2) {
+            f16x8 o[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int od = od0 + mb + h;
+                const bool ok = ok_hw && od < p.Do;
+                const unsigned voff = ok ? (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout) * 2 + coff : 0x80000000u;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    o[h][nb * 4 + 0] = (f16)(acc[mb + h][nb][0] + bv[nb].x);
+                    o[h][nb * 4 + 1] = (f16)(acc[mb + h][nb][1] + bv[nb].y);
+                    o[h][nb * 4 + 2] = (f16)(acc[mb + h][nb][2] + bv[nb].z);
+                    o[h][nb * 4 + 3] = (f16)(acc[mb + h][nb][3] + bv[nb].w);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fnn_i32x4, o[h]), rsrc, voff, 0, 0);
+                if (!ok) o[h] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f16x2 pr = {o[0][nb * 4 + j], o[1][nb * 4 + j]};
+                    t1[nb][j] = __builtin_amdgcn_fdot2(pr, ones, t1[nb][j], false);
+                    t2[nb][j] = __builtin_amdgcn_fdot2(pr, pr, t2[nb][j], false);
+                }
+        }
+        if (p.stats_out) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = row16_sum(t1[nb][j]), b = row16_sum(t2[nb][j]);
+                    if (r == 0) {
+                        const int c = q * 8 + nb * 4 + j;
+                        sRed[(wave * 32 + c) * 2] = a;
+                        sRed[(wave * 32 + c) * 2 + 1] = b;
+                    }
+                }
+            __syncthreads();
+            if (tid < 64) {
+                const int c = tid >> 1, which = tid & 1;
+                double v = 0;
+#pragma unroll
+                for (int w = 0; w < 9; ++w) v += (double)sRed[(w * 32 + c) * 2 + which];
+                p.stats_out[(((size_t)n * p.stats_slots + td) * p.Cout + cb0 * 16 + c) * 2 + which] = v;
+            }
+        }
+    }
+}
+
+template <int TD>
+static int launch_zr12(ConvParams p, hipStream_t st) {
+    p.tile_d = TD;
+    p.tiles_d = (p.Do + TD - 1) / TD; p.tiles_h = 1; p.tiles_w = 1;
+    const size_t lds = (size_t)((TD + 2) * 14 * 20 * 32) + (size_t)2 * 15 * 1024 + 9 * 32 * 2 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)conv3d_zr12_kernel<TD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    p.ident_ss = conv3d_identity_ss();
+    if (!p.ident_ss) return -2;
+    dim3 grid(p.N * p.tiles_d, (p.Cout / 16) / 2);
+    hipLaunchKernelGGL((conv3d_zr12_kernel<TD>), grid, dim3(576), lds, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ----------------------------------------------------------------------------
 // in-plane stride 2, depth stride 1 (the first down-sampling conv of an anisotropic network)
 // ----------------------------------------------------------------------------
 // The linear-tap persistent kernel serves this layer with 2 x 8 x 8 output tiles: four halo planes staged per two
@@ -1114,6 +1355,12 @@ int launch_conv3d_zr(const ConvParams &p, hipStream_t st) {
     if (p.fp8) {
         if (nb == 2) return td == 8 ? launch_zr8<2, 8>(p, st) : launch_zr8<2, 4>(p, st);
         return td == 8 ? launch_zr8<1, 8>(p, st) : launch_zr8<1, 4>(p, st);
+    }
+    {
+        // planes of 9 .. 12 x 9 .. 12 voxels (two half-empty 8 x 8 tiles per axis): whole planes per tile
+        static const bool no_zr12 = fnn_knob("FNN_NO_ZR12") != nullptr;                       // A-B aid
+        if (!no_zr12 && nb == 2 && p.Ho > 8 && p.Ho <= 12 && p.Wo > 8 && p.Wo <= 12 && conv3d_stats_slots(p) >= (p.Do + 3) / 4)
+            return launch_zr12<4>(p, st);
     }
     if (nb == 2) return td == 8 ? launch_zr<2, 8>(p, st) : launch_zr<2, 4>(p, st);
     return td == 8 ? launch_zr<1, 8>(p, st) : launch_zr<1, 4>(p, st);

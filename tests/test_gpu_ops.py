@@ -338,3 +338,40 @@ def test_conv3d_persistent_depth_shift_kernel_with_two_cout_groups():
     xn = _h(F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01))
     ref = F.conv3d(xn, w, b, stride, 1)
     assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('n,cin,cout,dims', [(8, 128, 128, (40, 12, 12)), (16, 48, 64, (21, 11, 9)), (32, 32, 32, (17, 12, 10))])
+def test_conv3d_zr_whole_plane_tiles(n, cin, cout, dims):
+    """conv3d_zr12_kernel (planes of 9 .. 12 voxels per axis: nine waves, one 4 x 4 column block each, whole planes per
+    tile): full and ragged planes, ragged depth, 2 - 8 chunks, 1 - 4 cout groups; identity input with statistics, then
+    fused InstanceNorm + LeakyReLU on load."""
+    from fast_nnunet_amd import capi
+    g = torch.Generator().manual_seed(91 + cin + dims[1])
+    x = _h(torch.randn(n, cin, *dims, generator=g) * 2 + 0.5)
+    gamma = torch.rand(cin, generator=g) + 0.5
+    beta = torch.randn(cin, generator=g) * 0.1
+    w = _h(torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    y, stats = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), (1, 1, 1), want_stats=True)
+    _check(y, F.conv3d(x, w, b, 1, 1), 'conv3d zr12')
+    y64 = y.astype(np.float64)
+    assert np.allclose(stats[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    assert np.allclose(stats[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    y = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), (1, 1, 1), gamma=gamma.numpy(), beta=beta.numpy(), slope=0.01)
+    xn = _h(F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01))
+    ref = F.conv3d(xn, w, b, 1, 1)
+    assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_conv3d_zr_whole_plane_operand_map_with_exact_integers():
+    """one-hot taps on integer data through conv3d_zr12_kernel: any wrong block / tap / depth shift shows up as inequality"""
+    from fast_nnunet_amd import capi
+    n, c, dims = 32, 32, (20, 12, 12)
+    base = (torch.arange(dims[0] * dims[1] * dims[2]).reshape(dims) * 7 % 23).float()
+    x = torch.stack([torch.stack([base + ch + 3 * i for ch in range(c)]) for i in range(n)])
+    w = torch.zeros(c, c, 3, 3, 3)
+    for co in range(c):
+        w[co, (co * 5 + 3) % c, co % 3, (co // 3) % 3, (co + 1) % 3] = 1.0
+        w[co, (co * 3 + 1) % c, (co + 2) % 3, (co + 1) % 3, co % 3] += 2.0
+    y = capi.op_conv3d(x.numpy(), w.numpy(), None, (3, 3, 3), (1, 1, 1))
+    assert np.array_equal(y, F.conv3d(x, w, None, 1, 1).numpy())
