@@ -105,8 +105,11 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
         const int c_glob = ch * 16;
         const int s = (c_glob < p.src[0].C) ? 0 : 1;
         const int c_loc = c_glob - (s ? p.src[0].C : 0) + cg * 8;
-        const f16 *sp = p.src[s].ptr;
         const int sC = p.src[s].C;
+        // activation layout (fnn_device.h, SrcDesc): item base + chunk base; sOff holds voxel indices that include the item
+        const size_t nvox = (size_t)n * p.Di * p.Hi * p.Wi;
+        const int vs = FNN_VS(p.src[s]);
+        const f16 *sp = p.src[s].ptr + nvox * sC + (c_loc >> 4) * FNN_CS(p.src[s]) + (c_loc & 15);
         const f16 slope_h = (f16)p.src[s].slope;
         float sc[8], sh[8];
 #pragma unroll
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)       // always a valid address; padding voxels are zeroed below
-                x[u] = *(const f16x8 *)(sp + (size_t)(off[u] >= 0 ? off[u] : 0) * sC + c_loc);
+                x[u] = *(const f16x8 *)(sp + (off[u] >= 0 ? (size_t)off[u] - nvox : 0) * vs);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (off[u] == -2) continue;
@@ -195,7 +198,8 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
     for (int mb = 0; mb < 4; ++mb) {
         const int oh = oh0 + 2 * mb + (r >> 3), ow = ow0 + (r & 7);
         const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
-        const size_t vox = ((size_t)(n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+        const size_t vox = ((size_t)od * p.Ho + oh) * p.Wo + ow;              // inside batch item n
+        f16 *outn = p.out + (size_t)n * p.Do * p.Ho * p.Wo * p.Cout;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int co = (cb0 + nb) * 16 + q * 4;
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(const ConvParams p) {
             o[2] = (f16)(acc[mb][nb][2] + bv.z);
             o[3] = (f16)(acc[mb][nb][3] + bv.w);
             if (ok) {
-                *(f16x4 *)(p.out + vox * p.Cout + co) = o;
+                *(f16x4 *)(outn + vox * FNN_OVS(p) + (co >> 4) * FNN_OCS(p) + (co & 15)) = o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float v = (float)o[j];
@@ -372,11 +376,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_lds_kernel(const ConvParams p) 
     auto issue = [&](int ch) {
         const int c_glob = ch * 16;
         const int s = (c_glob < p.src[0].C) ? 0 : 1;
-        const f16 *sp = p.src[s].ptr + (c_glob - (s ? p.src[0].C : 0) + cg * 8);
-        const int sC = p.src[s].C;
+        const int sC = p.src[s].C, c_loc = c_glob - (s ? p.src[0].C : 0) + cg * 8;
+        const size_t nvox = (size_t)n * p.Di * p.Hi * p.Wi;     // offv holds voxel indices that include the item
+        const int vs = FNN_VS(p.src[s]);                        // activation layout: fnn_device.h, SrcDesc
+        const f16 *sp = p.src[s].ptr + nvox * sC + (c_loc >> 4) * FNN_CS(p.src[s]) + (c_loc & 15);
 #pragma unroll
         for (int u = 0; u < PF; ++u)                        // unconditional: branches around loads make hipcc drain vmcnt
-            xr[u] = *(const f16x8 *)(sp + (size_t)(offv[u] >= 0 ? offv[u] : 0) * sC);
+            xr[u] = *(const f16x8 *)(sp + (offv[u] >= 0 ? (size_t)offv[u] - nvox : 0) * vs);
 #pragma unroll
         for (int u = 0; u < WPF; ++u) wr[u] = ((const f16x8 *)p.wpk)[wofs[u] + ch * per_nb];
         slope_next = p.src[s].slope;
@@ -662,7 +668,8 @@ __global__ __launch_bounds__(256, (NB == 1 && MB == 4 && WRES && PF == 4) ? 3 : 
         const int s = (c_glob < p.src[0].C) ? 0 : 1;
         const int c_loc = c_glob - (s ? p.src[0].C : 0) + cg * 8;
         const int sC = p.src[s].C;
-        const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + c_loc);   // uniform base
+        const int vs = FNN_VS(p.src[s]);                    // activation layout: fnn_device.h, SrcDesc
+        const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + (c_loc >> 4) * FNN_CS(p.src[s]) + (c_loc & 15));   // uniform base
         slope_next = p.src[s].slope;
         // scale / shift first (vmcnt retires in order: commit() needs them before the first halo element) and
         // unconditionally: the identity table stands in for a source without InstanceNorm
@@ -673,7 +680,7 @@ __global__ __launch_bounds__(256, (NB == 1 && MB == 4 && WRES && PF == 4) ? 3 : 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < PF; ++u)                        // unconditional: branches around loads make hipcc drain vmcnt
-            xr[u] = *(const f16x8 *)(sp + (unsigned)((offv[u] >= 0 ? offv[u] : 0) * sC * 2));
+            xr[u] = *(const f16x8 *)(sp + (unsigned)((offv[u] >= 0 ? offv[u] : 0) * vs * 2));
         if (!WRES) {
 #pragma unroll
             for (int u = 0; u < WPF; ++u) wr[u] = ((const f16x8 *)p.wpk)[wofs[u] + ch * per_nb];

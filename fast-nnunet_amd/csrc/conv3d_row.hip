@@ -170,8 +170,10 @@ __global__ __launch_bounds__(256, CH == 1 ? (NBLK <= 8 ? 3 : 2) : (NBLK <= 8 ? 2
                 const int lr = bb / (NBLK / 2), bl = bb - lr * (NBLK / 2);
                 int lrow = lbase + lr;
                 lrow = lrow < 0 ? 0 : (lrow >= Hl ? Hl - 1 : lrow);
-                const char *base = (const char *)(tp.low.ptr + (((size_t)c.n * tp.Dl + c.d) * Hl + lrow) * ((size_t)Wl * 32));
-                xl[t] = *(const f16x8 *)(base + (unsigned)((16 * bl + r) * 64 + q * 16));
+                // (voxel v, channels 8 q ..) of the 32-channel low tensor: v * vs + (q >> 1) * cs + (q & 1) * 8 (fnn_device.h, SrcDesc)
+                const char *base = (const char *)(tp.low.ptr + (size_t)c.n * tp.Dl * Hl * Wl * 32 + (q >> 1) * FNN_CS(tp.low) +
+                                                  (((size_t)c.d * Hl + lrow) * Wl) * FNN_VS(tp.low));
+                xl[t] = *(const f16x8 *)(base + (unsigned)((16 * bl + r) * (FNN_VS(tp.low) * 2) + (q & 1) * 16));
             }
         }
     };

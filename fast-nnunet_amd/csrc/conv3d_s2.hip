@@ -130,8 +130,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_s2_kernel(const ConvParams p, c
         const int s = (c_glob < p.src[0].C) ? 0 : 1;
         const int c_loc = c_glob - (s ? p.src[0].C : 0) + cg * 8;
         const int sC = p.src[s].C;
-        i_sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + c_loc);
-        i_sc2 = sC * 2;
+        i_sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + (c_loc >> 4) * FNN_CS(p.src[s]) + (c_loc & 15));
+        i_sc2 = FNN_VS(p.src[s]) * 2;                                    // activation layout: fnn_device.h, SrcDesc
         slope_next = p.src[s].slope;
         i_qs = p.src[s].ss ? p.src[s].ss + (size_t)(2 * n) * sC + c_loc : p.ident_ss + c_loc;
         i_qh = p.src[s].ss ? i_qs + sC : p.ident_ss + 512 + c_loc;

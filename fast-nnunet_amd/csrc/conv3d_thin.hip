@@ -387,7 +387,8 @@ __global__ __launch_bounds__(256, WPS) void conv_thin_kernel(const ThinParams tp
     auto issue_reg = [&](int n) {
         const SrcDesc &S = p.src[1];
         const int c_loc = cg * 8, sC = S.C;
-        const char *sp = (const char *)(S.ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + c_loc);
+        const int vs = FNN_VS(S);                                        // activation layout: fnn_device.h, SrcDesc
+        const char *sp = (const char *)(S.ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + (c_loc >> 4) * FNN_CS(S) + (c_loc & 15));
         slope_next = S.slope;
         const float *qs = S.ss ? S.ss + (size_t)(2 * n) * sC + c_loc : p.ident_ss + c_loc;
         const float *qh = S.ss ? qs + sC : p.ident_ss + 512 + c_loc;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256, WPS) void conv_thin_kernel(const ThinParams tp
         shr[0] = *(const float4 *)qh; shr[1] = *(const float4 *)(qh + 4);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < PF; ++u) xr[u] = *(const f16x8 *)(sp + (unsigned)((offv[u] >= 0 ? offv[u] : 0) * sC * 2));
+        for (int u = 0; u < PF; ++u) xr[u] = *(const f16x8 *)(sp + (unsigned)((offv[u] >= 0 ? offv[u] : 0) * vs * 2));
     };
     auto commit_reg = [&](char *dst) {
         const f16 slope_h = (f16)slope_next;
@@ -477,7 +478,8 @@ __global__ __launch_bounds__(256, WPS) void conv_thin_kernel(const ThinParams tp
         lo_w = tp.tsw == 2 ? (iw0 >> 1) : iw0;
         const int c0 = q * 8, sC = S.C;
         const int cc = c0 < sC ? c0 : 0;
-        const char *sp = (const char *)(S.ptr + (size_t)n * tp.Dl * tp.Hl * tp.Wl * sC + cc);
+        const int vs = FNN_VS(S);
+        const char *sp = (const char *)(S.ptr + (size_t)n * tp.Dl * tp.Hl * tp.Wl * sC + (cc >> 4) * FNN_CS(S) + (cc & 15));
         const float *qs = S.ss ? S.ss + (size_t)(2 * n) * sC + cc : p.ident_ss + cc;
         const float *qh = S.ss ? qs + sC : p.ident_ss + 512 + cc;
         scr[0] = *(const float4 *)qs; scr[1] = *(const float4 *)(qs + 4);
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(256, WPS) void conv_thin_kernel(const ThinParams tp
             const bool ok = l_zp[j] >= 0 && gd < (unsigned)tp.Dl && gh < (unsigned)tp.Hl && gw < (unsigned)tp.Wl;
             l_ok[j] = (ok && c0 < sC ? 1 : 0) | (ok ? 2 : 0);
             const unsigned off = ok ? __umul24(__umul24(gd, (unsigned)tp.Hl) + gh, (unsigned)tp.Wl) + gw : 0u;
-            xr[j] = *(const f16x8 *)(sp + off * (unsigned)(sC * 2));
+            xr[j] = *(const f16x8 *)(sp + off * (unsigned)(vs * 2));
         }
     };
     auto low_to_image = [&](char *dst) {

@@ -85,7 +85,8 @@ static __device__ __forceinline__ void zr_epilogue_pair(const ConvParams &p, con
     const unsigned item_bytes = (unsigned)p.Do * p.Ho * p.Wo * p.Cout * 2;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)n * (item_bytes >> 1), 0,
                                                                            item_bytes, 0x00020000);
-    const unsigned coff = (unsigned)(cb0 * 16 + q * 8) * 2;
+    const unsigned ovs2 = (unsigned)FNN_OVS(p) * 2;
+    const unsigned coff = (unsigned)(cb0 + (q >> 1)) * (unsigned)(FNN_OCS(p) * 2) + (unsigned)(q & 1) * 16;   // output layout: fnn_device.h
     const int oh = oh0 + 2 * wave + (r >> 3), ow = ow0 + (r & 7);
     const bool ok_hw = oh < p.Ho && ow < p.Wo;
     const f16x2 ones = {(f16)1.f, (f16)1.f};
@@ -96,7 +97,7 @@ static __device__ __forceinline__ void zr_epilogue_pair(const ConvParams &p, con
         for (int h = 0; h < 2; ++h) {
             const int od = od0 + mb + h;
             const bool ok = ok_hw && od < p.Do;
-            unsigned voff = ok ? (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout) * 2 + coff : 0x80000000u;
+            unsigned voff = ok ? (unsigned)((od * p.Ho + oh) * p.Wo + ow) * ovs2 + coff : 0x80000000u;
 #ifdef FNN_TMODE
             if (p.tmode & 4) voff = 0x80000000u;
 #endif
@@ -199,7 +200,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
         const int c_uni = c_glob - (s ? p.src[0].C : 0);
         const int sC = p.src[s].C;
         // uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset: one address VGPR per load (tensors < 4 GiB)
-        const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + c_uni);
+        const int vs = FNN_VS(p.src[s]);                      // activation layout: fnn_device.h, SrcDesc
+        const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + (c_uni >> 4) * FNN_CS(p.src[s]));
         // scale / shift of the chunk's 16 channels (identity table for a source without InstanceNorm): the address is
         // wave-uniform, so these are s_load_dwordx8 - as four 16-byte-per-lane vector loads they took a fifth of the
         // chunk's slots in the texture-address path, which paces this kernel
@@ -211,9 +213,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
 #pragma unroll
         for (int u = 0; u < PF; ++u)                          // unconditional: branches around loads make hipcc drain vmcnt
 #ifdef FNN_TMODE
-            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * t_hm * sC + cg * 8) * 2));
+            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * t_hm * vs + cg * 8) * 2));
 #else
-            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * sC + cg * 8) * 2));
+            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * vs + cg * 8) * 2));
 #endif
 #pragma unroll
 #ifdef FNN_TMODE
@@ -394,7 +396,8 @@ __global__ __launch_bounds__(576, 1) void conv3d_zr12_kernel(const ConvParams p)
         const int s = (c_glob < p.src[0].C) ? 0 : 1;
         const int c_uni = c_glob - (s ? p.src[0].C : 0);
         const int sC = p.src[s].C;
-        const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + c_uni);
+        const int vs = FNN_VS(p.src[s]);                      // activation layout: fnn_device.h, SrcDesc
+        const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + (c_uni >> 4) * FNN_CS(p.src[s]));
         slope_next = p.src[s].slope;
         const float *qs = p.src[s].ss ? p.src[s].ss + (size_t)(2 * n) * sC + c_uni : p.ident_ss + c_uni;
         const float *qh = p.src[s].ss ? qs + sC : p.ident_ss + 512 + c_uni;
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(576, 1) void conv3d_zr12_kernel(const ConvParams p)
         for (int j = 0; j < 16; ++j) { scu[j] = qs[j]; shu[j] = qh[j]; }
 #pragma unroll
         for (int u = 0; u < PF; ++u)
-            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * sC + cg * 8) * 2));
+            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * vs + cg * 8) * 2));
 #pragma unroll
         for (int u = 0; u < WPF; ++u) {
             const int idx = tid + u * NT, idc = idx < WTOT ? idx : WTOT - 1;
@@ -506,7 +509,8 @@ __global__ __launch_bounds__(576, 1) void conv3d_zr12_kernel(const ConvParams p)
             for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
         const unsigned item_bytes = (unsigned)p.Do * p.Ho * p.Wo * p.Cout * 2;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)n * (item_bytes >> 1), 0, item_bytes, 0x00020000);
-        const unsigned coff = (unsigned)(cb0 * 16 + q * 8) * 2;
+        const unsigned ovs2 = (unsigned)FNN_OVS(p) * 2;
+        const unsigned coff = (unsigned)(cb0 + (q >> 1)) * (unsigned)(FNN_OCS(p) * 2) + (unsigned)(q & 1) * 16;   // output layout: fnn_device.h
         const int oh = 4 * bh + (r >> 2), ow = 4 * bw + (r & 3);
         const bool ok_hw = oh < p.Ho && ow < p.Wo;
         const f16x2 ones = {(f16)1.f, (f16)1.f};
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(576, 1) void conv3d_zr12_kernel(const ConvParams p)
             for (int h = 0; h < 2; ++h) {
                 const int od = od0 + mb + h;
                 const bool ok = ok_hw && od < p.Do;
-                const unsigned voff = ok ? (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout) * 2 + coff : 0x80000000u;
+                const unsigned voff = ok ? (unsigned)((od * p.Ho + oh) * p.Wo + ow) * ovs2 + coff : 0x80000000u;
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
                     o[h][nb * 4 + 0] = (f16)(acc[mb + h][nb][0] + bv[nb].x);
@@ -657,7 +661,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_zs_kernel(const ConvParams p) {
         const int s = (c_glob < p.src[0].C) ? 0 : 1;
         const int c_uni = c_glob - (s ? p.src[0].C : 0);
         const int sC = p.src[s].C;
-        const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + c_uni);
+        const int vs = FNN_VS(p.src[s]);                      // activation layout: fnn_device.h, SrcDesc
+        const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + (c_uni >> 4) * FNN_CS(p.src[s]));
         slope_next = p.src[s].slope;
         const float *qs = p.src[s].ss ? p.src[s].ss + (size_t)(2 * n) * sC + c_uni : p.ident_ss + c_uni;
         const float *qh = p.src[s].ss ? qs + sC : p.ident_ss + 512 + c_uni;
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_zs_kernel(const ConvParams p) {
         for (int j = 0; j < 16; ++j) { scu[j] = qs[j]; shu[j] = qh[j]; }
 #pragma unroll
         for (int u = 0; u < PF; ++u)
-            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * sC + cg * 8) * 2));
+            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * vs + cg * 8) * 2));
 #pragma unroll
         for (int u = 0; u < WPF; ++u) wr[u] = *(const f16x8 *)((const char *)p.wpk + (unsigned)((wofs[u] + ch * (KS * 64)) * 16));
     };
@@ -765,7 +770,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_zs_kernel(const ConvParams p) {
             for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
         const unsigned item_bytes = (unsigned)p.Do * p.Ho * p.Wo * p.Cout * 2;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)n * (item_bytes >> 1), 0, item_bytes, 0x00020000);
-        const unsigned coff = (unsigned)(cb0 * 16 + q * 8) * 2;
+        const unsigned ovs2 = (unsigned)FNN_OVS(p) * 2;
+        const unsigned coff = (unsigned)(cb0 + (q >> 1)) * (unsigned)(FNN_OCS(p) * 2) + (unsigned)(q & 1) * 16;   // output layout: fnn_device.h
         const int oh = oh0 + 2 * hp + (r >> 3), ow = ow0 + (r & 7);
         const bool ok_hw = oh < p.Ho && ow < p.Wo;
         const f16x2 ones = {(f16)1.f, (f16)1.f};
@@ -776,7 +782,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_zs_kernel(const ConvParams p) {
             for (int h = 0; h < 2; ++h) {
                 const int od = od0 + TDW * dh + mb + h;
                 const bool ok = ok_hw && od < p.Do;
-                const unsigned voff = ok ? (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout) * 2 + coff : 0x80000000u;
+                const unsigned voff = ok ? (unsigned)((od * p.Ho + oh) * p.Wo + ow) * ovs2 + coff : 0x80000000u;
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
                     o[h][nb * 4 + 0] = (f16)(acc[mb + h][nb][0] + bv[nb].x);
@@ -895,6 +901,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_zsp_kernel(const ConvParams p, 
     };
     auto issue = [&](int n) {
         const int sC = p.src[0].C;
+        const int vs = FNN_VS(p.src[0]);
         const char *sp = (const char *)(p.src[0].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC);
         const float *qs = p.src[0].ss ? p.src[0].ss + (size_t)(2 * n) * sC : p.ident_ss;
         const float *qh = p.src[0].ss ? qs + sC : p.ident_ss + 512;
@@ -902,7 +909,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_zsp_kernel(const ConvParams p, 
         for (int j = 0; j < 16; ++j) { scu[j] = qs[j]; shu[j] = qh[j]; }
 #pragma unroll
         for (int u = 0; u < PF; ++u)
-            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * sC + cg * 8) * 2));
+            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * vs + cg * 8) * 2));
     };
     auto commit = [&]() {
         const f16 slope_h = (f16)p.src[0].slope;
@@ -978,7 +985,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_zsp_kernel(const ConvParams p, 
         {
             const unsigned item_bytes = (unsigned)p.Do * p.Ho * p.Wo * p.Cout * 2;
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)n_cur * (item_bytes >> 1), 0, item_bytes, 0x00020000);
-            const unsigned coff = (unsigned)(cb0 * 16 + q * 8) * 2;
+            const unsigned ovs2 = (unsigned)FNN_OVS(p) * 2;
+            const unsigned coff = (unsigned)(cb0 + (q >> 1)) * (unsigned)(FNN_OCS(p) * 2) + (unsigned)(q & 1) * 16;   // output layout: fnn_device.h
             const int oh = oh0 + 2 * hp + (r >> 3), ow = ow0 + (r & 7);
             const bool ok_hw = oh < p.Ho && ow < p.Wo;
 #pragma unroll
@@ -988,7 +996,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_zsp_kernel(const ConvParams p, 
                 for (int h = 0; h < 2; ++h) {
                     const int od = od0 + TDW * dh + mb + h;
                     const bool ok = ok_hw && od < p.Do;
-                    const unsigned voff = ok ? (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout) * 2 + coff : 0x80000000u;
+                    const unsigned voff = ok ? (unsigned)((od * p.Ho + oh) * p.Wo + ow) * ovs2 + coff : 0x80000000u;
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) {
                         o[h][nb * 4 + 0] = (f16)(acc[mb + h][nb][0] + bv[nb].x);
@@ -1163,7 +1171,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr8_kernel(const ConvParams p) 
         const int c_uni = c_glob - (s ? p.src[0].C : 0);
         const int c_loc = c_uni + cg * 8;
         const int sC = p.src[s].C;
-        const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + c_uni);
+        const int vs = FNN_VS(p.src[s]);                      // activation layout: fnn_device.h, SrcDesc
+        const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + (c_uni >> 4) * FNN_CS(p.src[s]));
         slope_next = p.src[s].slope;
         const float *qs = p.src[s].ss ? p.src[s].ss + (size_t)(2 * n) * sC + c_loc : p.ident_ss + c_loc;
         const float *qh = p.src[s].ss ? qs + sC : p.ident_ss + 512 + c_loc;
@@ -1172,7 +1181,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr8_kernel(const ConvParams p) 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < PF; ++u)
-            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * sC + cg * 8) * 2));
+            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * vs + cg * 8) * 2));
 #pragma unroll
         for (int u = 0; u < WPF; ++u) wr[u] = *(const fnn_u32x4 *)((const char *)p.wpk + (unsigned)((wofs[u] + ch * (KS * 32)) * 16));
     };

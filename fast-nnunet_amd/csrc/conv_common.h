@@ -62,7 +62,8 @@ static __device__ __forceinline__ void tile_epilogue(const ConvParams &p, const 
     const unsigned item_bytes = (unsigned)p.Do * p.Ho * p.Wo * p.Cout * 2;          // < 2^31 (checked by the launchers)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)n * (item_bytes >> 1), 0,
                                                                            item_bytes, 0x00020000);
-    const unsigned coff = (unsigned)(cb0 * 16 + q * 4) * 2;
+    const unsigned ovs2 = (unsigned)FNN_OVS(p) * 2, ocs2 = (unsigned)(FNN_OCS(p) * 2);     // output layout (fnn_device.h, SrcDesc)
+    const unsigned coff = (unsigned)cb0 * ocs2 + (unsigned)q * 8;
     // Statistics of the fp16-rounded outputs with packed dot products: the values of one channel at two voxels (m-blocks
     // mb, mb + 1) are packed into one register; v_dot2_f32_f16(pair, (1, 1), t1) adds both to the sum and
     // v_dot2_f32_f16(pair, pair, t2) both squares to the sum of squares - 1.5 instructions per value instead of 4
@@ -79,7 +80,7 @@ static __device__ __forceinline__ void tile_epilogue(const ConvParams &p, const 
             mb_coords<MB, ZR>(wave, mb + h, r, od_l, oh_l, ow_l);
             const int od = od0 + od_l, oh = oh0 + oh_l, ow = ow0 + ow_l;
             okv[h] = od < p.Do && oh < p.Ho && ow < p.Wo;
-            voff[h] = okv[h] ? (unsigned)(((od * p.Ho + oh) * p.Wo + ow) * p.Cout) * 2 + coff : 0x80000000u;
+            voff[h] = okv[h] ? (unsigned)((od * p.Ho + oh) * p.Wo + ow) * ovs2 + coff : 0x80000000u;
 #ifdef FNN_TMODE
             if (p.tmode & 4) voff[h] = 0x80000000u;
 #endif
@@ -93,7 +94,7 @@ static __device__ __forceinline__ void tile_epilogue(const ConvParams &p, const 
                 o[h][1] = (f16)(acc[mb + h][nb][1] + bv[nb].y);
                 o[h][2] = (f16)(acc[mb + h][nb][2] + bv[nb].z);
                 o[h][3] = (f16)(acc[mb + h][nb][3] + bv[nb].w);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fnn_i32x2, o[h]), rsrc, voff[h], nb * 32, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fnn_i32x2, o[h]), rsrc, voff[h], nb * ocs2, 0);
                 if (!okv[h]) o[h] = (f16x4){0, 0, 0, 0};
             }
 #pragma unroll

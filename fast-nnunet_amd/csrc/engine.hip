@@ -46,6 +46,7 @@ struct Layer {
     // conv3d_thin.hip: the stem as one MFMA per 16 voxels (w_off2 = its weight fragment in wpk); a CONV that recomputes
     // its producer while staging (fuse = FUSE_STEM / FUSE_TCONV); a producer whose output is never written (virtual)
     bool mfma_stem = false, virtual_out = false;
+    bool chunk_major = false;         // output stored [C / 16][voxels][16] (fnn_device.h, SrcDesc): convs / transposed convs whose consumers are convs
     bool fp8 = false;                 // conv3d_zr8_kernel: e4m3 operands; oscale_off = per-cout output scales (floats)
     size_t oscale_off = 0;
     int fuse = 0;
@@ -349,6 +350,20 @@ int build_plan(fnn_engine *e) {
         }
     }
 
+    // activation layouts: a tensor of more than 16 channels that only conv / transposed-conv kernels read is stored
+    // chunk-major, so that a consumer's 16-channel chunk is whole cache lines instead of 32 bytes of every record
+    if (fnn_knob("FNN_NO_CHUNK_MAJOR") == nullptr) {
+        std::vector<int> ok(e->layers.size(), 1);
+        for (const Layer &L : e->layers)
+            for (int i = 0; i < L.n_src; ++i)
+                if (L.src_layer[i] >= 0 && L.type != Layer::CONV && L.type != Layer::TCONV) ok[L.src_layer[i]] = 0;
+        for (size_t li = 0; li < e->layers.size(); ++li) {
+            Layer &L = e->layers[li];
+            L.chunk_major = ok[li] && (int)li != e->head_src && (L.type == Layer::CONV || L.type == Layer::TCONV) &&
+                            L.cout_pad > 16 && a.spatial_dims != 2;
+        }
+    }
+
     // device offsets
     size_t wpk = 0, fp = 0, st = 0, act = 0, ssn = 0;
     double flops = 0, bytes = 0;
@@ -569,6 +584,8 @@ SrcDesc make_src(fnn_engine *e, const FoldWeights &fw, int layer, int nb) {
     SrcDesc s{};
     s.ptr = e->act + L.out_off * e->max_batch;
     s.C = L.cout_pad;
+    if (L.chunk_major) { s.vs = 16; s.cs = 16LL * L.out_dims[0] * L.out_dims[1] * L.out_dims[2]; }
+    else { s.vs = L.cout_pad; s.cs = 16; }
     if (L.has_norm) {
         s.ss = e->ss + L.ss_off * e->max_batch * 2;
         s.slope = L.act ? e->arch.slope : 1.f;
@@ -623,6 +640,7 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.pd = (L.k[0] - 1) / 2; p.ph = (L.k[1] - 1) / 2; p.pw = (L.k[2] - 1) / 2;
             p.wpk = fw.wpk + L.w_off; p.bias = fw.fparam + L.bias_off;
             p.out = out; p.stats_out = stats_out; p.stats_slots = L.stats_slots;
+            if (L.chunk_major) { p.out_vs = 16; p.out_cs = 16LL * p.Do * p.Ho * p.Wo; }
             p.tiles_d = (p.Do + FNN_TILE_D - 1) / FNN_TILE_D;
             p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
             p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
@@ -672,6 +690,7 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.sd = L.s[0]; p.sh = L.s[1]; p.sw = L.s[2];
             p.Cout = L.cout_pad; p.wpk = fw.wpk + L.w_off; p.bias = fw.fparam + L.bias_off;
             p.out = out; p.ksteps = L.ksteps; p.nblk = L.cout_pad / 16;
+            if (L.chunk_major) { p.out_vs = 16; p.out_cs = 16LL * L.out_dims[0] * L.out_dims[1] * L.out_dims[2]; }
             if (L.virtual_out) continue;                              // computed inside its consumer (conv3d_thin.hip)
             Scope sc(e, st, FAM_TCONV, L.flops * nb);
             rc = launch_tconv(p, st);

@@ -35,7 +35,16 @@ struct SrcDesc {
     const float *ss;             // [N][2][C]: scale row then shift row of the producer's InstanceNorm, written
                                  // by stats_finalize_kernel; nullptr = identity
     float slope;                 // LeakyReLU slope applied after the affine (1.0 = none)
+    // Element (voxel v, channel c) of a batch item sits at v * vs + (c >> 4) * cs + (c & 15): channels-last is vs = C,
+    // cs = 16 (also what vs = 0 means); chunk-major [C / 16][voxels][16] is vs = 16, cs = 16 * voxels - a consumer's
+    // 16-channel chunk is then contiguous per voxel run instead of 32 bytes of every 2 C-byte record
+    int vs;
+    long long cs;
 };
+#define FNN_VS(S) ((S).vs ? (S).vs : (S).C)
+#define FNN_CS(S) ((S).vs ? (S).cs : 16LL)
+#define FNN_OVS(P) ((P).out_vs ? (P).out_vs : (P).Cout)
+#define FNN_OCS(P) ((P).out_vs ? (P).out_cs : 16LL)
 
 struct ConvParams {
     SrcDesc src[2];
@@ -47,7 +56,9 @@ struct ConvParams {
     int kd, kh, kw, sd, sh, sw, pd, ph, pw;
     const f16 *wpk;              // [cout_blk][chunk][kstep][64 lanes][8]
     const float *bias;           // [Cout]
-    f16 *out;                    // [N][Do][Ho][Wo][Cout]
+    f16 *out;                    // [N][Do][Ho][Wo][Cout], or chunk-major (out_vs, out_cs as SrcDesc::vs, cs; 0 = channels-last)
+    int out_vs;
+    long long out_cs;
     double *stats_out;           // [N][REPL][Cout][2] or nullptr
     int tiles_d, tiles_h, tiles_w;
     int tile_d;                  // output tile depth: 4, or 8 for the pipelined kernel with 8 column blocks per wave
@@ -117,7 +128,9 @@ struct TconvParams {
     int Cout;                    // padded
     const f16 *wpk;              // [tap][cout_blk][kstep][64][8]
     const float *bias;
-    f16 *out;                    // [N][Di*sd][Hi*sh][Wi*sw][Cout]
+    f16 *out;                    // [N][Di*sd][Hi*sh][Wi*sw][Cout], or chunk-major (out_vs, out_cs; 0 = channels-last)
+    int out_vs;
+    long long out_cs;
     int ksteps;                  // ceil(Cin / 32)
     int nblk;                    // Cout / 16
 };

@@ -99,13 +99,16 @@ static __device__ __forceinline__ f16x8 norm_act_frag(const SrcDesc &s, const f1
 
 // Activation fragment (MFMA B operand) of 16 voxels x 32 channels, read from a
 // channels-last tensor with the producer's norm + LeakyReLU applied.
+// `item`: element offset of the batch item when `vox` counts inside it - the form that honours the source's layout
+// (fnn_device.h, SrcDesc: v * vs + (c >> 4) * cs + (c & 15)); with item = 0 and a global voxel index the source must be
+// channels-last (the seg-head kernels' feature tensors are).
 static __device__ __forceinline__ f16x8 load_act_frag(const SrcDesc &s, size_t vox, bool vox_ok, int c0,
-                                                      const float2 *sSS) {
+                                                      const float2 *sSS, size_t item = 0) {
     // unconditional load from a clamped (always valid) address, zeroed afterwards: a per-lane branch around
     // the load makes hipcc wait for it immediately and serialises the loads of a k-step
     const bool live = vox_ok && c0 < s.C;
     const int cc = c0 < s.C ? c0 : 0;
-    const f16x8 x = *(const f16x8 *)(s.ptr + (vox_ok ? vox : 0) * s.C + cc);
+    const f16x8 x = *(const f16x8 *)(s.ptr + item + (vox_ok ? vox : 0) * FNN_VS(s) + (cc >> 4) * FNN_CS(s) + (cc & 15));
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const float2 ss = sSS[cc + j]; sc[j] = ss.x; sh[j] = ss.y; }
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void tconv_mfma_kernel(const TconvParams p)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const int v = v0 + mb * 16 + r;
-            xf[mb] = load_act_frag(p.src, (size_t)n * vox_in + (v < vox_in ? v : vox_in - 1), true, ks * 32 + q * 8, sSS);
+            xf[mb] = load_act_frag(p.src, (size_t)(v < vox_in ? v : vox_in - 1), true, ks * 32 + q * 8, sSS, (size_t)n * vox_in * p.src.C);
         }
 #pragma unroll
         for (int tg = 0; tg < TG; ++tg)
@@ -252,7 +255,9 @@ __global__ __launch_bounds__(256, 2) void tconv_mfma_kernel(const TconvParams p)
     float4 bv[NBT];
 #pragma unroll
     for (int nb = 0; nb < NBT; ++nb) bv[nb] = *(const float4 *)(p.bias + (cb0 + nb) * 16 + q * 4);
-    f16 *outn = p.out + (size_t)n * p.Di * p.sd * Ho * Wo * p.Cout + cb0 * 16 + q * 4;
+    const unsigned ovs = (unsigned)FNN_OVS(p);                               // output layout: fnn_device.h, SrcDesc
+    const long long ocs = FNN_OCS(p);
+    f16 *outi = p.out + (size_t)n * p.Di * p.sd * Ho * Wo * p.Cout;
     // output offsets: a per-voxel base (float-reciprocal division, 24-bit multiplies: input planes < 2^24 voxels, checked
     // by the launcher) plus a wave-uniform offset per tap - the index arithmetic was most of this kernel's instructions
     unsigned toff[TG];
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void tconv_mfma_kernel(const TconvParams p)
     for (int tg = 0; tg < TG; ++tg) {
         const int tap = tap0 + tg;
         const int jd = tap / (p.sh * p.sw), jh = (tap / p.sw) % p.sh, jw = tap % p.sw;     // uniform: scalar unit
-        toff[tg] = (unsigned)(((jd * Ho + jh) * Wo + jw) * p.Cout);
+        toff[tg] = (unsigned)((jd * Ho + jh) * Wo + jw) * ovs;
     }
     const float rcp_wi = 1.0f / (float)p.Wi, rcp_hi = 1.0f / (float)p.Hi;
 #pragma unroll
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void tconv_mfma_kernel(const TconvParams p)
         if (v >= vox_in) continue;
         const int row = recip_div(v, p.Wi, rcp_wi), iw = v - (int)__umul24(row, p.Wi);
         const int id = recip_div(row, p.Hi, rcp_hi), ih = row - (int)__umul24(id, p.Hi);
-        const unsigned ob = ((unsigned)(id * p.sd * Ho + ih * p.sh) * (unsigned)Wo + (unsigned)(iw * p.sw)) * (unsigned)p.Cout;
+        const unsigned ob = ((unsigned)(id * p.sd * Ho + ih * p.sh) * (unsigned)Wo + (unsigned)(iw * p.sw)) * ovs;
 #pragma unroll
         for (int tg = 0; tg < TG; ++tg) {
             const unsigned ov = ob + toff[tg];
@@ -284,9 +289,9 @@ __global__ __launch_bounds__(256, 2) void tconv_mfma_kernel(const TconvParams p)
             if constexpr (NBT == 2) {
                 // the two cout blocks of a voxel as ONE 16-byte store per lane (pair_to_b128: lane (r, q) then holds channels
                 // 8 (q >> 1) .. + 7 of block q & 1): 64 contiguous bytes per voxel and instruction instead of 2 x 32
-                *(fnn_u32x4r *)(p.out + (size_t)n * p.Di * p.sd * Ho * Wo * p.Cout + cb0 * 16 + ov + (q & 1) * 16 + (q >> 1) * 8) = pair_to_b128(o[0], o[1]);
+                *(fnn_u32x4r *)(outi + (cb0 + (q & 1)) * ocs + ov + (q >> 1) * 8) = pair_to_b128(o[0], o[1]);
             } else {
-                *(f16x4 *)(outn + ov) = o[0];
+                *(f16x4 *)(outi + cb0 * ocs + ov + q * 4) = o[0];
             }
         }
     }
