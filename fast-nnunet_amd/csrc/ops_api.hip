@@ -27,7 +27,11 @@ struct DevBuf {
 };
 
 // NCDHW fp32 -> NDHWC fp16 with channel padding; also the per-(n,c) statistics of the rounded values
-void to_ndhwc(const float *x, int n, int c, int cp, size_t vox, std::vector<uint16_t> &out, std::vector<double> *stats) {
+// FNN_OP_CHUNK_MAJOR=1 (next to FNN_KNOBS=1; read per call): tensors of more than 16 channels travel chunk-major
+// ([C / 16][voxels][16]; fnn_device.h, SrcDesc) through the conv / transposed-conv ops, as in the engine
+bool op_chunk_major(int cp) { const char *v = fnn_knob("FNN_OP_CHUNK_MAJOR"); return v && v[0] != '0' && cp > 16; }
+
+void to_ndhwc(const float *x, int n, int c, int cp, size_t vox, std::vector<uint16_t> &out, std::vector<double> *stats, bool cm = false) {
     out.assign((size_t)n * vox * cp, 0);
     if (stats) stats->assign((size_t)n * FNN_STAT_REPL * cp * 2, 0.0);
     for (int b = 0; b < n; ++b)
@@ -36,7 +40,7 @@ void to_ndhwc(const float *x, int n, int c, int cp, size_t vox, std::vector<uint
             const float *src = x + ((size_t)b * c + ch) * vox;
             for (size_t v = 0; v < vox; ++v) {
                 const uint16_t hb = f2h_bits(src[v]);
-                out[((size_t)b * vox + v) * cp + ch] = hb;
+                out[cm ? ((size_t)b * cp / 16 + ch / 16) * vox * 16 + v * 16 + ch % 16 : ((size_t)b * vox + v) * cp + ch] = hb;
                 const double f = h2f_bits(hb);
                 s1 += f; s2 += f * f;
             }
@@ -54,14 +58,17 @@ struct SrcHolder {
     SrcDesc d{};
 };
 
-bool make_src(SrcHolder &h, const float *x, int n, int c, size_t vox, const float *gamma, const float *beta, float slope) {
+bool make_src(SrcHolder &h, const float *x, int n, int c, size_t vox, const float *gamma, const float *beta, float slope,
+              bool layout_aware = false) {
     const int cp = pad16(c);
     std::vector<uint16_t> a;
     std::vector<double> st;
-    to_ndhwc(x, n, c, cp, vox, a, gamma ? &st : nullptr);
+    const bool cm = layout_aware && op_chunk_major(cp);
+    to_ndhwc(x, n, c, cp, vox, a, gamma ? &st : nullptr, cm);
     if (!h.act.alloc(a.size() * 2)) return false;
     if (hipMemcpy(h.act.p, a.data(), a.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return false;
     h.d.ptr = h.act.as<f16>(); h.d.C = cp; h.d.slope = 1.f;
+    if (cm) { h.d.vs = 16; h.d.cs = 16LL * (long long)vox; }
     if (gamma) {
         std::vector<float> g(cp, 0.f), b(cp, 0.f);
         for (int i = 0; i < c; ++i) { g[i] = gamma[i]; b[i] = beta ? beta[i] : 0.f; }
@@ -95,8 +102,8 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
     const size_t vox = (size_t)dims[0] * dims[1] * dims[2];
     const int nsrc = x2 ? 2 : 1;
     SrcHolder s1, s2;
-    if (!make_src(s1, x, n, cin, vox, gamma1, beta1, slope1)) return FNN_E_HIP;
-    if (x2 && !make_src(s2, x2, n, cin2, vox, gamma2, beta2, slope2)) return FNN_E_HIP;
+    if (!make_src(s1, x, n, cin, vox, gamma1, beta1, slope1, true)) return FNN_E_HIP;
+    if (x2 && !make_src(s2, x2, n, cin2, vox, gamma2, beta2, slope2, true)) return FNN_E_HIP;
     const int cp1 = pad16(cin), cp2 = x2 ? pad16(cin2) : 0, cop = pad16(cout);
     const int T = k[0] * k[1] * k[2], cin_tot = cin + (x2 ? cin2 : 0);
     ConvParams p{};
@@ -140,6 +147,8 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
     (void)hipMemset(dst.p, 0, (size_t)n * slots * cop * 16);
     (void)hipMemset(dout.p, 0, (size_t)n * ovox * cop * 2);
     p.wpk = dw.as<f16>(); p.bias = db.as<float>(); p.out = dout.as<f16>(); p.stats_out = dst.as<double>();
+    const bool ocm = op_chunk_major(cop);
+    if (ocm) { p.out_vs = 16; p.out_cs = 16LL * (long long)ovox; }
 #ifdef FNN_STAMPS
     DevBuf ddbg;
     const size_t dbg_n = (size_t)1 << 20;
@@ -203,7 +212,9 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
     (void)hipMemcpy(hs.data(), dst.p, hs.size() * 8, hipMemcpyDeviceToHost);
     for (int b = 0; b < n; ++b)
         for (int co = 0; co < cout; ++co) {
-            for (size_t v = 0; v < ovox; ++v) y[((size_t)b * cout + co) * ovox + v] = h2f_bits(ho[((size_t)b * ovox + v) * cop + co]);
+            for (size_t v = 0; v < ovox; ++v)
+                y[((size_t)b * cout + co) * ovox + v] =
+                    h2f_bits(ho[ocm ? ((size_t)b * cop / 16 + co / 16) * ovox * 16 + v * 16 + co % 16 : ((size_t)b * ovox + v) * cop + co]);
             if (stats_out) {
                 double a = 0, q = 0;
                 for (size_t r = 0; r < slots; ++r) {
@@ -224,7 +235,7 @@ int fnn_op_conv_transpose3d(int device, int n, const int dims[3],
     if (hipSetDevice(device) != hipSuccess) return FNN_E_HIP;
     const size_t vox = (size_t)dims[0] * dims[1] * dims[2];
     SrcHolder s1;
-    if (!make_src(s1, x, n, cin, vox, gamma1, beta1, slope1)) return FNN_E_HIP;
+    if (!make_src(s1, x, n, cin, vox, gamma1, beta1, slope1, true)) return FNN_E_HIP;
     const int cp = pad16(cin), cop = pad16(cout);
     const int taps = stride[0] * stride[1] * stride[2];
     TconvParams p{};
@@ -251,13 +262,17 @@ int fnn_op_conv_transpose3d(int device, int n, const int dims[3],
     (void)hipMemcpy(db.p, bp.data(), cop * 4, hipMemcpyHostToDevice);
     (void)hipMemset(dout.p, 0, (size_t)n * ovox * cop * 2);
     p.wpk = dw.as<f16>(); p.bias = db.as<float>(); p.out = dout.as<f16>();
+    const bool ocm = op_chunk_major(cop);
+    if (ocm) { p.out_vs = 16; p.out_cs = 16LL * (long long)ovox; }
     if (launch_tconv(p, 0) != 0) return FNN_E_HIP;
     if (hipDeviceSynchronize() != hipSuccess) return FNN_E_HIP;
     std::vector<uint16_t> ho((size_t)n * ovox * cop);
     (void)hipMemcpy(ho.data(), dout.p, ho.size() * 2, hipMemcpyDeviceToHost);
     for (int b = 0; b < n; ++b)
         for (int co = 0; co < cout; ++co)
-            for (size_t v = 0; v < ovox; ++v) y[((size_t)b * cout + co) * ovox + v] = h2f_bits(ho[((size_t)b * ovox + v) * cop + co]);
+            for (size_t v = 0; v < ovox; ++v)
+                y[((size_t)b * cout + co) * ovox + v] =
+                    h2f_bits(ho[ocm ? ((size_t)b * cop / 16 + co / 16) * ovox * 16 + v * 16 + co % 16 : ((size_t)b * ovox + v) * cop + co]);
     return 0;
 }
 

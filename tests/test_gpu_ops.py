@@ -375,3 +375,22 @@ def test_conv3d_zr_whole_plane_operand_map_with_exact_integers():
         w[co, (co * 3 + 1) % c, (co + 2) % 3, (co + 1) % 3, co % 3] += 2.0
     y = capi.op_conv3d(x.numpy(), w.numpy(), None, (3, 3, 3), (1, 1, 1))
     assert np.array_equal(y, F.conv3d(x, w, None, 1, 1).numpy())
+
+
+# ----------------------------------------------------------------------------------------------- chunk-major layout
+def test_conv_ops_with_chunk_major_tensors(monkeypatch):
+    """Tensors of more than 16 channels stored [C / 16][voxels][16] (fnn_device.h, SrcDesc: the engine's layout between
+    conv kernels) on both sides of every conv kernel family - generic, LDS-pipelined, persistent, ZR (8 x 8 x 8,
+    whole-plane, depth-shift strided and its persistent form), stride-2 grouped, two sources - and of the transposed
+    conv: the same cases as above, repacked by the op wrapper (FNN_OP_CHUNK_MAJOR=1)."""
+    monkeypatch.setenv('FNN_OP_CHUNK_MAJOR', '1')
+    for case in (CONV_CASES[1], CONV_CASES[5], CONV_CASES[6], CONV_CASES[7], CONV_CASES[8], CONV_CASES[11], CONV_CASES[12], CONV_CASES[15]):
+        test_conv3d_identity_input(*case)
+    test_conv3d_with_fused_instancenorm_lrelu_on_load(*CONV_CASES[5])
+    test_conv3d_zr_variants(*ZR_CASES[-1])
+    test_conv3d_zr_two_sources()
+    test_conv3d_zr_whole_plane_tiles(16, 48, 64, (21, 11, 9))
+    test_conv3d_stride2_grouped_kernel(64, 128)
+    test_conv3d_persistent_depth_shift_kernel_with_two_cout_groups()
+    for case in TCONV_CASES[:3] + TCONV_CASES[4:]:
+        test_conv_transpose3d(*case)
