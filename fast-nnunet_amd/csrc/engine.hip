@@ -353,6 +353,7 @@ int build_plan(fnn_engine *e) {
     // activation layouts: a tensor of more than 16 channels that only conv / transposed-conv kernels read is stored
     // chunk-major, so that a consumer's 16-channel chunk is whole cache lines instead of 32 bytes of every record
     if (fnn_knob("FNN_NO_CHUNK_MAJOR") == nullptr) {
+        const int cm_min = fnn_knob("FNN_CM_MIN") ? atoi(fnn_knob("FNN_CM_MIN")) : 16;       // A-B aid: chunk-major above this many channels
         std::vector<int> ok(e->layers.size(), 1);
         for (const Layer &L : e->layers)
             for (int i = 0; i < L.n_src; ++i)
@@ -360,7 +361,7 @@ int build_plan(fnn_engine *e) {
         for (size_t li = 0; li < e->layers.size(); ++li) {
             Layer &L = e->layers[li];
             L.chunk_major = ok[li] && (int)li != e->head_src && (L.type == Layer::CONV || L.type == Layer::TCONV) &&
-                            L.cout_pad > 16 && a.spatial_dims != 2;
+                            L.cout_pad > cm_min && a.spatial_dims != 2;
         }
     }
 
