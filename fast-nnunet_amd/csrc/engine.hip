@@ -357,10 +357,12 @@ int build_plan(fnn_engine *e) {
         std::vector<int> ok(e->layers.size(), 1);
         for (const Layer &L : e->layers)
             for (int i = 0; i < L.n_src; ++i)
-                if (L.src_layer[i] >= 0 && L.type != Layer::CONV && L.type != Layer::TCONV) ok[L.src_layer[i]] = 0;
+                if (L.src_layer[i] >= 0 && L.type != Layer::CONV && L.type != Layer::TCONV && L.type != Layer::POOL &&
+                    L.type != Layer::COMBINE) ok[L.src_layer[i]] = 0;
         for (size_t li = 0; li < e->layers.size(); ++li) {
             Layer &L = e->layers[li];
-            L.chunk_major = ok[li] && (int)li != e->head_src && (L.type == Layer::CONV || L.type == Layer::TCONV) &&
+            L.chunk_major = ok[li] && (int)li != e->head_src &&
+                            (L.type == Layer::CONV || L.type == Layer::TCONV || L.type == Layer::POOL || L.type == Layer::COMBINE) &&
                             L.cout_pad > cm_min && a.spatial_dims != 2;
         }
     }
@@ -674,6 +676,7 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.N = nb; p.Di = L.in_dims[0]; p.Hi = L.in_dims[1]; p.Wi = L.in_dims[2];
             p.sd = L.s[0]; p.sh = L.s[1]; p.sw = L.s[2];
             p.out = out;
+            if (L.chunk_major) { p.out_vs = 16; p.out_cs = 16LL * L.out_dims[0] * L.out_dims[1] * L.out_dims[2]; }
             Scope sc(e, st, FAM_TCONV, 0);
             rc = launch_avgpool(p, st);
         } else if (L.type == Layer::COMBINE) {
@@ -682,6 +685,7 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.b = make_src(e, fw, L.src_layer[1], nb);
             p.vox = (long long)L.out_dims[0] * L.out_dims[1] * L.out_dims[2];
             p.N = nb; p.slope = e->arch.slope; p.out = out;
+            if (L.chunk_major) { p.out_vs = 16; p.out_cs = 16LL * p.vox; }
             Scope sc(e, st, FAM_TCONV, 0);
             rc = launch_combine(p, st);
         } else {

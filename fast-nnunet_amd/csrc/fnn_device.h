@@ -275,7 +275,9 @@ struct PoolParams {
     SrcDesc src;                 // [N][Di][Hi][Wi][C] with its on-load transform
     int N, Di, Hi, Wi;
     int sd, sh, sw;              // AvgPool3d(kernel = stride)
-    f16 *out;                    // [N][Di/sd][Hi/sh][Wi/sw][C], final values
+    f16 *out;                    // [N][Di/sd][Hi/sh][Wi/sw][C], final values; or chunk-major (out_vs, out_cs; 0 = channels-last)
+    int out_vs;
+    long long out_cs;
 };
 
 struct CombineParams {
@@ -284,7 +286,9 @@ struct CombineParams {
     long long vox;               // voxels per batch item
     int N;
     float slope;                 // LeakyReLU slope of the block output
-    f16 *out;                    // [N][vox][C], final values
+    f16 *out;                    // [N][vox][C], final values; or chunk-major (out_vs, out_cs; 0 = channels-last)
+    int out_vs;
+    long long out_cs;
 };
 
 struct StatsFinalizeParams {

@@ -132,29 +132,45 @@ static __device__ __forceinline__ void apply8(const SrcDesc &s, int n, int c0, c
     }
 }
 
-// skip path of a strided block: AvgPool3d(stride, stride) of the (transformed) block input
+// skip path of a strided block: AvgPool3d(stride, stride) of the (transformed) block input.  Thread -> (voxel, 8-channel
+// group): the group runs fastest for a channels-last output, the voxel (inside a 16-channel chunk) for a chunk-major
+// one, so that a wave's stores are contiguous either way; element addresses by the one formula of fnn_device.h.
 __global__ __launch_bounds__(256) void avgpool_kernel(const PoolParams p) {
     const int Do = p.Di / p.sd, Ho = p.Hi / p.sh, Wo = p.Wi / p.sw;
     const int cg = p.src.C >> 3;
-    const long long total = (long long)p.N * Do * Ho * Wo * cg;
+    const long long ovox = (long long)Do * Ho * Wo;
+    const long long total = (long long)p.N * ovox * cg;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int g = (int)(i % cg);
-    long long v = i / cg;
-    const int ow = (int)(v % Wo); v /= Wo;
-    const int oh = (int)(v % Ho); v /= Ho;
-    const int od = (int)(v % Do);
-    const int n = (int)(v / Do);
+    int g, n;
+    long long v;                                                          // output voxel inside item n
+    if (p.out_vs) {                                                       // chunk-major: (n, chunk, voxel, half)
+        const int half = (int)(i & 1);
+        long long t = i >> 1;
+        v = t % ovox; t /= ovox;
+        const int chunk = (int)(t % (cg >> 1));
+        n = (int)(t / (cg >> 1));
+        g = chunk * 2 + half;
+    } else {
+        g = (int)(i % cg);
+        const long long t = i / cg;
+        v = t % ovox;
+        n = (int)(t / ovox);
+    }
+    const int ow = (int)(v % Wo), oh = (int)((v / Wo) % Ho), od = (int)(v / ((long long)Wo * Ho));
+    const int c0 = g * 8;
+    const f16 *srcn = p.src.ptr + (size_t)n * p.Di * p.Hi * p.Wi * p.src.C + (c0 >> 4) * FNN_CS(p.src) + (c0 & 15);
+    const int vs = FNN_VS(p.src);
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     for (int a = 0; a < p.sd; ++a)
         for (int b = 0; b < p.sh; ++b)
             for (int c = 0; c < p.sw; ++c) {
-                const size_t vin = (((size_t)n * p.Di + od * p.sd + a) * p.Hi + oh * p.sh + b) * p.Wi + ow * p.sw + c;
-                const f16x8 x = *(const f16x8 *)(p.src.ptr + vin * p.src.C + g * 8);
+                const size_t vin = (((size_t)od * p.sd + a) * p.Hi + oh * p.sh + b) * p.Wi + ow * p.sw + c;
+                const f16x8 x = *(const f16x8 *)(srcn + vin * vs);
                 float y[8];
-                apply8(p.src, n, g * 8, x, y);
+                apply8(p.src, n, c0, x, y);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += y[j];
             }
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const PoolParams p) {
     f16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (f16)(acc[j] * inv);
-    *(f16x8 *)(p.out + ((((size_t)n * Do + od) * Ho + oh) * Wo + ow) * p.src.C + g * 8) = o;
+    *(f16x8 *)(p.out + (size_t)n * ovox * p.src.C + (size_t)v * (p.out_vs ? p.out_vs : p.src.C) + (c0 >> 4) * (p.out_vs ? p.out_cs : 16LL) + (c0 & 15)) = o;
 }
 
 int launch_avgpool(const PoolParams &p, hipStream_t st) {
@@ -171,24 +187,39 @@ int launch_avgpool(const PoolParams &p, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-// y = LeakyReLU(T_a(a) + T_b(b)): the closing add of a residual block, stored as final values
+// y = LeakyReLU(T_a(a) + T_b(b)): the closing add of a residual block, stored as final values (thread mapping and
+// addresses as in avgpool_kernel: either layout on every operand)
 __global__ __launch_bounds__(256) void combine_kernel(const CombineParams p) {
     const int cg = p.a.C >> 3;
     const long long total = (long long)p.N * p.vox * cg;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int g = (int)(i % cg);
-    const long long v = i / cg;
-    const int n = (int)(v / p.vox);
-    const f16x8 xa = *(const f16x8 *)(p.a.ptr + (size_t)v * p.a.C + g * 8);
-    const f16x8 xb = *(const f16x8 *)(p.b.ptr + (size_t)v * p.b.C + g * 8);
+    int g, n;
+    long long v;
+    if (p.out_vs) {
+        const int half = (int)(i & 1);
+        long long t = i >> 1;
+        v = t % p.vox; t /= p.vox;
+        const int chunk = (int)(t % (cg >> 1));
+        n = (int)(t / (cg >> 1));
+        g = chunk * 2 + half;
+    } else {
+        g = (int)(i % cg);
+        const long long t = i / cg;
+        v = t % p.vox;
+        n = (int)(t / p.vox);
+    }
+    const int c0 = g * 8;
+    const size_t item = (size_t)n * p.vox * p.a.C;
+    const f16x8 xa = *(const f16x8 *)(p.a.ptr + item + (size_t)v * FNN_VS(p.a) + (c0 >> 4) * FNN_CS(p.a) + (c0 & 15));
+    const f16x8 xb = *(const f16x8 *)(p.b.ptr + item + (size_t)v * FNN_VS(p.b) + (c0 >> 4) * FNN_CS(p.b) + (c0 & 15));
     float ya[8], yb[8];
-    apply8(p.a, n, g * 8, xa, ya);
-    apply8(p.b, n, g * 8, xb, yb);
+    apply8(p.a, n, c0, xa, ya);
+    apply8(p.b, n, c0, xb, yb);
     f16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (f16)leaky(ya[j] + yb[j], p.slope);
-    *(f16x8 *)(p.out + (size_t)v * p.a.C + g * 8) = o;
+    *(f16x8 *)(p.out + item + (size_t)v * (p.out_vs ? p.out_vs : p.a.C) + (c0 >> 4) * (p.out_vs ? p.out_cs : 16LL) + (c0 & 15)) = o;
 }
 
 int launch_combine(const CombineParams &p, hipStream_t st) {
