@@ -63,7 +63,7 @@ class Profile(C.Structure):
 EXPORTS = ['fnn_abi_version', 'fnn_last_error', 'fnn_create', 'fnn_destroy', 'fnn_weight_count', 'fnn_load_weights',
            'fnn_set_gaussian', 'fnn_predict_volume', 'fnn_predict_volume_ensemble', 'fnn_predict_labels',
            'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_labels_box', 'fnn_feature_channels', 'fnn_patch_features', 'fnn_gather_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_export_probabilities', 'fnn_resample', 'fnn_compute_steps', 'fnn_plan_volume', 'fnn_fp8_e4m3_encode',
-           'fnn_set_profiling', 'fnn_get_profile', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d']
+           'fnn_set_profiling', 'fnn_get_profile', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d', 'fnn_op_quotient_check']
 
 _lib = None
 
@@ -126,6 +126,7 @@ def load_library() -> C.CDLL:
     lib.fnn_op_conv3d.argtypes = [i32, i32, I3, f32p, i32, f32p, f32p, C.c_float, f32p, i32, f32p, f32p, C.c_float,
                                   f32p, f32p, i32, I3, I3, f32p, C.POINTER(C.c_double)]
     lib.fnn_op_conv_transpose3d.argtypes = [i32, i32, I3, f32p, i32, f32p, f32p, C.c_float, f32p, f32p, i32, I3, f32p]
+    lib.fnn_op_quotient_check.argtypes = [i32, C.POINTER(C.c_uint64)]
     if lib.fnn_abi_version() != 2:
         raise EngineError('libfnn_hip.so has an unexpected ABI version')
     _lib = lib
@@ -273,6 +274,14 @@ def op_conv_transpose3d(x, w, bias, stride, gamma=None, beta=None, slope=1.0, de
                                      _f32p(w), _f32p(bias), cout, ss, _f32p(y))
     check(rc, lib)
     return y
+
+
+def op_quotient_check(device=0):
+    """(differing pairs, pairs on the fast route, (a bits, b bits) of one differing pair) of the gather epilogue's quotient over all fp16 a, b >= +0."""
+    lib = load_library()
+    counts = (C.c_uint64 * 3)()
+    check(lib.fnn_op_quotient_check(device, counts), lib)
+    return int(counts[0]), int(counts[1]), (int(counts[2]) & 0xFFFF, int(counts[2]) >> 16)
 
 
 class Engine:

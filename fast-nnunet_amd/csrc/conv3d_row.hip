@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, CH == 1 ? (NBLK <= 8 ? 3 : 2) : (NBLK <= 8 ? 2
 // border.  Arithmetic: x and the weights rounded to fp16, fp32 accumulation, bias, one rounding - as stem_mfma_kernel
 // (whose k order differs: the fp32 sums can differ in their last bit).  Statistics: one row per (plane, strip).
 template <int NBLK>
-__global__ __launch_bounds__(256, 4) void stem_row_kernel(const StemParams p, const int total_units, const int strips,
+__global__ __launch_bounds__(256, 8) void stem_row_kernel(const StemParams p, const int total_units, const int strips,
                                                            const int SH, const int slots) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int W = 16 * NBLK, PB = W * 8, RINGB = 12 * PB;
@@ -613,7 +613,8 @@ int launch_stem_row(const StemParams &p, int N, hipStream_t st) {
     const int strips = pick_strips(p.PH, SH);
     const int total = N * p.PD * strips, slots = stem_mfma_stats_slots(p.PD, p.PH, p.PW);
     const size_t lds = (size_t)12 * p.PW * 8 + 4 * 16 * 2 * 4;
-    int gx = 256 * 4;
+    static const int wpc = fnn_knob("FNN_STEM_WPC") ? atoi(fnn_knob("FNN_STEM_WPC")) : 8;          // A-B aid: workgroups per CU
+    int gx = 256 * wpc;
     if (gx > total) gx = total;
     switch (p.PW) {
         case 64: hipLaunchKernelGGL(stem_row_kernel<4>, dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots); break;

@@ -201,6 +201,7 @@ struct GatherParams {
     int label_u16;
     const int *order;            // regions_class_order or nullptr (argmax)
     int *inf_flag;
+    int ieee_div;                    // A-B aid (FNN_GATHER_IEEE): IEEE division per value in the epilogue
 };
 
 struct FinalizeParams {
@@ -324,6 +325,7 @@ int stem_mfma_ksteps(int C, int taps);
 int launch_stem_mfma(const StemParams &p, const f16 *wfrag, int N, hipStream_t st);    // p.out == nullptr: statistics only
 bool gather_ok(const GatherParams &p);
 int launch_gather(const GatherParams &p, hipStream_t st);
+int launch_quotient_check(unsigned long long *counts, hipStream_t st);   // counts[0] = differing pairs, [1] = pairs on the fast route, [2] = an example
 bool conv_thin_ok(const ThinParams &tp);
 int launch_conv_thin(const ThinParams &tp, hipStream_t st);
 bool conv_row_ok(const ThinParams &tp);                                 // conv3d_row.hip: tp.fuse = 0 or FUSE_TCONV

@@ -47,6 +47,35 @@ static __device__ __forceinline__ f16x2 add_h2(f16x2 a, f16x2 b) {
 }
 static __device__ __forceinline__ f16x2 round_h2(float a, float b) { f16x2 r; r[0] = (f16)a; r[1] = (f16)b; return r; }
 
+// The closing division (predict_from_raw_data.py:619: predicted_logits /= n_predictions, half tensors: torch divides in
+// fp32 and rounds the quotient to fp16).  IEEE division costs 11 instructions and a quarter-rate v_rcp_f32 per value,
+// and the 64 values of a lane share their divisor: the reciprocal is taken ONCE per 16 voxels (v_rcp_f32 + one Newton
+// step = the correctly rounded reciprocal) and a value costs q0 = a y and two rounds of r = a - b q, q += r y
+// (Markstein's correction; ONE round is a unit of fp32 off often enough to flip the fp16 rounding of 3900 pairs where
+// the quotient sits on an fp16 tie).  For fp16-valued a and b > 0 rounding q to fp16 gives the bits of the IEEE route - checked over ALL
+// 2^16 x 2^15 pairs by quotient_check_kernel below (tests/test_gpu_ops.py) - apart from the sign of a zero, copied
+// from a afterwards, and non-finite a or b = 0 / inf / NaN, which leave q NaN: any q that is not |q| < 65520 (fp16
+// infinity's rounding boundary) sends the group down the IEEE route, which then also raises the reference's inf flag.
+static __device__ __forceinline__ float quot_rcp(float b) {
+#pragma clang fp contract(off)
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y0, 1.f);
+    return __builtin_fmaf(e, y0, y0);
+}
+static __device__ __forceinline__ float quot_fast(float a, float b, float y) {
+#pragma clang fp contract(off)
+    const float q0 = a * y;
+    const float r0 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(r0, y, q0);
+    const float r1 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(r1, y, q1);
+}
+static __device__ __forceinline__ bool quot_odd(float q) { return !(__builtin_fabsf(q) < 65520.f); }
+static __device__ __forceinline__ f16x2 quot_sign(f16x2 q, f16x2 a) {          // magnitude of q, sign of a
+    const unsigned r = (__builtin_bit_cast(unsigned, q) & 0x7FFF7FFFu) | (__builtin_bit_cast(unsigned, a) & 0x80008000u);
+    return __builtin_bit_cast(f16x2, r);
+}
+
 struct Pick {                                                  // LabelPick of misc.hip over this lane's heads, mergeable
     float best; int arg; int nan; int hit;
 };
@@ -257,27 +286,40 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? 4 : 1) void gather_head_
     bool bad = false;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        f32x4 v4[HB];
-#pragma unroll
-        for (int hb = 0; hb < HB; ++hb)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v4[hb][j] = PKS ? (float)ah[PKS ? g : 0][hb][j >> 1][j & 1] : acc[g][hb][j];
+        const auto sum_of = [&](int hb, int j) -> float { return PKS ? (float)ah[PKS ? g : 0][hb][j >> 1][j & 1] : acc[g][hb][j]; };
         float wsum = 0.f;
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (hb == whb && j == wj) wsum = v4[hb][j];
+            for (int j = 0; j < 4; ++j) if (hb == whb && j == wj) wsum = sum_of(hb, j);
         wsum = __shfl(wsum, wq * 16 + r, 64);
         const bool zok = z0 + 16 * g + r < p.z_hi;
+        bool odd = true;
+        f16x2 qh[HB][2];                                       // the group's logits: heads 4q + {0,1}, {2,3} per block
+        if (PKS) {                                             // fp16-valued sums: the shared-reciprocal quotient (above)
+            const float yr = quot_rcp(wsum);
+            unsigned long long om = 0;                         // lanes with an odd quotient: compares into scalar masks
 #pragma unroll
-        for (int hb = 0; hb < HB; ++hb)
+            for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f16 rr = (f16)__fdiv_rn(v4[hb][j], wsum);
-                const int head = hb * 16 + q * 4 + j;
-                bad |= zok && head < p.heads && isinf((float)rr);
-                v4[hb][j] = (float)rr;
-            }
+                for (int e = 0; e < 2; ++e) {
+                    const float q0 = quot_fast(sum_of(hb, 2 * e), wsum, yr), q1 = quot_fast(sum_of(hb, 2 * e + 1), wsum, yr);
+                    om |= __builtin_amdgcn_ballot_w64(quot_odd(q0)) | __builtin_amdgcn_ballot_w64(quot_odd(q1));
+                    qh[hb][e] = quot_sign(round_h2(q0, q1), ah[PKS ? g : 0][hb][e]);
+                }
+            odd = om != 0 || p.ieee_div;                       // wave-uniform; never taken on finite data
+        }
+        if (odd) {
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f16 rr = (f16)__fdiv_rn(sum_of(hb, j), wsum);
+                    const int head = hb * 16 + q * 4 + j;
+                    bad |= zok && head < p.heads && isinf((float)rr);
+                    qh[hb][j >> 1][j & 1] = rr;
+                }
+        }
         if (LABELS) {
             // LabelPick (misc.hip): argmax with torch's rules - the first NaN wins, else the largest value, the lowest
             // head among equals - is a maximum under a total order, so the lane picks over ITS 16 heads (ascending: a
@@ -292,7 +334,7 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? 4 : 1) void gather_head_
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int head = hb * 16 + q * 4 + j;
-                    const float v = v4[hb][j];
+                    const float v = (float)qh[hb][j >> 1][j & 1];
                     if (head < p.heads) {
                         if (v > 0x1.8p-24f) h = head;
                         if (a < 0) { b = v; a = head; n = v != v; }
@@ -323,7 +365,7 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? 4 : 1) void gather_head_
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sT[(hb * 16 + q * 4 + j) * TP + 16 * g + r] = (f16)v4[hb][j];
+                for (int j = 0; j < 4; ++j) sT[(hb * 16 + q * 4 + j) * TP + 16 * g + r] = qh[hb][j >> 1][j & 1];
         }
     }
     if (bad) atomicOr(p.inf_flag, 1);
@@ -367,6 +409,33 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? 4 : 1) void gather_head_
     }
 }
 
+// Exhaustive check of the epilogue's quotient: every fp16 bit pattern a against every b with a clear sign bit (the
+// weight sum is a sum of non-negative products).  Counts the pairs where the shared-reciprocal route, taken the way
+// the kernel takes it (quot_odd -> IEEE), and the IEEE route differ in the fp16 bits of the result.
+__global__ __launch_bounds__(256) void quotient_check_kernel(unsigned long long *n_diff, unsigned long long *n_fast) {
+    const unsigned id = blockIdx.x * 256u + threadIdx.x;
+    const unsigned short ab = (unsigned short)(id & 0xFFFFu), bb = (unsigned short)(id >> 16);
+    const f16 ah = __builtin_bit_cast(f16, ab), bh = __builtin_bit_cast(f16, bb);
+    const float a = (float)ah, b = (float)bh;
+    const f16 ref = (f16)__fdiv_rn(a, b);
+    const float q = quot_fast(a, b, quot_rcp(b));
+    const bool odd = quot_odd(q);
+    const f16x2 fast2 = quot_sign(round_h2(q, q), (f16x2){ah, ah});
+    const unsigned short rb = __builtin_bit_cast(unsigned short, ref), fb = __builtin_bit_cast(unsigned short, (f16)fast2[0]);
+    const bool diff = !odd && rb != fb;
+    const unsigned long long md = __builtin_amdgcn_ballot_w64(diff), mf = __builtin_amdgcn_ballot_w64(!odd);
+    if (diff) atomicMax(n_diff + 2, (unsigned long long)id);           // an example for the failure message: a | b << 16
+    if ((threadIdx.x & 63) == 0) {
+        if (md) atomicAdd(n_diff, (unsigned long long)__builtin_popcountll(md));
+        if (mf) atomicAdd(n_fast, (unsigned long long)__builtin_popcountll(mf));
+    }
+}
+
+int launch_quotient_check(unsigned long long *counts, hipStream_t st) {          // counts[3], zeroed by the caller
+    hipLaunchKernelGGL(quotient_check_kernel, dim3(1u << 23), dim3(256), 0, st, counts, counts + 1);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 bool gather_ok(const GatherParams &p) {
     const int hblocks = (p.heads + 1 + 15) / 16;
     return hblocks <= 4 && p.C <= 32 && p.C % 8 == 0 && (long long)p.PD * p.PH * p.PW < (1LL << 31) / 32 && p.n_eval <= 8;
@@ -392,8 +461,10 @@ static int launch_gather_hb(const GatherParams &p, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-int launch_gather(const GatherParams &p, hipStream_t st) {
-    if (!gather_ok(p)) return -1;
+int launch_gather(const GatherParams &p0, hipStream_t st) {
+    if (!gather_ok(p0)) return -1;
+    GatherParams p = p0;
+    p.ieee_div = fnn_knob("FNN_GATHER_IEEE") != nullptr;
     const int hblocks = (p.heads + 1 + 15) / 16;
     if (p.n_eval > 1) {
         if (hblocks == 1) return launch_gather_hb<1, true>(p, st);

@@ -276,4 +276,16 @@ int fnn_op_conv_transpose3d(int device, int n, const int dims[3],
     return 0;
 }
 
+int fnn_op_quotient_check(int device, unsigned long long counts[3]) {
+    if (!counts) return FNN_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return FNN_E_HIP;
+    DevBuf d;
+    if (!d.alloc(24)) return FNN_E_HIP;
+    (void)hipMemset(d.p, 0, 24);
+    if (launch_quotient_check(d.as<unsigned long long>(), 0) != 0) return FNN_E_HIP;
+    if (hipDeviceSynchronize() != hipSuccess) return FNN_E_HIP;
+    (void)hipMemcpy(counts, d.p, 24, hipMemcpyDeviceToHost);
+    return 0;
+}
+
 }  // extern "C"

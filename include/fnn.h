@@ -347,6 +347,13 @@ int fnn_op_conv_transpose3d(int device, int n, const int dims[3],
                             const float *x, int cin, const float *gamma1, const float *beta1, float slope1,
                             const float *w, const float *bias, int cout, const int stride[3], float *y);
 
+/* Self-check of the closing division of the seg-head gather (predicted_logits /= n_predictions,
+ * predict_from_raw_data.py:619): runs the kernel's shared-reciprocal quotient over every fp16 value a and every fp16
+ * b with a clear sign bit and counts the pairs whose fp16 result differs from IEEE fp32 division rounded to fp16
+ * (counts[0], must be 0), the pairs that took the fast route at all (counts[1]) and one differing pair as
+ * a_bits | b_bits << 16 (counts[2], 0 when there is none). */
+int fnn_op_quotient_check(int device, unsigned long long counts[3]);
+
 #ifdef __cplusplus
 }
 #endif

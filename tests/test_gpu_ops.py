@@ -394,3 +394,15 @@ def test_conv_ops_with_chunk_major_tensors(monkeypatch):
     test_conv3d_persistent_depth_shift_kernel_with_two_cout_groups()
     for case in TCONV_CASES[:3] + TCONV_CASES[4:]:
         test_conv_transpose3d(*case)
+
+
+def test_gather_quotient_matches_ieee_division_on_every_fp16_pair():
+    """The seg-head gather divides by the weight sum through one shared reciprocal per 16 voxels
+    (gather.hip: quot_rcp / quot_fast) instead of IEEE division per value (predict_from_raw_data.py:619:
+    predicted_logits /= n_predictions on half tensors).  Exhaustive: all 2^16 sums x all 2^15 non-negative
+    weight sums - the fp16 bits must be those of fp32 division rounded to fp16 wherever the fast route is taken."""
+    from fast_nnunet_amd import capi
+    diff, fast, example = capi.op_quotient_check()
+    assert diff == 0, f'{diff} pairs differ, e.g. a = {example[0]:#06x}, b = {example[1]:#06x}'
+    # finite a, finite b > 0 whose quotient stays below fp16's overflow boundary: ~1.78e9 of the 2^31 pairs
+    assert 1.7e9 < fast < 1.85e9
