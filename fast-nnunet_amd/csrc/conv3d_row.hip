@@ -347,9 +347,10 @@ __global__ __launch_bounds__(256, CH == 1 ? (NBLK <= 8 ? 3 : 2) : (NBLK <= 8 ? 2
 // entries of rows h - 1 and h (lane quarter 0), k = 8 .. 11 = the entry of row h + 1 (quarter 1), the remaining k
 // carry zero weights - and ONE MFMA per 16 voxels.  A raw value is written into the three entries it belongs to
 // (ds_write_b16); x[-1], x[W] and the fourth slot stay zero from the start: the conv's zero padding at the PATCH
-// border.  Arithmetic: x and the weights rounded to fp16, fp32 accumulation, bias, one rounding - as stem_mfma_kernel
-// (whose k order differs: the fp32 sums can differ in their last bit).  Statistics: one row per (plane, strip).
-template <int NBLK>
+// border.  Arithmetic: x and the weights rounded to fp16, fp32 accumulation on top of the bias (the MFMA's C operand),
+// one rounding - as stem_mfma_kernel up to the order of the fp32 sums (their last bit can differ).  Statistics: one row
+// per (plane, strip).  STORE = false: the statistics pass in front of conv_row_stem_kernel (p.out == nullptr).
+template <int NBLK, bool STORE>
 __global__ __launch_bounds__(256, 8) void stem_row_kernel(const StemParams p, const int total_units, const int strips,
                                                            const int SH, const int slots) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256, 8) void stem_row_kernel(const StemParams p, co
             for (int t = 6; t < 9; ++t) wf[t - 6] = (f16)p.w[(size_t)t * p.Cout + m];
         }
     }
-    const float4 bv = *(const float4 *)(p.bias + q * 4);
+    const f32x4 bv = *(const f32x4 *)(p.bias + q * 4);
     // staging: element e = tid + 256 u = (row i of the group, column w)
     int e_row[PF], e_col[PF];
 #pragma unroll
@@ -401,9 +402,13 @@ __global__ __launch_bounds__(256, 8) void stem_row_kernel(const StemParams p, co
     }
     float xr[PF];
     const float *voln0 = p.vol;
+    // the patch origin is re-read only when the batch item changes: the load is a VECTOR memory load (the kernel stores
+    // to global memory, so hipcc will not use the scalar cache for it) whose wait would drain the loads and stores in
+    // flight once per step
+    int n_org = -1, ox = 0, oy = 0, oz = 0;
     auto issue = [&](const RowCur &c) {
         const int rbase = c.h0 - 1 + 4 * c.g;
-        const int ox = p.origins[c.n * 3 + 0], oy = p.origins[c.n * 3 + 1], oz = p.origins[c.n * 3 + 2];
+        if (c.n != n_org) { ox = p.origins[c.n * 3 + 0]; oy = p.origins[c.n * 3 + 1]; oz = p.origins[c.n * 3 + 2]; n_org = c.n; }
         const int dd = p.flip_d ? D - 1 - c.d : c.d;
         const float *plane = voln0 + (size_t)c.n * p.vol_batch_stride + (size_t)(ox + dd) * p.Y * p.Z + oz;
 #pragma unroll
@@ -414,6 +419,8 @@ __global__ __launch_bounds__(256, 8) void stem_row_kernel(const StemParams p, co
             xr[u] = plane[(size_t)(oy + hh) * p.Z + ww];
         }
     };
+    // (Measured and dropped: a thread loading the three values of its entry and writing it whole - one ds_write_b64
+    // instead of three ds_write_b16 per value, three loads instead of one: 180 -> 190 us for the statistics pass.)
     auto commit = [&](const RowCur &c, int slot) {
         const int rbase = c.h0 - 1 + 4 * c.g;
 #pragma unroll
@@ -458,10 +465,10 @@ __global__ __launch_bounds__(256, 8) void stem_row_kernel(const StemParams p, co
             for (int h = 0; h < 2; ++h) {
                 const f16x4 ea = *(const f16x4 *)(smem + va + (b + h) * 128), eb = *(const f16x4 *)(smem + vb + (b + h) * 128);
                 const f16x8 xb = {ea[0], ea[1], ea[2], ea[3], eb[0], eb[1], eb[2], eb[3]};
-                const f32x4 dd = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xb, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                o[h][0] = (f16)(dd[0] + bv.x); o[h][1] = (f16)(dd[1] + bv.y); o[h][2] = (f16)(dd[2] + bv.z); o[h][3] = (f16)(dd[3] + bv.w);
+                const f32x4 dd = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xb, bv, 0, 0, 0);          // the bias is the C operand
+                o[h][0] = (f16)dd[0]; o[h][1] = (f16)dd[1]; o[h][2] = (f16)dd[2]; o[h][3] = (f16)dd[3];
             }
-            __builtin_amdgcn_raw_buffer_store_b128(pair_to_b128(o[0], o[1]), rsrc, vbase + b * 512, 0, 0);
+            if (STORE) __builtin_amdgcn_raw_buffer_store_b128(pair_to_b128(o[0], o[1]), rsrc, vbase + b * 512, 0, 0);
             if (valid) {                                                 // uniform; no memory operation inside
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -526,6 +533,268 @@ __global__ __launch_bounds__(256, 8) void stem_row_kernel(const StemParams p, co
     }
 }
 
+// ----------------------------------------------------------------------------
+// stem + first conv: conv_row_kernel<NBLK, 1, false> whose 16-channel rows are COMPUTED, not loaded
+// ----------------------------------------------------------------------------
+// FUSE_STEM: the conv's source LeakyReLU(norm(stem(x))) is recomputed from the fp32 volume while staging - the stem's
+// raw output (32 B per voxel written by stem_row_kernel, read back here: 3 GB per 32 patches of 160 x 96 x 96) never
+// exists.  The stem's InstanceNorm statistics come from stem_row_kernel run with out == nullptr (same entry ring, same
+// k order, same MFMA: the values recomputed here are the ones it counted, bit for bit).
+// Per step: the conv's k-loop of group gi | the stem rows of group gi + 2 (wave j: row j of the group, one MFMA per
+// 16 voxels from a ring of x entries, bias, rounding, normalise, LeakyReLU, ds_write_b64 into the conv's ring) | the x
+// entries of group gi + 3 (six raw rows: the group's four and one either side, re-read per group - 4 B per voxel) |
+// the raw loads of group gi + 4.  One barrier per step.
+template <int NBLK>
+__global__ __launch_bounds__(256, NBLK <= 8 ? 3 : 2) void conv_row_stem_kernel(const ThinParams tp, const int total_units,
+                                                                                const int strips, const int SH) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ConvParams &p = tp.c;
+    constexpr int W = 16 * NBLK, PB = (W + 2) * 32, RINGB = 12 * PB;     // the conv's ring: 3 groups x 4 rows
+    constexpr int XPB = W * 8, XSLOT = 6 * XPB;                          // x entries: (x[w-1], x[w], x[w+1], 0) fp16; 2 slots x 6 rows
+    constexpr int PF = (6 * W + 255) / 256;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4, hl = lane >> 5, kh = q & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.Hi, D = p.Di, G = SH >> 2;
+    char *xring = smem + RINGB;
+    double *sRed = (double *)(smem + RINGB + 2 * XSLOT);                 // [4 waves][16][2]
+
+    int u_begin, u_end;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        const int g = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+        u_begin = (int)((long long)total_units * g / nwg);
+        u_end = (int)((long long)total_units * (g + 1) / nwg);
+    }
+    if (u_begin >= u_end) return;
+    const int n_groups = (u_end - u_begin) * (G + 1);
+    auto advance = [&](RowCur &c) {
+        if (++c.g > G) {
+            c.g = 0; c.h0 += SH;
+            if (c.h0 >= H) { c.h0 = 0; if (++c.d >= D) { c.d = 0; ++c.n; } }
+        }
+    };
+
+    // ---- one-time set-up: zero padding columns of the conv's ring, the whole x ring (its border slots stay zero)
+    if (tid < 12 * 4) {
+        const int row = tid >> 2, which = (tid >> 1) & 1, half = tid & 1;
+        *(f16x8 *)(smem + row * PB + (which ? (W + 1) * 32 : 0) + half * 16) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    for (int i = tid; i < 2 * XSLOT / 16; i += 256) ((uint4 *)xring)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 4 * 16 * 2; i += 256) sRed[i] = 0.0;
+    // conv operand reads and weights (conv_row_kernel)
+    int lanec[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        const int t = 2 * ks + hl < 9 ? 2 * ks + hl : 8;
+        const int col = r + t % 3;
+        lanec[ks] = col * 32 + ((kh ^ ((col >> 2) & 1)) * 16);
+    }
+    f16x8 wf[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) wf[ks] = *(const f16x8 *)(p.wpk + ((size_t)ks * 64 + lane) * 8);
+    const float4 bv = *(const float4 *)(p.bias + q * 4);
+    // the stem's A fragment in stem_row_kernel's k order, rebuilt from tp.fw (k = tap: lane (cout, k >> 3), element k & 7)
+    f16x8 swf = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (q == 0) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) swf[t + t / 3] = tp.fw[(size_t)r * 8 + t];
+    } else if (q == 1) {
+        swf[0] = tp.fw[(size_t)r * 8 + 6]; swf[1] = tp.fw[(size_t)r * 8 + 7]; swf[2] = tp.fw[(size_t)(16 + r) * 8];
+    }
+    const f32x4 sbv = *(const f32x4 *)(tp.fbias + q * 4);
+    const f16 sslope = (f16)tp.fslope;
+    const int st_lds = (r + 1) * 32 + (((q >> 1) ^ (((r + 1) >> 2) & 1)) * 16) + (q & 1) * 8;   // + 512 per column block: bit 2 unchanged
+    // raw staging: element e = tid + 256 u = (row i of the six, column w)
+    int e_row[PF], e_col[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int e = tid + 256 * u, i = e / W;
+        e_row[u] = i < 6 ? i : -1;
+        e_col[u] = e - i * W;
+    }
+    float xr[PF];
+    int n_org = -1, ox = 0, oy = 0, oz = 0;                              // re-read when the batch item changes (stem_row_kernel)
+    auto issue = [&](const RowCur &c) {
+        const int rbase = c.h0 - 2 + 4 * c.g;                            // raw row of element row 0
+        if (c.n != n_org) { ox = tp.origins[c.n * 3 + 0]; oy = tp.origins[c.n * 3 + 1]; oz = tp.origins[c.n * 3 + 2]; n_org = c.n; }
+        const int dd = tp.flip_d ? D - 1 - c.d : c.d;
+        const float *plane = tp.vol + (size_t)c.n * tp.vol_batch_stride + (size_t)(ox + dd) * tp.Y * tp.Z + oz;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            int row = rbase + (e_row[u] < 0 ? 0 : e_row[u]);
+            row = row < 0 ? 0 : (row >= H ? H - 1 : row);                // invalid rows: any valid address (zeroed in xcommit)
+            const int hh = tp.flip_h ? H - 1 - row : row, ww = tp.flip_w ? W - 1 - e_col[u] : e_col[u];
+            xr[u] = plane[(size_t)(oy + hh) * tp.Z + ww];
+        }
+    };
+    auto xcommit = [&](const RowCur &c, int xs) {
+        const int rbase = c.h0 - 2 + 4 * c.g;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (e_row[u] < 0) continue;
+            const int row = rbase + e_row[u];
+            const f16 v = (row < 0 || row >= H) ? (f16)0.f : (f16)xr[u];  // the stem's zero padding along h
+            char *rowp = xring + xs * XSLOT + e_row[u] * XPB;
+            const int w = e_col[u];
+            *(f16 *)(rowp + w * 8 + 2) = v;
+            if (w + 1 < W) *(f16 *)(rowp + (w + 1) * 8) = v;
+            if (w > 0) *(f16 *)(rowp + (w - 1) * 8 + 4) = v;
+        }
+    };
+    // the stem's InstanceNorm of this lane's four channels (tp.fss: [N][2][16])
+    f16x4 ssc = {0, 0, 0, 0}, ssh = {0, 0, 0, 0};
+    int n_ss = -1;
+    auto stem_rows = [&](const RowCur &c, int slot, int xs) {
+        if (c.n != n_ss) {
+            const float *qs = tp.fss + (size_t)(2 * c.n) * 16 + q * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ssc[j] = (f16)qs[j]; ssh[j] = (f16)qs[16 + j]; }
+            n_ss = c.n;
+        }
+        const int row = c.h0 - 1 + 4 * c.g + wave;                       // this wave's stem row = row `wave` of the conv's group
+        const bool ok = row >= 0 && row < H;                             // uniform: outside the patch the CONV pads with zeros
+        const char *xb0 = xring + xs * XSLOT + wave * XPB + r * 8;
+        const char *pa = xb0 + (q == 1 ? 2 * XPB : 0), *pb = xb0 + (q == 1 ? 2 * XPB : XPB);
+        char *dst = smem + (slot * 4 + wave) * PB + st_lds;
+        if (!ok) {
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) *(f16x4 *)(dst + b * 512) = (f16x4){0, 0, 0, 0};
+            return;
+        }
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            const f16x4 ea = *(const f16x4 *)(pa + b * 128), eb = *(const f16x4 *)(pb + b * 128);
+            const f16x8 xb = {ea[0], ea[1], ea[2], ea[3], eb[0], eb[1], eb[2], eb[3]};
+            const f32x4 dd = __builtin_amdgcn_mfma_f32_16x16x32_f16(swf, xb, sbv, 0, 0, 0);      // bias = the C operand: stem_row_kernel's value
+            f16x4 o = {(f16)dd[0], (f16)dd[1], (f16)dd[2], (f16)dd[3]};
+            o = o * ssc + ssh;                                           // conv_row_kernel's commit on it
+            o = __builtin_elementwise_max(o, o * sslope);
+            *(f16x4 *)(dst + b * 512) = o;
+        }
+    };
+
+    // ---- statistics and the conv step: conv_row_kernel<NBLK, 1, false>
+    double dsum[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dsum[j][0] = 0.0; dsum[j][1] = 0.0; }
+    auto flush_stats = [&](int n) {
+        if (!p.stats_out) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double a = row16_sum_f64(dsum[j][0]), b = row16_sum_f64(dsum[j][1]);
+            if (r == 0) { double *slot = sRed + (wave * 16 + q * 4 + j) * 2; slot[0] = a; slot[1] = b; }
+            dsum[j][0] = 0.0; dsum[j][1] = 0.0;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int c = tid >> 1, which = tid & 1;
+            double v = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { v += sRed[(w * 16 + c) * 2 + which]; sRed[(w * 16 + c) * 2 + which] = 0.0; }
+            unsafeAtomicAdd(p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout + c) * 2 + which, v);
+        }
+        __syncthreads();
+    };
+    const unsigned out_lane = (unsigned)((r + 16 * (q & 1)) * 32 + (q >> 1) * 16);
+    const f16x2 ones = {(f16)1.f, (f16)1.f};
+    // The k-loop is skipped for a unit's tail group, the STORES are not (sent beyond num_records, the hardware drops
+    // them): with the stores inside the branch hipcc's waitcnt pass does not know how many are in flight, and xcommit,
+    // whose loads are older than the step's stores, waits for vmcnt(0) - the store acknowledgements - once per step.
+    const unsigned item_bytes = (unsigned)D * H * W * 32;
+    auto step = [&](const RowCur &c, int slot, const bool valid) {
+        const int slot1 = slot == 2 ? 0 : slot + 1;
+        f16x4 o[NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) o[b] = (f16x4){0, 0, 0, 0};
+      if (valid) {
+        f32x4 acc[NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int ro[3];
+#pragma unroll
+        for (int tr = 0; tr < 3; ++tr) {
+            const int wi = wave + tr;
+            ro[tr] = (wi < 4 ? slot * 4 + wi : slot1 * 4 + wi - 4) * PB;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+            const int vo = lanec[ks] + (ks == 1 ? (hl ? ro[1] : ro[0]) : ro[ks == 0 ? 0 : ks == 2 ? 1 : 2]);
+            constexpr int BG = NBLK <= 8 ? NBLK : NBLK / 2;
+#pragma unroll
+            for (int b0 = 0; b0 < NBLK; b0 += BG) {
+                f16x8 xf[BG];
+#pragma unroll
+                for (int b = 0; b < BG; ++b) xf[b] = *(const f16x8 *)(smem + vo + (b0 + b) * 512);
+#pragma unroll
+                for (int b = 0; b < BG; ++b) acc[b0 + b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks], xf[b], acc[b0 + b], 0, 0, 0);
+            }
+        }
+        float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < NBLK; b += 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                o[b + h][0] = (f16)(acc[b + h][0] + bv.x);
+                o[b + h][1] = (f16)(acc[b + h][1] + bv.y);
+                o[b + h][2] = (f16)(acc[b + h][2] + bv.z);
+                o[b + h][3] = (f16)(acc[b + h][3] + bv.w);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f16x2 pr = {o[b][j], o[b + 1][j]};
+                t1[j] = __builtin_amdgcn_fdot2(pr, ones, t1[j], false);
+                t2[j] = __builtin_amdgcn_fdot2(pr, pr, t2[j], false);
+            }
+        }
+        if (p.stats_out) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dsum[j][0] += (double)t1[j]; dsum[j][1] += (double)t2[j]; }
+        }
+      }
+        const int orow = c.h0 + 4 * c.g + wave;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)c.n * (item_bytes >> 1), 0, item_bytes, 0x00020000);
+        const unsigned vbase = valid ? out_lane + (unsigned)((c.d * H + orow) * (W * 32)) : 0x80000000u;
+#pragma unroll
+        for (int b = 0; b < NBLK; b += 2) __builtin_amdgcn_raw_buffer_store_b128(pair_to_b128(o[b], o[b + 1]), rsrc, vbase + b * 512, 0, 0);
+    };
+
+    // ---- the stream: cc = group gi (conv), cs = gi + 2 (stem rows), cx = gi + 3 (x entries), ci = gi + 4 (raw loads)
+    RowCur cc;
+    {
+        const int u = u_begin, strip = u % strips, pd = u / strips;
+        cc.h0 = strip * SH; cc.d = pd % D; cc.n = pd / D; cc.g = 0;
+    }
+    RowCur cs = cc, cx = cc, ci = cc;
+    int gs = 0, gx = 0, gl = 0;
+    auto next = [&](RowCur &c, int &g) { if (g < n_groups - 1) { advance(c); ++g; } };
+    __syncthreads();                                                     // zeroed rings
+    issue(ci);
+    xcommit(cx, 0); next(cx, gx); next(ci, gl);
+    issue(ci);
+    __syncthreads();
+    stem_rows(cs, 0, 0); next(cs, gs);
+    xcommit(cx, 1); next(cx, gx); next(ci, gl);
+    issue(ci);
+    __syncthreads();
+    stem_rows(cs, 1, 1); next(cs, gs);
+    xcommit(cx, 0); next(cx, gx); next(ci, gl);
+    issue(ci);
+    __syncthreads();
+    int slot = 0;
+    for (int gi = 0; gi < n_groups; ++gi) {
+        step(cc, slot, cc.g < G);
+        stem_rows(cs, slot == 0 ? 2 : slot - 1, gi & 1); next(cs, gs);   // group gi + 2 -> ring slot (gi + 2) % 3, x slot (gi + 2) & 1
+        xcommit(cx, (gi + 1) & 1); next(cx, gx); next(ci, gl);           // group gi + 3
+        issue(ci);
+        __syncthreads();
+        const int n_prev = cc.n;
+        advance(cc);
+        slot = slot == 2 ? 0 : slot + 1;
+        if (cc.n != n_prev || gi + 1 == n_groups) flush_stats(n_prev);
+    }
+}
+
 int pick_strips(int H, int &SH) {
     for (int k = 1; k <= 8; ++k)
         if (H % k == 0 && (H / k) % 4 == 0 && H / k <= 64) { SH = H / k; return k; }
@@ -569,9 +838,43 @@ int launch_row_n(const ThinParams &tp, hipStream_t st) {
     return -1;
 }
 
+template <int NBLK>
+int launch_row_stem_t(ThinParams tp, hipStream_t st) {
+    ConvParams &p = tp.c;
+    int SH;
+    const int strips = pick_strips(p.Hi, SH);
+    const int total = p.N * p.Di * strips;
+    constexpr int W = 16 * NBLK;
+    const size_t lds = (size_t)12 * (W + 2) * 32 + (size_t)2 * 6 * W * 8 + 4 * 16 * 2 * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)conv_row_stem_kernel<NBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    int per_cu = (int)((160 * 1024) / lds);
+    const int cap = NBLK <= 8 ? 3 : 2;
+    if (per_cu > cap) per_cu = cap;
+    int gx = 256 * per_cu;
+    if (gx > total) gx = total;
+    hipLaunchKernelGGL((conv_row_stem_kernel<NBLK>), dim3(gx), dim3(256), lds, st, tp, total, strips, SH);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_row_stem(const ThinParams &tp, hipStream_t st) {
+    switch (tp.c.Wi) {
+        case 64: return launch_row_stem_t<4>(tp, st);
+        case 96: return launch_row_stem_t<6>(tp, st);
+        case 128: return launch_row_stem_t<8>(tp, st);
+        case 160: return launch_row_stem_t<10>(tp, st);
+        case 192: return launch_row_stem_t<12>(tp, st);
+    }
+    return -1;
+}
+
 }  // namespace
 
-// Can the row kernel run this layer?  tp.fuse = 0 (plain sources) or FUSE_TCONV.
+// Can the row kernel run this layer?  tp.fuse = 0 (plain sources), FUSE_TCONV or FUSE_STEM (the producer then is a
+// one-channel (1, 3, 3) stem whose statistics pass is stem_row_kernel: engine.hip asks stem_row_ok too).
 bool conv_row_ok(const ThinParams &tp) {
     const bool off = fnn_knob("FNN_NO_ROW") != nullptr;                              // A-B aid (read per call: tests toggle it)
     const ConvParams &p = tp.c;
@@ -584,6 +887,8 @@ bool conv_row_ok(const ThinParams &tp) {
         if (tp.tsd != 1 || tp.tsh != 2 || tp.tsw != 2 || tp.Dl != p.Di || tp.Hl * 2 != p.Hi || tp.Wl * 2 != p.Wi) return false;
         return true;
     }
+    if (tp.fuse == FUSE_STEM)
+        return fnn_knob("FNN_NO_STEM_ROW") == nullptr && p.n_src == 1 && p.chunks == 1 && p.src[0].C == 16;
     if (tp.fuse != 0) return false;
     if (p.chunks != p.n_src || p.chunks < 1 || p.chunks > 2) return false;
     for (int i = 0; i < p.n_src; ++i) if (p.src[i].C != 16) return false;
@@ -593,6 +898,7 @@ bool conv_row_ok(const ThinParams &tp) {
 int launch_conv_row(const ThinParams &tp, hipStream_t st) {
     if (!conv_row_ok(tp)) return -1;
     if (tp.fuse == FUSE_TCONV) return launch_row_n<2, true>(tp, st);
+    if (tp.fuse == FUSE_STEM) return launch_row_stem(tp, st);
     return tp.c.chunks == 1 ? launch_row_n<1, false>(tp, st) : launch_row_n<2, false>(tp, st);
 }
 
@@ -616,12 +922,19 @@ int launch_stem_row(const StemParams &p, int N, hipStream_t st) {
     static const int wpc = fnn_knob("FNN_STEM_WPC") ? atoi(fnn_knob("FNN_STEM_WPC")) : 8;          // A-B aid: workgroups per CU
     int gx = 256 * wpc;
     if (gx > total) gx = total;
+    // p.out == nullptr: the statistics pass of a fused consumer (conv_row_stem_kernel) - no stores, no 16-byte shuffles
+#define STEM_ROW_LAUNCH(NB)                                                                                            \
+    do {                                                                                                               \
+        if (p.out) hipLaunchKernelGGL((stem_row_kernel<NB, true>), dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots);    \
+        else hipLaunchKernelGGL((stem_row_kernel<NB, false>), dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots);         \
+    } while (0)
     switch (p.PW) {
-        case 64: hipLaunchKernelGGL(stem_row_kernel<4>, dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots); break;
-        case 96: hipLaunchKernelGGL(stem_row_kernel<6>, dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots); break;
-        case 128: hipLaunchKernelGGL(stem_row_kernel<8>, dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots); break;
-        case 160: hipLaunchKernelGGL(stem_row_kernel<10>, dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots); break;
-        default: hipLaunchKernelGGL(stem_row_kernel<12>, dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots); break;
+        case 64: STEM_ROW_LAUNCH(4); break;
+        case 96: STEM_ROW_LAUNCH(6); break;
+        case 128: STEM_ROW_LAUNCH(8); break;
+        case 160: STEM_ROW_LAUNCH(10); break;
+        default: STEM_ROW_LAUNCH(12); break;
     }
+#undef STEM_ROW_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

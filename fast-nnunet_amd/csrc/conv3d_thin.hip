@@ -685,7 +685,7 @@ static int launch_thin_t(const ThinParams &tp, hipStream_t st) {
 
 int launch_conv_thin(const ThinParams &tp, hipStream_t st) {
     if (!conv_thin_ok(tp)) return -1;
-    if (tp.fuse == FUSE_TCONV) {                                         // stride (1, 2, 2), full rows: the row-streaming form
+    {                                                                    // full rows (and stride (1, 2, 2) for the transposed conv): the row-streaming form
         const int rc = launch_conv_row(tp, st);
         if (rc != -1) return rc;
     }

@@ -73,10 +73,13 @@ struct fnn_engine {
     int max_batch = 1;
     std::string err;
     bool fuse_enabled = true;               // FNN_NO_FUSE (read when the engine is created) keeps every layer a kernel of its own
-    // FNN_FUSE_STEM / FNN_FUSE_TCONV = 0 | 1.  The transposed-conv fusion is on (+1.2 % on the benchmark); the stem
-    // fusion is built and tested but off: its consumer is instruction-bound (one MFMA per 16 halo voxels needs ~45
-    // instructions around it), 1020 + 340 us per batch against 575 + 756 us unfused (-1.3 % end to end).
-    bool fuse_stem = false, fuse_tconv = true;
+    // FNN_FUSE_STEM / FNN_FUSE_TCONV = 0 | 1.  The transposed-conv fusion is on (+1.2 % on the benchmark).  The stem
+    // fusion is on where the row-streaming kernels take both halves (conv_row_stem_kernel + stem_row_kernel's statistics
+    // pass, conv3d_row.hip); in tile form (FNN_FUSE_STEM=1 forces it) it is built and tested but slower than two kernels:
+    // its consumer is instruction-bound (one MFMA per 16 halo voxels needs ~45 instructions around it), 1020 + 340 us
+    // per batch against 575 + 756 us unfused.
+    int fuse_stem = -1;                     // -1: where the row kernels run it
+    bool fuse_tconv = true;
     std::vector<Layer> layers;
     int head_src = -1;                      // layer feeding the seg head
     int hblocks = 0, head_ksteps = 0;
@@ -325,6 +328,20 @@ int build_plan(fnn_engine *e) {
         } else { tp.tsd = tp.tsh = tp.tsw = 1; }
         return conv_thin_ok(tp);
     };
+    auto row_stem_probe = [&](const Layer &L, const Layer &P) {          // conv_row_stem_kernel + stem_row_kernel (statistics)
+        ThinParams tp{};
+        ConvParams &q = tp.c;
+        q.n_src = 1; q.chunks = L.cin_pad[0] / 16; q.src[0].C = L.cin_pad[0];
+        q.Di = L.in_dims[0]; q.Hi = L.in_dims[1]; q.Wi = L.in_dims[2];
+        q.Do = L.out_dims[0]; q.Ho = L.out_dims[1]; q.Wo = L.out_dims[2];
+        q.Cout = L.cout_pad; q.kd = L.k[0]; q.kh = L.k[1]; q.kw = L.k[2]; q.sd = L.s[0]; q.sh = L.s[1]; q.sw = L.s[2];
+        q.packing = FNN_PACK_LINEAR; q.ksteps = conv3d_ksteps(FNN_PACK_LINEAR, L.k[0] * L.k[1] * L.k[2]);
+        tp.fuse = FUSE_STEM;
+        StemParams sp{};
+        sp.C = P.cin_real[0]; sp.kd = P.k[0]; sp.kh = P.k[1]; sp.kw = P.k[2]; sp.Cout = P.cout_pad;
+        sp.PD = P.out_dims[0]; sp.PH = P.out_dims[1]; sp.PW = P.out_dims[2];
+        return conv_row_ok(tp) && stem_row_ok(sp);
+    };
     for (Layer &L : e->layers)
         if (L.type == Layer::STEM) {
             if (!stem_mfma_ok(L.cin_real[0], L.k[0], L.k[1], L.k[2], L.cout_pad)) return fail(e, FNN_E_UNSUPPORTED, "stem conv shape");
@@ -340,9 +357,9 @@ int build_plan(fnn_engine *e) {
             const int s0 = L.src_layer[0];
             if (s0 < 0) continue;
             Layer &P = e->layers[s0];
-            if (e->fuse_stem && L.n_src == 1 && P.type == Layer::STEM && P.mfma_stem && P.cin_real[0] == 1 && P.cout_pad == 16 &&
+            if (e->fuse_stem != 0 && L.n_src == 1 && P.type == Layer::STEM && P.mfma_stem && P.cin_real[0] == 1 && P.cout_pad == 16 &&
                 consumers[s0] == 1 && P.k[0] == L.k[0] &&
-                thin_probe(L, FUSE_STEM, nullptr)) {
+                thin_probe(L, FUSE_STEM, nullptr) && (e->fuse_stem == 1 || row_stem_probe(L, P))) {
                 L.fuse = FUSE_STEM; P.virtual_out = true;
             } else if (e->fuse_tconv && L.n_src == 2 && P.type == Layer::TCONV && consumers[s0] == 1 && P.cout_pad == 16 && thin_probe(L, FUSE_TCONV, &P)) {
                 L.fuse = FUSE_TCONV; P.virtual_out = true;
@@ -1254,7 +1271,7 @@ int fnn_create(const fnn_arch_desc *arch, int device, int max_batch, fnn_engine 
     fnn_engine *e = new fnn_engine();
     e->arch = *arch; e->device = device; e->max_batch = max_batch;
     e->fuse_enabled = fnn_knob("FNN_NO_FUSE") == nullptr;
-    if (const char *v = fnn_knob("FNN_FUSE_STEM")) e->fuse_stem = atoi(v) != 0;
+    if (const char *v = fnn_knob("FNN_FUSE_STEM")) e->fuse_stem = atoi(v) != 0 ? 1 : 0;
     if (const char *v = fnn_knob("FNN_FUSE_TCONV")) e->fuse_tconv = atoi(v) != 0;
     e->gather_enabled = fnn_knob("FNN_NO_GATHER") == nullptr;
     if (e->arch.eps <= 0) e->arch.eps = 1e-5f;

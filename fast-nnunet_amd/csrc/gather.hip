@@ -96,6 +96,11 @@ struct Pick {                                                  // LabelPick of m
 // feature / weight / scale registers: 168 registers, three waves per SIMD): 20.2 -> 24.1 ms - the fourth wave hides more
 // than the prefetch does; packed-fp16 normalisation and the head bias as the MFMA's C operand (-25 % VALU work per
 // visit) changed nothing: neither instruction issue nor a single wave's round trips bound it, the number of waves does.
+// A FIFTH wave per SIMD (96 registers: the head's fragments and biases read from LDS at every use instead of sitting in 32
+// registers, the logits leaving through a half-size transpose buffer in two passes) took 24.1 ms instead of 19.0, a
+// sixth (80 registers, spills) 31.6: the LDS round trip in front of every MFMA costs more than the wave brings.
+// The closing division through one reciprocal per 16 voxels (quot_fast below: ~280 fewer instructions per group)
+// took 20.0 -> 19.0 ms.
 template <int HB, int ACCM, bool LABELS, bool TTA>
 __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? 4 : 1) void gather_head_kernel(const GatherParams p) {
     constexpr int G = 4, ZW = 16 * G, TP = ZW + 8;             // 16-voxel groups and z voxels per wave; row pitch of the LDS transpose

@@ -261,8 +261,8 @@ FUSE_SPECS = {
 
 
 def _fused_and_plain(spec, patch, sd, batch, mirror=None, stem=True):
-    """(engine with BOTH stage-0 fusions, layer-by-layer engine).  The stem fusion is off by default (it does not pay on
-    the benchmark yet) but stays under test."""
+    """(engine with BOTH stage-0 fusions - stem=False: the transposed-conv fusion only -, layer-by-layer engine).  By
+    default the stem fusion is on only where the row-streaming kernels run it; FNN_FUSE_STEM=1 forces it (tile form)."""
     os.environ.pop('FNN_NO_FUSE', None)
     os.environ['FNN_FUSE_STEM'] = '1' if stem else '0'
     try:
@@ -305,19 +305,25 @@ def test_fused_stage0_producers_match_the_unfused_engine_and_the_oracle(name):
     assert (_bits(fused.predict_sliding_window_return_logits(image).cpu()) == _bits(want)).all()
 
 
+@pytest.mark.parametrize('stem', [False, True])
 @pytest.mark.parametrize('patch', [(32, 64, 64), (12, 48, 96)])
-def test_fused_transposed_conv_is_bit_identical_to_the_unfused_engine_in_the_row_kernels(patch):
-    """Rows of 64 / 96 voxels: the stage-0 convs run in conv3d_row.hip with or without the fusion (same row groups,
-    same statistics order) and the stand-alone transposed conv is the same arithmetic as the one computed while staging:
-    every bit of the logits must agree.  (With the stem fusion on, the second conv runs the tile kernel of
-    conv3d_thin.hip, whose statistics are summed in another order: fp16 resolution, previous test.)"""
+def test_fused_stage0_producers_are_bit_identical_to_the_unfused_engine_in_the_row_kernels(patch, stem):
+    """Rows of 64 / 96 voxels: the stage-0 convs run in conv3d_row.hip with or without the fusions (same row groups,
+    same statistics order); the stand-alone transposed conv is the same arithmetic as the one computed while staging,
+    and the stem rows recomputed by conv_row_stem_kernel are the values stem_row_kernel's statistics pass counted:
+    every bit of the logits must agree, mirrored evaluations included."""
     spec, _ = FUSE_SPECS['aniso']
     sd = synthetic_state_dict(spec, 601)
-    fused, plain = _fused_and_plain(spec, patch, sd, 4, stem=False)
+    fused, plain = _fused_and_plain(spec, patch, sd, 4, stem=stem)
     x = torch.randn(4, 1, *patch, generator=torch.Generator().manual_seed(62))
     a, b = fused.forward_patches(x), plain.forward_patches(x)
     print('max |fused - unfused|', float((a - b).abs().max()))
     assert torch.equal(a, b)
+    if stem:
+        image = torch.randn(1, patch[0] + 5, patch[1] + 9, patch[2], generator=torch.Generator().manual_seed(63))
+        fm, pm = _fused_and_plain(spec, patch, sd, 3, mirror=[0, 1, 2], stem=True)
+        va, vb = fm.predict_sliding_window_return_logits(image), pm.predict_sliding_window_return_logits(image)
+        assert (_bits(va.cpu()) == _bits(vb.cpu())).all()
 
 
 # ----------------------------------------------------------------------------------------------- C5: fp8 conv path
