@@ -15,6 +15,8 @@
 //     constant + immediate;
 //   * one barrier per step; groups s + 2 (LDS write) and s + 3 (global loads) are in flight during step s (a second
 //     group of loads in flight - two register sets, branch-free step - measured on the fused kernel: -1.3 % end to end).
+//     Also measured and dropped here (kept in the two stem kernels below, where it pays): the step's stores outside the
+//     tail-group branch as buffer stores that the hardware drops - 584 -> 617 us and 902 -> 915 us.
 // LDS image: row pitch (W + 2) voxels x 32 B; the two 16-byte channel halves of a voxel are swapped where bit 2 of its
 // column is set, which makes the 16 lanes of an operand read (16 consecutive voxels, one half) hit every bank group
 // exactly twice = the full ds_read_b128 rate.
