@@ -703,6 +703,8 @@ __global__ __launch_bounds__(256, NBLK <= 8 ? 3 : 2) void conv_row_stem_kernel(c
     // The k-loop is skipped for a unit's tail group, the STORES are not (sent beyond num_records, the hardware drops
     // them): with the stores inside the branch hipcc's waitcnt pass does not know how many are in flight, and xcommit,
     // whose loads are older than the step's stores, waits for vmcnt(0) - the store acknowledgements - once per step.
+    // (The k-loop run for the tail group too - one basic block, the scheduler free to mix the phases - measured: +0.3 %
+    // time on the conv family, dropped.)
     const unsigned item_bytes = (unsigned)D * H * W * 32;
     auto step = [&](const RowCur &c, int slot, const bool valid) {
         const int slot1 = slot == 2 ? 0 : slot + 1;
