@@ -411,7 +411,7 @@ def main():
             except Exception:
                 pass
         result['roofline'] = {
-            'kernel': 'MFMA conv family: conv3d_zr / zsp / s2 / lds / persist kernels and conv_row_kernel', 'bound': 'mfma',
+            'kernel': 'MFMA conv family: conv3d_zr / zsp / s2 / lds / persist kernels, conv_row_kernel and conv_row_stem_kernel', 'bound': 'mfma',
             'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
             'traffic': traffic, 'traffic_source': traffic_src,
