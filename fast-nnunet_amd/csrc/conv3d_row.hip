@@ -15,7 +15,7 @@
 //     constant + immediate;
 //   * one barrier per step; groups s + 2 (LDS write) and s + 3 (global loads) are in flight during step s (a second
 //     group of loads in flight - two register sets, branch-free step - measured on the fused kernel: -1.3 % end to end).
-//     Also measured and dropped here (kept in the two stem kernels below, where it pays): the step's stores outside the
+//     Also measured and dropped here (kept in stem_row_kernel, where it pays): the step's stores outside the
 //     tail-group branch as buffer stores that the hardware drops - 584 -> 617 us and 902 -> 915 us.
 // LDS image: row pitch (W + 2) voxels x 32 B; the two 16-byte channel halves of a voxel are swapped where bit 2 of its
 // column is set, which makes the 16 lanes of an operand read (16 consecutive voxels, one half) hit every bank group
@@ -700,11 +700,10 @@ __global__ __launch_bounds__(256, NBLK <= 8 ? 3 : 2) void conv_row_stem_kernel(c
     };
     const unsigned out_lane = (unsigned)((r + 16 * (q & 1)) * 32 + (q >> 1) * 16);
     const f16x2 ones = {(f16)1.f, (f16)1.f};
-    // The k-loop is skipped for a unit's tail group, the STORES are not (sent beyond num_records, the hardware drops
-    // them): with the stores inside the branch hipcc's waitcnt pass does not know how many are in flight, and xcommit,
-    // whose loads are older than the step's stores, waits for vmcnt(0) - the store acknowledgements - once per step.
-    // (The k-loop run for the tail group too - one basic block, the scheduler free to mix the phases - measured: +0.3 %
-    // time on the conv family, dropped.)
+    // A unit's tail group has no output rows: k-loop and stores skipped.  (Measured, both slightly slower: the stores
+    // outside the branch, dropped by the hardware beyond num_records, so that xcommit's wait for its older loads is
+    // vmcnt(5) instead of vmcnt(0) = the store acknowledgements - what pays in stem_row_kernel costs 30 us per launch here;
+    // the k-loop run for the tail group too - one basic block, the scheduler free to mix the phases: +0.3 % on the family.)
     const unsigned item_bytes = (unsigned)D * H * W * 32;
     auto step = [&](const RowCur &c, int slot, const bool valid) {
         const int slot1 = slot == 2 ? 0 : slot + 1;
@@ -759,6 +758,7 @@ __global__ __launch_bounds__(256, NBLK <= 8 ? 3 : 2) void conv_row_stem_kernel(c
         const int orow = c.h0 + 4 * c.g + wave;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)c.n * (item_bytes >> 1), 0, item_bytes, 0x00020000);
         const unsigned vbase = valid ? out_lane + (unsigned)((c.d * H + orow) * (W * 32)) : 0x80000000u;
+        if (valid)
 #pragma unroll
         for (int b = 0; b < NBLK; b += 2) __builtin_amdgcn_raw_buffer_store_b128(pair_to_b128(o[b], o[b + 1]), rsrc, vbase + b * 512, 0, 0);
     };
