@@ -204,6 +204,43 @@ def sliding_window_logits(net: Callable[[torch.Tensor], torch.Tensor], image: to
 
 
 @torch.inference_mode()
+def sliding_window_logits_box(net: Callable[[torch.Tensor], torch.Tensor], image: torch.Tensor,
+                              patch: Sequence[int], num_heads: int, box: Sequence[Tuple[int, int]],
+                              step: float = 0.5, use_gaussian: bool = True,
+                              mirror_axes: Optional[Sequence[int]] = None, accum: str = 'fp16') -> torch.Tensor:
+    """``sliding_window_logits(...)[:, box]`` computed from only the patches that touch ``box``.
+
+    The same statements as ``sliding_window_logits`` (predict_from_raw_data.py:560-680); patches that do not
+    intersect ``box = ((x0, x1), (y0, y1), (z0, z1))`` (coordinates of the padded image = of the image when no
+    axis is smaller than the patch) are skipped - they never touch a voxel of the box, and the patches that do
+    are visited in the reference's order, so every value inside the box goes through the same arithmetic.  The
+    accumulators cover only the hull of the visited patches.  For full-size volumes whose complete
+    evaluation would take the CPU half an hour."""
+    assert image.ndim == 4 and all(s >= p for s, p in zip(image.shape[1:], patch)), 'box form: no padding'
+    slicers = [sl for sl in patch_slicers(image.shape[1:], patch, step)
+               if all(s.start < hi and s.stop > lo for s, (lo, hi) in zip(sl[1:], box))]
+    lo = [min(sl[1 + a].start for sl in slicers) for a in range(3)]
+    hi = [max(sl[1 + a].stop for sl in slicers) for a in range(3)]
+    acc_dtype = torch.half if accum == 'fp16' else torch.float32
+    acc = torch.zeros((num_heads, *[h - l for l, h in zip(lo, hi)]), dtype=acc_dtype)
+    wsum = torch.zeros(acc.shape[1:], dtype=acc_dtype)
+    g = gaussian_weight(tuple(patch)) if use_gaussian else 1
+    if use_gaussian and accum != 'fp16':
+        g = g.float()
+    for sl in slicers:
+        x = image[sl][None].contiguous()
+        pred = predict_with_mirroring(net, x, mirror_axes)[0]
+        if use_gaussian:
+            pred = pred * g
+        rel = (slice(None), *[slice(s.start - l, s.stop - l) for s, l in zip(sl[1:], lo)])
+        acc[rel] += pred
+        wsum[rel[1:]] += g
+    inner = tuple(slice(b0 - l, b1 - l) for (b0, b1), l in zip(box, lo))
+    out = acc[(slice(None), *inner)] / wsum[inner]
+    return out, len(slicers)
+
+
+@torch.inference_mode()
 def ensemble_logits(nets: Sequence[Callable[[torch.Tensor], torch.Tensor]], image: torch.Tensor,
                     patch: Sequence[int], num_heads: int, **kw) -> torch.Tensor:
     """Mean of the per-fold sliding-window logits.

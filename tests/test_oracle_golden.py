@@ -268,3 +268,24 @@ def test_export_with_probabilities_matches_reference_golden(golden_dir):
         outside_t[tuple(slice(lo, hi) for lo, hi in case['bbox'])] = False
         outside = outside_t.transpose(tb)
         assert np.array_equal(probs[:, outside], ref[:, outside])
+
+
+def test_box_restricted_driver_equals_the_full_driver_on_the_box():
+    """``sliding_window_logits_box`` (used by the full-size GPU tests, where the whole volume would cost the CPU half
+    an hour) must be the full driver restricted to the box, bit for bit - corner, interior and ragged boxes."""
+    import torch
+    from oracle import sliding_window as osw
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(3, 1, 3, 3, 3, generator=g)
+
+    def net(x):
+        return torch.nn.functional.conv3d(x, w, padding=1)
+
+    image = torch.randn(1, 40, 36, 50, generator=g)
+    patch = (16, 12, 20)
+    full = osw.sliding_window_logits(net, image, patch, 3, step=0.5, accum='fp16')
+    for box in (((0, 8), (0, 6), (0, 10)), ((13, 22), (9, 17), (21, 33)), ((30, 40), (0, 36), (45, 50))):
+        got, n = osw.sliding_window_logits_box(net, image, patch, 3, box, step=0.5, accum='fp16')
+        want = full[(slice(None), *[slice(a, b) for a, b in box])]
+        assert n >= 1 and got.dtype == torch.half
+        assert torch.equal(got.view(torch.int16), want.contiguous().view(torch.int16))
