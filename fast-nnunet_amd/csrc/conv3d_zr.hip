@@ -77,7 +77,7 @@ int conv3d_packing(const ConvParams &p) {
 // Epilogue of a ZR tile at NB = 2 in the interleaved channel order of conv3d_pack_cout: bias (after `osc` for the fp8
 // form), round to fp16, one 16-byte channels-last store per (voxel, lane), statistics as in tile_epilogue (conv_common.h).
 typedef int fnn_i32x4 __attribute__((ext_vector_type(4)));
-template <int TD>
+template <int TD, bool BIAS = true>
 static __device__ __forceinline__ void zr_epilogue_pair(const ConvParams &p, const f32x4 (&acc)[TD][2], const float4 (&bv)[2],
                                                         int n, int od0, int oh0, int ow0, int cb0, int wave, int lane,
                                                         float (&t1)[2][4], float (&t2)[2][4]) {
@@ -103,10 +103,10 @@ static __device__ __forceinline__ void zr_epilogue_pair(const ConvParams &p, con
 #endif
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-                o[h][nb * 4 + 0] = (f16)(acc[mb + h][nb][0] + bv[nb].x);
-                o[h][nb * 4 + 1] = (f16)(acc[mb + h][nb][1] + bv[nb].y);
-                o[h][nb * 4 + 2] = (f16)(acc[mb + h][nb][2] + bv[nb].z);
-                o[h][nb * 4 + 3] = (f16)(acc[mb + h][nb][3] + bv[nb].w);
+                o[h][nb * 4 + 0] = (f16)(BIAS ? acc[mb + h][nb][0] + bv[nb].x : acc[mb + h][nb][0]);
+                o[h][nb * 4 + 1] = (f16)(BIAS ? acc[mb + h][nb][1] + bv[nb].y : acc[mb + h][nb][1]);
+                o[h][nb * 4 + 2] = (f16)(BIAS ? acc[mb + h][nb][2] + bv[nb].z : acc[mb + h][nb][2]);
+                o[h][nb * 4 + 3] = (f16)(BIAS ? acc[mb + h][nb][3] + bv[nb].w : acc[mb + h][nb][3]);
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fnn_i32x4, o[h]), rsrc, voff, 0, 0);
             if (!ok) o[h] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
@@ -122,113 +122,118 @@ static __device__ __forceinline__ void zr_epilogue_pair(const ConvParams &p, con
     }
 }
 
+// Staging (round 3): a thread owns one COLUMN of the halo - (row zh, column zw, 8-channel half cg), 200 of the 256
+// threads - and walks the TD + 2 planes.  Everything that used to be a per-element table (16 registers and ~35 VALU
+// instructions per element to build: 43 % of the kernel's vector instructions sat in front of the first load) is now
+// either one per-thread constant (the in-plane byte offset; 0x80000000 where the column lies outside the tensor: the
+// buffer load's range check returns zeros without touching memory), a scalar per plane (the plane's byte offset as the
+// load's soffset, clamped into the tensor; a plane outside it is not written - its LDS image was zeroed once) or an
+// immediate (LDS offsets).  The weights' two cout blocks get a buffer descriptor each whose num_records ends the block's
+// 15 k-steps: fragment element tid + 256 u needs no per-lane address either.  The bias is the accumulators' initial value.
+typedef unsigned fnn_u32x4v __attribute__((ext_vector_type(4)));
 template <int NB, int TD>
 __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     FNN_STAMP_DECL
     FNN_STAMP();                                              // 0: entry
     constexpr int IH = 10, IW = 10, PW = 12, ID = TD + 2;    // halo tile, row pitch 12 = 4 (mod 8) voxels
     constexpr int PS = IH * PW * 32;                          // bytes per halo plane
     constexpr int ABYTES = ID * PS;                           // no rounding: at TD = 4 the workgroup is 42 LDS granules (3 per CU)
     constexpr int KS = 15;
-    constexpr int IELEM = ID * IH * IW * 2;                   // 16-byte halo elements per chunk
-    constexpr int PF = (IELEM + 255) / 256;
-    constexpr int WTOT = NB * KS * 64;                        // 16-byte weight elements per chunk
-    constexpr int WPF = (WTOT + 255) / 256;
+    constexpr int WB = KS * 64;                               // 16-byte weight elements per cout block and chunk
+    constexpr int WPB = (WB + 255) / 256;                     // loads per thread and cout block (the last one: waves 0 .. 2 only)
+    static_assert(WB - (WPB - 1) * 256 == 192, "the last weight element group covers exactly waves 0 .. 2");
 
     // XCD-aware, bijective remap (blocks b and b + 8 share an XCD)
     int t;
     {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+        t = __builtin_amdgcn_readfirstlane((xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx);
     }
-    const int tw = t % p.tiles_w; t /= p.tiles_w;
-    const int th = t % p.tiles_h; t /= p.tiles_h;
-    const int td = t % p.tiles_d;
-    const int n = t / p.tiles_d;
+    const int tw = __builtin_amdgcn_readfirstlane(t % p.tiles_w); t = __builtin_amdgcn_readfirstlane(t / p.tiles_w);
+    const int th = __builtin_amdgcn_readfirstlane(t % p.tiles_h); t = __builtin_amdgcn_readfirstlane(t / p.tiles_h);
+    const int td = __builtin_amdgcn_readfirstlane(t % p.tiles_d);
+    const int n = __builtin_amdgcn_readfirstlane(t / p.tiles_d);
     const int cb0 = blockIdx.y * NB;
     const int od0 = td * TD, oh0 = th * 8, ow0 = tw * 8;
 
     char *sA = smem;                                          // halo image: [ID][IH][PW] voxels x 32 B, halves swapped on odd rows
     char *sW = smem + ABYTES;                                 // [NB][15][64 lanes][16 B]
-    // bias: in the two unused voxel slots behind rows 0 and 1 of halo plane 0 (pitch 12, 10 used) - 16 floats each
-    auto bias_slot = [&](int i) { return (float *)(sA + (((i >> 4) * PW + IW) * 32)) + (i & 15); };
 
-    int toff[5];                                              // filled in after the first loads have left
-    f32x4 acc[TD][NB];
-    // this thread's share of the prefetch: PF halo elements (voxel, 8-channel half) + WPF weight elements
-    const int cg = tid & 1;
-    int offv[PF];                                             // global voxel index; -1 = zero padding, -2 = no element
-    int ldso[PF];
+    // ---- this thread's halo column
+    const int col = tid >> 1, cg = tid & 1;
+    const int zh = (col * 205) >> 11, zw = col - zh * IW;     // col / 10 for col < 128
+    const bool has_col = tid < 2 * IH * IW;
+    const int gh = oh0 - 1 + zh, gw = ow0 - 1 + zw;
+    const bool ok_hw = has_col & ((unsigned)gh < (unsigned)p.Hi) & ((unsigned)gw < (unsigned)p.Wi);
+    const int hw_lin = __mul24(gh, p.Wi) + gw;
+    const int ldso0 = (zh * PW + zw) * 32 + ((cg ^ (zh & 1)) * 16);
+    const int wlds = ABYTES + tid * 16;
+    // planes of the halo that lie inside the tensor (bit u), and the clamped plane numbers
+    unsigned pmask = (1u << ID) - 1;                          // (scalar arithmetic: a plane test is one s_bitcmp)
+    if (od0 == 0) pmask &= ~1u;
     {
-        const int id0 = od0 - 1, ih0 = oh0 - 1, iw0 = ow0 - 1;
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int idx = tid + u * 256;
-            const int v = idx >> 1;
-            const int zd = v / (IH * IW), rem = v - zd * (IH * IW), zh = rem / IW, zw = rem - zh * IW;
-            const int gd = id0 + zd, gh = ih0 + zh, gw = iw0 + zw;
-            // branch-free (one unsigned compare per axis, 24-bit multiplies: the launcher checks Di * Hi * Wi < 2^24)
-            const bool ok = ((unsigned)gd < (unsigned)p.Di) & ((unsigned)gh < (unsigned)p.Hi) & ((unsigned)gw < (unsigned)p.Wi);
-            const int lin = __mul24(__mul24(gd, p.Hi) + gh, p.Wi) + gw;
-            offv[u] = idx < IELEM ? (ok ? lin : -1) : -2;                                // inside batch item n
-            ldso[u] = zd * PS + (zh * PW + zw) * 32 + ((cg ^ (zh & 1)) * 16);
-        }
+        const int over = od0 + TD + 1 - p.Di;                 // planes beyond the last one
+        if (over > 0) pmask &= (1u << (ID - over)) - 1;
     }
-    int wofs[WPF];
-#pragma unroll
-    for (int u = 0; u < WPF; ++u) {
-        const int idx = tid + u * 256;
-        const int idc = idx < WTOT ? idx : WTOT - 1;
-        const int nb = idc >= KS * 64 ? 1 : 0;                // NB <= 2
-        wofs[u] = (cb0 + nb) * p.chunks * (KS * 64) + idc - nb * (KS * 64);
-    }
-    f16x8 xr[PF], wr[WPF];
-    float scu[16], shu[16];                                   // the chunk's scale / shift rows: wave-uniform -> scalar loads, no TA slots
-    float slope_next = 1.f;
-#ifdef FNN_TMODE
-    // timing-only switches (results are wrong): 1 = every halo load reads voxel 0 (one cache line per instruction),
-    // 2 = every weight load reads element 0, 4 = output stores dropped (conv_common.h), 8 = no normalisation in commit
-    const int t_hm = (p.tmode & 1) ? 0 : 1, t_wm = (p.tmode & 2) ? 0 : 1;
-#endif
+    pmask = __builtin_amdgcn_readfirstlane(pmask);
 
-    auto issue = [&](int ch) {
+    f32x4 acc[TD][NB];
+    fnn_u32x4v xr[ID], wr[NB][WPB];
+    float scu[16], shu[16];                                   // the chunk's scale / shift rows: wave-uniform -> scalar loads
+    float slope_next = 1.f;
+
+    // The chunk's loads in five slices, one per tap pair of the k-loop: issued in one block the 18 wave-wide loads of
+    // every wave of the CU queue up in the texture-address path and the MFMAs behind them cannot issue (in-order waves).
+    __amdgpu_buffer_rsrc_t rx, rw[NB];
+    unsigned voff = 0x80000000u, plane_bytes = 0;
+    auto prep = [&](int ch) {
         const int c_glob = ch * 16;
         const int s = (c_glob < p.src[0].C) ? 0 : 1;
         const int c_uni = c_glob - (s ? p.src[0].C : 0);
         const int sC = p.src[s].C;
-        // uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset: one address VGPR per load (tensors < 4 GiB)
         const int vs = FNN_VS(p.src[s]);                      // activation layout: fnn_device.h, SrcDesc
-        const char *sp = (const char *)(p.src[s].ptr + (size_t)n * p.Di * p.Hi * p.Wi * sC + (c_uni >> 4) * FNN_CS(p.src[s]));
-        // scale / shift of the chunk's 16 channels (identity table for a source without InstanceNorm): the address is
-        // wave-uniform, so these are s_load_dwordx8 - as four 16-byte-per-lane vector loads they took a fifth of the
-        // chunk's slots in the texture-address path, which paces this kernel
+        const unsigned item_bytes = (unsigned)p.Di * p.Hi * p.Wi * sC * 2;
+        const f16 *sp = p.src[s].ptr + (size_t)n * (item_bytes >> 1) + (c_uni >> 4) * FNN_CS(p.src[s]);
+        rx = __builtin_amdgcn_make_buffer_rsrc((void *)sp, 0, item_bytes, 0x00020000);
         slope_next = p.src[s].slope;
         const float *qs = p.src[s].ss ? p.src[s].ss + (size_t)(2 * n) * sC + c_uni : p.ident_ss + c_uni;
         const float *qh = p.src[s].ss ? qs + sC : p.ident_ss + 512 + c_uni;
 #pragma unroll
         for (int j = 0; j < 16; ++j) { scu[j] = qs[j]; shu[j] = qh[j]; }
+        voff = ok_hw ? (unsigned)hw_lin * (unsigned)(vs * 2) + cg * 16 : 0x80000000u;
+        plane_bytes = (unsigned)p.Hi * p.Wi * vs * 2;
 #pragma unroll
-        for (int u = 0; u < PF; ++u)                          // unconditional: branches around loads make hipcc drain vmcnt
-#ifdef FNN_TMODE
-            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * t_hm * vs + cg * 8) * 2));
-#else
-            xr[u] = *(const f16x8 *)(sp + (unsigned)(((offv[u] >= 0 ? offv[u] : 0) * vs + cg * 8) * 2));
-#endif
+        for (int nb = 0; nb < NB; ++nb) {
+            const f16 *wp = p.wpk + ((size_t)((cb0 + nb) * p.chunks + ch) * WB) * 8;
+            rw[nb] = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, WB * 16, 0x00020000);
+        }
+    };
+    auto load_part = [&](int part) {                          // part 0 .. 4
 #pragma unroll
-#ifdef FNN_TMODE
-        for (int u = 0; u < WPF; ++u) wr[u] = *(const f16x8 *)((const char *)p.wpk + (unsigned)((wofs[u] + ch * (KS * 64)) * t_wm * 16));
-#else
-        for (int u = 0; u < WPF; ++u) wr[u] = *(const f16x8 *)((const char *)p.wpk + (unsigned)((wofs[u] + ch * (KS * 64)) * 16));
-#endif
+        for (int u = 0; u < ID; ++u) {
+            if (u * 5 / ID != part) continue;
+            int gd = od0 - 1 + u;
+            gd = gd < 0 ? 0 : (gd >= p.Di ? p.Di - 1 : gd);   // scalar; a clamped plane's image is zeroed in commit()
+            xr[u] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, (unsigned)gd * plane_bytes, 0));
+        }
+#pragma unroll
+        for (int e = 0; e < NB * WPB; ++e) {                  // element tid + 256 u of block nb; beyond the block: range check, zeros, no traffic
+            if (e * 5 / (NB * WPB) != part) continue;
+            const int nb = e / WPB, u = e % WPB;
+            wr[nb][u] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw[nb], tid * 16, u * 4096, 0));
+        }
     };
     auto commit = [&]() {
         const f16 slope_h = (f16)slope_next;
         float sc[8], sh[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { sc[j] = cg ? scu[8 + j] : scu[j]; sh[j] = cg ? shu[8 + j] : shu[j]; }
+        for (int j = 0; j < 8; ++j) {                         // a column outside the tensor: 0 * 0 + 0 = the conv's zero padding
+            sc[j] = ok_hw ? (cg ? scu[8 + j] : scu[j]) : 0.f;
+            sh[j] = ok_hw ? (cg ? shu[8 + j] : shu[j]) : 0.f;
+        }
 #ifndef FNN_NORM_FP32
         // x*scale+shift with scale and shift rounded to fp16 (v_pk_fma_f16): in fp32 (convert, fma, convert back) the
         // staging's normalisation was 8 % of the benchmark's time.  Measured cost in accuracy: relative RMSE of the 64^3
@@ -237,32 +242,39 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { sc_h[j] = (f16)sc[j]; sh_h[j] = (f16)sh[j]; }
 #endif
+        if (has_col) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            if ((u + 1) * 256 > IELEM && offv[u] == -2) continue;
+            for (int u = 0; u < ID; ++u) {
+                const f16x8 x = __builtin_bit_cast(f16x8, xr[u]);
 #ifdef FNN_NORM_FP32
-            f16x8 o;
+                f16x8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)xr[u][j], sc[j], sh[j]);
+                for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)x[j], sc[j], sh[j]);
 #else
-            f16x8 o = xr[u] * sc_h + sh_h;                               // 4 x v_pk_fma_f16 instead of 16 instructions
+                f16x8 o = x * sc_h + sh_h;                                   // 4 x v_pk_fma_f16 instead of 16 instructions
 #endif
-            o = __builtin_elementwise_max(o, o * slope_h);
-            if (offv[u] < 0) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};      // the conv's zero padding
-#ifdef FNN_TMODE
-            if (p.tmode & 8) o = xr[u];
-#endif
-            *(f16x8 *)(sA + ldso[u]) = o;
+                o = __builtin_elementwise_max(o, o * slope_h);
+                *(f16x8 *)(sA + ldso0 + u * PS) = o;
+            }
+            if (pmask != (1u << ID) - 1) {                    // border tiles along d: planes outside the tensor (a clamped plane's data were written above)
+                unsigned pm = pmask;
+                asm volatile("" : "+s"(pm));                  // (hoisted out of the chunk loop the tests become lane masks: 20 SGPRs, spilled)
+#pragma unroll
+                for (int u = 0; u < ID; ++u)
+                    if (!((pm >> u) & 1)) *(f16x8 *)(sA + ldso0 + u * PS) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
         }
 #pragma unroll
-        for (int u = 0; u < WPF; ++u) {
-            const int idx = tid + u * 256;
-            if ((u + 1) * 256 <= WTOT || idx < WTOT) ((f16x8 *)sW)[idx] = wr[u];
-        }
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int u = 0; u < WPB; ++u)
+                if (u + 1 < WPB || wave < 3) *(fnn_u32x4v *)(smem + wlds + (nb * WB + u * 256) * 16) = wr[nb][u];
     };
-    auto kloop = [&]() {
+    int toff[5];                                              // filled in after the first loads have left
+    auto kloop = [&](bool prefetch) {
 #pragma unroll
         for (int pr = 0; pr < 5; ++pr) {
+            if (prefetch) load_part(pr);
             const char *bp = sA + toff[pr];
             f16x8 xf[ID];
 #pragma unroll
@@ -282,11 +294,23 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
         }
     };
 
-    FNN_STAMP();                                              // 1: prefetch coordinates done
-    if (tid < NB * 16) *bias_slot(tid) = p.bias[cb0 * 16 + tid];   // before the chunk's loads: vmcnt retires in order
-    issue(0);
+    prep(0);
+#pragma unroll
+    for (int part = 0; part < 5; ++part) load_part(part);
     __builtin_amdgcn_sched_barrier(0);                        // the loads leave first; the rest of the set-up runs under them
-    FNN_STAMP();                                              // 2: first loads issued
+    FNN_STAMP();                                              // 1: first loads issued
+    // the bias is where the accumulators start (lane = channels (lane >> 4) * 8 + nb * 4 .. + 3 of its block pair in the
+    // interleaved order of conv3d_pack_cout at NB = 2, (lane >> 4) * 4 .. + 3 of block nb otherwise)
+    {
+        f32x4 b0[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            b0[nb] = *(const f32x4 *)(p.bias + cb0 * 16 + (NB == 2 ? (lane >> 4) * 8 + nb * 4 : nb * 16 + (lane >> 4) * 4));
+#pragma unroll
+        for (int j = 0; j < TD; ++j)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[j][nb] = b0[nb];
+    }
     // MFMA "B" operand: lane = (voxel r of the wave's two rows, k-group): k-group bit 1 picks the tap of the pair,
     // bit 0 the 8-channel half
     {
@@ -294,45 +318,40 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
 #pragma unroll
         for (int pr = 0; pr < 5; ++pr) {
             const int tp = 2 * pr + hl < 9 ? 2 * pr + hl : 8;   // padded slot: any finite data (its weights are 0)
-            const int row = 2 * wave + (r >> 3) + tp / 3, col = (r & 7) + tp % 3;
-            toff[pr] = (row * PW + col) * 32 + ((kh ^ (row & 1)) * 16);
+            const int row = 2 * wave + (r >> 3) + tp / 3, col2 = (r & 7) + tp % 3;
+            toff[pr] = (row * PW + col2) * 32 + ((kh ^ (row & 1)) * 16);
         }
     }
 
-#pragma unroll
-    for (int j = 0; j < TD; ++j)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[j][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     commit();
     __syncthreads();
-    FNN_STAMP();                                              // 3: first chunk staged
+    FNN_STAMP();                                              // 2: first chunk staged
     // the last chunk is peeled off so that the wait for the prefetch sits on an unconditional path (see conv3d_lds_kernel)
     for (int ch = 0; ch + 1 < p.chunks; ++ch) {
-        issue(ch + 1);                                        // global loads stay in flight during the MFMAs
-        kloop();
+        prep(ch + 1);
+        kloop(true);                                          // global loads stay in flight during the MFMAs
         FNN_STAMP();                                          // k-loop done
         __syncthreads();                                      // every wave is done reading this chunk
         commit();
         __syncthreads();
         FNN_STAMP();                                          // next chunk staged
     }
-    kloop();
+    kloop(false);
     FNN_STAMP();
     __syncthreads();
 
-    // ---- epilogue: bias, fp16 store, statistics
+    // ---- epilogue: fp16 store, statistics (the bias is in the accumulators)
     {
         float4 bv[NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const float4 *)bias_slot(NB == 2 ? (lane >> 4) * 8 + nb * 4 : nb * 16 + (lane >> 4) * 4);
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
         float t1[NB][4], t2[NB][4];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
-        if constexpr (NB == 2) zr_epilogue_pair<TD>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
-        else tile_epilogue<NB, TD, true>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
+        if constexpr (NB == 2) zr_epilogue_pair<TD, false>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
+        else tile_epilogue<NB, TD, true, false>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
         if (p.stats_out) stats_to_global<NB, true, NB == 2>(p, t1, t2, (float *)smem, n, cb0, wave, lane, tid, (td * p.tiles_h + th) * p.tiles_w + tw);
     }
     FNN_STAMP();                                              // epilogue done

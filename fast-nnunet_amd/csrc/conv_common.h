@@ -54,7 +54,7 @@ static __device__ __forceinline__ void mb_coords(int wave, int mb, int r, int &o
 // waitcnt pass, and a persistent kernel that prefetches its next tile across the epilogue had to wait
 // for vmcnt(0) - the store acknowledgements - before it could touch the prefetched data.
 typedef int fnn_i32x2 __attribute__((ext_vector_type(2)));
-template <int NB, int MB, bool ZR = false>
+template <int NB, int MB, bool ZR = false, bool BIAS = true>
 static __device__ __forceinline__ void tile_epilogue(const ConvParams &p, const f32x4 (&acc)[MB][NB], const float4 (&bv)[NB],
                                                      int n, int od0, int oh0, int ow0, int cb0, int wave, int lane,
                                                      float (&t1)[NB][4], float (&t2)[NB][4]) {
@@ -90,10 +90,10 @@ static __device__ __forceinline__ void tile_epilogue(const ConvParams &p, const 
             f16x4 o[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                o[h][0] = (f16)(acc[mb + h][nb][0] + bv[nb].x);
-                o[h][1] = (f16)(acc[mb + h][nb][1] + bv[nb].y);
-                o[h][2] = (f16)(acc[mb + h][nb][2] + bv[nb].z);
-                o[h][3] = (f16)(acc[mb + h][nb][3] + bv[nb].w);
+                o[h][0] = (f16)(BIAS ? acc[mb + h][nb][0] + bv[nb].x : acc[mb + h][nb][0]);
+                o[h][1] = (f16)(BIAS ? acc[mb + h][nb][1] + bv[nb].y : acc[mb + h][nb][1]);
+                o[h][2] = (f16)(BIAS ? acc[mb + h][nb][2] + bv[nb].z : acc[mb + h][nb][2]);
+                o[h][3] = (f16)(BIAS ? acc[mb + h][nb][3] + bv[nb].w : acc[mb + h][nb][3]);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fnn_i32x2, o[h]), rsrc, voff[h], nb * ocs2, 0);
                 if (!okv[h]) o[h] = (f16x4){0, 0, 0, 0};
             }

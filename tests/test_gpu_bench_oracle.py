@@ -35,6 +35,18 @@ pytestmark = pytest.mark.gpu
 
 _CACHE = {}
 _ORACLE_BOX = {}
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _release_engines_when_the_module_is_done():
+    """The cached engine (one at a time) keeps tens of GB of HBM; the modules that run after this one plan their own
+    whole-volume buffers from what is free."""
+    yield
+    _CACHE.clear()
+    _ORACLE_BOX.clear()
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
 FACE = 16
 ORACLE_THREADS = 8                                               # the reference's own cap (predict_from_raw_data.py:479-480); torch's CPU convs get slower beyond a few dozen
 

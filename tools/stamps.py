@@ -4,7 +4,7 @@ import os
 os.environ.setdefault('FNN_KNOBS', '1')
 import sys
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fast_nnunet_amd import capi
 a = [int(v) for v in sys.argv[1:]]
 n, cin, cout, d, h, w = a[:6]
