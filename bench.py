@@ -387,6 +387,25 @@ def main():
     }
     if dt_nogather is not None:
         result['ms_per_step_compute_and_halo_only'] = round(dt_nogather / args.steps * 1e3, 3)
+    if distributed:
+        # one extra, profiled step (the device is synchronised at every phase boundary, so it is slower than the timed
+        # ones): where a rank's time goes and what it exchanges - per phase the MAX over ranks, bytes per rank as a list
+        ph = runner.start_phases()
+        out = step_fn()
+        del out
+        runner.phases = None
+        keys = sorted(ph)
+        mine = torch.tensor([float(ph[k]) for k in keys], device=device, dtype=torch.float64)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        allv = torch.stack(allv).cpu()
+        result['phases_profiled_step'] = {
+            'note': 'wall ms per phase of one extra step with a device synchronisation at every phase boundary; max over ranks',
+            **{k: round(float(allv[:, i].max()), 3) for i, k in enumerate(keys) if k.endswith('_ms')},
+            'per_rank': {k: [int(v) for v in allv[:, i]] for i, k in enumerate(keys) if not k.endswith('_ms')},
+            'mode': 'gather' if runner._use_gather() else 'accumulate',
+            'rccl_ranks': dist.get_world_size()}
+        assert dist.get_world_size() == args.gpus, 'the process group does not have one rank per requested GPU'
 
     if rank == 0 and not distributed and not args.no_roofline:
         # one extra, identical step with HIP events around every launch (recorded by the engine on the
@@ -430,11 +449,12 @@ def main():
         }
     if rank == 0 and not distributed and not args.no_cpu_baseline and not info['resenc']:
         result['cpu_baseline'] = cpu_baseline(sd, info)
-    if rank == 0:
-        print(json.dumps(result), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:                                              # last, so that the JSON is the last line on stdout
+        sys.stderr.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == '__main__':

@@ -105,8 +105,8 @@ def load_library() -> C.CDLL:
     lib.fnn_labels_box.argtypes = [vp, vp, P64, C.POINTER(Opts), P64, P64, P64, P64, vp]
     lib.fnn_feature_channels.argtypes = [vp]
     lib.fnn_feature_channels.restype = i64
-    lib.fnn_patch_features.argtypes = [vp, i32, vp, P64, C.POINTER(Opts), P64, i64, vp, vp]
-    lib.fnn_gather_box.argtypes = [vp, i32, vp, vp, C.POINTER(C.c_int32), P64, C.POINTER(Opts), P64, P64, vp, vp]
+    lib.fnn_patch_features.argtypes = [vp, i32, vp, P64, C.POINTER(Opts), P64, i64, vp, vp, i64, i64]
+    lib.fnn_gather_box.argtypes = [vp, i32, vp, vp, C.POINTER(C.c_int32), i64, P64, C.POINTER(Opts), P64, P64, vp, vp]
     lib.fnn_forward_patches.argtypes = [vp, i32, vp, i32, vp, vp]
     lib.fnn_argmax_labels.argtypes = [vp, vp, i32, i32, i64, vp, vp]
     lib.fnn_nonzero_bbox.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64), vp]
@@ -127,7 +127,7 @@ def load_library() -> C.CDLL:
                                   f32p, f32p, i32, I3, I3, f32p, C.POINTER(C.c_double)]
     lib.fnn_op_conv_transpose3d.argtypes = [i32, i32, I3, f32p, i32, f32p, f32p, C.c_float, f32p, f32p, i32, I3, f32p]
     lib.fnn_op_quotient_check.argtypes = [i32, C.POINTER(C.c_uint64)]
-    if lib.fnn_abi_version() != 2:
+    if lib.fnn_abi_version() != 3:
         raise EngineError('libfnn_hip.so has an unexpected ABI version')
     _lib = lib
     return lib
@@ -365,18 +365,23 @@ class Engine:
     def feature_channels(self) -> int:
         return int(self.lib.fnn_feature_channels(self.handle))
 
-    def patch_features(self, vol_ptr, shape, opts, patch_ids, feat_ptr, fss_ptr, fold=0):
+    def patch_features(self, vol_ptr, shape, opts, patch_ids, feat_ptr, fss_ptr, fold=0, slot0=0, n_slots=None):
+        """feat [n_eval][n_slots][P][C] / fss [n_eval][n_slots][2][C] (base pointers): patch_ids[i] -> slot slot0 + i."""
         shp = (C.c_int64 * 4)(*[int(i) for i in shape])
         ids = (C.c_int64 * max(1, len(patch_ids)))(*[int(i) for i in patch_ids])
-        check(self.lib.fnn_patch_features(self.handle, fold, vol_ptr, shp, C.byref(opts), ids, len(patch_ids), feat_ptr, fss_ptr),
-              self.lib, self.handle)
+        n_slots = slot0 + len(patch_ids) if n_slots is None else n_slots
+        check(self.lib.fnn_patch_features(self.handle, fold, vol_ptr, shp, C.byref(opts), ids, len(patch_ids), feat_ptr, fss_ptr,
+                                          C.c_int64(slot0), C.c_int64(n_slots)), self.lib, self.handle)
 
-    def gather_box(self, feat_ptr, fss_ptr, slot_of_patch, shape, opts, out_lo, out_hi, logits_ptr=None, labels_ptr=None, fold=0):
+    def gather_box(self, feat_ptr, fss_ptr, slot_of_patch, shape, opts, out_lo, out_hi, logits_ptr=None, labels_ptr=None, fold=0,
+                   n_slots=None):
         shp = (C.c_int64 * 4)(*[int(i) for i in shape])
         tab = np.ascontiguousarray(slot_of_patch, np.int32)
+        n_slots = int(tab.max()) + 1 if n_slots is None else n_slots
         lo, hi = (C.c_int64 * 3)(*[int(i) for i in out_lo]), (C.c_int64 * 3)(*[int(i) for i in out_hi])
-        check(self.lib.fnn_gather_box(self.handle, fold, feat_ptr, fss_ptr, tab.ctypes.data_as(C.POINTER(C.c_int32)), shp,
-                                      C.byref(opts), lo, hi, logits_ptr, labels_ptr), self.lib, self.handle)
+        check(self.lib.fnn_gather_box(self.handle, fold, feat_ptr, fss_ptr, tab.ctypes.data_as(C.POINTER(C.c_int32)),
+                                      C.c_int64(max(1, n_slots)), shp, C.byref(opts), lo, hi, logits_ptr, labels_ptr),
+              self.lib, self.handle)
 
     def labels_box(self, acc_ptr, shape, opts, box_lo, box_hi, out_lo, out_hi, labels_ptr):
         shp = (C.c_int64 * 4)(*[int(i) for i in shape])

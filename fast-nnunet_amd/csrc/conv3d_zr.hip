@@ -211,17 +211,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
             rw[nb] = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, WB * 16, 0x00020000);
         }
     };
-    auto load_part = [&](int part) {                          // part 0 .. 4
+#ifndef FNN_ZR_SLICES
+#define FNN_ZR_SLICES 5
+#endif
+    constexpr int SL = FNN_ZR_SLICES;
+    auto load_part = [&](int part) {                          // part 0 .. SL - 1
 #pragma unroll
         for (int u = 0; u < ID; ++u) {
-            if (u * 5 / ID != part) continue;
+            if (u * SL / ID != part) continue;
             int gd = od0 - 1 + u;
             gd = gd < 0 ? 0 : (gd >= p.Di ? p.Di - 1 : gd);   // scalar; a clamped plane's image is zeroed in commit()
             xr[u] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, (unsigned)gd * plane_bytes, 0));
         }
 #pragma unroll
         for (int e = 0; e < NB * WPB; ++e) {                  // element tid + 256 u of block nb; beyond the block: range check, zeros, no traffic
-            if (e * 5 / (NB * WPB) != part) continue;
+            if (e * SL / (NB * WPB) != part) continue;
             const int nb = e / WPB, u = e % WPB;
             wr[nb][u] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw[nb], tid * 16, u * 4096, 0));
         }
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
     auto kloop = [&](bool prefetch) {
 #pragma unroll
         for (int pr = 0; pr < 5; ++pr) {
-            if (prefetch) load_part(pr);
+            if (prefetch && pr < SL) load_part(pr);
             const char *bp = sA + toff[pr];
             f16x8 xf[ID];
 #pragma unroll
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
 
     prep(0);
 #pragma unroll
-    for (int part = 0; part < 5; ++part) load_part(part);
+    for (int part = 0; part < SL; ++part) load_part(part);
     __builtin_amdgcn_sched_barrier(0);                        // the loads leave first; the rest of the set-up runs under them
     FNN_STAMP();                                              // 1: first loads issued
     // the bias is where the accumulators start (lane = channels (lane >> 4) * 8 + nb * 4 .. + 3 of its block pair in the
@@ -1337,9 +1341,6 @@ static int launch_zr(ConvParams p, hipStream_t st) {
     p.ident_ss = conv3d_identity_ss();
     if (!p.ident_ss) return -2;
     dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
-#ifdef FNN_TMODE
-    p.tmode = fnn_knob("FNN_ZR_TMODE") ? atoi(fnn_knob("FNN_ZR_TMODE")) : 0;
-#endif
     hipLaunchKernelGGL((conv3d_zr_kernel<NB, TD>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -1492,11 +1492,12 @@ int fnn_labels_box(fnn_engine *e, const void *acc, const int64_t shape[4], const
 int64_t fnn_feature_channels(const fnn_engine *e) { return e ? e->layers[e->head_src].cout_pad : -1; }
 
 int fnn_patch_features(fnn_engine *e, int fold, const float *vol, const int64_t shape[4], const fnn_opts *opts,
-                       const int64_t *patch_ids, int64_t n_ids, void *feat, float *fss) {
+                       const int64_t *patch_ids, int64_t n_ids, void *feat, float *fss, int64_t slot0, int64_t n_slots) {
     if (int rc = check_ready(e, fold, opts)) return rc;
     if (!vol || !feat || !fss || (n_ids > 0 && !patch_ids)) return fail(e, FNN_E_INVALID, "NULL argument");
     if (!is_device_ptr(feat) || !is_device_ptr(fss)) return fail(e, FNN_E_INVALID, "feature buffers must be device memory");
-    if (opts->n_mirror_axes != 0) return fail(e, FNN_E_UNSUPPORTED, "fnn_patch_features does not mirror");
+    if (slot0 < 0 || n_slots < slot0 + n_ids) return fail(e, FNN_E_INVALID, "slots [%lld, %lld) do not fit %lld slots", (long long)slot0, (long long)(slot0 + n_ids), (long long)n_slots);
+    if (1 + (int)mirror_combos(*opts).size() > 8) return fail(e, FNN_E_UNSUPPORTED, "more than 8 evaluations per patch");
     if (!e->layers[e->head_src].has_norm) return fail(e, FNN_E_UNSUPPORTED, "the network's last layer has no InstanceNorm");
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)opts->stream;
@@ -1511,19 +1512,20 @@ int fnn_patch_features(fnn_engine *e, int fold, const float *vol, const int64_t 
     Box box;
     for (int d = 0; d < 3; ++d) { box.lo[d] = 0; box.hi[d] = vp.padded[d]; }
     e->ev_used = 0;
-    if (int rc = run_patches(e, fold, vol_dev, vp, *opts, ids, e->origins, box, nullptr, 0, st, false, true, 0, n_ids, feat, fss)) return rc;
+    if (int rc = run_patches(e, fold, vol_dev, vp, *opts, ids, e->origins, box, nullptr, 0, st, false, true, slot0, n_slots, feat, fss)) return rc;
     if (e->profiling) { HIPCHK(e, hipStreamSynchronize(st)); collect_profile(e, n_ids); }
     return 0;
 }
 
 int fnn_gather_box(fnn_engine *e, int fold, const void *feat, const float *fss, const int32_t *slot_of_patch,
-                   const int64_t shape[4], const fnn_opts *opts, const int64_t out_lo[3], const int64_t out_hi[3],
+                   int64_t n_slots, const int64_t shape[4], const fnn_opts *opts, const int64_t out_lo[3], const int64_t out_hi[3],
                    void *out_logits, void *labels) {
     if (int rc = check_ready(e, fold, opts)) return rc;
     if (!feat || !fss || !slot_of_patch || !out_lo || !out_hi || (!out_logits && !labels)) return fail(e, FNN_E_INVALID, "NULL argument");
     if (!is_device_ptr(feat) || !is_device_ptr(fss) || (out_logits && !is_device_ptr(out_logits)) || (labels && !is_device_ptr(labels)))
         return fail(e, FNN_E_INVALID, "fnn_gather_box needs device pointers");
-    if (opts->n_mirror_axes != 0 || opts->out_dtype != FNN_OUT_F16) return fail(e, FNN_E_UNSUPPORTED, "fnn_gather_box: no mirroring, fp16 logits");
+    if (opts->out_dtype != FNN_OUT_F16) return fail(e, FNN_E_UNSUPPORTED, "fnn_gather_box: fp16 logits");
+    const auto combos = mirror_combos(*opts);
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)opts->stream;
     VolPlan vp;
@@ -1533,8 +1535,10 @@ int fnn_gather_box(fnn_engine *e, int fold, const void *feat, const float *fss, 
     const fnn_arch_desc &a = e->arch;
     const Layer &H = e->layers[e->head_src];
     GatherParams g{};
-    g.heads = a.num_heads; g.C = H.cout_pad; g.PD = a.patch[0]; g.PH = a.patch[1]; g.PW = a.patch[2]; g.n_eval = 1;
+    g.heads = a.num_heads; g.C = H.cout_pad; g.PD = a.patch[0]; g.PH = a.patch[1]; g.PW = a.patch[2]; g.n_eval = 1 + (int)combos.size();
     if (!H.has_norm || e->head_ksteps != 1 || !gather_ok(g)) return fail(e, FNN_E_UNSUPPORTED, "this network's head does not fit the gather kernel");
+    for (int64_t i = 0; i < vp.n_patches; ++i)
+        if (slot_of_patch[i] >= n_slots) return fail(e, FNN_E_INVALID, "slot %d of patch %lld is beyond the %lld slots", slot_of_patch[i], (long long)i, (long long)n_slots);
     // tile starts, then the slot table, in one device buffer
     std::vector<int> tab;
     for (int d = 0; d < 3; ++d) for (int64_t v : vp.steps[d]) tab.push_back((int)v);
@@ -1550,7 +1554,12 @@ int fnn_gather_box(fnn_engine *e, int fold, const void *feat, const float *fss, 
     HIPCHK(e, hipMemsetAsync(e->inf_flag, 0, sizeof(int), st));
     const FoldWeights &fw = e->folds[fold];
     g.feat = (const f16 *)feat; g.fss = fss;
-    g.n_slots = 0; g.ring = 1; g.flipmask[0] = 0;
+    g.n_slots = (int)n_slots; g.ring = 1; g.flipmask[0] = 0;       // evaluation f of slot s: item f * n_slots + s (fnn_patch_features)
+    for (size_t ci = 0; ci < combos.size() && ci + 1 < 8; ++ci) {
+        int m = 0;
+        for (int ax : combos[ci]) m |= 1 << ax;
+        g.flipmask[ci + 1] = m;
+    }
     g.slope = H.act ? a.slope : 1.f;
     g.steps = e->steps_dev; g.slot_tab = e->steps_dev + n_steps;
     g.nx = (int)vp.steps[0].size(); g.ny = (int)vp.steps[1].size(); g.nz = (int)vp.steps[2].size();

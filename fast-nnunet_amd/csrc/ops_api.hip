@@ -159,17 +159,17 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
     (void)hipDeviceSynchronize();
     (void)hipMemset(dst.p, 0, (size_t)n * slots * cop * 16);
 #endif
-    if (fnn_knob("FNN_OP_TIME")) {                    // diagnostic: mean duration of 10 launches of this layer (after 2 warm-ups)
+    if (fnn_knob("FNN_OP_TIME")) {                    // diagnostic: mean duration of 30 launches of this layer (after 2 warm-ups)
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         for (int i = 0; i < 2; ++i) (void)launch_conv3d(p, 0);
         (void)hipEventRecord(e0, 0);
-        for (int i = 0; i < 10; ++i) (void)launch_conv3d(p, 0);
+        for (int i = 0; i < 30; ++i) (void)launch_conv3d(p, 0);
         (void)hipEventRecord(e1, 0);
         (void)hipDeviceSynchronize();
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        fprintf(stderr, "[op time] conv3d %d+%d -> %d at %dx%dx%d, N = %d: %.1f us per launch\n", cin, cin2, cout, p.Di, p.Hi, p.Wi, n, ms * 100.f);
+        fprintf(stderr, "[op time] conv3d %d+%d -> %d at %dx%dx%d, N = %d: %.1f us per launch\n", cin, cin2, cout, p.Di, p.Hi, p.Wi, n, ms * (1000.f / 30.f));
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         (void)hipMemset(dst.p, 0, (size_t)n * slots * cop * 16);
     }

@@ -219,22 +219,42 @@ def exchange_halos(acc: torch.Tensor, dec: Decomposition, rank: int, group=None)
     HaloExchange(acc, dec, rank, group).start().finish()
 
 
-class FeatureExchange:
-    """Gather-path exchange (SURVEY.md 8e with csrc/gather.hip): `feat` is [n_slots, PD, PH, PW, C] (fp16 on the GPUs),
-    `fss` [n_slots, 2, C]; `slot_of[pid]` says where a patch sits.  ``start()`` sends the regions of this rank's patches
-    that other ranks' owned boxes need (call it once those patches are computed), ``finish()`` lands the foreign regions
-    in their slots.  One packed buffer per peer and direction; both sides derive the same (peer, patch, region) lists
-    from the decomposition, so no metadata travels."""
+def mirror_flips(mirror_axes) -> List[Tuple[int, ...]]:
+    """The evaluations of one patch under test-time mirroring as tuples of flipped axes, the un-mirrored one first, then
+    the non-empty subsets of `mirror_axes` by size, then lexicographically - the order of
+    _internal_maybe_mirror_and_predict (predict_from_raw_data.py:541-557) and of the engine's evaluation index."""
+    if not mirror_axes:
+        return [()]
+    axes = list(mirror_axes)
+    return [()] + [c for k in range(len(axes)) for c in itertools.combinations(axes, k + 1)]
 
-    def __init__(self, feat: torch.Tensor, fss: torch.Tensor, dec: Decomposition, rank: int, patch, origins, slot_of, group=None):
+
+class FeatureExchange:
+    """Gather-path exchange (SURVEY.md 8e with csrc/gather.hip): `feat` is [n_eval, n_slots, PD, PH, PW, C] (fp16 on the
+    GPUs; a 5-D tensor is taken as n_eval = 1), `fss` [n_eval, n_slots, 2, C]; `slot_of[pid]` says where a patch sits.
+    ``start()`` sends the regions of this rank's patches that other ranks' owned boxes need (call it once those patches
+    are computed), ``finish()`` lands the foreign regions in their slots.  One packed buffer per peer and direction; both
+    sides derive the same (peer, patch, region) lists from the decomposition, so no metadata travels.  `flips`: the
+    evaluations under test-time mirroring (``mirror_flips``): the activation of a mirrored evaluation is stored in the
+    network's coordinates, so the block of a region sits at [P - hi, P - lo) along every flipped axis - on both sides."""
+
+    def __init__(self, feat: torch.Tensor, fss: torch.Tensor, dec: Decomposition, rank: int, patch, origins, slot_of, group=None,
+                 flips=((),)):
+        if feat.ndim == 5:
+            feat, fss = feat[None], fss[None]
         self.feat, self.fss, self.dec, self.rank, self.patch, self.origins, self.slot_of, self.group = \
             feat, fss, dec, rank, tuple(patch), origins, slot_of, group
+        self.flips = [tuple(f) for f in flips]
+        assert feat.shape[0] == len(self.flips)
         self.sends, self.recvs = dec.feature_transfers(rank, patch, origins)
         self.reqs, self.landing, self.keep = [], [], []
+        self.bytes_sent = self.bytes_received = 0
 
-    def _local(self, pid: int, region: Box):
+    def _local(self, pid: int, region: Box, flip=()):
         o = [int(v) for v in self.origins[pid]]
-        return tuple(slice(region[0][d] - o[d], region[1][d] - o[d]) for d in range(3))
+        lo = [region[0][d] - o[d] for d in range(3)]
+        hi = [region[1][d] - o[d] for d in range(3)]
+        return tuple(slice(self.patch[d] - hi[d], self.patch[d] - lo[d]) if d in flip else slice(lo[d], hi[d]) for d in range(3))
 
     def _peers(self, items):
         out = {}
@@ -248,17 +268,20 @@ class FeatureExchange:
         g = self.group
         dst = (lambda r: dist.get_global_rank(g, r)) if g is not None else (lambda r: r)
         ops = []
+        C, E = self.feat.shape[-1], len(self.flips)
         for peer, items in sorted(self._peers(self.sends).items()):
-            blocks = [self.feat[(self.slot_of[pid], *self._local(pid, reg))].reshape(-1) for pid, reg in items]
-            rows = torch.stack([self.fss[self.slot_of[pid]] for pid, _ in items])
+            blocks = [self.feat[(f, self.slot_of[pid], *self._local(pid, reg, fl))].reshape(-1)
+                      for f, fl in enumerate(self.flips) for pid, reg in items]
+            rows = torch.stack([self.fss[f, self.slot_of[pid]] for f in range(E) for pid, _ in items])
             buf = torch.cat(blocks)
             self.keep += [buf, rows]
+            self.bytes_sent += buf.numel() * buf.element_size() + rows.numel() * rows.element_size()
             ops += [dist.P2POp(dist.isend, buf, dst(peer), g), dist.P2POp(dist.isend, rows, dst(peer), g)]
         for peer, items in sorted(self._peers(self.recvs).items()):
-            C = self.feat.shape[-1]
-            n = sum(int(np.prod([reg[1][d] - reg[0][d] for d in range(3)])) * C for _, reg in items)
+            n = E * sum(int(np.prod([reg[1][d] - reg[0][d] for d in range(3)])) * C for _, reg in items)
             buf = torch.empty(n, dtype=self.feat.dtype, device=self.feat.device)
-            rows = torch.empty((len(items), 2, C), dtype=self.fss.dtype, device=self.fss.device)
+            rows = torch.empty((E * len(items), 2, C), dtype=self.fss.dtype, device=self.fss.device)
+            self.bytes_received += buf.numel() * buf.element_size() + rows.numel() * rows.element_size()
             ops += [dist.P2POp(dist.irecv, buf, dst(peer), g), dist.P2POp(dist.irecv, rows, dst(peer), g)]
             self.landing.append((items, buf, rows))
         self.reqs = dist.batch_isend_irecv(ops)
@@ -269,13 +292,15 @@ class FeatureExchange:
             req.wait()
         C = self.feat.shape[-1]
         for items, buf, rows in self.landing:
-            off = 0
-            for k, (pid, reg) in enumerate(items):
-                shape = tuple(reg[1][d] - reg[0][d] for d in range(3)) + (C,)
-                n = int(np.prod(shape))
-                self.feat[(self.slot_of[pid], *self._local(pid, reg))] = buf[off:off + n].view(shape)
-                self.fss[self.slot_of[pid]] = rows[k]
-                off += n
+            off, k = 0, 0
+            for f, fl in enumerate(self.flips):
+                for pid, reg in items:
+                    shape = tuple(reg[1][d] - reg[0][d] for d in range(3)) + (C,)
+                    n = int(np.prod(shape))
+                    self.feat[(f, self.slot_of[pid], *self._local(pid, reg, fl))] = buf[off:off + n].view(shape)
+                    self.fss[f, self.slot_of[pid]] = rows[k]
+                    off += n
+                    k += 1
         self.reqs, self.landing, self.keep = [], [], []
 
 
@@ -331,9 +356,10 @@ class ShardedPredictor:
 
     def __init__(self, predictor, group=None, mode: str = 'auto'):
         """mode: 'gather' - ranks keep patch activations and exchange the parts that reach into a neighbour's box
-        (csrc/gather.hip: no accumulators, results bit-identical to one GPU); 'accumulate' - ranks exchange partial sums
-        of read-modify-write accumulators; 'auto' - gather where the engine's gather kernel applies (<= 63 classes, no
-        mirroring)."""
+        (csrc/gather.hip: no accumulators, results bit-identical to one GPU, test-time mirroring included: the 2^k
+        evaluations' activations travel like any other); 'accumulate' - ranks exchange partial sums of read-modify-write
+        accumulators; 'auto' - gather where the engine's gather kernel applies (<= 63 classes) and the kept activations
+        fit in HBM."""
         self.p = predictor
         self.group = group
         self.rank = dist.get_rank(group)
@@ -341,46 +367,112 @@ class ShardedPredictor:
         assert mode in ('auto', 'gather', 'accumulate')
         self.mode = mode
 
-    def _use_gather(self) -> bool:
+    def _flips(self):
         p = self.p
-        ok = p._spec.num_heads <= 63 and not (p.use_mirroring and p.allowed_mirroring_axes) and p._spec.features[0] <= 32
+        return mirror_flips(p.allowed_mirroring_axes if p.use_mirroring else None)
+
+    def _use_gather(self, n_slots: Optional[int] = None) -> bool:
+        """The gather path applies where the engine's gather kernel does (<= 63 classes, <= 32 channels at full
+        resolution, <= 8 evaluations per patch) AND the kept activations fit: `n_slots` patch slots per evaluation
+        against 80 % of the free HBM (the single-GPU engine bounds the same buffers, csrc/engine.hip gather_plan).
+        'auto' falls back to the accumulate path; 'gather' raises."""
+        p = self.p
+        n_eval = len(self._flips())
+        ok = p._spec.num_heads <= 63 and n_eval <= 8 and p._spec.features[0] <= 32
+        why = 'the gather path needs <= 63 classes, <= 32 channels at full resolution and <= 8 evaluations per patch'
+        if ok and n_slots is not None and p.device.type == 'cuda':
+            C = p._engine.feature_channels
+            need = n_eval * n_slots * (int(np.prod(p._spec.patch)) * C * 2 + 2 * C * 4)
+            free = torch.cuda.mem_get_info(p.device)[0]
+            if need > 0.8 * free:
+                ok, why = False, f'the kept patch activations need {need / 2 ** 30:.1f} GiB, {free / 2 ** 30:.1f} GiB are free'
         if self.mode == 'gather' and not ok:
-            raise NotImplementedError('the gather path needs <= 63 classes, <= 32 channels at full resolution and no mirroring')
+            raise NotImplementedError(why)
         return ok and self.mode != 'accumulate'
 
-    def _features_fold(self, x, dec, origins, opts, fold):
-        """(feat [n_slots, PD, PH, PW, C], fss, slot table over all patches) with this rank's own patches and the
-        foreign regions its owned box needs; None on an idle rank."""
+    def _use_gather_all(self, slots) -> bool:
+        """The same path on every rank: a rank whose activations do not fit sends the whole group to the accumulate path
+        (the two exchanges do not pair up)."""
+        local = self._use_gather(None if slots is None else len(slots[2]))
+        if self.world == 1:
+            return local
+        flag = torch.tensor([1 if local else 0], dtype=torch.int32, device=self.p.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
+
+    def _slots(self, dec, origins):
+        """(boundary, interior, slot_of) of this rank: own patches first (boundary, then interior), then the foreign ones."""
+        patch = self.p._spec.patch
+        boundary, interior = dec.split_patches_for_features(self.rank, patch, origins)
+        _, recvs = dec.feature_transfers(self.rank, patch, origins)
+        slot_of = {pid: i for i, pid in enumerate(boundary + interior)}
+        for _, pid, _ in recvs:
+            slot_of.setdefault(pid, len(slot_of))
+        return boundary, interior, slot_of
+
+    def _features_fold(self, x, dec, origins, opts, fold, slots=None):
+        """(feat [n_eval, n_slots, PD, PH, PW, C], fss, slot table over all patches, n_slots) with this rank's own patches
+        and the foreign regions its owned box needs; None on an idle rank."""
         p, eng, patch = self.p, self.p._engine, self.p._spec.patch
         n_patches = int(origins.shape[0])
         table = np.full(n_patches, -1, np.int32)
+        flips = self._flips()
+        ph = self.phases
         if dec.owned[self.rank] is None:
-            FeatureExchange(torch.empty((0, *patch, 1)), torch.empty((0, 2, 1)), dec, self.rank, patch, origins, {}, self.group).start().finish()
+            FeatureExchange(torch.empty((len(flips), 0, *patch, 1)), torch.empty((len(flips), 0, 2, 1)), dec, self.rank, patch, origins,
+                            {}, self.group, flips).start().finish()
             return None
-        boundary, interior = dec.split_patches_for_features(self.rank, patch, origins)
-        _, recvs = dec.feature_transfers(self.rank, patch, origins)
-        local = boundary + interior
-        slot_of = {pid: i for i, pid in enumerate(local)}
-        for _, pid, _ in recvs:
-            slot_of.setdefault(pid, len(slot_of))
-        C = eng.feature_channels
+        boundary, interior, slot_of = slots if slots is not None else self._slots(dec, origins)
+        C, n_slots = eng.feature_channels, len(slot_of)
         # no zero fill: own slots are written whole by fnn_patch_features, a foreign slot exactly where it overlaps this
         # rank's owned box - the only part of it fnn_gather_box reads
-        feat = torch.empty((len(slot_of), *patch, C), dtype=torch.half, device=p.device)
-        fss = torch.empty((len(slot_of), 2, C), dtype=torch.float32, device=p.device)
-        P = int(np.prod(patch))
-        fx = FeatureExchange(feat, fss, dec, self.rank, patch, origins, slot_of, self.group)
+        feat = torch.empty((len(flips), n_slots, *patch, C), dtype=torch.half, device=p.device)
+        fss = torch.empty((len(flips), n_slots, 2, C), dtype=torch.float32, device=p.device)
+        fx = FeatureExchange(feat, fss, dec, self.rank, patch, origins, slot_of, self.group, flips)
+        t0 = self._tick()
         if boundary:
-            eng.patch_features(x.data_ptr(), x.shape, opts, boundary, feat.data_ptr(), fss.data_ptr(), fold=fold)
+            eng.patch_features(x.data_ptr(), x.shape, opts, boundary, feat.data_ptr(), fss.data_ptr(), fold=fold, slot0=0, n_slots=n_slots)
+        t1 = self._tick()
         fx.start()
+        t2 = self._tick()
         if interior:
-            nb = len(boundary)
-            eng.patch_features(x.data_ptr(), x.shape, opts, interior, feat.data_ptr() + nb * P * C * 2,
-                               fss.data_ptr() + nb * 2 * C * 4, fold=fold)
+            eng.patch_features(x.data_ptr(), x.shape, opts, interior, feat.data_ptr(), fss.data_ptr(), fold=fold,
+                               slot0=len(boundary), n_slots=n_slots)
+        t3 = self._tick()
         fx.finish()
+        t4 = self._tick()
+        if ph is not None:
+            ph['boundary_patches_ms'] += (t1 - t0) * 1e3
+            ph['exchange_post_ms'] += (t2 - t1) * 1e3
+            ph['interior_patches_ms'] += (t3 - t2) * 1e3
+            ph['exchange_wait_ms'] += (t4 - t3) * 1e3
+            ph['n_boundary_patches'] += len(boundary)
+            ph['n_interior_patches'] += len(interior)
+            ph['n_foreign_patches'] += n_slots - len(boundary) - len(interior)
+            ph['exchange_bytes_sent'] += fx.bytes_sent
+            ph['exchange_bytes_received'] += fx.bytes_received
         for pid, sl in slot_of.items():
             table[pid] = sl
-        return feat, fss, table
+        return feat, fss, table, n_slots
+
+    # ---- per-phase wall times of one step (bench.py --gpus N, tools/sharded_phases.py): `phases` is None (off) or a dict
+    # that the step fills; every boundary then synchronises the device, so a profiled step is slower than a timed one
+    phases = None
+
+    def start_phases(self):
+        self.phases = {k: 0.0 for k in ('boundary_patches_ms', 'exchange_post_ms', 'interior_patches_ms', 'exchange_wait_ms',
+                                        'gather_box_ms', 'assemble_all_gather_ms')}
+        self.phases.update({k: 0 for k in ('n_boundary_patches', 'n_interior_patches', 'n_foreign_patches',
+                                           'exchange_bytes_sent', 'exchange_bytes_received')})
+        return self.phases
+
+    def _tick(self):
+        if self.phases is None:
+            return 0.0
+        import time
+        if self.p.device.type == 'cuda':
+            torch.cuda.synchronize(self.p.device)
+        return time.perf_counter()
 
     def _plan(self, x):
         from . import capi
@@ -428,14 +520,18 @@ class ShardedPredictor:
                 out = torch.empty((p._spec.num_heads, *x.shape[1:]), dtype=torch.half, device=p.device)
             box, own = dec.boxes[self.rank], owns[self.rank]
             part = None
-            use_gather = self._use_gather()
+            slots = self._slots(dec, origins) if dec.owned[self.rank] is not None else None
+            use_gather = self._use_gather_all(slots)
             for i, f in enumerate(folds):
                 if use_gather:
-                    got = self._features_fold(x, dec, origins, opts, f)
+                    got = self._features_fold(x, dec, origins, opts, f, slots)
                     if own is None:
                         continue
+                    t0 = self._tick()
                     eng.gather_box(got[0].data_ptr(), got[1].data_ptr(), got[2], x.shape, opts, own[0], own[1],
-                                   logits_ptr=out.data_ptr(), fold=f)
+                                   logits_ptr=out.data_ptr(), fold=f, n_slots=got[3])
+                    if self.phases is not None:
+                        self.phases['gather_box_ms'] += (self._tick() - t0) * 1e3
                 else:
                     acc = self._accumulate_fold(x, dec, origins, opts, f)
                     if own is None:
@@ -447,7 +543,11 @@ class ShardedPredictor:
             if part is not None:
                 out[(slice(None), *[slice(own[0][d], own[1][d]) for d in range(3)])] = part.div_(len(folds))
             if gather:
-                return gather_owned_boxes(out, owns, self.rank, self.group)
+                t0 = self._tick()
+                res = gather_owned_boxes(out, owns, self.rank, self.group)
+                if self.phases is not None:
+                    self.phases['assemble_all_gather_ms'] += (self._tick() - t0) * 1e3
+                return res
         return out, own
 
     @torch.inference_mode()
@@ -477,17 +577,24 @@ class ShardedPredictor:
                 dec, origins, owns = self._plan(x)
                 opts = p._opts()
                 box, own = dec.boxes[self.rank], owns[self.rank]
-                if self._use_gather():
-                    got = self._features_fold(x, dec, origins, opts, p._active_fold)
+                slots = self._slots(dec, origins) if dec.owned[self.rank] is not None else None
+                if self._use_gather_all(slots):
+                    got = self._features_fold(x, dec, origins, opts, p._active_fold, slots)
                     if own is not None:
+                        t0 = self._tick()
                         eng.gather_box(got[0].data_ptr(), got[1].data_ptr(), got[2], x.shape, opts, own[0], own[1],
-                                       labels_ptr=labels.data_ptr(), fold=p._active_fold)
+                                       labels_ptr=labels.data_ptr(), fold=p._active_fold, n_slots=got[3])
+                        if self.phases is not None:
+                            self.phases['gather_box_ms'] += (self._tick() - t0) * 1e3
                 else:
                     acc = self._accumulate_fold(x, dec, origins, opts, p._active_fold)
                     if own is not None:
                         eng.labels_box(acc.data_ptr(), x.shape, opts, box[0], box[1], own[0], own[1], labels.data_ptr())
             if gather:
+                t0 = self._tick()
                 gather_owned_boxes(labels, owns, self.rank, self.group)
+                if self.phases is not None:
+                    self.phases['assemble_all_gather_ms'] += (self._tick() - t0) * 1e3
             if u16:
                 labels = labels.to(torch.int32) & 0xffff
         return labels

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define FNN_MAX_STAGES 8
-#define FNN_ABI_VERSION 2
+#define FNN_ABI_VERSION 3
 
 enum {
     FNN_OK = 0,
@@ -212,13 +212,19 @@ int fnn_labels_box(fnn_engine *e, const void *acc, const int64_t shape[4], const
  * all patches that cover it, in the reference's visiting order: slot_of_patch[pid] (HOST array over the x-major patch
  * list of fnn_plan_volume) = where patch pid's activation sits in feat / fss, or -1 where the caller knows the patch
  * does not reach the box.  Writes fp16 logits [heads][X][Y][Z] and / or labels [X][Y][Z] (either may be NULL) of the
- * full-size tensors.  Mirroring is not available on this pair (opts->n_mirror_axes must be 0). */
+ * full-size tensors.
+ * Slots and mirroring (ABI 3): the caller's buffers hold `n_slots` patch slots per evaluation - feat
+ * [n_eval][n_slots][P][C], fss [n_eval][n_slots][2][C], n_eval = 2^(opts->n_mirror_axes) in the order of
+ * _internal_maybe_mirror_and_predict (predict_from_raw_data.py:541-557; 1 without mirroring); fnn_patch_features
+ * writes patch patch_ids[i] into slot slot0 + i of every evaluation.  The activation of a mirrored evaluation is
+ * stored in the network's (flipped) coordinates: voxel v of the patch sits at P - 1 - v along every flipped axis, which
+ * is where a caller that moves sub-blocks between ranks has to put them (fast-nnunet_amd/dist.py, FeatureExchange). */
 int64_t fnn_feature_channels(const fnn_engine *e);
 int fnn_patch_features(fnn_engine *e, int fold, const float *vol, const int64_t shape[4], const fnn_opts *opts,
-                       const int64_t *patch_ids, int64_t n_ids, void *feat, float *fss);
+                       const int64_t *patch_ids, int64_t n_ids, void *feat, float *fss, int64_t slot0, int64_t n_slots);
 int fnn_gather_box(fnn_engine *e, int fold, const void *feat, const float *fss, const int32_t *slot_of_patch,
-                   const int64_t shape[4], const fnn_opts *opts, const int64_t out_lo[3], const int64_t out_hi[3],
-                   void *out_logits, void *labels);
+                   int64_t n_slots, const int64_t shape[4], const fnn_opts *opts, const int64_t out_lo[3],
+                   const int64_t out_hi[3], void *out_logits, void *labels);
 
 /* LabelManager.convert_logits_to_segmentation on resident logits with the
  * engine's label rule: logits [heads, n_vox] f16/f32 -> labels uint8/uint16. */

@@ -236,16 +236,24 @@ def test_feature_transfers_cover_every_voxel_of_every_owned_box(shape, patch, st
         assert sorted(boundary + interior) == sorted(dec.patch_ids[r]) and {i for _, i, _ in sends} == set(boundary)
 
 
-def _gather_worker(rank, world, port, shape, patch, step, heads, q):
+def _gather_worker(rank, world, port, shape, patch, step, heads, mirror, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        from fast_nnunet_amd.dist import Decomposition, FeatureExchange, gather_owned_boxes, unpadded
+        from fast_nnunet_amd.dist import Decomposition, FeatureExchange, gather_owned_boxes, mirror_flips, unpadded
         padded, pad_lo, steps = _geometry(shape, patch, step)
         origins = [(x, y, z) for x in steps[0] for y in steps[1] for z in steps[2]]
         gauss = osw.gaussian_weight(patch).float()
         dec = Decomposition.build(patch, padded, steps, world)
+        flips = mirror_flips(mirror)
+        E = len(flips)
+
+        def stored(pid, f):
+            """Evaluation f of patch pid as the engine keeps it: value toy + 100 f, in the network's (flipped) coordinates."""
+            v = _toy_logits(origins[pid], patch, heads) + 100.0 * f
+            return torch.flip(v, list(flips[f])) if flips[f] else v
+
         out = torch.full((heads, *shape), float('nan'))
         if dec.owned[rank] is not None:
             boundary, interior = dec.split_patches_for_features(rank, patch, origins)
@@ -253,18 +261,22 @@ def _gather_worker(rank, world, port, shape, patch, step, heads, q):
             slot_of = {pid: i for i, pid in enumerate(boundary + interior)}
             for _, pid, _ in recvs:
                 slot_of.setdefault(pid, len(slot_of))
-            feat = torch.full((len(slot_of), *patch, heads), float('nan'))
-            fss = torch.zeros((len(slot_of), 2, heads))
+            feat = torch.full((E, len(slot_of), *patch, heads), float('nan'))
+            fss = torch.zeros((E, len(slot_of), 2, heads))
             for pid in boundary:                                   # the order ShardedPredictor uses
-                feat[slot_of[pid]] = _toy_logits(origins[pid], patch, heads)
-                fss[slot_of[pid], 0] = float(pid)
-            fx = FeatureExchange(feat, fss, dec, rank, patch, origins, slot_of, None).start()
+                for f in range(E):
+                    feat[f, slot_of[pid]] = stored(pid, f)
+                    fss[f, slot_of[pid], 0] = float(pid * 10 + f)
+            fx = FeatureExchange(feat, fss, dec, rank, patch, origins, slot_of, None, flips).start()
             for pid in interior:
-                feat[slot_of[pid]] = _toy_logits(origins[pid], patch, heads)
-                fss[slot_of[pid], 0] = float(pid)
+                for f in range(E):
+                    feat[f, slot_of[pid]] = stored(pid, f)
+                    fss[f, slot_of[pid], 0] = float(pid * 10 + f)
             fx.finish()
-            assert all(float(fss[sl, 0, 0]) == pid for pid, sl in slot_of.items())     # every slot's rows arrived with it
-            # what gather.hip does over the owned box: every covering patch, ascending
+            assert all(float(fss[f, sl, 0, 0]) == pid * 10 + f for pid, sl in slot_of.items() for f in range(E))   # rows arrived with their slots
+            assert fx.bytes_sent > 0 or world == 1
+            # what gather.hip does over the owned box: every covering patch, ascending; per visit the mean of the
+            # evaluations, each read at the flipped voxel
             ob = dec.owned[rank]
             own = unpadded(ob, pad_lo, shape)
             if own is not None:
@@ -279,12 +291,15 @@ def _gather_worker(rank, world, port, shape, patch, step, heads, q):
                         continue
                     dst = tuple(slice(a[d] - lo[d], b[d] - lo[d]) for d in range(3))
                     src = tuple(slice(a[d] - o[d], b[d] - o[d]) for d in range(3))
-                    num[dst] += feat[(slot_of[pid], *src)] * gauss[src][..., None]
+                    logit = sum((torch.flip(feat[f, slot_of[pid]], list(flips[f])) if flips[f] else feat[f, slot_of[pid]])[src]
+                                for f in range(E)) / E
+                    num[dst] += logit * gauss[src][..., None]
                     den[dst] += gauss[src]
                 sl = tuple(slice(own[0][d], own[1][d]) for d in range(3))
                 out[(slice(None), *sl)] = (num / den[..., None]).permute(3, 0, 1, 2)
         else:
-            FeatureExchange(torch.empty((0, *patch, heads)), torch.empty((0, 2, heads)), dec, rank, patch, origins, {}, None).start().finish()
+            FeatureExchange(torch.empty((E, 0, *patch, heads)), torch.empty((E, 0, 2, heads)), dec, rank, patch, origins, {}, None,
+                            flips).start().finish()
         owns = [None if b is None else unpadded(b, pad_lo, shape) for b in dec.owned]
         gather_owned_boxes(out, owns, rank, None)
         q.put((rank, out.numpy()))
@@ -292,13 +307,15 @@ def _gather_worker(rank, world, port, shape, patch, step, heads, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_feature_exchange_matches_single_process_gloo(world):
+@pytest.mark.parametrize('world,mirror', [(2, None), (3, None), (8, None), (2, (0, 2)), (4, (0, 1, 2))])
+def test_feature_exchange_matches_single_process_gloo(world, mirror):
+    """Worlds 2 / 3 / 8 (the node has eight GPUs) and test-time mirroring: the 2^k evaluations' activations
+    travel as flipped sub-blocks and land where the gather kernel reads them."""
     shape, patch, step, heads = (30, 41, 26), (16, 16, 16), 0.5, 3
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, shape, patch, step, heads, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, shape, patch, step, heads, mirror, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in range(world)]
@@ -311,5 +328,7 @@ def test_feature_exchange_matches_single_process_gloo(world):
     acc = _accumulate(range(len(origins)), origins, ((0, 0, 0), tuple(padded)), patch, heads, hp, osw.gaussian_weight(patch).float())
     sl = tuple(slice(pad_lo[d], pad_lo[d] + shape[d]) for d in range(3))
     want = (acc[sl][..., :heads] / acc[sl][..., heads:heads + 1]).permute(3, 0, 1, 2).numpy()
+    n_eval = 1 if mirror is None else 2 ** len(mirror)
+    want = want + 100.0 * (n_eval - 1) / 2                       # evaluation f carries toy + 100 f: the mean over f
     for _, got in results:
-        assert not np.isnan(got).any() and np.allclose(got, want, rtol=1e-5, atol=1e-5)
+        assert not np.isnan(got).any() and np.allclose(got, want, rtol=1e-4, atol=1e-3)

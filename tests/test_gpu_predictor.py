@@ -475,6 +475,18 @@ def test_sharded_predictor_single_rank_process_group():
                 labels = sp.predict_segmentation_from_preprocessed_data(image)
                 assert labels.dtype == torch.uint8 and torch.equal(labels, p.predict_segmentation_from_preprocessed_data(image))
                 assert torch.equal(labels.long(), want.float().argmax(0))
+        # test-time mirroring (the reference's default): the gather mode keeps all 2^k evaluations, 'auto' takes it
+        pm = _predictor(spec, patch, sds[:1], mirror=(0, 1, 2))
+        want_m = pm.predict_sliding_window_return_logits(image)
+        for mode in ('auto', 'gather', 'accumulate'):
+            spm = ShardedPredictor(pm, mode=mode)
+            ph = spm.start_phases()
+            got_m, _ = spm.predict_sliding_window_return_logits(image)
+            if mode != 'accumulate':
+                assert torch.equal(got_m, want_m) and ph['gather_box_ms'] > 0 and ph['n_interior_patches'] > 0
+            else:                                             # partial sums in another visiting order: the reference's error class
+                assert (got_m.float() - want_m.float()).abs().max() <= 2e-2 * float(want_m.float().abs().max())
+            spm.phases = None
         p2 = _predictor(spec, patch, sds)
         sp2 = ShardedPredictor(p2)
         assert torch.equal(sp2.predict_logits_from_preprocessed_data(image).cpu(), p2.predict_logits_from_preprocessed_data(image))
@@ -914,17 +926,18 @@ def test_autocast_accumulation_whole_ring_labels_and_refusals(heads, mirror):
         os.environ.pop('FNN_NO_GATHER', None)
 
 
-@pytest.mark.parametrize('heads,world', [(3, 2), (3, 4), (61, 8)])
-def test_sharded_gather_path_through_c_abi_is_bit_identical_to_single_gpu(heads, world):
+@pytest.mark.parametrize('heads,world,mirror', [(3, 2, None), (3, 4, None), (61, 8, None), (3, 4, (0, 1, 2)), (61, 2, (1,))])
+def test_sharded_gather_path_through_c_abi_is_bit_identical_to_single_gpu(heads, world, mirror):
     """fnn_patch_features / fnn_gather_box for `world` virtual ranks on one GPU, the feature exchange done with local
     copies of exactly the regions FeatureExchange would send: logits and labels of every owned box must be the bits of
     the single-GPU predictor (the gather kernel visits a voxel's covering patches in the reference's order whoever
-    computed them)."""
+    computed them).  With test-time mirroring (the reference's default, predict_from_raw_data.py:42) the 2^k
+    evaluations' activations travel too, each as the flipped sub-block the kernel reads."""
     from fast_nnunet_amd import capi
-    from fast_nnunet_amd.dist import Decomposition, unpadded
+    from fast_nnunet_amd.dist import Decomposition, mirror_flips, unpadded
     spec = UNetSpec('plain', 1, heads, [16, 32], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
     patch = (16, 16, 32)
-    p = _predictor(spec, patch, [synthetic_state_dict(spec, 33)])
+    p = _predictor(spec, patch, [synthetic_state_dict(spec, 33)], mirror=mirror)
     image = torch.randn(1, 37, 30, 70, generator=torch.Generator().manual_seed(6))
     want = p.predict_sliding_window_return_logits(image)
     want_labels = p.predict_segmentation_from_preprocessed_data(image)
@@ -933,22 +946,24 @@ def test_sharded_gather_path_through_c_abi_is_bit_identical_to_single_gpu(heads,
     steps = [sorted(set(int(v) for v in origins[:, d])) for d in range(3)]
     dec = Decomposition.build(patch, padded, steps, world)
     opts, eng = p._opts(), p._engine
-    C, P = eng.feature_channels, int(np.prod(patch))
-    feats, tables = [], []
+    C = eng.feature_channels
+    flips = mirror_flips(mirror)
+    E = len(flips)
+    feats = []
     for r in range(world):                                           # every rank: its own patches (boundary first)
         if dec.owned[r] is None:
-            feats.append(None); tables.append(None)
+            feats.append(None)
             continue
         boundary, interior = dec.split_patches_for_features(r, patch, origins)
         slot_of = {pid: i for i, pid in enumerate(boundary + interior)}
         for _, pid, _ in dec.feature_transfers(r, patch, origins)[1]:
             slot_of.setdefault(pid, len(slot_of))
-        feat = torch.zeros((len(slot_of), *patch, C), dtype=torch.half, device='cuda')
-        fss = torch.zeros((len(slot_of), 2, C), dtype=torch.float32, device='cuda')
-        nb = len(boundary)
-        for ids, off in ((boundary, 0), (interior, nb)):
+        n_slots = len(slot_of)
+        feat = torch.zeros((E, n_slots, *patch, C), dtype=torch.half, device='cuda')
+        fss = torch.zeros((E, n_slots, 2, C), dtype=torch.float32, device='cuda')
+        for ids, off in ((boundary, 0), (interior, len(boundary))):
             if ids:
-                eng.patch_features(x.data_ptr(), x.shape, opts, ids, feat.data_ptr() + off * P * C * 2, fss.data_ptr() + off * 2 * C * 4)
+                eng.patch_features(x.data_ptr(), x.shape, opts, ids, feat.data_ptr(), fss.data_ptr(), slot0=off, n_slots=n_slots)
         feats.append((feat, fss, slot_of))
     torch.cuda.synchronize()
     for r in range(world):                                           # local stand-in for FeatureExchange
@@ -958,9 +973,11 @@ def test_sharded_gather_path_through_c_abi_is_bit_identical_to_single_gpu(heads,
         for peer, pid, reg in dec.feature_transfers(r, patch, origins)[1]:
             pf, ps, pslot = feats[peer]
             o = [int(v) for v in origins[pid]]
-            loc = tuple(slice(reg[0][d] - o[d], reg[1][d] - o[d]) for d in range(3))
-            feat[(slot_of[pid], *loc)] = pf[(pslot[pid], *loc)]
-            fss[slot_of[pid]] = ps[pslot[pid]]
+            for f, fl in enumerate(flips):
+                loc = tuple(slice(patch[d] - (reg[1][d] - o[d]), patch[d] - (reg[0][d] - o[d])) if d in fl
+                            else slice(reg[0][d] - o[d], reg[1][d] - o[d]) for d in range(3))
+                feat[(f, slot_of[pid], *loc)] = pf[(f, pslot[pid], *loc)]
+                fss[f, slot_of[pid]] = ps[f, pslot[pid]]
     got = torch.zeros_like(want)
     labels = torch.full_like(want_labels, 255)
     for r in range(world):
@@ -973,6 +990,6 @@ def test_sharded_gather_path_through_c_abi_is_bit_identical_to_single_gpu(heads,
         own = unpadded(dec.owned[r], pad_lo, x.shape[1:])
         if own is not None:
             eng.gather_box(feat.data_ptr(), fss.data_ptr(), table, x.shape, opts, own[0], own[1], logits_ptr=got.data_ptr(),
-                           labels_ptr=labels.data_ptr())
+                           labels_ptr=labels.data_ptr(), n_slots=len(slot_of))
     torch.cuda.synchronize()
     assert torch.equal(got, want) and torch.equal(labels, want_labels)
