@@ -34,7 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16, MI355X_MICROARCH.md "Chip-level parameters"
-TRAFFIC_FILE = 'r02_traffic.json'  # per-launch HBM bytes of the conv family from separate rocprofv3 --pmc passes
+TRAFFIC_FILE = 'r03_traffic.json'  # per-launch HBM bytes of the conv family from separate rocprofv3 --pmc passes, per workload, keyed by csrc_sha256()
 
 WORKLOADS = {
     # name: (spacing, patch, heads, reduction)
@@ -236,15 +236,34 @@ def cpu_baseline(sd, info, seconds_budget=60.0):
         return {'value': round(n_patches / dt, 4), 'cores': threads, 's_per_patch': round(dt / n_patches, 4),
                 'sample': f'{n_patches} patches ({shape[0]}x{shape[1]}x{shape[2]} sub-volume of the same synthetic CT)'}
 
-    full = run(all_threads)
-    eight = run(min(8, all_threads)) if all_threads > 8 else dict(full)
+    eight = run(min(8, all_threads))
+    full = run(all_threads) if all_threads > 8 else dict(eight)
     torch.set_num_threads(all_threads)
-    return {'value': full['value'], 'unit': 'patches/s', 'cores': full['cores'], 'kind': 'port',
-            'sample': full['sample'] + f', fp32 network + fp16 accumulators, torch {torch.__version__} CPU, '
-                                       f'{os.cpu_count()} host cpus visible',
-            's_per_patch': full['s_per_patch'],
-            'threads_8_reference_default': {'value': eight['value'], 'unit': 'patches/s', 'cores': eight['cores'],
-                                            'sample': eight['sample'], 's_per_patch': eight['s_per_patch']}}
+    # `value` is the reference's own behaviour: predict_logits_from_preprocessed_data caps torch at default_num_processes
+    # = 8 threads (predict_from_raw_data.py:479-480, configuration.py:5) whatever its CLI set before (:954-958); the
+    # all-cores figure (slower: torch's CPU convs lose beyond a few dozen threads) is kept next to it
+    return {'value': eight['value'], 'unit': 'patches/s', 'cores': eight['cores'], 'kind': 'port',
+            'sample': eight['sample'] + f', fp32 network + fp16 accumulators, torch {torch.__version__} CPU, '
+                                        f'{os.cpu_count()} host cpus visible',
+            's_per_patch': eight['s_per_patch'],
+            'all_cores': {'value': full['value'], 'unit': 'patches/s', 'cores': full['cores'],
+                          'sample': full['sample'], 's_per_patch': full['s_per_patch']}}
+
+
+def csrc_sha256():
+    """Hash of the HIP sources the library is built from: the key that ties committed counter traffic to the code."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'fast-nnunet_amd', 'csrc')
+    for f in sorted(glob.glob(os.path.join(d, '*.hip')) + glob.glob(os.path.join(d, '*.h')) + [os.path.join(d, 'Makefile')]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()
+
+
+def traffic_key(args):
+    return f'{args.workload}|{args.dtype}|mirror={int(args.mirror)}|{args.accum}|vol={args.volume}|batch={args.batch}'
 
 
 def spawn_ranks(n):
@@ -421,14 +440,20 @@ def main():
         algo_bytes = pr.conv_bytes / launches
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, 'profiles', TRAFFIC_FILE)
-        if os.path.isfile(tpath) and args.workload == 'bone_turbo_r2' and args.volume == 512 and args.batch == 32:
+        if os.path.isfile(tpath):
             try:                                  # HBM bytes per launch of the same kernel family from separate PMC passes
-                fam = json.load(open(tpath))['families']['conv3d_mfma']
-                traffic = int(fam['bytes_per_launch'])
-                traffic_src = (f'profiles/{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on '
-                               f'the same build (reads x2 as MI355X_MICROARCH.md prescribes); not measured in this run')
-            except Exception:
-                pass
+                tj = json.load(open(tpath))
+                if tj.get('csrc_sha256') != csrc_sha256():
+                    traffic_src = f'profiles/{TRAFFIC_FILE} was captured on other kernel sources (csrc_sha256 differs): stale, not quoted'
+                elif traffic_key(args) not in tj.get('workloads', {}):
+                    traffic_src = f'profiles/{TRAFFIC_FILE} holds no capture of {traffic_key(args)}'
+                else:
+                    fam = tj['workloads'][traffic_key(args)]['families']['conv3d_mfma']
+                    traffic = int(fam['bytes_per_launch'])
+                    traffic_src = (f'profiles/{TRAFFIC_FILE}[{traffic_key(args)}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this '
+                                   f'command on these kernel sources (reads x2 as MI355X_MICROARCH.md prescribes); not measured in this run')
+            except Exception as ex:
+                traffic_src = f'profiles/{TRAFFIC_FILE} unreadable: {ex}'
         result['roofline'] = {
             'kernel': 'MFMA conv family: conv3d_zr / zsp / s2 / lds / persist kernels, conv_row_kernel and conv_row_stem_kernel', 'bound': 'mfma',
             'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',

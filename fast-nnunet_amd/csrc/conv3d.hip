@@ -937,6 +937,22 @@ const float *conv3d_identity_ss() {
     return tab[dev];
 }
 
+// SrcDesc::ssh rows of a source without InstanceNorm: per group of 8 channels 8 x 1.0 then 8 x 0.0 (fp16), 512 channels
+const unsigned short *conv3d_identity_ssh() {
+    static const unsigned short *tab[16] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!tab[dev]) {
+        unsigned short h[1024];
+        for (int i = 0; i < 1024; ++i) h[i] = (i & 8) ? 0 : 0x3c00;
+        unsigned short *d = nullptr;
+        if (hipMalloc((void **)&d, sizeof(h)) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+        tab[dev] = d;
+    }
+    return tab[dev];
+}
+
 int conv3d_pick_nb(int nblk) { return (nblk % 4 == 0) ? 4 : (nblk % 2 == 0) ? 2 : 1; }
 
 template <int NB>

@@ -182,7 +182,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
 
     f32x4 acc[TD][NB];
     fnn_u32x4v xr[ID], wr[NB][WPB];
+#ifdef FNN_NORM_FP32
     float scu[16], shu[16];                                   // the chunk's scale / shift rows: wave-uniform -> scalar loads
+#else
+    fnn_u32x4v ssv[2];                                        // this thread's 8 scales and 8 shifts in fp16 (SrcDesc::ssh): two 16-byte loads
+#endif
     float slope_next = 1.f;
 
     // The chunk's loads in five slices, one per tap pair of the k-loop: issued in one block the 18 wave-wide loads of
@@ -199,10 +203,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
         const f16 *sp = p.src[s].ptr + (size_t)n * (item_bytes >> 1) + (c_uni >> 4) * FNN_CS(p.src[s]);
         rx = __builtin_amdgcn_make_buffer_rsrc((void *)sp, 0, item_bytes, 0x00020000);
         slope_next = p.src[s].slope;
+#ifdef FNN_NORM_FP32
         const float *qs = p.src[s].ss ? p.src[s].ss + (size_t)(2 * n) * sC + c_uni : p.ident_ss + c_uni;
         const float *qh = p.src[s].ss ? qs + sC : p.ident_ss + 512 + c_uni;
 #pragma unroll
         for (int j = 0; j < 16; ++j) { scu[j] = qs[j]; shu[j] = qh[j]; }
+#else
+        {
+            const unsigned short *q = p.src[s].ssh ? p.src[s].ssh + ((size_t)n * sC + c_uni) * 2 : p.ident_ssh + c_uni * 2;
+            const fnn_u32x4v *qv = (const fnn_u32x4v *)(q + cg * 16);
+            ssv[0] = qv[0]; ssv[1] = qv[1];
+        }
+#endif
         voff = ok_hw ? (unsigned)hw_lin * (unsigned)(vs * 2) + cg * 16 : 0x80000000u;
         plane_bytes = (unsigned)p.Hi * p.Wi * vs * 2;
 #pragma unroll
@@ -232,19 +244,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
     };
     auto commit = [&]() {
         const f16 slope_h = (f16)slope_next;
+#ifdef FNN_NORM_FP32
         float sc[8], sh[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {                         // a column outside the tensor: 0 * 0 + 0 = the conv's zero padding
             sc[j] = ok_hw ? (cg ? scu[8 + j] : scu[j]) : 0.f;
             sh[j] = ok_hw ? (cg ? shu[8 + j] : shu[j]) : 0.f;
         }
-#ifndef FNN_NORM_FP32
+#else
         // x*scale+shift with scale and shift rounded to fp16 (v_pk_fma_f16): in fp32 (convert, fma, convert back) the
         // staging's normalisation was 8 % of the benchmark's time.  Measured cost in accuracy: relative RMSE of the 64^3
         // student 1.56e-3 -> 1.64e-3 against the 5e-3 limit.  `make NORM_FP32=1` builds the fp32 form.
-        f16x8 sc_h, sh_h;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { sc_h[j] = (f16)sc[j]; sh_h[j] = (f16)sh[j]; }
+        // A column outside the tensor: 0 * 0 + 0 = the conv's zero padding.
+        const fnn_u32x4v zero4 = {0u, 0u, 0u, 0u};
+        const f16x8 sc_h = __builtin_bit_cast(f16x8, ok_hw ? ssv[0] : zero4), sh_h = __builtin_bit_cast(f16x8, ok_hw ? ssv[1] : zero4);
 #endif
         if (has_col) {
 #pragma unroll
@@ -1339,7 +1352,8 @@ static int launch_zr(ConvParams p, hipStream_t st) {
         attr_set = true;
     }
     p.ident_ss = conv3d_identity_ss();
-    if (!p.ident_ss) return -2;
+    p.ident_ssh = conv3d_identity_ssh();
+    if (!p.ident_ss || !p.ident_ssh) return -2;
     dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
     hipLaunchKernelGGL((conv3d_zr_kernel<NB, TD>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -599,6 +599,10 @@ void collect_profile(fnn_engine *e, int64_t n_patches) {
 // ---------------------------------------------------------------------------
 // one network forward for `nb` patches (activations only; the head is separate)
 // ---------------------------------------------------------------------------
+// the fp16 scale / shift rows (SrcDesc::ssh) live behind the fp32 rows of the same arena: [ss_count * max_batch * 2 + 4] floats,
+// then ss_count * max_batch * 2 halves
+static unsigned short *ssh_rows(fnn_engine *e) { return (unsigned short *)(e->ss + e->ss_count * e->max_batch * 2 + 4); }
+
 SrcDesc make_src(fnn_engine *e, const FoldWeights &fw, int layer, int nb) {
     const Layer &L = e->layers[layer];
     SrcDesc s{};
@@ -608,9 +612,10 @@ SrcDesc make_src(fnn_engine *e, const FoldWeights &fw, int layer, int nb) {
     else { s.vs = L.cout_pad; s.cs = 16; }
     if (L.has_norm) {
         s.ss = e->ss + L.ss_off * e->max_batch * 2;
+        s.ssh = ssh_rows(e) + L.ss_off * e->max_batch * 2;           // halves: [N][C / 8][16] = 2 C per item
         s.slope = L.act ? e->arch.slope : 1.f;
     } else {
-        s.ss = nullptr; s.slope = 1.f;
+        s.ss = nullptr; s.ssh = nullptr; s.slope = 1.f;
     }
     (void)fw;
     (void)nb;
@@ -722,6 +727,7 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             StatsFinalizeParams q{};
             q.stats = stats_out; q.gamma = fw.fparam + L.gamma_off; q.beta = fw.fparam + L.beta_off;
             q.ss = e->ss + L.ss_off * e->max_batch * 2; q.C = L.cout_pad; q.nrep = L.stats_slots;
+            q.ssh = ssh_rows(e) + L.ss_off * e->max_batch * 2;
             if (head_ss && (int)li == e->head_src) q.ss = head_ss;
             q.inv_count = 1.f / ((float)L.out_dims[0] * L.out_dims[1] * L.out_dims[2]); q.eps = e->arch.eps;
             if (launch_stats_finalize(q, nb, st) != 0) return fail(e, FNN_E_HIP, "stats finalize launch failed");
@@ -883,7 +889,7 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
                 if (k > 0) {
                     HIPCHK(e, hipMalloc((void **)&e->actp[k], e->act_halves * e->max_batch * sizeof(f16)));
                     HIPCHK(e, hipMalloc((void **)&e->statsp[k], e->stats_doubles * e->max_batch * sizeof(double)));
-                    HIPCHK(e, hipMalloc((void **)&e->ssp[k], (e->ss_count * e->max_batch * 2 + 4) * sizeof(float)));
+                    HIPCHK(e, hipMalloc((void **)&e->ssp[k], (e->ss_count * e->max_batch * 3 + 8) * sizeof(float)));   // fp32 rows + fp16 rows (ssh_rows)
                 }
                 HIPCHK(e, hipStreamCreateWithFlags(&e->pipe[k], hipStreamNonBlocking));
                 HIPCHK(e, hipEventCreateWithFlags(&e->ev_head[k], hipEventDisableTiming));
@@ -1286,7 +1292,7 @@ int fnn_create(const fnn_arch_desc *arch, int device, int max_batch, fnn_engine 
     if ((r = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", r);
     if ((r = hipMalloc((void **)&e->act, e->act_halves * max_batch * sizeof(f16))) != hipSuccess) return bail("hipMalloc(activations)", r);
     if ((r = hipMalloc((void **)&e->stats, e->stats_doubles * max_batch * sizeof(double))) != hipSuccess) return bail("hipMalloc(stats)", r);
-    if ((r = hipMalloc((void **)&e->ss, (e->ss_count * max_batch * 2 + 4) * sizeof(float))) != hipSuccess) return bail("hipMalloc(scale/shift)", r);
+    if ((r = hipMalloc((void **)&e->ss, (e->ss_count * max_batch * 3 + 8) * sizeof(float))) != hipSuccess) return bail("hipMalloc(scale/shift)", r);
     if ((r = hipMalloc((void **)&e->inf_flag, sizeof(int))) != hipSuccess) return bail("hipMalloc(flag)", r);
     {
         const size_t P = (size_t)arch->patch[0] * arch->patch[1] * arch->patch[2];

@@ -40,6 +40,11 @@ struct SrcDesc {
     // 16-channel chunk is then contiguous per voxel run instead of 32 bytes of every 2 C-byte record
     int vs;
     long long cs;
+    // The same scale / shift rows rounded to fp16 and packed the way a staging thread wants them (round 3): per batch
+    // item and group of 8 channels 16 halves - 8 scales, then 8 shifts - i.e. [N][C / 8][16]: one 32-byte load instead of
+    // 16 scalars + select + convert per chunk.  Written by stats_finalize_kernel next to `ss`; nullptr with ss = nullptr
+    // (identity: conv3d_identity_ssh()).
+    const unsigned short *ssh;
 };
 #define FNN_VS(S) ((S).vs ? (S).vs : (S).C)
 #define FNN_CS(S) ((S).vs ? (S).cs : 16LL)
@@ -67,6 +72,7 @@ struct ConvParams {
     int chunks;                  // 16-channel chunks over all sources
     int ksteps;                  // MFMA k-steps per chunk: conv3d_ksteps(packing, taps)
     const float *ident_ss;       // conv3d_identity_ss(): ones[512] then zeros[512] (set by the launchers that need it)
+    const unsigned short *ident_ssh;   // conv3d_identity_ssh(): the same as SrcDesc::ssh rows for 512 channels
     int packing;                 // FNN_PACK_*: which taps share a k-step (fixed per layer when the weights are packed)
     int fp8;                     // conv3d_zr8_kernel: e4m3 operands (weights packed at 8 B per lane)
     const float *oscale;         // fp8: [Cout] w_scale[cout] / act_mult, applied to the accumulators before the bias
@@ -297,6 +303,7 @@ struct StatsFinalizeParams {
     int nrep;                    // rows per batch item (ConvParams::stats_slots of the producer)
     const float *gamma, *beta;   // [C]
     float *ss;                   // [N][2][C]
+    unsigned short *ssh;         // [N][C / 8][16] halves (8 scales, 8 shifts), or nullptr (SrcDesc::ssh)
     int C;
     float inv_count, eps;
 };
@@ -311,6 +318,7 @@ int conv3d_pick_nb(int nblk);
 const float *conv3d_identity_ss();
 // packing the launcher will expect for a layer of this shape (decided from the PLANNED batch size)
 int conv3d_packing(const ConvParams &p);
+const unsigned short *conv3d_identity_ssh();
 int conv3d_ksteps(int packing, int taps);
 int conv3d_kstep_tap(int packing, int ks, int half, int taps);     // linear tap index, or -1 = zero padding
 int conv3d_pack_cout(int packing, int nblk, int cb, int m);        // output channel in row m of cout block cb of the packed weights

@@ -74,8 +74,14 @@ __global__ __launch_bounds__(1024) void stats_finalize_kernel(const StatsFinaliz
     var = var > 0 ? var : 0;
     const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
     const float sc = p.gamma[c] * rstd;
+    const float sh = p.beta[c] - (float)mean * sc;
     p.ss[(size_t)(2 * n) * p.C + c] = sc;
-    p.ss[(size_t)(2 * n + 1) * p.C + c] = p.beta[c] - (float)mean * sc;
+    p.ss[(size_t)(2 * n + 1) * p.C + c] = sh;
+    if (p.ssh) {                                                      // fp16 rows for the staging threads (SrcDesc::ssh)
+        f16 *h = (f16 *)p.ssh + ((size_t)n * p.C + (c & ~7)) * 2 + (c & 7);
+        h[0] = (f16)sc;
+        h[8] = (f16)sh;
+    }
 }
 
 int launch_stats_finalize(const StatsFinalizeParams &p, int N, hipStream_t st) {

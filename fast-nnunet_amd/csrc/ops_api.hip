@@ -54,7 +54,7 @@ void to_ndhwc(const float *x, int n, int c, int cp, size_t vox, std::vector<uint
 }
 
 struct SrcHolder {
-    DevBuf act, stats, gamma, beta, ss;
+    DevBuf act, stats, gamma, beta, ss, ssh;
     SrcDesc d{};
 };
 
@@ -77,12 +77,13 @@ bool make_src(SrcHolder &h, const float *x, int n, int c, size_t vox, const floa
         (void)hipMemcpy(h.gamma.p, g.data(), cp * 4, hipMemcpyHostToDevice);
         (void)hipMemcpy(h.beta.p, b.data(), cp * 4, hipMemcpyHostToDevice);
         // what the engine does between producer and consumer: statistics -> (scale, shift)
-        if (!h.ss.alloc((size_t)n * cp * 8)) return false;
+        if (!h.ss.alloc((size_t)n * cp * 8) || !h.ssh.alloc((size_t)n * cp * 4)) return false;
         StatsFinalizeParams q{};
         q.stats = h.stats.as<double>(); q.gamma = h.gamma.as<float>(); q.beta = h.beta.as<float>();
-        q.ss = h.ss.as<float>(); q.C = cp; q.nrep = FNN_STAT_REPL; q.inv_count = 1.f / (float)vox; q.eps = 1e-5f;
+        q.ss = h.ss.as<float>(); q.ssh = h.ssh.as<unsigned short>(); q.C = cp; q.nrep = FNN_STAT_REPL; q.inv_count = 1.f / (float)vox; q.eps = 1e-5f;
         if (launch_stats_finalize(q, n, 0) != 0) return false;
         h.d.ss = h.ss.as<float>();
+        h.d.ssh = h.ssh.as<unsigned short>();
         h.d.slope = slope;
     }
     return true;

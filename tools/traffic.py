@@ -43,5 +43,21 @@ for fam in sorted(set(fetch) | set(write)):
                 'bytes_per_launch': (rd + wr) / max(1, n), 'total_GB': (rd + wr) / 1e9}
 print(json.dumps(out, indent=1))
 if len(sys.argv) > 3:
-    json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), reads x2 per the gfx950 correction; '
-                       'bench.py --steps 1 --warmup 0 on the default workload', 'families': out}, open(sys.argv[3], 'w'), indent=1)
+    # argv[3] = the per-round traffic file (profiles/rNN_traffic.json), argv[4] = the workload key of bench.traffic_key();
+    # captures on other kernel sources are dropped (bench.py quotes a figure only when csrc_sha256 matches)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    sha = bench.csrc_sha256()
+    key = sys.argv[4] if len(sys.argv) > 4 else 'bone_turbo_r2|f16|mirror=0|fp16|vol=512|batch=32'
+    doc = {}
+    if os.path.isfile(sys.argv[3]):
+        try:
+            doc = json.load(open(sys.argv[3]))
+        except Exception:
+            doc = {}
+    if doc.get('csrc_sha256') != sha:
+        doc = {'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), reads x2 per the gfx950 correction; '
+                       'bench.py --steps 1 --warmup 0 per workload key', 'csrc_sha256': sha, 'workloads': {}}
+    doc['workloads'][key] = {'families': out}
+    json.dump(doc, open(sys.argv[3], 'w'), indent=1)
