@@ -72,6 +72,10 @@ static __device__ __forceinline__ f16x4 stem_block(const float *sRaw, int rawbas
 // flips the window read.  GEMM K = C * taps in k-steps of 32 (one for a single-channel CT): element k of the im2col
 // column is input channel k / taps, tap k % taps; the per-k LDS offsets come from a table.
 #define STEMM_TD 16
+#define STEMM_CG 8                                                   // input channels staged at a time (57.6 KB of raw window at 3x3x3)
+// More than STEMM_CG input channels (a cascade stage with many foreground labels, label_handling.py:294-311: image + one
+// one-hot channel per label) run as groups of STEMM_CG channels: a group's window is staged, its k-steps (K = 8 channels x
+// taps, padded to a multiple of 32) are accumulated into the 16 column blocks' accumulators, the next group follows.
 template <bool ONE>                                                  // ONE: a single k-step (C * taps <= 32): offsets and weights in registers
 __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, const f16 *wfrag, const int ksteps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -83,27 +87,33 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, cons
     const int n = t / p.tiles_d;
     const int cb = blockIdx.y;
     const int pd = (p.kd - 1) / 2, ph = (p.kh - 1) / 2, pw = (p.kw - 1) / 2;
-    const int RD = STEMM_TD - 1 + p.kd, RH = 7 + p.kh, RW = 7 + p.kw, RVOX = RD * RH * RW, T = p.kd * p.kh * p.kw, K = p.C * T;
-    float *sRaw = (float *)smem;                                         // [C][RD][RH][RW]
-    int *sTab = (int *)(sRaw + ((p.C * RVOX + 3) & ~3));                 // [ksteps * 32] LDS offset of im2col element k
-    float *sRed = (float *)(sTab + ksteps * 32);                         // [4 waves][16][2]
+    const int RD = STEMM_TD - 1 + p.kd, RH = 7 + p.kh, RW = 7 + p.kw, RVOX = RD * RH * RW, T = p.kd * p.kh * p.kw;
+    const int CGn = p.C < STEMM_CG ? p.C : STEMM_CG;                     // channels per group
+    const int ngroups = (p.C + STEMM_CG - 1) / STEMM_CG, ksg = ksteps / ngroups;   // k-steps per group
+    float *sRaw = (float *)smem;                                         // [CGn][RD][RH][RW]
+    int *sTab = (int *)(sRaw + ((CGn * RVOX + 3) & ~3));                 // [ksg * 32] LDS offset of im2col element k of a group
+    float *sRed = (float *)(sTab + ksg * 32);                            // [4 waves][16][2]
 
     const int ox = p.origins[n * 3 + 0], oy = p.origins[n * 3 + 1], oz = p.origins[n * 3 + 2];
     const int d0 = td * STEMM_TD - pd, h0 = th * 8 - ph, w0 = tw * 8 - pw;
     const float *voln = p.vol + (size_t)n * p.vol_batch_stride;
-    for (int c = 0; c < p.C; ++c)
-        for (int v = tid; v < RVOX; v += 256) {
-            const int zd = v / (RH * RW), rem = v - zd * (RH * RW), zh = rem / RW, zw = rem - zh * RW;
-            int d = d0 + zd, h = h0 + zh, w = w0 + zw;
-            const bool ok = d >= 0 && d < p.PD && h >= 0 && h < p.PH && w >= 0 && w < p.PW;
-            if (p.flip_d) d = p.PD - 1 - d;
-            if (p.flip_h) h = p.PH - 1 - h;
-            if (p.flip_w) w = p.PW - 1 - w;
-            const float val = voln[(((size_t)c * p.X + (ox + (ok ? d : 0))) * p.Y + (oy + (ok ? h : 0))) * p.Z + (oz + (ok ? w : 0))];
-            sRaw[c * RVOX + v] = ok ? val : 0.f;
-        }
-    for (int k = tid; k < ksteps * 32; k += 256) {
-        const int kk = k < K ? k : 0;                                    // padding elements: any finite value, their weights are zero
+    auto stage = [&](int c0) {                                           // channels c0 .. c0 + CGn - 1 (beyond C: zeros, their weights are zero too)
+        for (int cl = 0; cl < CGn; ++cl)
+            for (int v = tid; v < RVOX; v += 256) {
+                const int zd = v / (RH * RW), rem = v - zd * (RH * RW), zh = rem / RW, zw = rem - zh * RW;
+                int d = d0 + zd, h = h0 + zh, w = w0 + zw;
+                const bool ok = d >= 0 && d < p.PD && h >= 0 && h < p.PH && w >= 0 && w < p.PW && c0 + cl < p.C;
+                if (p.flip_d) d = p.PD - 1 - d;
+                if (p.flip_h) h = p.PH - 1 - h;
+                if (p.flip_w) w = p.PW - 1 - w;
+                const int c = c0 + cl < p.C ? c0 + cl : 0;
+                const float val = voln[(((size_t)c * p.X + (ox + (ok ? d : 0))) * p.Y + (oy + (ok ? h : 0))) * p.Z + (oz + (ok ? w : 0))];
+                sRaw[cl * RVOX + v] = ok ? val : 0.f;
+            }
+    };
+    stage(0);
+    for (int k = tid; k < ksg * 32; k += 256) {
+        const int kk = k < CGn * T ? k : 0;                              // padding elements: any finite value, their weights are zero
         const int c = kk / T, tap = kk - c * T;
         sTab[k] = c * RVOX + ((tap / (p.kh * p.kw)) * RH + (tap / p.kw) % p.kh) * RW + tap % p.kw;
     }
@@ -120,26 +130,9 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, cons
     float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
     const f16x2 ones = {(f16)1.f, (f16)1.f};
     const int oh = th * 8 + (r >> 3), ow = tw * 8 + (r & 7);
-#pragma unroll 4
-    for (int j = 0; j < 16; ++j) {                                       // column block = (depth slice, pair of h rows)
+    auto finish = [&](int j, const f32x4 &d) {                           // bias, store, statistics of column block j
         const int dl = wave * 4 + (j >> 2), hp = j & 3;
         const int od = td * STEMM_TD + dl, ohh = oh + 2 * hp;
-        const int rawbase = (dl * RH + 2 * hp + (r >> 3)) * RW + (r & 7);
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
-        if (ONE) {
-            f16x8 xb;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) xb[e] = (f16)sRaw[rawbase + tapoff[e]];
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1, xb, d, 0, 0, 0);
-        } else {
-            for (int ks = 0; ks < ksteps; ++ks) {
-                const f16x8 wf = *(const f16x8 *)(wfrag + ((size_t)(cb * ksteps + ks) * 64 + lane) * 8);
-                f16x8 xb;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xb[e] = (f16)sRaw[rawbase + sTab[ks * 32 + 8 * q + e]];
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xb, d, 0, 0, 0);
-            }
-        }
         f16x4 h;
         h[0] = (f16)(d[0] + bias.x); h[1] = (f16)(d[1] + bias.y); h[2] = (f16)(d[2] + bias.z); h[3] = (f16)(d[3] + bias.w);
         const bool ok = od < p.PD && ohh < p.PH && ow < p.PW;
@@ -151,6 +144,54 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, cons
             t1[c] = __builtin_amdgcn_fdot2(pr, ones, t1[c], false);
             t2[c] = __builtin_amdgcn_fdot2(pr, pr, t2[c], false);
         }
+    };
+    if (ONE || ngroups == 1) {
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {                                   // column block = (depth slice, pair of h rows)
+            const int dl = wave * 4 + (j >> 2), hp = j & 3;
+            const int rawbase = (dl * RH + 2 * hp + (r >> 3)) * RW + (r & 7);
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            if (ONE) {
+                f16x8 xb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xb[e] = (f16)sRaw[rawbase + tapoff[e]];
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1, xb, d, 0, 0, 0);
+            } else {
+                for (int ks = 0; ks < ksteps; ++ks) {
+                    const f16x8 wf = *(const f16x8 *)(wfrag + ((size_t)(cb * ksteps + ks) * 64 + lane) * 8);
+                    f16x8 xb;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xb[e] = (f16)sRaw[rawbase + sTab[ks * 32 + 8 * q + e]];
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xb, d, 0, 0, 0);
+                }
+            }
+            finish(j, d);
+        }
+    } else {
+        f32x4 dacc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < ngroups; ++g) {
+            if (g > 0) {
+                __syncthreads();                                         // every wave is done with the previous group's window
+                stage(g * STEMM_CG);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int dl = wave * 4 + (j >> 2), hp = j & 3;
+                const int rawbase = (dl * RH + 2 * hp + (r >> 3)) * RW + (r & 7);
+                for (int ks = 0; ks < ksg; ++ks) {
+                    const f16x8 wf = *(const f16x8 *)(wfrag + ((size_t)(cb * ksteps + g * ksg + ks) * 64 + lane) * 8);
+                    f16x8 xb;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xb[e] = (f16)sRaw[rawbase + sTab[ks * 32 + 8 * q + e]];
+                    dacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xb, dacc[j], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) finish(j, dacc[j]);
     }
     if (p.stats_out) {
 #pragma unroll
@@ -170,12 +211,31 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, cons
     }
 }
 
-// every stem the engine accepts: 1..8 input channels, per-axis kernel 1 | 3
+// every stem the engine accepts: any number of input channels (groups of STEMM_CG beyond that many), per-axis kernel 1 | 3
 bool stem_mfma_ok(int C, int kd, int kh, int kw, int cout_pad) {
     auto k13 = [](int k) { return k == 1 || k == 3; };
-    return C >= 1 && C <= 8 && k13(kd) && k13(kh) && k13(kw) && cout_pad % 16 == 0;
+    return C >= 1 && C <= 4096 && k13(kd) && k13(kh) && k13(kw) && cout_pad % 16 == 0;
 }
-int stem_mfma_ksteps(int C, int taps) { return (C * taps + 31) / 32; }
+// k-steps of the packed stem weights: C <= STEMM_CG: K = C * taps; more: per group of STEMM_CG channels K = STEMM_CG * taps
+// padded to a multiple of 32 (element k of group g: channel g * STEMM_CG + k / taps, tap k % taps)
+int stem_mfma_ksteps(int C, int taps) {
+    if (C <= STEMM_CG) return (C * taps + 31) / 32;
+    return ((C + STEMM_CG - 1) / STEMM_CG) * ((STEMM_CG * taps + 31) / 32);
+}
+// (channel, tap) of element k of k-step ks of the packed stem weights, or false = zero padding
+bool stem_mfma_kmap(int C, int taps, int ks, int k, int *c, int *tap) {
+    if (C <= STEMM_CG) {
+        const int kk = ks * 32 + k;
+        if (kk >= C * taps) return false;
+        *c = kk / taps; *tap = kk % taps;
+        return true;
+    }
+    const int ksg = (STEMM_CG * taps + 31) / 32, g = ks / ksg, kk = (ks % ksg) * 32 + k;
+    const int cc = g * STEMM_CG + kk / taps;
+    if (kk >= STEMM_CG * taps || cc >= C) return false;
+    *c = cc; *tap = kk % taps;
+    return true;
+}
 
 int stem_mfma_stats_slots(int PD, int PH, int PW) { return ((PD + STEMM_TD - 1) / STEMM_TD) * ((PH + 7) / 8) * ((PW + 7) / 8); }
 
@@ -192,7 +252,8 @@ int launch_stem_mfma(const StemParams &p_in, const f16 *wfrag, int N, hipStream_
     p.tiles_w = (p.PW + 7) / 8;
     const int ks = stem_mfma_ksteps(p.C, p.kd * p.kh * p.kw);
     const int RVOX = (STEMM_TD - 1 + p.kd) * (7 + p.kh) * (7 + p.kw);
-    const size_t lds = (size_t)((p.C * RVOX + 3) & ~3) * 4 + (size_t)ks * 32 * 4 + 4 * 16 * 2 * 4;
+    const int cgn = p.C < STEMM_CG ? p.C : STEMM_CG, ngroups = (p.C + STEMM_CG - 1) / STEMM_CG;
+    const size_t lds = (size_t)((cgn * RVOX + 3) & ~3) * 4 + (size_t)(ks / ngroups) * 32 * 4 + 4 * 16 * 2 * 4;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)stem_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -84,6 +84,8 @@ struct fnn_engine {
     int head_src = -1;                      // layer feeding the seg head
     int hblocks = 0, head_ksteps = 0;
     size_t head_w_off = 0, head_bias_off = 0;
+    int n_gpass = 1;                        // gather passes of <= 63 heads (GatherParams::n_pass); > 1: their own packs below
+    size_t gpass_w_off = 0, gpass_bias_off = 0;
     int64_t blob_head_w = 0, blob_head_b = 0;
     int64_t blob_count = 0;
     size_t wpk_halves = 0, fparam_floats = 0, stats_doubles = 0, act_halves = 0, ss_count = 0;
@@ -170,7 +172,7 @@ int build_plan(fnn_engine *e) {
     const fnn_arch_desc &a = e->arch;
     if (a.kind != FNN_NET_PLAIN && a.kind != FNN_NET_RESENC) return fail(e, FNN_E_UNSUPPORTED, "unknown network kind %d", a.kind);
     if (a.n_stages < 2 || a.n_stages > FNN_MAX_STAGES) return fail(e, FNN_E_INVALID, "n_stages out of range");
-    if (a.in_channels < 1 || a.in_channels > 8) return fail(e, FNN_E_UNSUPPORTED, "in_channels must be 1..8");
+    if (a.in_channels < 1 || a.in_channels > 4096) return fail(e, FNN_E_UNSUPPORTED, "in_channels must be 1..4096");
     if (a.num_heads < 1 || a.num_heads > 256) return fail(e, FNN_E_UNSUPPORTED, "num_heads must be 1..256");
     for (int s = 0; s < a.n_stages; ++s)
         for (int d = 0; d < 3; ++d) {
@@ -434,6 +436,11 @@ int build_plan(fnn_engine *e) {
     e->head_ksteps = (pad16(a.features[0]) + 31) / 32;
     e->head_w_off = wpk; wpk += (size_t)e->hblocks * e->head_ksteps * 512;
     e->head_bias_off = fp; fp += (size_t)e->hblocks * 16;
+    e->n_gpass = (a.num_heads + 62) / 63;
+    if (e->n_gpass > 1) {
+        e->gpass_w_off = wpk; wpk += (size_t)e->n_gpass * 4 * 512;
+        e->gpass_bias_off = fp; fp += (size_t)e->n_gpass * 64;
+    }
     const double P = (double)a.patch[0] * a.patch[1] * a.patch[2];
     e->head_flops = 2.0 * a.num_heads * a.features[0] * P;
     e->patch_flops = flops + e->head_flops;
@@ -1065,20 +1072,23 @@ int accumulate_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const
 }
 
 // Plan of the gather path (gather.hip) for a volume: how many x layers of patches are kept at a time.
-struct GatherPlan { bool ok = false; int n_eval = 1, ring = 0, cover = 1; size_t layer_items = 0, feat_bytes = 0; };
+struct GatherPlan { bool ok = false; int n_eval = 1, ring = 0, cover = 1; size_t layer_items = 0, feat_bytes = 0; const char *why = ""; };
 
 // No gather when the head does not fit the kernel's registers or when not even the layers that cover one output slab fit
 // next to what is already allocated; otherwise the whole volume's patches when they fit (one launch at the end), else
 // a ring of `cover` layers with one launch per output slab.
 GatherPlan gather_plan(fnn_engine *e, const VolPlan &vp, const fnn_opts &o) {
     GatherPlan gp;
+    gp.why = "FNN_NO_GATHER is set or the output is not fp16";
     if (!e->gather_enabled || o.out_dtype != FNN_OUT_F16) return gp;
     const Layer &H = e->layers[e->head_src];
     GatherParams g{};
     g.heads = e->arch.num_heads; g.C = H.cout_pad; g.PD = e->arch.patch[0]; g.PH = e->arch.patch[1]; g.PW = e->arch.patch[2];
     gp.n_eval = 1 + (int)mirror_combos(o).size();
-    g.n_eval = gp.n_eval;
+    g.n_eval = gp.n_eval; g.n_pass = e->n_gpass;
+    gp.why = "the network's head does not fit the gather kernel (a normalised last layer of <= 32 channels, <= 8 evaluations per patch)";
     if (!H.has_norm || e->head_ksteps != 1 || !gather_ok(g)) return gp;
+    gp.why = "not enough free HBM for the patch activations that cover one output slab";
     const auto &sx = vp.steps[0];
     const int nx = (int)sx.size();
     gp.cover = 1;
@@ -1141,6 +1151,7 @@ int gather_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const Vol
     g.steps = e->steps_dev; g.nx = (int)vp.steps[0].size(); g.ny = (int)vp.steps[1].size(); g.nz = (int)vp.steps[2].size();
     g.PD = a.patch[0]; g.PH = a.patch[1]; g.PW = a.patch[2];
     g.wpk = fw.wpk + e->head_w_off; g.bias = fw.fparam + e->head_bias_off; g.heads = a.num_heads; g.hblocks = e->hblocks;
+    g.n_pass = e->n_gpass; g.pass_wpk = fw.wpk + e->gpass_w_off; g.pass_bias = fw.fparam + e->gpass_bias_off;
     g.gauss = o.use_gaussian ? e->gauss : e->ones;
     g.lo_x = (int)vp.lo[0]; g.lo_y = (int)vp.lo[1]; g.lo_z = (int)vp.lo[2];
     g.OX = shape[1]; g.OY = shape[2]; g.OZ = shape[3];
@@ -1196,7 +1207,13 @@ int predict_impl(fnn_engine *e, int fold0, int n_folds, const float *vol, const 
     const size_t nout = (size_t)a.num_heads * nvox_out;
     const size_t osz = o->out_dtype == FNN_OUT_F32 ? 4 : 2;
     const bool want_logits = out != nullptr;
-    const bool labels_direct = labels && !want_logits && n_folds == 1;     // argmax straight from the accumulators
+    // (the plan first: nothing is allocated yet when it refuses the request, and it decides how labels are formed)
+    const GatherPlan gp = gather_plan(e, vp, *o);
+    if (!gp.ok && o->accum == FNN_ACC_FP16_AUTOCAST)
+        return fail(e, FNN_E_UNSUPPORTED, "FNN_ACC_FP16_AUTOCAST needs the gather path: %s", gp.why);
+    // argmax straight from the accumulators / the gather kernel's registers; with more than 63 classes the gather kernel
+    // runs in passes over the heads, so the labels come from its logits
+    const bool labels_direct = labels && !want_logits && n_folds == 1 && !(gp.ok && e->n_gpass > 1);
     void *out_dev = out;
     const bool out_on_dev = out && is_device_ptr(out);
     if (!labels_direct && !out_on_dev) {
@@ -1216,9 +1233,6 @@ int predict_impl(fnn_engine *e, int fold0, int n_folds, const float *vol, const 
     const int acc_fp32 = o->accum == FNN_ACC_FP32;
     const int64_t zero3[3] = {0, 0, 0}, full3[3] = {shape[1], shape[2], shape[3]};
     int rc = 0;
-    const GatherPlan gp = gather_plan(e, vp, *o);
-    if (!gp.ok && o->accum == FNN_ACC_FP16_AUTOCAST)
-        return fail(e, FNN_E_UNSUPPORTED, "FNN_ACC_FP16_AUTOCAST needs the gather path (<= 63 classes, a normalised last layer, FNN_NO_GATHER unset)");
     for (int f = 0; f < n_folds && rc == 0; ++f) {
         if (gp.ok) {
             rc = gather_whole_volume(e, fold0 + f, vol_dev, vp, shape, *o, gp, f > 0 ? 1 : 0, labels_direct ? nullptr : out_dev,
@@ -1348,9 +1362,11 @@ int fnn_load_weights(fnn_engine *e, int fold, const float *blob, int64_t count) 
                     for (int ks = 0; ks < KST; ++ks)
                         for (int lane = 0; lane < 64; ++lane)
                             for (int j = 0; j < 8; ++j) {
-                                const int k = ks * 32 + 8 * (lane >> 4) + j, co = cb * 16 + (lane & 15);
+                                const int co = cb * 16 + (lane & 15);
+                                int c = 0, tap = 0;
+                                const bool live = stem_mfma_kmap(C, T, ks, 8 * (lane >> 4) + j, &c, &tap) && co < L.cout_real;
                                 wpk[L.w_off2 + ((size_t)(cb * KST + ks) * 64 + lane) * 8 + j] =
-                                    f2h_bits(k < C * T && co < L.cout_real ? W[(size_t)co * C * T + k] : 0.f);
+                                    f2h_bits(live ? W[((size_t)co * C + c) * T + tap] : 0.f);
                             }
             }
         } else if (L.type == Layer::CONV) {
@@ -1370,6 +1386,12 @@ int fnn_load_weights(fnn_engine *e, int fold, const float *blob, int64_t count) 
     pack_head(e->arch.num_heads, e->arch.features[0], e->hblocks, e->head_ksteps, blob + e->blob_head_w, wpk.data() + e->head_w_off);
     for (int h = 0; h < e->arch.num_heads; ++h) fp[e->head_bias_off + h] = blob[e->blob_head_b + h];
     fp[e->head_bias_off + e->arch.num_heads] = 1.f;         // accumulator channel `heads`: 1 * gaussian = the weight itself
+    for (int k = 0; k < (e->n_gpass > 1 ? e->n_gpass : 0); ++k) {      // gather passes: heads 63 k .. + cnt - 1, then the weight-sum row
+        const int h0 = 63 * k, cnt = std::min(63, e->arch.num_heads - h0), cin = e->arch.features[0];
+        pack_head(cnt, cin, 4, 1, blob + e->blob_head_w + (size_t)h0 * cin, wpk.data() + e->gpass_w_off + (size_t)k * 4 * 512);
+        for (int h = 0; h < cnt; ++h) fp[e->gpass_bias_off + (size_t)k * 64 + h] = blob[e->blob_head_b + h0 + h];
+        fp[e->gpass_bias_off + (size_t)k * 64 + cnt] = 1.f;
+    }
     if (!fw.wpk) HIPCHK(e, hipMalloc((void **)&fw.wpk, wpk.size() * 2));
     if (!fw.fparam) HIPCHK(e, hipMalloc((void **)&fw.fparam, fp.size() * 4));
     HIPCHK(e, hipMemcpy(fw.wpk, wpk.data(), wpk.size() * 2, hipMemcpyHostToDevice));
@@ -1542,6 +1564,9 @@ int fnn_gather_box(fnn_engine *e, int fold, const void *feat, const float *fss, 
     const Layer &H = e->layers[e->head_src];
     GatherParams g{};
     g.heads = a.num_heads; g.C = H.cout_pad; g.PD = a.patch[0]; g.PH = a.patch[1]; g.PW = a.patch[2]; g.n_eval = 1 + (int)combos.size();
+    g.n_pass = e->n_gpass;
+    if (labels && e->n_gpass > 1)
+        return fail(e, FNN_E_UNSUPPORTED, "fnn_gather_box writes labels for <= 63 classes; with %d take the logits and fnn_argmax_labels", a.num_heads);
     if (!H.has_norm || e->head_ksteps != 1 || !gather_ok(g)) return fail(e, FNN_E_UNSUPPORTED, "this network's head does not fit the gather kernel");
     for (int64_t i = 0; i < vp.n_patches; ++i)
         if (slot_of_patch[i] >= n_slots) return fail(e, FNN_E_INVALID, "slot %d of patch %lld is beyond the %lld slots", slot_of_patch[i], (long long)i, (long long)n_slots);
@@ -1570,6 +1595,7 @@ int fnn_gather_box(fnn_engine *e, int fold, const void *feat, const float *fss, 
     g.steps = e->steps_dev; g.slot_tab = e->steps_dev + n_steps;
     g.nx = (int)vp.steps[0].size(); g.ny = (int)vp.steps[1].size(); g.nz = (int)vp.steps[2].size();
     g.wpk = fw.wpk + e->head_w_off; g.bias = fw.fparam + e->head_bias_off; g.hblocks = e->hblocks;
+    g.pass_wpk = fw.wpk + e->gpass_w_off; g.pass_bias = fw.fparam + e->gpass_bias_off;
     g.gauss = opts->use_gaussian ? e->gauss : e->ones;
     g.lo_x = (int)vp.lo[0]; g.lo_y = (int)vp.lo[1]; g.lo_z = (int)vp.lo[2];
     g.OX = shape[1]; g.OY = shape[2]; g.OZ = shape[3];

@@ -197,6 +197,12 @@ struct GatherParams {
     const f16 *wpk;              // seg head [hblock][64][8] (one k-step)
     const float *bias;           // [hblocks * 16], bias[heads] = 1 (the weight-sum channel)
     int heads, hblocks;
+    // more than 63 classes (heads + the weight-sum row > 4 blocks of 16): passes of <= 63 heads, each with its own packed
+    // fragments [4][64][8] and biases [64] (row `heads of the pass` = the weight-sum channel) - launch_gather runs them one
+    // after the other over the same kept activations, every pass writing its own planes of `out` (logits only)
+    int n_pass;                  // 0 / 1: the single pack above
+    const f16 *pass_wpk;         // [n_pass][4][64][8]
+    const float *pass_bias;      // [n_pass][64]
     const f16 *gauss;            // [PD][PH][PW] (all ones without Gaussian weighting)
     int lo_x, lo_y, lo_z;        // un-padded voxel (0, 0, 0) in the padded volume
     long long OX, OY, OZ;        // un-padded size = output size
@@ -330,6 +336,7 @@ int launch_tconv(const TconvParams &p, hipStream_t st);
 bool stem_mfma_ok(int C, int kd, int kh, int kw, int cout_pad);
 int stem_mfma_stats_slots(int PD, int PH, int PW);
 int stem_mfma_ksteps(int C, int taps);
+bool stem_mfma_kmap(int C, int taps, int ks, int k, int *c, int *tap);   // (channel, tap) of element k of k-step ks; false = padding
 int launch_stem_mfma(const StemParams &p, const f16 *wfrag, int N, hipStream_t st);    // p.out == nullptr: statistics only
 bool gather_ok(const GatherParams &p);
 int launch_gather(const GatherParams &p, hipStream_t st);

@@ -441,9 +441,10 @@ int launch_quotient_check(unsigned long long *counts, hipStream_t st) {         
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+#define FNN_GATHER_PASS_HEADS 63                                   // heads per pass: 63 + the weight-sum row = 4 blocks of 16
 bool gather_ok(const GatherParams &p) {
     const int hblocks = (p.heads + 1 + 15) / 16;
-    return hblocks <= 4 && p.C <= 32 && p.C % 8 == 0 && (long long)p.PD * p.PH * p.PW < (1LL << 31) / 32 && p.n_eval <= 8;
+    return (hblocks <= 4 || p.n_pass > 1) && p.C <= 32 && p.C % 8 == 0 && (long long)p.PD * p.PH * p.PW < (1LL << 31) / 32 && p.n_eval <= 8;
 }
 
 template <int HB, bool TTA>
@@ -466,10 +467,32 @@ static int launch_gather_hb(const GatherParams &p, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+static int launch_gather_one(const GatherParams &p, hipStream_t st);
+
 int launch_gather(const GatherParams &p0, hipStream_t st) {
     if (!gather_ok(p0)) return -1;
     GatherParams p = p0;
     p.ieee_div = fnn_knob("FNN_GATHER_IEEE") != nullptr;
+    if ((p.heads + 1 + 15) / 16 <= 4) return launch_gather_one(p, st);
+    // more than 63 classes: one pass per 63 heads over the same activations (the reference has no such limit,
+    // predict_from_raw_data.py:587-590); labels need all heads at once - the caller takes the argmax of the logits
+    if (p.labels || !p.out || !p.pass_wpk || !p.pass_bias) return -1;
+    const size_t plane = (size_t)p.OX * p.OY * p.OZ * (p.out_fp32 ? 4 : 2);
+    const int total = p.heads;
+    for (int k = 0; k < p.n_pass; ++k) {
+        GatherParams q = p;
+        const int h0 = k * FNN_GATHER_PASS_HEADS;
+        q.heads = total - h0 < FNN_GATHER_PASS_HEADS ? total - h0 : FNN_GATHER_PASS_HEADS;
+        q.hblocks = (q.heads + 1 + 15) / 16;
+        q.wpk = p.pass_wpk + (size_t)k * 4 * 512;
+        q.bias = p.pass_bias + (size_t)k * 64;
+        q.out = (char *)p.out + (size_t)h0 * plane;
+        if (int rc = launch_gather_one(q, st)) return rc;
+    }
+    return 0;
+}
+
+static int launch_gather_one(const GatherParams &p, hipStream_t st) {
     const int hblocks = (p.heads + 1 + 15) / 16;
     if (p.n_eval > 1) {
         if (hblocks == 1) return launch_gather_hb<1, true>(p, st);

@@ -358,8 +358,7 @@ class ShardedPredictor:
         """mode: 'gather' - ranks keep patch activations and exchange the parts that reach into a neighbour's box
         (csrc/gather.hip: no accumulators, results bit-identical to one GPU, test-time mirroring included: the 2^k
         evaluations' activations travel like any other); 'accumulate' - ranks exchange partial sums of read-modify-write
-        accumulators; 'auto' - gather where the engine's gather kernel applies (<= 63 classes) and the kept activations
-        fit in HBM."""
+        accumulators; 'auto' - gather where the engine's gather kernel applies and the kept activations fit in HBM."""
         self.p = predictor
         self.group = group
         self.rank = dist.get_rank(group)
@@ -372,14 +371,14 @@ class ShardedPredictor:
         return mirror_flips(p.allowed_mirroring_axes if p.use_mirroring else None)
 
     def _use_gather(self, n_slots: Optional[int] = None) -> bool:
-        """The gather path applies where the engine's gather kernel does (<= 63 classes, <= 32 channels at full
-        resolution, <= 8 evaluations per patch) AND the kept activations fit: `n_slots` patch slots per evaluation
+        """The gather path applies where the engine's gather kernel does (<= 32 channels at full resolution, <= 8
+        evaluations per patch; more than 63 classes run as passes over the heads) AND the kept activations fit: `n_slots` patch slots per evaluation
         against 80 % of the free HBM (the single-GPU engine bounds the same buffers, csrc/engine.hip gather_plan).
         'auto' falls back to the accumulate path; 'gather' raises."""
         p = self.p
         n_eval = len(self._flips())
-        ok = p._spec.num_heads <= 63 and n_eval <= 8 and p._spec.features[0] <= 32
-        why = 'the gather path needs <= 63 classes, <= 32 channels at full resolution and <= 8 evaluations per patch'
+        ok = n_eval <= 8 and p._spec.features[0] <= 32
+        why = 'the gather path needs <= 32 channels at full resolution and <= 8 evaluations per patch'
         if ok and n_slots is not None and p.device.type == 'cuda':
             C = p._engine.feature_channels
             need = n_eval * n_slots * (int(np.prod(p._spec.patch)) * C * 2 + 2 * C * 4)
@@ -567,8 +566,8 @@ class ShardedPredictor:
             x = data.to(device=p.device, dtype=torch.float32).contiguous()
             eng.set_label_rule(order, uint16=u16)
             labels = torch.zeros(x.shape[1:], dtype=torch.int16 if u16 else torch.uint8, device=p.device)
-            if p._n_folds > 1:
-                logits, own = self.predict_sliding_window_return_logits(x, folds=range(p._n_folds))
+            if p._n_folds > 1 or p._spec.num_heads > 63:          # (> 63 classes: the gather kernel forms the logits in passes over the heads)
+                logits, own = self.predict_sliding_window_return_logits(x, folds=range(p._n_folds) if p._n_folds > 1 else None)
                 if own is not None:
                     sl = tuple(slice(own[0][d], own[1][d]) for d in range(3))
                     labels[sl] = p.convert_logits_to_segmentation(logits[(slice(None), *sl)].contiguous()).to(labels.dtype)

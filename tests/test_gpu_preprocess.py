@@ -291,17 +291,18 @@ def test_segmentation_resampling_matches_the_restatement(shape, new_shape, order
     assert set(np.unique(got)) <= set(np.unique(seg))
 
 
-def test_cascade_input_one_hot_channels_through_the_predictor():
+@pytest.mark.parametrize('n_fg', [3, 9])
+def test_cascade_input_one_hot_channels_through_the_predictor(n_fg):
     """predict_single_npy_array(image, props, segmentation_previous_stage): the previous stage's labels are cropped and
     resampled with the image and enter the network as one-hot channels (data_iterators.py:195-204); the result must equal
-    running the predictor on the hand-built [image, one-hot] input."""
+    running the predictor on the hand-built [image, one-hot] input.  9 foreground labels = 10 input channels: more than
+    the stem stages at once (two channel groups)."""
     from fast_nnunet_amd import nnUNetPredictor
     from fast_nnunet_amd.plans import PlansManager
     from fast_nnunet_amd.preprocess import DevicePreprocessor
     from oracle import resample as ores
     from oracle.topology import UNetSpec
     from oracle.unet import synthetic_state_dict
-    n_fg = 3
     spec = UNetSpec('plain', 1 + n_fg, n_fg + 1, [16, 32], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
     patch = (16, 16, 32)
     pm = PlansManager({'dataset_name': 'Dataset998_Cascade', 'plans_name': 'nnUNetPlans', 'transpose_forward': [0, 1, 2],
@@ -319,7 +320,7 @@ def test_cascade_input_one_hot_channels_through_the_predictor():
                                                                  'architecture': {'network_class_name': 'PlainConvUNet', 'arch_kwargs': {},
                                                                                   '_kw_requires_import': []}}}})
     cm = pm.get_configuration('3d_cascade_fullres')
-    dj = {'labels': {'background': 0, 'a': 1, 'b': 2, 'c': 3}, 'channel_names': {'0': 'CT'}, 'file_ending': '.nii.gz'}
+    dj = {'labels': {'background': 0, **{f'l{i}': i for i in range(1, n_fg + 1)}}, 'channel_names': {'0': 'CT'}, 'file_ending': '.nii.gz'}
     p = nnUNetPredictor(tile_step_size=0.5, use_gaussian=True, use_mirroring=False, device=torch.device('cuda', 0),
                         allow_tqdm=False, patches_per_forward=2)
     p.manual_initialization(None, pm, cm, [synthetic_state_dict(spec, 12)], dj, 'nnUNetTrainer', None)
@@ -337,7 +338,7 @@ def test_cascade_input_one_hot_channels_through_the_predictor():
     crop = prev[(slice(None), *[slice(lo, hi) for lo, hi in bbox])]
     want_seg = ores.resample_seg(crop, data.shape[1:], order=1)
     assert (seg.cpu().numpy() != want_seg).mean() <= 1e-3
-    onehot = torch.stack([(seg[0] == l) for l in (1, 2, 3)]).float()
+    onehot = torch.stack([(seg[0] == l) for l in range(1, n_fg + 1)]).float()
     logits = p.predict_logits_from_preprocessed_data(torch.cat((data, onehot), 0))
     want = pp.convert_predicted_logits_to_segmentation_with_correct_shape(logits.cuda(), p, pm, cm, pr).cpu().numpy()
     assert np.array_equal(labels, want)
