@@ -1003,10 +1003,11 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
         // decisions use the engine's planned batch, not this call's, so that a layer always runs the same
         // variant (bit-reproducible statistics whatever the number of patches in the batch)
         const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;
-        const int cand[5][2] = {{4, 4}, {2, 8}, {2, 4}, {1, 8}, {1, 4}};
+        // ((4, 4) - four cout blocks per workgroup - kept 44 B of scratch per lane and is gone: round 3)
+        const int cand[4][2] = {{2, 8}, {2, 4}, {1, 8}, {1, 4}};
         int pick = -1, best = -1;
         long long best_wgs = -1;
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int cnb = cand[i][0], cmb = cand[i][1];
             if (nblk % cnb) continue;
             if (cmb == 8 && p.Do < 8) continue;
@@ -1042,8 +1043,7 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
         }
         if (p.ksteps <= 14) {
             if (nb == 1) return mbsel == 8 ? launch_ldsk<1, 8>(p, st) : launch_ldsk<1, 4>(p, st);
-            if (nb == 2) return mbsel == 8 ? launch_ldsk<2, 8>(p, st) : launch_ldsk<2, 4>(p, st);
-            return launch_ldsk<4, 4>(p, st);
+            return mbsel == 8 ? launch_ldsk<2, 8>(p, st) : launch_ldsk<2, 4>(p, st);
         }
     }
     static const bool strided_v1 = fnn_knob("FNN_CONV_STRIDED_V1") != nullptr;   // A-B aid
@@ -1072,11 +1072,10 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
                     static const bool wres = fnn_knob("FNN_STRIDED_NO_WRES") == nullptr;              // A-B aid
                     if (wres && persist_lds_bytes(p, 2, 2, true, true, 12) <= 80 * 1024)
                         return launch_persist_ks<2, 2, true, 0, 1, 12, true>(p, 2, st, gx);
-                    return launch_persist_ks<2, 2, false, 0, 1, 12>(p, 2, st, gx);
                 }
-                // more chunks: the generic (runtime chunk count) form; the unrolled two-chunk variant spilled and lost
-                static const bool sp_single = fnn_knob("FNN_STRIDED_PERSIST_SINGLE") != nullptr;   // A-B aid
-                if (!sp_single) return launch_persist_ks<2, 2, false, 0, 0, 12>(p, 2, st, gx);
+                // (the forms whose weights travel with every halo tile - one chunk without room for resident weights,
+                // or several chunks - kept 20 / 48 B of scratch per lane and are gone: those layers take the
+                // one-tile-per-workgroup strided kernels below.  Round 3: no kernel of the library keeps scratch.)
             }
         }
         if (ID * IH * IW * 2 <= 16 * 256 && ldsk_lds_bytes(p, nbs, 2) <= 80 * 1024) {

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256, CH == 1 ? (NBLK <= 8 ? 3 : 2) : (NBLK <= 8 ? 2
 // one rounding - as stem_mfma_kernel up to the order of the fp32 sums (their last bit can differ).  Statistics: one row
 // per (plane, strip).  STORE = false: the statistics pass in front of conv_row_stem_kernel (p.out == nullptr).
 template <int NBLK, bool STORE>
-__global__ __launch_bounds__(256, 8) void stem_row_kernel(const StemParams p, const int total_units, const int strips,
+__global__ __launch_bounds__(256, NBLK <= 8 ? 8 : 6) void stem_row_kernel(const StemParams p, const int total_units, const int strips,
                                                            const int SH, const int slots) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int W = 16 * NBLK, PB = W * 8, RINGB = 12 * PB;

@@ -738,9 +738,9 @@ static int launch_thin_w(ThinParams tp, hipStream_t st) {
 
 template <int KD, int CH, int FUSE, int NCLS>
 static int launch_thin_t(const ThinParams &tp, hipStream_t st) {
-    // three workgroups per CU (168 registers, 24 B of scratch per lane) measured 1.2 % faster end to end than two (no scratch)
-    static const int wps = fnn_knob("FNN_THIN_WPS") ? atoi(fnn_knob("FNN_THIN_WPS")) : 3;       // A-B aid
-    if (KD == 1 && wps == 3) return launch_thin_w<KD, CH, FUSE, NCLS, KD == 1 ? 3 : 2>(tp, st);
+    // two workgroups per CU.  (Three - 168 registers, 24 B of scratch per lane - were 1.2 % faster end to end while these
+    // kernels ran the benchmark's full-resolution layers; the row-streaming kernels took those over, and no kernel of the
+    // library keeps scratch: round 3.)
     return launch_thin_w<KD, CH, FUSE, NCLS, 2>(tp, st);
 }
 

@@ -765,7 +765,6 @@ int launch_head(const HeadParams &p, hipStream_t st) {
                     // two workgroups per SIMD's worth of registers asked for: 177 VGPRs instead of 214 (three: 8 spills, slower)
                     static const int minb = fnn_knob("FNN_HEAD_MINB") ? atoi(fnn_knob("FNN_HEAD_MINB")) : 2;            // A-B aid
                     if (minb == 2) hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 3, 2>), grid, dim3(256), lds, st, p);
-                    else if (minb == 3) hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 3, 3>), grid, dim3(256), lds, st, p);
                     else hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 3>), grid, dim3(256), lds, st, p);
                 }
                 else hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2>), grid, dim3(256), lds, st, p);
