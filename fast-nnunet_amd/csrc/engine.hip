@@ -407,6 +407,13 @@ int build_plan(fnn_engine *e) {
             }
             L.ksteps = conv3d_ksteps(L.packing, T);
             L.fp8 = a.precision == FNN_PREC_F8 && L.packing == FNN_PACK_ZR && L.s[0] == 1 && L.s[1] == 1 && L.s[2] == 1;   // (the strided depth-shift kernel is fp16 only)
+            if (L.fp8 && fnn_knob("FNN_FP8_LEVELS")) {
+                // sensitivity studies (tools/fp8_sensitivity.py): e4m3 operands only at the resolution levels of the bit mask
+                // (level = how many times the patch's voxel count was divided by ~8 on the way to this layer's output)
+                const double P = (double)a.patch[0] * a.patch[1] * a.patch[2];
+                const int level = (int)std::lround(std::log2(P / (double)ovox) / 3.0);
+                L.fp8 = ((atoi(fnn_knob("FNN_FP8_LEVELS")) >> level) & 1) != 0;
+            }
             L.w_off = wpk; wpk += (size_t)(L.cout_pad / 16) * L.chunks * L.ksteps * 512;
         } else if (L.type == Layer::TCONV) {
             const int taps = L.s[0] * L.s[1] * L.s[2];
