@@ -376,6 +376,201 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
 }
 
 // ----------------------------------------------------------------------------
+// single-chunk layers (Cin <= 16): the same kernel WALKING along d (round 3)
+// ----------------------------------------------------------------------------
+// A 16 -> 16 (or 16 -> 32) 3x3x3 layer at full resolution - stage 0 of every isotropic network: 38 % of the 128^3
+// student's time, 22 % of the ResEnc student's - is one chunk per tile: conv3d_zr_kernel has nothing to prefetch behind
+// (load, wait, stage, 120 MFMAs per wave, store) and re-reads the chunk's 15 KB of weights and two of its ten halo planes
+// for every tile.  Here a workgroup owns an 8 x 8 in-plane window and walks `tps` consecutive d-tiles: the weights are
+// staged once, the halo image is a RING of ten planes - a tile brings its eight new planes, the last two of its
+// predecessor stay where they are - and the next tile's planes are in flight during the current tile's k-loop.  Same
+// per-tile arithmetic, tile decomposition and statistics rows as conv3d_zr_kernel<NB, 8>: bit-identical results.
+template <int NB>
+__global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void conv3d_zrw_kernel(const ConvParams p, const int segs, const int tps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int TD = 8, IH = 10, IW = 10, PW = 12, ID = TD + 2;
+    constexpr int PS = IH * PW * 32, ABYTES = ID * PS, KS = 15, WB = KS * 64, WPB = (WB + 255) / 256;
+
+    int t;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        t = __builtin_amdgcn_readfirstlane((xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx);
+    }
+    const int tw = __builtin_amdgcn_readfirstlane(t % p.tiles_w); t = __builtin_amdgcn_readfirstlane(t / p.tiles_w);
+    const int th = __builtin_amdgcn_readfirstlane(t % p.tiles_h); t = __builtin_amdgcn_readfirstlane(t / p.tiles_h);
+    const int seg = __builtin_amdgcn_readfirstlane(t % segs);
+    const int n = __builtin_amdgcn_readfirstlane(t / segs);
+    const int td0 = seg * tps, td1 = td0 + tps < p.tiles_d ? td0 + tps : p.tiles_d;
+    if (td0 >= td1) return;
+    const int cb0 = blockIdx.y * NB;
+    const int oh0 = th * 8, ow0 = tw * 8;
+
+    char *sA = smem;                                          // ring of ID halo planes: plane 8 td0 - 1 + k sits in slot k % ID
+    char *sW = smem + ABYTES;                                 // [NB][15][64 lanes][16 B], resident
+    // the statistics' reduction floats (4 waves x NB x 16 channels x 2) live in the two unused voxel slots behind the ten
+    // used ones of every halo row (pitch 12): 16 floats per row - a kilobyte of their own would cost the third workgroup per CU
+    auto sred_at = [&](int i) { const int k = i >> 4; return (float *)(sA + (k / IH) * PS + ((k % IH) * PW + IW) * 32) + (i & 15); };
+
+    const int col = tid >> 1, cg = tid & 1;
+    const int zh = (col * 205) >> 11, zw = col - zh * IW;
+    const bool has_col = tid < 2 * IH * IW;
+    const int gh = oh0 - 1 + zh, gw = ow0 - 1 + zw;
+    const bool ok_hw = has_col & ((unsigned)gh < (unsigned)p.Hi) & ((unsigned)gw < (unsigned)p.Wi);
+    const int hw_lin = __mul24(gh, p.Wi) + gw;
+    const int ldso0 = (zh * PW + zw) * 32 + ((cg ^ (zh & 1)) * 16);
+
+    // the one chunk: source 0, channels 0 .. 15 - descriptors, offsets and the normalisation are the walk's constants
+    const int sC = p.src[0].C, vs = FNN_VS(p.src[0]);
+    const unsigned item_bytes = (unsigned)p.Di * p.Hi * p.Wi * sC * 2;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(p.src[0].ptr + (size_t)n * (item_bytes >> 1)), 0, item_bytes, 0x00020000);
+    const unsigned voff = ok_hw ? (unsigned)hw_lin * (unsigned)(vs * 2) + cg * 16 : 0x80000000u;
+    const unsigned plane_bytes = (unsigned)p.Hi * p.Wi * vs * 2;
+    const f16 slope_h = (f16)p.src[0].slope;
+#ifdef FNN_NORM_FP32
+    float sc[8], sh[8];
+    {
+        const float *qs = p.src[0].ss ? p.src[0].ss + (size_t)(2 * n) * sC : p.ident_ss;
+        const float *qh = p.src[0].ss ? qs + sC : p.ident_ss + 512;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = ok_hw ? qs[cg * 8 + j] : 0.f; sh[j] = ok_hw ? qh[cg * 8 + j] : 0.f; }
+    }
+#else
+    f16x8 sc_h, sh_h;
+    {
+        const unsigned short *q = p.src[0].ssh ? p.src[0].ssh + (size_t)n * sC * 2 : p.ident_ssh;
+        const fnn_u32x4v *qv = (const fnn_u32x4v *)(q + cg * 16);
+        const fnn_u32x4v zero4 = {0u, 0u, 0u, 0u};
+        sc_h = __builtin_bit_cast(f16x8, ok_hw ? qv[0] : zero4); sh_h = __builtin_bit_cast(f16x8, ok_hw ? qv[1] : zero4);
+    }
+#endif
+
+    fnn_u32x4v xr[ID];
+    auto load_planes = [&](int td, int u0) {                  // the planes u0 .. 9 of tile td: 8 td - 1 + u, clamped (see stage())
+#pragma unroll
+        for (int u = 0; u < ID; ++u) {
+            if (u < u0) continue;
+            int gd = td * TD - 1 + u;
+            gd = gd < 0 ? 0 : (gd >= p.Di ? p.Di - 1 : gd);
+            xr[u] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, (unsigned)gd * plane_bytes, 0));
+        }
+    };
+    auto stage = [&](int td, int u0) {                        // normalise + LeakyReLU, into the planes' ring slots; planes outside the tensor: zeros
+        if (!has_col) return;
+        const int k0 = (td - td0) * TD;
+#pragma unroll
+        for (int u = 0; u < ID; ++u) {
+            if (u < u0) continue;
+            const f16x8 x = __builtin_bit_cast(f16x8, xr[u]);
+#ifdef FNN_NORM_FP32
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)x[j], sc[j], sh[j]);
+#else
+            f16x8 o = x * sc_h + sh_h;
+#endif
+            o = __builtin_elementwise_max(o, o * slope_h);
+            const int gd = td * TD - 1 + u;                   // (scalar)
+            if ((unsigned)gd >= (unsigned)p.Di) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            *(f16x8 *)(sA + ldso0 + ((k0 + u) % ID) * PS) = o;
+        }
+    };
+    int toff[5];
+    f32x4 acc[TD][NB];
+    auto kloop = [&](int td) {
+        const int k0 = (td - td0) * TD;
+        int roff[ID];                                         // (scalars) where the tile's ten planes sit in the ring
+#pragma unroll
+        for (int pl = 0; pl < ID; ++pl) roff[pl] = ((k0 + pl) % ID) * PS;
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const char *bp = sA + toff[pr];
+            f16x8 xf[ID];
+#pragma unroll
+            for (int pl = 0; pl < ID; ++pl) xf[pl] = *(const f16x8 *)(bp + roff[pl]);
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                f16x8 wf[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wf[nb] = *(const f16x8 *)(sW + ((nb * KS + pr * 3 + dz) * 64 + lane) * 16);
+#pragma unroll
+                for (int j = 0; j < TD; ++j)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nb], xf[j + dz], acc[j][nb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- prologue: the first tile's ten planes and the weights
+    load_planes(td0, 0);
+    fnn_u32x4v wr[NB][WPB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const f16 *wp = p.wpk + ((size_t)((cb0 + nb) * p.chunks) * WB) * 8;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, WB * 16, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < WPB; ++u) wr[nb][u] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw, tid * 16, u * 4096, 0));
+    }
+    f32x4 b0[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+        b0[nb] = *(const f32x4 *)(p.bias + cb0 * 16 + (NB == 2 ? (lane >> 4) * 8 + nb * 4 : nb * 16 + (lane >> 4) * 4));
+    {
+        const int r = lane & 15, hl = lane >> 5, kh = (lane >> 4) & 1;
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const int tp = 2 * pr + hl < 9 ? 2 * pr + hl : 8;
+            const int row = 2 * wave + (r >> 3) + tp / 3, col2 = (r & 7) + tp % 3;
+            toff[pr] = (row * PW + col2) * 32 + ((kh ^ (row & 1)) * 16);
+        }
+    }
+    stage(td0, 0);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int u = 0; u < WPB; ++u)
+            if (u + 1 < WPB || wave < 3) *(fnn_u32x4v *)(sW + ((nb * WB + u * 256) + tid) * 16) = wr[nb][u];
+    __syncthreads();
+
+    auto finish = [&](int td) {                               // fp16 stores + the tile's statistics row (the bias is in the accumulators)
+        float4 bv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float t1[NB][4], t2[NB][4];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
+        if constexpr (NB == 2) zr_epilogue_pair<TD, false>(p, acc, bv, n, td * TD, oh0, ow0, cb0, wave, lane, t1, t2);
+        else tile_epilogue<NB, TD, true, false>(p, acc, bv, n, td * TD, oh0, ow0, cb0, wave, lane, t1, t2);
+        if (p.stats_out) stats_to_global_at<NB, true, NB == 2>(p, t1, t2, sred_at, n, cb0, wave, lane, tid, (td * p.tiles_h + th) * p.tiles_w + tw);
+        else __syncthreads();
+    };
+    // ---- the walk: the last tile is peeled off (nothing to prefetch behind it)
+    for (int td = td0; td + 1 < td1; ++td) {
+#pragma unroll
+        for (int j = 0; j < TD; ++j)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[j][nb] = b0[nb];
+        load_planes(td + 1, 2);                               // eight new planes, in flight during the MFMAs
+        kloop(td);
+        __syncthreads();                                      // every wave is done with this tile's planes
+        stage(td + 1, 2);                                     // over the slots of this tile's first eight planes
+        finish(td);                                           // (its barrier also publishes the staged planes)
+    }
+#pragma unroll
+    for (int j = 0; j < TD; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[j][nb] = b0[nb];
+    kloop(td1 - 1);
+    __syncthreads();
+    finish(td1 - 1);
+}
+
+// ----------------------------------------------------------------------------
 // whole 12 x 12 planes per tile (the 128-channel stage of a 96 x 96 in-plane patch)
 // ----------------------------------------------------------------------------
 // 8 x 8 in-plane tiles cover a 12 x 12 plane with four tiles that are filled to 56 %: the MFMAs of the empty columns are
@@ -1359,6 +1554,34 @@ static int launch_zr(ConvParams p, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// the walking form for single-chunk layers: `segs` d-segments of `tps` tiles per in-plane window
+template <int NB>
+static int launch_zrw(ConvParams p, hipStream_t st) {
+    constexpr int TD = 8;
+    p.tile_d = TD;
+    p.tiles_d = (p.Do + TD - 1) / TD;
+    p.tiles_h = (p.Ho + 7) / 8;
+    p.tiles_w = (p.Wo + 7) / 8;
+    const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;
+    const long long cols = (long long)plan_n * p.tiles_h * p.tiles_w * ((p.Cout / 16) / NB);
+    int segs = 1;                                             // enough workgroups for two rounds of the chip's slots, tiles permitting
+    while (cols * segs < 2 * 768 && segs * 2 <= p.tiles_d / 2) segs *= 2;
+    const int tps = (p.tiles_d + segs - 1) / segs;
+    segs = (p.tiles_d + tps - 1) / tps;
+    const size_t lds = (size_t)((TD + 2) * 10 * 12 * 32) + (size_t)NB * 15 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)conv3d_zrw_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    p.ident_ss = conv3d_identity_ss();
+    p.ident_ssh = conv3d_identity_ssh();
+    if (!p.ident_ss || !p.ident_ssh) return -2;
+    dim3 grid(p.N * p.tiles_h * p.tiles_w * segs, (p.Cout / 16) / NB);
+    hipLaunchKernelGGL((conv3d_zrw_kernel<NB>), grid, dim3(256), lds, st, p, segs, tps);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // A persistent form of this kernel (tile ranges per workgroup, cross-tile prefetch, like conv3d_persist_kernel) was
 // built and measured: 5-20 % SLOWER on every layer of the benchmark net - <2, 8> does not fit 256 VGPRs next to the
 // prefetch registers, <2, 4> loses the operand reuse - so one tile per workgroup it stays.
@@ -1404,6 +1627,11 @@ int launch_conv3d_zr(const ConvParams &p, hipStream_t st) {
         static const bool no_zr12 = fnn_knob("FNN_NO_ZR12") != nullptr;                       // A-B aid
         if (!no_zr12 && nb == 2 && p.Ho > 8 && p.Ho <= 12 && p.Wo > 8 && p.Wo <= 12 && conv3d_stats_slots(p) >= (p.Do + 3) / 4)
             return launch_zr12<4>(p, st);                                            // (TD = 6: 60 B of scratch, -1.5 %; TD = 8: 140-224 B, -3 %)
+    }
+    {
+        // one chunk (Cin <= 16) and at least four tiles along d: the walking form
+        static const bool no_walk = fnn_knob("FNN_NO_ZRW") != nullptr;                        // A-B aid
+        if (!no_walk && p.chunks == 1 && td == 8 && (p.Do + 7) / 8 >= 4) return nb == 2 ? launch_zrw<2>(p, st) : launch_zrw<1>(p, st);
     }
     if (nb == 2) return td == 8 ? launch_zr<2, 8>(p, st) : launch_zr<2, 4>(p, st);
     return td == 8 ? launch_zr<1, 8>(p, st) : launch_zr<1, 4>(p, st);

@@ -112,9 +112,10 @@ static __device__ __forceinline__ void tile_epilogue(const ConvParams &p, const 
 // SLOT: the workgroup owns row `slot` of the item's stats rows and stores its sums there (no atomics: the double
 // atomics of one-tile-per-workgroup kernels cost 5 % of the whole benchmark - 1.5 M of them per launch).
 // PERM: the ZR kernels' channel order at NB = 2 (conv3d_pack_cout): lane quarter q holds channels q * 8 + nb * 4 + j.
-template <int NB, bool SLOT = false, bool PERM = false>
-static __device__ __forceinline__ void stats_to_global(const ConvParams &p, float (&t1)[NB][4], float (&t2)[NB][4], float *sRed,
-                                                       int n, int cb0, int wave, int lane, int tid, int slot = 0) {
+// `at(i)`: where float i of the 4 * NB * 32 reduction floats lives in LDS (a plain array, or slots that a kernel has free)
+template <int NB, bool SLOT = false, bool PERM = false, typename At>
+static __device__ __forceinline__ void stats_to_global_at(const ConvParams &p, float (&t1)[NB][4], float (&t2)[NB][4], At at,
+                                                          int n, int cb0, int wave, int lane, int tid, int slot = 0) {
     const int q = lane >> 4, r = lane & 15;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -123,8 +124,8 @@ static __device__ __forceinline__ void stats_to_global(const ConvParams &p, floa
             const float a = row16_sum(t1[nb][j]), b = row16_sum(t2[nb][j]);
             if (r == 0) {
                 const int c = PERM ? q * 8 + nb * 4 + j : nb * 16 + q * 4 + j;
-                sRed[(wave * NB * 16 + c) * 2] = a;
-                sRed[(wave * NB * 16 + c) * 2 + 1] = b;
+                *at((wave * NB * 16 + c) * 2) = a;
+                *at((wave * NB * 16 + c) * 2 + 1) = b;
             }
         }
     __syncthreads();
@@ -132,9 +133,15 @@ static __device__ __forceinline__ void stats_to_global(const ConvParams &p, floa
         const int c = tid >> 1, which = tid & 1;
         double v = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) v += (double)sRed[(w * NB * 16 + c) * 2 + which];
+        for (int w = 0; w < 4; ++w) v += (double)*at((w * NB * 16 + c) * 2 + which);
         if (SLOT) p.stats_out[(((size_t)n * p.stats_slots + slot) * p.Cout + cb0 * 16 + c) * 2 + which] = v;
         else unsafeAtomicAdd(p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout + cb0 * 16 + c) * 2 + which, v);
     }
+}
+
+template <int NB, bool SLOT = false, bool PERM = false>
+static __device__ __forceinline__ void stats_to_global(const ConvParams &p, float (&t1)[NB][4], float (&t2)[NB][4], float *sRed,
+                                                       int n, int cb0, int wave, int lane, int tid, int slot = 0) {
+    stats_to_global_at<NB, SLOT, PERM>(p, t1, t2, [sRed](int i) { return sRed + i; }, n, cb0, wave, lane, tid, slot);
 }
 

@@ -182,6 +182,37 @@ def test_conv3d_zr_variants(n, cin, cout, dims):
     assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize('n,cin,cout,dims', [(1, 16, 16, (45, 16, 16)),     # few windows: three d-segments per window, the last tile ragged
+                                             (2, 8, 32, (37, 24, 9)),       # two cout blocks, padded input channels, ragged everywhere
+                                             (3, 16, 16, (64, 40, 40))])    # one segment of eight tiles per window
+def test_conv3d_zr_walking_kernel_for_single_chunk_layers(n, cin, cout, dims):
+    """conv3d_zrw_kernel (Cin <= 16, >= 4 tiles along d): a workgroup walks the d-tiles of an 8 x 8 window with the
+    weights resident and the halo planes in a ring - exact on integer data (ring slots, plane order, segment starts, the
+    zero planes at both ends), within the op tolerance with the fused norm, and its per-tile statistics rows add up."""
+    from fast_nnunet_amd import capi
+    base = (torch.arange(dims[0] * dims[1] * dims[2]).reshape(dims) * 5 % 19).float()
+    x = torch.stack([torch.stack([base + ch + 2 * i for ch in range(cin)]) for i in range(n)])
+    w = torch.zeros(cout, cin, 3, 3, 3)
+    for co in range(cout):
+        w[co, (co * 5 + 3) % cin, co % 3, (co // 3) % 3, (co + 1) % 3] = 1.0
+        w[co, (co * 3 + 1) % cin, (co + 2) % 3, (co + 1) % 3, co % 3] += 2.0
+    y = capi.op_conv3d(x.numpy(), w.numpy(), None, (3, 3, 3), (1, 1, 1))
+    assert np.array_equal(y, F.conv3d(x, w, None, 1, 1).numpy())
+    g = torch.Generator().manual_seed(21 + cin + cout)
+    x = _h(torch.randn(n, cin, *dims, generator=g) * 2 + 0.5)
+    gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+    w = _h(torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    y, stats = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), (1, 1, 1), gamma=gamma.numpy(), beta=beta.numpy(),
+                              slope=0.01, want_stats=True)
+    xn = _h(F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01))
+    ref = F.conv3d(xn, w, b, 1, 1)
+    assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
+    y64 = y.astype(np.float64)
+    assert np.allclose(stats[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    assert np.allclose(stats[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+
+
 def test_conv3d_zr_two_sources():
     from fast_nnunet_amd import capi
     g = torch.Generator().manual_seed(5)
