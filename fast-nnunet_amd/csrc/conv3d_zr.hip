@@ -1613,6 +1613,21 @@ static int launch_zrw(ConvParams p, hipStream_t st) {
 // one tile per workgroup the dispatcher starts a workgroup whenever one ends, and the two workgroups of a CU drift into
 // complementary phases; two walkers that start together stay together.  The single-chunk strided layer is the
 // exception (conv3d_zsp_kernel, +25 %): there the serial chain IS the tile.
+// Round 3, on the kernel with column-per-thread staging (all bit-identical unless marked; per-layer times from 30 back-to-back
+// launches, tools/layer_time.py):
+// * the k-loop's matrix work as v_mfma_f32_32x32x16_f16 with 27 exact k-steps (108 instead of 240 MFMAs per chunk and
+//   wave, -10 % matrix cycles, same LDS reads; timing-only): 32 -> 32 875 -> 882 us, 64 -> 32 1489 -> 1526: neither the
+//   MFMA count nor the zero-padded tap slot is what this kernel waits for;
+// * two tiles per 512-thread workgroup IN PHASE (shared barriers, own LDS images - the lock-step a shared-weights
+//   8-wave design would run in): 796 -> 915 us, 1390 -> 1491, 397 -> 443: independent workgroups overlap each other's
+//   staging, lock-step does not;
+// * TD = 4 at three workgroups per CU (141 registers, 53.8 KB): 767 -> 928 us;
+// * runs of 2 .. 20 d-tiles per workgroup with (tile, chunk) as one sequence of stages - every k-loop carries the next
+//   stage's loads, a tile's epilogue runs behind the staging of its successor's first chunk (245 registers, no scratch):
+//   788 -> 770 us at 5 and 10 tiles, 1359 -> 1342: the other workgroup of the CU already hides what this hides; not kept;
+// * PMC per wave and two-chunk tile (tools/pmc_layer.sh): 480 MFMAs = 7.7 k cycles, ~1280 other vector instructions
+//   before / ~900 after the staging rewrite, 417 scalar, 202 LDS; SQ_WAIT_ANY 15 % of the wave's life, issue stalls
+//   48 %, matrix pipe busy 50 -> 55 %; clock under 30 back-to-back launches 1.80 GHz, inside the network 2.13 GHz.
 // Runs the layer on the ZR kernel; the weights must have been packed as FNN_PACK_ZR (p.packing).
 int launch_conv3d_zr(const ConvParams &p, hipStream_t st) {
     int nb, td;
