@@ -1,0 +1,12 @@
+#!/bin/bash
+# usage (GPU box, repo root): FNN_ROUND=r03 bash tools/capture_all.sh   - every workload DESIGN.md quotes, each with tools/capture.sh
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $root
+run() { tag=$1; shift; echo "######## $tag: $*"; bash tools/capture.sh $tag "$@" 2>&1 | tail -28; }
+run bone
+run iso128_r2 --workload iso128_r2
+run iso128_teacher --workload iso128_teacher
+run resenc160_r2 --workload resenc160_r2
+run resenc160_r2_f8 --workload resenc160_r2 --dtype f8
+run bone_autocast --accum fp16_autocast
+run bone_mirror --mirror
