@@ -434,6 +434,8 @@ def main():
         del out
         torch.cuda.synchronize()
         pr = predictor._engine.profile()
+        import collections
+        kernel_counts = dict(collections.Counter(predictor._engine.kernel_log()))   # which variant served every launch of that volume
         predictor._engine.set_profiling(False)
         achieved = pr.conv_flops / (pr.conv_ms * 1e-3) / 1e12 if pr.conv_ms > 0 else 0.0
         launches = max(1, pr.conv_launches)
@@ -471,6 +473,7 @@ def main():
                               'tconv': round(pr.tconv_ms, 2), 'seg_head_accumulate': round(pr.head_ms, 2),
                               'finalize': round(pr.finalize_ms, 2)},
             'whole_net_tflops': round(flops_patch * n_patches / (dt / args.steps) / 1e12, 2),
+            'launches_by_kernel': kernel_counts,
         }
     if rank == 0 and not distributed and not args.no_cpu_baseline and not info['resenc']:
         result['cpu_baseline'] = cpu_baseline(sd, info)

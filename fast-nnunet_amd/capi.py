@@ -63,7 +63,7 @@ class Profile(C.Structure):
 EXPORTS = ['fnn_abi_version', 'fnn_last_error', 'fnn_create', 'fnn_destroy', 'fnn_weight_count', 'fnn_load_weights',
            'fnn_set_gaussian', 'fnn_predict_volume', 'fnn_predict_volume_ensemble', 'fnn_predict_labels',
            'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_labels_box', 'fnn_feature_channels', 'fnn_patch_features', 'fnn_gather_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_export_probabilities', 'fnn_resample', 'fnn_compute_steps', 'fnn_plan_volume', 'fnn_fp8_e4m3_encode',
-           'fnn_set_profiling', 'fnn_get_profile', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d', 'fnn_op_quotient_check']
+           'fnn_set_profiling', 'fnn_get_profile', 'fnn_kernel_log', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d', 'fnn_op_quotient_check']
 
 _lib = None
 
@@ -121,6 +121,8 @@ def load_library() -> C.CDLL:
     lib.fnn_fp8_e4m3_encode.argtypes = [vp, i64, vp]
     lib.fnn_set_profiling.argtypes = [vp, i32]
     lib.fnn_get_profile.argtypes = [vp, C.POINTER(Profile)]
+    lib.fnn_kernel_log.argtypes = [vp, C.c_char_p, i64]
+    lib.fnn_kernel_log.restype = i64
     lib.fnn_patch_work.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     I3 = C.POINTER(C.c_int)
     lib.fnn_op_conv3d.argtypes = [i32, i32, I3, f32p, i32, f32p, f32p, C.c_float, f32p, i32, f32p, f32p, C.c_float,
@@ -325,6 +327,13 @@ class Engine:
         p = Profile()
         check(self.lib.fnn_get_profile(self.handle, C.byref(p)), self.lib, self.handle)
         return p
+
+    def kernel_log(self):
+        """Kernel variants of the last call made with profiling on, one per launch."""
+        n = self.lib.fnn_kernel_log(self.handle, None, 0)
+        buf = C.create_string_buffer(int(n))
+        self.lib.fnn_kernel_log(self.handle, buf, n)
+        return [k for k in buf.value.decode().split('\n') if k]
 
     def patch_work(self):
         fl, by = C.c_double(), C.c_double()

@@ -501,6 +501,7 @@ static int launch_ldsk(ConvParams p, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
+    fnn_note_kernel("conv3d_lds_kernel<%d,%d,%d>", NB, MB, PF);
     hipLaunchKernelGGL((conv3d_lds_kernel<NB, MB, PF>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -877,6 +878,7 @@ static int launch_persist_ks(ConvParams p, int wgs_per_cu, hipStream_t st, int g
     int gx = gx_exact > 0 ? gx_exact : 256 * wgs_per_cu;
     if (gx > total) gx = total;
     dim3 grid(gx, (p.Cout / 16) / NB);
+    fnn_note_kernel("conv3d_persist_kernel<%d,%d,%d,%d,%d,%d,%d>", NB, MB, (int)WRES, KS, CH, PF, (int)SBUF);
     hipLaunchKernelGGL((conv3d_persist_kernel<NB, MB, WRES, KS, CH, PF, SBUF>), grid, dim3(256), lds, st, p, total);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -966,6 +968,7 @@ static int launch_conv_nb(const ConvParams &p, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
+    fnn_note_kernel("conv3d_mfma_kernel<%d> (generic fallback)", NB);
     hipLaunchKernelGGL(conv3d_mfma_kernel<NB>, grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

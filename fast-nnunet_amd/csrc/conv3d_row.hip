@@ -826,6 +826,7 @@ int launch_row_t(ThinParams tp, hipStream_t st) {
     if (per_cu > cap) per_cu = cap;
     int gx = 256 * per_cu;
     if (gx > total) gx = total;
+    fnn_note_kernel("conv_row_kernel<%d,%d,%d>", NBLK, CH, (int)TCONV);
     hipLaunchKernelGGL((conv_row_kernel<NBLK, CH, TCONV>), dim3(gx), dim3(256), lds, st, tp, total, strips, SH);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -860,6 +861,7 @@ int launch_row_stem_t(ThinParams tp, hipStream_t st) {
     if (per_cu > cap) per_cu = cap;
     int gx = 256 * per_cu;
     if (gx > total) gx = total;
+    fnn_note_kernel("conv_row_stem_kernel<%d>", NBLK);
     hipLaunchKernelGGL((conv_row_stem_kernel<NBLK>), dim3(gx), dim3(256), lds, st, tp, total, strips, SH);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -929,6 +931,7 @@ int launch_stem_row(const StemParams &p, int N, hipStream_t st) {
     // p.out == nullptr: the statistics pass of a fused consumer (conv_row_stem_kernel) - no stores, no 16-byte shuffles
 #define STEM_ROW_LAUNCH(NB)                                                                                            \
     do {                                                                                                               \
+        fnn_note_kernel("stem_row_kernel<%d,%d>", NB, p.out ? 1 : 0);                                                  \
         if (p.out) hipLaunchKernelGGL((stem_row_kernel<NB, true>), dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots);    \
         else hipLaunchKernelGGL((stem_row_kernel<NB, false>), dim3(gx), dim3(256), lds, st, p, total, strips, SH, slots);         \
     } while (0)

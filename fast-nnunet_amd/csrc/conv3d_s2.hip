@@ -352,6 +352,7 @@ int launch_conv3d_s2(ConvParams p, hipStream_t st) {
         attr_set = true;
     }
     const int gx = total < 256 ? total : 256;
+    fnn_note_kernel("conv3d_s2_kernel");
     hipLaunchKernelGGL(conv3d_s2_kernel, dim3(gx), dim3(512), lds, st, p, total, groups);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -260,6 +260,7 @@ int launch_stem_mfma(const StemParams &p_in, const f16 *wfrag, int N, hipStream_
         attr_set = true;
     }
     const dim3 grid(N * p.tiles_d * p.tiles_h * p.tiles_w, p.Cout / 16);
+    fnn_note_kernel("stem_mfma_kernel<%d>", ks == 1 ? 1 : 0);
     if (ks == 1) hipLaunchKernelGGL(stem_mfma_kernel<true>, grid, dim3(256), lds, st, p, wfrag, ks);
     else hipLaunchKernelGGL(stem_mfma_kernel<false>, grid, dim3(256), lds, st, p, wfrag, ks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -732,6 +733,7 @@ static int launch_thin_w(ThinParams tp, hipStream_t st) {
     if (per_cu > WPS) per_cu = WPS;
     int gx = 256 * per_cu;
     if (gx > total) gx = total;
+    fnn_note_kernel("conv_thin_kernel<%d,%d,%d,%d,%d>", KD, CH, FUSE, NCLS, WPS);
     hipLaunchKernelGGL((conv_thin_kernel<KD, CH, FUSE, NCLS, WPS>), dim3(gx), dim3(256), lds, st, tp, total);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

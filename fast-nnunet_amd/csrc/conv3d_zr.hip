@@ -809,6 +809,7 @@ static int launch_zr12(ConvParams p, hipStream_t st) {
     p.ident_ss = conv3d_identity_ss();
     if (!p.ident_ss) return -2;
     dim3 grid(p.N * p.tiles_d, (p.Cout / 16) / 2);
+    fnn_note_kernel("conv3d_zr12_kernel<%d>", TD);
     hipLaunchKernelGGL((conv3d_zr12_kernel<TD>), grid, dim3(576), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -1302,10 +1303,12 @@ static int launch_zs(ConvParams p, hipStream_t st) {
         }
         int gx = 512 / groups;
         if (gx < 8) gx = 8;
+        fnn_note_kernel("conv3d_zsp_kernel");
         hipLaunchKernelGGL(conv3d_zsp_kernel, dim3(gx, groups), dim3(256), ldsp, st, p, total);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     dim3 grid(total, groups);
+    fnn_note_kernel("conv3d_zs_kernel<2>");
     hipLaunchKernelGGL((conv3d_zs_kernel<2>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -1530,6 +1533,7 @@ static int launch_zr8(ConvParams p, hipStream_t st) {
     p.ident_ss = conv3d_identity_ss();
     if (!p.ident_ss || !p.oscale) return -2;
     dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
+    fnn_note_kernel("conv3d_zr8_kernel<%d,%d>", NB, TD);
     hipLaunchKernelGGL((conv3d_zr8_kernel<NB, TD>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -1550,6 +1554,7 @@ static int launch_zr(ConvParams p, hipStream_t st) {
     p.ident_ssh = conv3d_identity_ssh();
     if (!p.ident_ss || !p.ident_ssh) return -2;
     dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
+    fnn_note_kernel("conv3d_zr_kernel<%d,%d>", NB, TD);
     hipLaunchKernelGGL((conv3d_zr_kernel<NB, TD>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -1578,6 +1583,7 @@ static int launch_zrw(ConvParams p, hipStream_t st) {
     p.ident_ssh = conv3d_identity_ssh();
     if (!p.ident_ss || !p.ident_ssh) return -2;
     dim3 grid(p.N * p.tiles_h * p.tiles_w * segs, (p.Cout / 16) / NB);
+    fnn_note_kernel("conv3d_zrw_kernel<%d>", NB);
     hipLaunchKernelGGL((conv3d_zrw_kernel<NB>), grid, dim3(256), lds, st, p, segs, tps);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -119,6 +119,7 @@ struct fnn_engine {
     void *feat = nullptr; size_t feat_bytes = 0;
     void *featss = nullptr; size_t featss_bytes = 0;
     int *steps_dev = nullptr; size_t steps_cap = 0;
+    std::vector<std::string> klog;          // kernel variants of the last profiled call, one entry per launch (fnn_kernel_log)
     bool gather_enabled = true;             // FNN_NO_GATHER (read when the engine is created): always accumulate in HBM
     double head_flops = 0, patch_flops = 0, patch_act_bytes = 0;
     // profiling
@@ -578,6 +579,7 @@ enum { FAM_CONV = 0, FAM_STEM, FAM_TCONV, FAM_HEAD, FAM_FINAL };
 struct Scope {
     fnn_engine *e; hipStream_t st; int idx = -1;
     Scope(fnn_engine *e_, hipStream_t st_, int family, double flops, double bytes = 0) : e(e_), st(st_) {
+        fnn_klog_target(e->profiling ? &e->klog : nullptr);  // the launchers inside this scope note their kernel variant
         if (!e->profiling) return;
         if (e->ev_used == e->evs.size()) {
             fnn_engine::Ev ev{};
@@ -1236,7 +1238,7 @@ int predict_impl(fnn_engine *e, int fold0, int n_folds, const float *vol, const 
         return fail(e, FNN_E_INVALID, "%d classes do not fit uint8 labels: fnn_set_label_rule(..., FNN_LABEL_U16)", a.num_heads);
     if (labels && !lab_on_dev) { HIPCHK(e, hipMalloc(&lab_tmp, lab_bytes)); lab_dev = lab_tmp; }
     HIPCHK(e, hipMemsetAsync(e->inf_flag, 0, sizeof(int), st));
-    e->ev_used = 0;
+    e->ev_used = 0; e->klog.clear();
     const int acc_fp32 = o->accum == FNN_ACC_FP32;
     const int64_t zero3[3] = {0, 0, 0}, full3[3] = {shape[1], shape[2], shape[3]};
     int rc = 0;
@@ -1459,7 +1461,7 @@ int fnn_accumulate_patches(fnn_engine *e, int fold, const float *vol, const int6
     const float *vol_dev = nullptr;
     if (int rc = stage_volume(e, vol, shape, vp, st, &vol_dev)) return rc;
     if (int rc = upload_origins(e, vp, ids, st)) return rc;
-    e->ev_used = 0;
+    e->ev_used = 0; e->klog.clear();
     if (int rc = run_patches(e, fold, vol_dev, vp, *opts, ids, e->origins, box, acc, opts->accum == FNN_ACC_FP32, st)) return rc;
     if (e->profiling) { HIPCHK(e, hipStreamSynchronize(st)); collect_profile(e, n_ids); }
     return 0;
@@ -1546,7 +1548,7 @@ int fnn_patch_features(fnn_engine *e, int fold, const float *vol, const int64_t 
     if (int rc = upload_origins(e, vp, ids, st)) return rc;
     Box box;
     for (int d = 0; d < 3; ++d) { box.lo[d] = 0; box.hi[d] = vp.padded[d]; }
-    e->ev_used = 0;
+    e->ev_used = 0; e->klog.clear();
     if (int rc = run_patches(e, fold, vol_dev, vp, *opts, ids, e->origins, box, nullptr, 0, st, false, true, slot0, n_slots, feat, fss)) return rc;
     if (e->profiling) { HIPCHK(e, hipStreamSynchronize(st)); collect_profile(e, n_ids); }
     return 0;
@@ -1612,7 +1614,7 @@ int fnn_gather_box(fnn_engine *e, int fold, const void *feat, const float *fss, 
     g.label_u16 = e->label_u16; g.order = e->label_mode == FNN_LABELS_REGIONS ? e->label_order : nullptr;
     if (labels && !e->label_u16 && e->label_mode == FNN_LABELS_ARGMAX && a.num_heads > 256)
         return fail(e, FNN_E_INVALID, "%d classes do not fit uint8 labels", a.num_heads);
-    e->ev_used = 0;
+    e->ev_used = 0; e->klog.clear();
     if (out_logits) {
         g.out = out_logits; g.labels = nullptr;
         g.out_vec = shape[3] % 8 == 0 && ((size_t)out_logits % 16) == 0;
@@ -1662,7 +1664,7 @@ int fnn_forward_patches(fnn_engine *e, int fold, const float *x, int n, float *l
     HIPCHK(e, hipStreamSynchronize(st));
     const long long vdim[3] = {a.patch[0], a.patch[1], a.patch[2]};
     const int flip[3] = {0, 0, 0};
-    e->ev_used = 0;
+    e->ev_used = 0; e->klog.clear();
     for (int p0 = 0; p0 < n; p0 += e->max_batch) {
         const int nb = (n - p0 < e->max_batch) ? n - p0 : e->max_batch;
         if (int rc = forward_batch(e, fold, xd + (size_t)p0 * a.in_channels * P, (long long)(a.in_channels * P), vdim,
@@ -1748,6 +1750,18 @@ int fnn_fp8_e4m3_encode(const float *in, int64_t n, uint8_t *out) {
 int fnn_set_profiling(fnn_engine *e, int enabled) { if (!e) return FNN_E_INVALID; e->profiling = enabled != 0; return 0; }
 
 int fnn_get_profile(const fnn_engine *e, fnn_profile *out) { if (!e || !out) return FNN_E_INVALID; *out = e->prof; return 0; }
+
+int64_t fnn_kernel_log(const fnn_engine *e, char *buf, int64_t cap) {
+    if (!e) return FNN_E_INVALID;
+    std::string all;
+    for (const std::string &k : e->klog) { all += k; all += '\n'; }
+    if (buf && cap > 0) {
+        const size_t n = std::min((size_t)cap - 1, all.size());
+        memcpy(buf, all.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)all.size() + 1;
+}
 
 int fnn_patch_work(const fnn_engine *e, double *flops, double *act_bytes) {
     if (!e) return FNN_E_INVALID;

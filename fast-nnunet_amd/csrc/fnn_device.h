@@ -246,6 +246,9 @@ struct FinalizeParams {
 // variables that are honoured ONLY when FNN_KNOBS=1 is set as well - a production process does not change behaviour
 // because of a stray variable; the tests and tools/ set it.
 const char *fnn_knob(const char *name);
+// Which kernel variant a launcher picked: recorded per launch while the engine profiles (fnn_kernel_log), a no-op otherwise.
+void fnn_note_kernel(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+void fnn_klog_target(void *vector_of_strings);          // where this thread's notes go (nullptr: nowhere)
 
 static __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
 

@@ -6,12 +6,28 @@
 //   finalize_kernel     acc / weight-sum, inf check, un-pad (K8)
 //   argmax_kernel       logits -> labels (K10)
 #include "fnn_device.h"
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
 #include <cstdlib>
 #include <cstring>
 
 const char *fnn_knob(const char *name) {
     static const bool on = [] { const char *v = getenv("FNN_KNOBS"); return v && strcmp(v, "0") != 0; }();
     return on ? getenv(name) : nullptr;
+}
+
+static thread_local std::vector<std::string> *g_klog = nullptr;
+void fnn_klog_target(void *v) { g_klog = (std::vector<std::string> *)v; }
+void fnn_note_kernel(const char *fmt, ...) {
+    if (!g_klog) return;
+    char buf[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_klog->push_back(buf);
 }
 #include <cstdlib>
 #include <type_traits>
@@ -189,6 +205,7 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const PoolParams p) {
 
 int launch_avgpool(const PoolParams &p, hipStream_t st) {
     const long long total = (long long)p.N * (p.Di / p.sd) * (p.Hi / p.sh) * (p.Wi / p.sw) * (p.src.C >> 3);
+    fnn_note_kernel("avgpool_kernel");
     hipLaunchKernelGGL(avgpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -230,6 +247,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineParams p) {
 
 int launch_combine(const CombineParams &p, hipStream_t st) {
     const long long total = (long long)p.N * p.vox * (p.a.C >> 3);
+    fnn_note_kernel("combine_kernel");
     hipLaunchKernelGGL(combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -349,7 +367,7 @@ int launch_tconv(const TconvParams &p, hipStream_t st) {
     const int tg_cap = nbt == 2 ? tg_max2 : 4;
     const int tg = taps >= tg_cap ? (tg_cap > 4 ? 4 : tg_cap) : taps;     // taps is 1, 2, 4 or 8
     dim3 grid(p.N * ((vox_in + 255) / 256), (taps / tg) * (p.nblk / nbt));
-#define FNN_TCONV(NBTv, TGv) hipLaunchKernelGGL((tconv_mfma_kernel<NBTv, TGv>), grid, dim3(256), lds, st, p)
+#define FNN_TCONV(NBTv, TGv) do { fnn_note_kernel("tconv_mfma_kernel<%d,%d>", NBTv, TGv); hipLaunchKernelGGL((tconv_mfma_kernel<NBTv, TGv>), grid, dim3(256), lds, st, p); } while (0)
     if (nbt == 2) { if (tg == 4) FNN_TCONV(2, 4); else if (tg == 2) FNN_TCONV(2, 2); else FNN_TCONV(2, 1); }
     else          { if (tg == 4) FNN_TCONV(1, 4); else if (tg == 2) FNN_TCONV(1, 2); else FNN_TCONV(1, 1); }
 #undef FNN_TCONV

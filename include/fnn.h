@@ -327,6 +327,11 @@ typedef struct fnn_profile {
 } fnn_profile;
 int fnn_set_profiling(fnn_engine *e, int enabled);
 int fnn_get_profile(const fnn_engine *e, fnn_profile *out);
+/* Which kernel variant served every launch of the last call made while profiling was on (one line per launch, in launch
+ * order: "conv3d_zr_kernel<2,8>", "conv_row_kernel<6,1,0>", ...): the launchers choose variants from the layer shape and
+ * the planned batch, and a silent fall-back to a generic kernel is otherwise invisible.  Returns the bytes needed
+ * (with the terminating 0); writes at most `cap`.  No counterpart in the reference. */
+int64_t fnn_kernel_log(const fnn_engine *e, char *buf, int64_t cap);
 
 /* Algorithmic work of one patch forward: 2*MACs of convs, transposed convs and
  * the seg head; ideal fp16 activation bytes (each activation written once and

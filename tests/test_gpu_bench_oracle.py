@@ -202,3 +202,47 @@ def test_resenc_f8_step_stays_within_its_budget_at_full_patch_size():
     agree = float((got.argmax(0) == ref.argmax(0)).float().mean())
     print(f'[resenc160_r2 f8] label agreement with the fp32 oracle {agree:.4f}')
     assert rr <= 0.15 and agree >= 0.94
+
+
+# ------------------------------------------------------------------------------------------ which kernels the workloads launch
+# The launchers pick a variant per layer from its shape and the planned batch; a silent fall-back to the generic
+# conv3d_mfma_kernel (or to a variant no full-size test covers) would keep every small-shape test green.  fnn_kernel_log
+# lists the variant of every launch of a profiled call: the benchmark's set is pinned, and no BASELINE workload may reach
+# the generic fallback.
+BENCH_KERNELS = {
+    'stem_row_kernel<6,0>', 'conv_row_stem_kernel<6>', 'conv3d_zsp_kernel', 'conv3d_zr_kernel<2,8>', 'conv3d_s2_kernel',
+    'conv3d_zr12_kernel<4>', 'conv3d_lds_kernel<2,2,16>', 'conv3d_lds_kernel<2,2,8>', 'conv3d_zr_kernel<2,4>',
+    'tconv_mfma_kernel<2,2>', 'tconv_mfma_kernel<2,4>', 'conv_row_kernel<6,2,1>', 'conv_row_kernel<6,1,0>',
+}
+
+
+def _kernels_of_one_forward(p, info, vol):
+    P = info['patch']
+    x = torch.stack([vol[sl] for sl in osw.patch_slicers(vol.shape[1:], P, 0.5)[:32]])
+    p._engine.set_profiling(True)
+    try:
+        p.forward_patches(x)
+        torch.cuda.synchronize()
+        return p._engine.kernel_log()
+    finally:
+        p._engine.set_profiling(False)
+
+
+def test_bench_forward_launches_exactly_the_pinned_kernel_variants():
+    p, _, info, vol = _bench_setup('bone_turbo_r2')
+    log = _kernels_of_one_forward(p, info, vol)
+    conv_like = {k for k in log if not k.startswith(('seg_head', 'gather'))}
+    print(sorted(conv_like))
+    assert conv_like == BENCH_KERNELS, (sorted(conv_like - BENCH_KERNELS), sorted(BENCH_KERNELS - conv_like))
+
+
+@pytest.mark.parametrize('workload,dtype', [('iso128_r2', 'f16'), ('iso128_teacher', 'f16'), ('resenc160_r2', 'f16'), ('resenc160_r2', 'f8')])
+def test_no_baseline_workload_reaches_the_generic_fallback(workload, dtype):
+    p, _, info, vol = _bench_setup(workload, dtype)
+    log = _kernels_of_one_forward(p, info, vol)
+    print(workload, dtype, sorted(set(log)))
+    assert log and not any('generic' in k for k in log)
+    if workload != 'iso128_teacher' and dtype == 'f16':       # 16 -> 16 3x3x3 at full resolution: the walking kernel
+        assert 'conv3d_zrw_kernel<1>' in log
+    if dtype == 'f8':
+        assert any(k.startswith('conv3d_zr8_kernel') for k in log)
