@@ -1127,7 +1127,6 @@ int gather_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const Vol
                         hipStream_t st) {
     const fnn_arch_desc &a = e->arch;
     const Layer &H = e->layers[e->head_src];
-    const size_t P = (size_t)a.patch[0] * a.patch[1] * a.patch[2];
     if (gp.feat_bytes > e->feat_bytes && e->acc) { (void)hipFree(e->acc); e->acc = nullptr; e->acc_bytes = 0; }
     if (int rc = ensure(e, &e->feat, &e->feat_bytes, gp.feat_bytes)) return rc;
     const int64_t n_slots = (int64_t)gp.layer_items * gp.ring;

@@ -210,45 +210,67 @@ int launch_avgpool(const PoolParams &p, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-// y = LeakyReLU(T_a(a) + T_b(b)): the closing add of a residual block, stored as final values (thread mapping and
-// addresses as in avgpool_kernel: either layout on every operand)
+// y = LeakyReLU(T_a(a) + T_b(b)): the closing add of a residual block, stored as final values.  Either layout on every
+// operand (the one address formula of fnn_device.h).  grid.y = batch item (x 16-channel chunk for a chunk-major output),
+// grid.x walks the item's 16-byte vectors in the output's storage order, FNN_CMB_U of them per thread at a stride of
+// 256: all index arithmetic is 32-bit (round 2's one-vector-per-thread form spent its time in two 64-bit divisions per
+// thread and ran at 2.5 TB/s) and the 2 x FNN_CMB_U loads of a thread are in flight together.
+#define FNN_CMB_U 4
 __global__ __launch_bounds__(256) void combine_kernel(const CombineParams p) {
-    const int cg = p.a.C >> 3;
-    const long long total = (long long)p.N * p.vox * cg;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    int g, n;
-    long long v;
-    if (p.out_vs) {
-        const int half = (int)(i & 1);
-        long long t = i >> 1;
-        v = t % p.vox; t /= p.vox;
-        const int chunk = (int)(t % (cg >> 1));
-        n = (int)(t / (cg >> 1));
-        g = chunk * 2 + half;
-    } else {
-        g = (int)(i % cg);
-        const long long t = i / cg;
-        v = t % p.vox;
-        n = (int)(t / p.vox);
-    }
-    const int c0 = g * 8;
+    const unsigned cg = (unsigned)(p.a.C >> 3);
+    const unsigned per = p.out_vs ? 2u : cg;                              // vectors per voxel inside one grid row
+    const unsigned rowlen = (unsigned)p.vox * per;
+    const unsigned n = p.out_vs ? blockIdx.y / (cg >> 1) : blockIdx.y;
+    const unsigned chunk = p.out_vs ? blockIdx.y % (cg >> 1) : 0u;
+    const bool fixed = p.out_vs || (256u % cg) == 0u;                     // the thread's channel group is the same for every u
     const size_t item = (size_t)n * p.vox * p.a.C;
-    const f16x8 xa = *(const f16x8 *)(p.a.ptr + item + (size_t)v * FNN_VS(p.a) + (c0 >> 4) * FNN_CS(p.a) + (c0 & 15));
-    const f16x8 xb = *(const f16x8 *)(p.b.ptr + item + (size_t)v * FNN_VS(p.b) + (c0 >> 4) * FNN_CS(p.b) + (c0 & 15));
-    float ya[8], yb[8];
-    apply8(p.a, n, c0, xa, ya);
-    apply8(p.b, n, c0, xb, yb);
-    f16x8 o;
+    const unsigned j0 = blockIdx.x * (256u * FNN_CMB_U) + threadIdx.x;
+    f16x8 xa[FNN_CMB_U], xb[FNN_CMB_U];
+    unsigned vv[FNN_CMB_U], cc[FNN_CMB_U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (f16)leaky(ya[j] + yb[j], p.slope);
-    *(f16x8 *)(p.out + item + (size_t)v * (p.out_vs ? p.out_vs : p.a.C) + (c0 >> 4) * (p.out_vs ? p.out_cs : 16LL) + (c0 & 15)) = o;
+    for (int u = 0; u < FNN_CMB_U; ++u) {
+        const unsigned j = j0 + 256u * u;
+        const unsigned jj = j < rowlen ? j : rowlen - 1;                  // clamped, always valid address
+        const unsigned g = p.out_vs ? chunk * 2 + (jj & 1u) : jj % cg;
+        vv[u] = p.out_vs ? jj >> 1 : jj / cg;
+        cc[u] = g * 8;
+        xa[u] = *(const f16x8 *)(p.a.ptr + item + (size_t)vv[u] * FNN_VS(p.a) + (cc[u] >> 4) * FNN_CS(p.a) + (cc[u] & 15));
+        xb[u] = *(const f16x8 *)(p.b.ptr + item + (size_t)vv[u] * FNN_VS(p.b) + (cc[u] >> 4) * FNN_CS(p.b) + (cc[u] & 15));
+    }
+    float sa[8], ha[8], sb[8], hb[8];
+#pragma unroll
+    for (int u = 0; u < FNN_CMB_U; ++u) {
+        if (u == 0 || !fixed) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sa[j] = p.a.ss ? p.a.ss[(size_t)(2 * n) * p.a.C + cc[u] + j] : 1.f;
+                ha[j] = p.a.ss ? p.a.ss[(size_t)(2 * n + 1) * p.a.C + cc[u] + j] : 0.f;
+                sb[j] = p.b.ss ? p.b.ss[(size_t)(2 * n) * p.b.C + cc[u] + j] : 1.f;
+                hb[j] = p.b.ss ? p.b.ss[(size_t)(2 * n + 1) * p.b.C + cc[u] + j] : 0.f;
+            }
+        }
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float ya = (float)xa[u][j], yb = (float)xb[u][j];
+            if (p.a.ss) ya = fmaf(ya, sa[j], ha[j]);
+            if (p.b.ss) yb = fmaf(yb, sb[j], hb[j]);
+            o[j] = (f16)leaky(leaky(ya, p.a.slope) + leaky(yb, p.b.slope), p.slope);
+        }
+        if (j0 + 256u * u < rowlen)
+            *(f16x8 *)(p.out + item + (size_t)vv[u] * (p.out_vs ? p.out_vs : p.a.C) + (cc[u] >> 4) * (p.out_vs ? p.out_cs : 16LL) +
+                       (cc[u] & 15)) = o;
+    }
 }
 
 int launch_combine(const CombineParams &p, hipStream_t st) {
-    const long long total = (long long)p.N * p.vox * (p.a.C >> 3);
+    const int cg = p.a.C >> 3;
+    const long long rowlen = p.vox * (p.out_vs ? 2 : cg);
+    const long long rows = (long long)p.N * (p.out_vs ? cg >> 1 : 1);
+    if (rowlen >= (1LL << 32) - 256 * FNN_CMB_U || rows > 65535) return -1;
     fnn_note_kernel("combine_kernel");
-    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)((rowlen + 256 * FNN_CMB_U - 1) / (256 * FNN_CMB_U)), (unsigned)rows), dim3(256), 0,
+                       st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
