@@ -29,6 +29,7 @@
 #include "fnn_device.h"
 #include "conv_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -76,7 +77,7 @@ static __device__ __forceinline__ f16x4 stem_block(const float *sRaw, int rawbas
 // More than STEMM_CG input channels (a cascade stage with many foreground labels, label_handling.py:294-311: image + one
 // one-hot channel per label) run as groups of STEMM_CG channels: a group's window is staged, its k-steps (K = 8 channels x
 // taps, padded to a multiple of 32) are accumulated into the 16 column blocks' accumulators, the next group follows.
-template <bool ONE>                                                  // ONE: a single k-step (C * taps <= 32): offsets and weights in registers
+// (A single k-step with 16 or 32 output channels - every single-channel CT stem - runs stem_mfma1_kernel below.)
 __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, const f16 *wfrag, const int ksteps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
@@ -119,13 +120,6 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, cons
     }
     const float4 bias = *(const float4 *)(p.bias + cb * 16 + q * 4);
     __syncthreads();
-    int tapoff[8];
-    f16x8 wf1 = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (ONE) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) tapoff[e] = sTab[8 * q + e];
-        wf1 = *(const f16x8 *)(wfrag + ((size_t)cb * 64 + lane) * 8);
-    }
 
     float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
     const f16x2 ones = {(f16)1.f, (f16)1.f};
@@ -145,25 +139,18 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, cons
             t2[c] = __builtin_amdgcn_fdot2(pr, pr, t2[c], false);
         }
     };
-    if (ONE || ngroups == 1) {
+    if (ngroups == 1) {
 #pragma unroll 4
         for (int j = 0; j < 16; ++j) {                                   // column block = (depth slice, pair of h rows)
             const int dl = wave * 4 + (j >> 2), hp = j & 3;
             const int rawbase = (dl * RH + 2 * hp + (r >> 3)) * RW + (r & 7);
             f32x4 d = {0.f, 0.f, 0.f, 0.f};
-            if (ONE) {
+            for (int ks = 0; ks < ksteps; ++ks) {
+                const f16x8 wf = *(const f16x8 *)(wfrag + ((size_t)(cb * ksteps + ks) * 64 + lane) * 8);
                 f16x8 xb;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) xb[e] = (f16)sRaw[rawbase + tapoff[e]];
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1, xb, d, 0, 0, 0);
-            } else {
-                for (int ks = 0; ks < ksteps; ++ks) {
-                    const f16x8 wf = *(const f16x8 *)(wfrag + ((size_t)(cb * ksteps + ks) * 64 + lane) * 8);
-                    f16x8 xb;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) xb[e] = (f16)sRaw[rawbase + sTab[ks * 32 + 8 * q + e]];
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xb, d, 0, 0, 0);
-                }
+                for (int e = 0; e < 8; ++e) xb[e] = (f16)sRaw[rawbase + sTab[ks * 32 + 8 * q + e]];
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xb, d, 0, 0, 0);
             }
             finish(j, d);
         }
@@ -207,6 +194,188 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, cons
             for (int w = 0; w < 4; ++w) v += (double)sRed[(w * 16 + c) * 2 + which];
             const int slot = (td * p.tiles_h + th) * p.tiles_w + tw;
             p.stats_out[(((size_t)n * (p.tiles_d * p.tiles_h * p.tiles_w) + slot) * p.Cout + cb * 16 + c) * 2 + which] = v;
+        }
+    }
+}
+
+// Single-channel stems with (KD, 3, 3) taps and 16 or 32 output channels: every CT stem of the isotropic baseline
+// workloads (3 x 3 x 3; the (1, 3, 3) stems with full rows run stem_row_kernel).  Same tile, window, k order, arithmetic
+// (fp32 accumulation from zero, + bias, one rounding) and statistics row per tile as stem_mfma_kernel, so the values are
+// its values bit for bit; what differs is the instruction count per output byte (round 3: the generic kernel ran the
+// teacher's 32-channel stem at 1.05 TB/s of output, 10 % of that workload's time; 55 vector instructions per 16 voxels):
+//   * ALL cout blocks of a tile in one workgroup: the window is staged once and a column block's operand (8 LDS reads,
+//     4 packed converts) feeds NCB MFMAs;
+//   * the window's dimensions are compile-time: a lane's 8 tap addresses are computed once, the column block is the
+//     ds_read's immediate offset; staging walks (zd, zh, zw) incrementally instead of dividing per element;
+//   * 16-byte buffer stores: the two cout blocks of a voxel (NCB = 2) or two column blocks (NCB = 1) exchanged with
+//     v_permlane16_swap (pair_to_b128), voxels beyond the patch sent past num_records.  The block part of the address is
+//     ADDED to the lane part, not passed as the scalar offset: with an SGPR soffset hipcc places the next block's first
+//     write of a data register directly behind the store (LLVM's hazard recogniser exempts stores with a register
+//     soffset from the "VALU write of >8-byte store data" wait state), and on gfx950 the store then picks up the new
+//     value in some lanes - seen as sporadic wrong channel pairs 4-5 of lanes 12-15 (tools/stem_check.cpp);
+//   * statistics two column blocks at a time (v_dot2 on pairs).
+template <int NCB, int KD>
+__global__ __launch_bounds__(256, 4) void stem_mfma1_kernel(const StemParams p, const f16 *wfrag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int t = blockIdx.x;
+    const int tw = t % p.tiles_w; t /= p.tiles_w;
+    const int th = t % p.tiles_h; t /= p.tiles_h;
+    const int td = t % p.tiles_d;
+    const int n = t / p.tiles_d;
+    constexpr int PDK = (KD - 1) / 2, RD = STEMM_TD - 1 + KD, RH = 10, RW = 10, RHW = RH * RW, RVOX = RD * RHW, T = KD * 9;
+    float *sRaw = (float *)smem;                                         // [RD][RH][RW]
+    float *sRed = sRaw + ((RVOX + 3) & ~3);                              // [4 waves][16 NCB][2]
+
+    const int ox = p.origins[n * 3 + 0], oy = p.origins[n * 3 + 1], oz = p.origins[n * 3 + 2];
+    const int d0 = td * STEMM_TD - PDK, h0 = th * 8 - 1, w0 = tw * 8 - 1;
+    {
+        // window element e = (zd, zh, zw), e + 256 by increments; its address = patch origin + one 32-bit offset built with
+        // 24-bit multiplies (the launcher checks Y Z < 2^24); mirroring = coordinate a + s x with (a, s) = (P - 1, -1);
+        // elements outside the patch read the origin and are zeroed (the conv's padding)
+        const float *org = p.vol + (size_t)n * p.vol_batch_stride + ((size_t)ox * p.Y + oy) * p.Z + oz;
+        const unsigned YZ = (unsigned)(p.Y * p.Z), Zs = (unsigned)p.Z;
+        const int ad = p.flip_d ? p.PD - 1 : 0, sd = p.flip_d ? -1 : 1, ah = p.flip_h ? p.PH - 1 : 0, sh = p.flip_h ? -1 : 1;
+        const int aw = p.flip_w ? p.PW - 1 : 0, sw = p.flip_w ? -1 : 1;
+        constexpr int s_d = 256 / RHW, s_rem = 256 - s_d * RHW, s_h = s_rem / RW, s_w = s_rem - s_h * RW;
+        int zd = tid / RHW, zh = (tid - zd * RHW) / RW, zw = tid - zd * RHW - zh * RW;
+        constexpr int NE = (RVOX + 255) / 256;
+        float xr[NE];
+        bool okr[NE];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int d = d0 + zd, h = h0 + zh, w = w0 + zw;
+            okr[u] = (unsigned)d < (unsigned)p.PD && (unsigned)h < (unsigned)p.PH && (unsigned)w < (unsigned)p.PW &&
+                     (u + 1 < NE || tid + u * 256 < RVOX);
+            const unsigned off = __umul24((unsigned)(ad + sd * d), YZ) + __umul24((unsigned)(ah + sh * h), Zs) + (unsigned)(aw + sw * w);
+            xr[u] = org[okr[u] ? off : 0u];
+            zw += s_w;
+            const int cw = zw >= RW;
+            zw -= cw ? RW : 0;
+            zh += s_h + cw;
+            const int ch = zh >= RH;
+            zh -= ch ? RH : 0;
+            zd += s_d + ch;
+        }
+#pragma unroll
+        for (int u = 0; u < NE; ++u)
+            if (u + 1 < NE || tid + u * 256 < RVOX) sRaw[tid + u * 256] = okr[u] ? xr[u] : 0.f;
+    }
+    f16x8 wf[NCB];
+    float4 bias[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        wf[cb] = *(const f16x8 *)(wfrag + ((size_t)cb * 64 + lane) * 8);
+        bias[cb] = *(const float4 *)(p.bias + cb * 16 + q * 4);
+    }
+    // byte address of tap k = 8 q + e of this lane's voxel of column block (0, 0); k >= taps: tap 0 (its weights are zero)
+    int tapaddr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * q + e, tap = k < T ? k : 0;
+        tapaddr[e] = (((tap / 9) * RH + (tap / 3) % 3 + (r >> 3)) * RW + tap % 3 + (r & 7)) * 4;
+    }
+    __syncthreads();
+
+    float t1[NCB][4], t2[NCB][4];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { t1[cb][c] = 0.f; t2[cb][c] = 0.f; }
+    const f16x2 ones = {(f16)1.f, (f16)1.f};
+    const unsigned item_bytes = (unsigned)p.PD * p.PH * p.PW * (NCB * 32);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out ? p.out + (size_t)n * (item_bytes >> 1) : p.out, 0,
+                                                                           p.out ? item_bytes : 0u, 0x00020000);
+    // NCB = 2: lane (r, q) stores channels 16 (q & 1) + 8 (q >> 1) .. + 7 of voxel r of its block; NCB = 1: channels
+    // 8 (q >> 1) .. + 7 of voxel r of block j + (q & 1) (two h rows further down)
+    const int oh_l = th * 8 + (r >> 3) + (NCB == 1 ? 2 * (q & 1) : 0), ow_l = tw * 8 + (r & 7);
+    const unsigned lane_off = (unsigned)(oh_l * p.PW + ow_l) * (NCB * 32) + (NCB == 2 ? (q & 1) * 32 + (q >> 1) * 16 : (q >> 1) * 16);
+    const bool full_tile = td * STEMM_TD + STEMM_TD <= p.PD && th * 8 + 8 <= p.PH && tw * 8 + 8 <= p.PW;   // the tile lies inside the patch
+    // (launch bounds of >= 2 waves per SIMD: hipcc then keeps the MFMA results in VGPRs instead of copying them out of AGPRs)
+    const auto blocks = [&](auto FULL) {
+    constexpr bool full = decltype(FULL)::value;
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {                                    // column blocks j, j + 1 = (depth slice, two pairs of h rows)
+        const int dl = wave * 4 + (j >> 2), od = td * STEMM_TD + dl;
+        f16x2 h[2][NCB][2];                                              // [block][cout block][channel pair]
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int hp = (j & 3) + s;
+            const char *bp = (const char *)sRaw + wave * (4 * RHW * 4);   // the wave's depth slices; the rest is the immediate offset
+            f32x2 xv[4];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[e >> 1][e & 1] = *(const float *)(bp + tapaddr[e] + (((j >> 2) * RH + 2 * hp) * RW) * 4);
+            f16x8 xb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f16x2 c2 = __builtin_convertvector(xv[e], f16x2);
+                xb[2 * e] = c2[0]; xb[2 * e + 1] = c2[1];
+            }
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cb], xb, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const f32x2 s01 = {d[0] + bias[cb].x, d[1] + bias[cb].y}, s23 = {d[2] + bias[cb].z, d[3] + bias[cb].w};
+                h[s][cb][0] = __builtin_convertvector(s01, f16x2);
+                h[s][cb][1] = __builtin_convertvector(s23, f16x2);
+            }
+        }
+        bool ok[2] = {true, true};
+        if (!full) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                ok[s] = od < p.PD && th * 8 + 2 * ((j & 3) + s) + (r >> 3) < p.PH && tw * 8 + (r & 7) < p.PW;
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    if (!ok[s]) { h[s][cb][0] = (f16x2){0, 0}; h[s][cb][1] = (f16x2){0, 0}; }
+                }
+            }
+        }
+        if (p.out) {                                                     // uniform
+            const unsigned blk = (unsigned)((od * p.PH + 2 * (j & 3)) * p.PW) * (NCB * 32);      // uniform part of the address
+            if (NCB == 2) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const f16x4 a = {h[s][0][0][0], h[s][0][0][1], h[s][0][1][0], h[s][0][1][1]};
+                    const f16x4 b = {h[s][NCB - 1][0][0], h[s][NCB - 1][0][1], h[s][NCB - 1][1][0], h[s][NCB - 1][1][1]};
+                    const unsigned vo = full || ok[s] ? lane_off : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(pair_to_b128(a, b), rsrc, vo + blk + (unsigned)(s * 2 * p.PW) * (NCB * 32), 0, 0);
+                }
+            } else {
+                const f16x4 a = {h[0][0][0][0], h[0][0][0][1], h[0][0][1][0], h[0][0][1][1]};
+                const f16x4 b = {h[1][0][0][0], h[1][0][0][1], h[1][0][1][0], h[1][0][1][1]};
+                const unsigned vo = full || ((q & 1) ? ok[1] : ok[0]) ? lane_off : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(pair_to_b128(a, b), rsrc, vo + blk, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f16x2 pr = {h[0][cb][c >> 1][c & 1], h[1][cb][c >> 1][c & 1]};
+                t1[cb][c] = __builtin_amdgcn_fdot2(pr, ones, t1[cb][c], false);
+                t2[cb][c] = __builtin_amdgcn_fdot2(pr, pr, t2[cb][c], false);
+            }
+    }
+    };
+    if (full_tile) blocks(std::true_type{}); else blocks(std::false_type{});
+    if (p.stats_out) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float a = row16_sum(t1[cb][c]), b = row16_sum(t2[cb][c]);
+                if (r == 0) { sRed[((wave * NCB + cb) * 16 + q * 4 + c) * 2] = a; sRed[((wave * NCB + cb) * 16 + q * 4 + c) * 2 + 1] = b; }
+            }
+        __syncthreads();
+        if (tid < 32 * NCB) {
+            const int c = tid >> 1, which = tid & 1;                     // c = channel = cb * 16 + (q * 4 + c)
+            double v = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += (double)sRed[(w * NCB * 16 + c) * 2 + which];
+            const int slot = (td * p.tiles_h + th) * p.tiles_w + tw;
+            p.stats_out[(((size_t)n * (p.tiles_d * p.tiles_h * p.tiles_w) + slot) * p.Cout + c) * 2 + which] = v;
         }
     }
 }
@@ -256,13 +425,25 @@ int launch_stem_mfma(const StemParams &p_in, const f16 *wfrag, int N, hipStream_
     const size_t lds = (size_t)((cgn * RVOX + 3) & ~3) * 4 + (size_t)(ks / ngroups) * 32 * 4 + 4 * 16 * 2 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)stem_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)stem_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    const bool no_one = fnn_knob("FNN_NO_STEM1") != nullptr;    // A-B aid, read per launch: a test compares the two kernels in one process
+    if (p.C == 1 && p.kh == 3 && p.kw == 3 && (p.Cout == 16 || p.Cout == 32) && !no_one &&
+        (size_t)p.PD * p.PH * p.PW * p.Cout * 2 < (1ull << 31) && p.Y * p.Z < (1 << 24) && (size_t)p.PD * p.Y * p.Z < (1ull << 32)) {
+        const int RV = (STEMM_TD - 1 + p.kd) * 100;
+        const size_t lds1 = (size_t)((RV + 3) & ~3) * 4 + (size_t)4 * (p.Cout / 16) * 16 * 2 * 4;
+        const dim3 grid1(N * p.tiles_d * p.tiles_h * p.tiles_w);
+        fnn_note_kernel("stem_mfma1_kernel<%d,%d>", p.Cout / 16, p.kd);
+        if (p.Cout == 16 && p.kd == 3) hipLaunchKernelGGL((stem_mfma1_kernel<1, 3>), grid1, dim3(256), lds1, st, p, wfrag);
+        else if (p.Cout == 16) hipLaunchKernelGGL((stem_mfma1_kernel<1, 1>), grid1, dim3(256), lds1, st, p, wfrag);
+        else if (p.kd == 3) hipLaunchKernelGGL((stem_mfma1_kernel<2, 3>), grid1, dim3(256), lds1, st, p, wfrag);
+        else hipLaunchKernelGGL((stem_mfma1_kernel<2, 1>), grid1, dim3(256), lds1, st, p, wfrag);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     const dim3 grid(N * p.tiles_d * p.tiles_h * p.tiles_w, p.Cout / 16);
-    fnn_note_kernel("stem_mfma_kernel<%d>", ks == 1 ? 1 : 0);
-    if (ks == 1) hipLaunchKernelGGL(stem_mfma_kernel<true>, grid, dim3(256), lds, st, p, wfrag, ks);
-    else hipLaunchKernelGGL(stem_mfma_kernel<false>, grid, dim3(256), lds, st, p, wfrag, ks);
+    fnn_note_kernel("stem_mfma_kernel");
+    hipLaunchKernelGGL(stem_mfma_kernel, grid, dim3(256), lds, st, p, wfrag, ks);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

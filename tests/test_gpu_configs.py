@@ -46,6 +46,43 @@ def _label_report(name, got, ref):
     return float(flips.float().mean())
 
 
+# ------------------------------------------------------------------------- the single-channel CT stem's own kernel
+def _forward_and_kernels(p, x):
+    p._engine.set_profiling(True)
+    try:
+        out = p.forward_patches(x).float().cpu()
+        return out, set(p._engine.kernel_log())
+    finally:
+        p._engine.set_profiling(False)
+
+
+@pytest.mark.parametrize('features,k0,patch', [([32, 64], (3, 3, 3), (48, 40, 56)), ([16, 32], (3, 3, 3), (44, 36, 52)),
+                                                ([32, 64], (1, 3, 3), (16, 72, 24)), ([16, 32], (1, 3, 3), (12, 40, 88))])
+def test_single_channel_stem_kernel_agrees_with_the_generic_stem_kernel(features, k0, patch):
+    """stem_mfma1_kernel<NCB, KD> (conv3d_thin.hip: all cout blocks of a tile in one workgroup, 16-byte buffer stores through
+    pair_to_b128) against stem_mfma_kernel on the same engine (FNN_NO_STEM1 is read per launch).  The stem's values are the
+    same bits; its InstanceNorm statistics are summed in another order, so the logits agree to a few fp16 roundings (~1e-3 of their range).  A first
+    version passed the stores' block offset as an SGPR soffset: hipcc then wrote the next block's data into a store-data
+    register directly behind the store and gfx950 stored the new value in some lanes (sporadic wrong channel pairs, an
+    error of the size of the activations) - full and ragged tiles, 16 and 32 output channels, three batches each."""
+    spec = UNetSpec('plain', 1, 3, features, [k0, (3, 3, 3)], [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
+    p = _predictor(spec, patch, [synthetic_state_dict(spec, 321)], batch=4)
+    name = f'stem_mfma1_kernel<{features[0] // 16},{k0[0]}>'
+    for rep in range(3):
+        x = torch.randn(4, 1, *patch, generator=torch.Generator().manual_seed(90 + rep))
+        a, ka = _forward_and_kernels(p, x)
+        os.environ['FNN_NO_STEM1'] = '1'
+        try:
+            b, kb = _forward_and_kernels(p, x)
+        finally:
+            del os.environ['FNN_NO_STEM1']
+        assert name in ka and 'stem_mfma_kernel' not in ka, sorted(ka)
+        assert 'stem_mfma_kernel' in kb and name not in kb, sorted(kb)
+        err = float((a - b).abs().max()) / float(b.abs().max())
+        print(f'[{name} {patch} #{rep}] max |new - generic| / max |generic| = {err:.2e}')
+        assert err <= 5e-3                                           # statistics order: ~1e-3; a corrupted channel pair: > 0.1
+
+
 # ----------------------------------------------------------------------------------------------- C4: teacher
 def test_c4_teacher_forward_matches_fp32_oracle():
     assert TEACHER.features == [32, 64, 128, 256, 320, 320]

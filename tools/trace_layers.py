@@ -15,7 +15,7 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 fw, cur = [], None
 for r in rows:
     name = r['Kernel_Name']
-    if 'stem_mfma_kernel' in name or 'stem_row_kernel' in name:
+    if 'stem_mfma' in name or 'stem_row_kernel' in name:
         if cur:
             fw.append(cur)
         cur = []
