@@ -412,13 +412,16 @@ __global__ __launch_bounds__(256, NBLK <= 8 ? 8 : 6) void stem_row_kernel(const 
         const int rbase = c.h0 - 1 + 4 * c.g;
         if (c.n != n_org) { ox = p.origins[c.n * 3 + 0]; oy = p.origins[c.n * 3 + 1]; oz = p.origins[c.n * 3 + 2]; n_org = c.n; }
         const int dd = p.flip_d ? D - 1 - c.d : c.d;
-        const float *plane = voln0 + (size_t)c.n * p.vol_batch_stride + (size_t)(ox + dd) * p.Y * p.Z + oz;
+        // scalar base of the patch's plane + one 32-bit offset per element (stem_row_ok: Y Z < 2^30, so the byte offset fits too): as 64-bit products
+        // of the long long strides the addresses were a third of this kernel's vector instructions
+        const float *plane = voln0 + (size_t)c.n * p.vol_batch_stride + ((size_t)(ox + dd) * p.Y + oy) * p.Z + oz;
+        const unsigned Zu = (unsigned)p.Z;
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             int row = rbase + (e_row[u] < 0 ? 0 : e_row[u]);
             row = row < 0 ? 0 : (row >= H ? H - 1 : row);                // invalid rows: any valid address (zeroed in commit)
             const int hh = p.flip_h ? H - 1 - row : row, ww = p.flip_w ? W - 1 - e_col[u] : e_col[u];
-            xr[u] = plane[(size_t)(oy + hh) * p.Z + ww];
+            xr[u] = *(const float *)((const char *)plane + ((unsigned)hh * Zu + (unsigned)ww) * 4u);   // 32-bit BYTE offset: scalar base + VGPR offset load
         }
     };
     // (Measured and dropped: a thread loading the three values of its entry and writing it whole - one ds_write_b64
@@ -621,13 +624,14 @@ __global__ __launch_bounds__(256, NBLK <= 8 ? 3 : 2) void conv_row_stem_kernel(c
         const int rbase = c.h0 - 2 + 4 * c.g;                            // raw row of element row 0
         if (c.n != n_org) { ox = tp.origins[c.n * 3 + 0]; oy = tp.origins[c.n * 3 + 1]; oz = tp.origins[c.n * 3 + 2]; n_org = c.n; }
         const int dd = tp.flip_d ? D - 1 - c.d : c.d;
-        const float *plane = tp.vol + (size_t)c.n * tp.vol_batch_stride + (size_t)(ox + dd) * tp.Y * tp.Z + oz;
+        const float *plane = tp.vol + (size_t)c.n * tp.vol_batch_stride + ((size_t)(ox + dd) * tp.Y + oy) * tp.Z + oz;   // (stem_row_kernel)
+        const unsigned Zu = (unsigned)tp.Z;
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             int row = rbase + (e_row[u] < 0 ? 0 : e_row[u]);
             row = row < 0 ? 0 : (row >= H ? H - 1 : row);                // invalid rows: any valid address (zeroed in xcommit)
             const int hh = tp.flip_h ? H - 1 - row : row, ww = tp.flip_w ? W - 1 - e_col[u] : e_col[u];
-            xr[u] = plane[(size_t)(oy + hh) * tp.Z + ww];
+            xr[u] = *(const float *)((const char *)plane + ((unsigned)hh * Zu + (unsigned)ww) * 4u);   // 32-bit BYTE offset: scalar base + VGPR offset load
         }
     };
     auto xcommit = [&](const RowCur &c, int xs) {
@@ -894,7 +898,7 @@ bool conv_row_ok(const ThinParams &tp) {
         return true;
     }
     if (tp.fuse == FUSE_STEM)
-        return fnn_knob("FNN_NO_STEM_ROW") == nullptr && p.n_src == 1 && p.chunks == 1 && p.src[0].C == 16;
+        return fnn_knob("FNN_NO_STEM_ROW") == nullptr && p.n_src == 1 && p.chunks == 1 && p.src[0].C == 16 && tp.Y * tp.Z < (1ll << 30);
     if (tp.fuse != 0) return false;
     if (p.chunks != p.n_src || p.chunks < 1 || p.chunks > 2) return false;
     for (int i = 0; i < p.n_src; ++i) if (p.src[i].C != 16) return false;
@@ -913,7 +917,7 @@ bool stem_row_ok(const StemParams &p) {
     const bool off = fnn_knob("FNN_NO_ROW") != nullptr || fnn_knob("FNN_NO_STEM_ROW") != nullptr;            // A-B aids
     if (off || p.C != 1 || p.kd != 1 || p.kh != 3 || p.kw != 3 || p.Cout != 16) return false;
     if ((p.PW != 64 && p.PW != 96 && p.PW != 128 && p.PW != 160 && p.PW != 192) || p.PH % 4 != 0 || p.PH < 8) return false;
-    if (2ull * p.PD * p.PH * p.PW * 16 >= (1ull << 31)) return false;
+    if (2ull * p.PD * p.PH * p.PW * 16 >= (1ull << 31) || p.Y * p.Z >= (1ll << 30)) return false;     // 32-bit output and in-plane input offsets
     int SH;
     const int strips = pick_strips(p.PH, SH);
     return p.PD * strips <= stem_mfma_stats_slots(p.PD, p.PH, p.PW);     // one statistics row per (plane, strip)

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, 4) void stem_mfma1_kernel(const StemParams p, 
             okr[u] = (unsigned)d < (unsigned)p.PD && (unsigned)h < (unsigned)p.PH && (unsigned)w < (unsigned)p.PW &&
                      (u + 1 < NE || tid + u * 256 < RVOX);
             const unsigned off = __umul24((unsigned)(ad + sd * d), YZ) + __umul24((unsigned)(ah + sh * h), Zs) + (unsigned)(aw + sw * w);
-            xr[u] = org[okr[u] ? off : 0u];
+            xr[u] = *(const float *)((const char *)org + (okr[u] ? off * 4u : 0u));   // 32-bit BYTE offset: scalar base + VGPR offset load
             zw += s_w;
             const int cw = zw >= RW;
             zw -= cw ? RW : 0;
@@ -430,7 +430,7 @@ int launch_stem_mfma(const StemParams &p_in, const f16 *wfrag, int N, hipStream_
     }
     const bool no_one = fnn_knob("FNN_NO_STEM1") != nullptr;    // A-B aid, read per launch: a test compares the two kernels in one process
     if (p.C == 1 && p.kh == 3 && p.kw == 3 && (p.Cout == 16 || p.Cout == 32) && !no_one &&
-        (size_t)p.PD * p.PH * p.PW * p.Cout * 2 < (1ull << 31) && p.Y * p.Z < (1 << 24) && (size_t)p.PD * p.Y * p.Z < (1ull << 32)) {
+        (size_t)p.PD * p.PH * p.PW * p.Cout * 2 < (1ull << 31) && p.Y * p.Z < (1 << 24) && (size_t)p.PD * p.Y * p.Z < (1ull << 30)) {
         const int RV = (STEMM_TD - 1 + p.kd) * 100;
         const size_t lds1 = (size_t)((RV + 3) & ~3) * 4 + (size_t)4 * (p.Cout / 16) * 16 * 2 * 4;
         const dim3 grid1(N * p.tiles_d * p.tiles_h * p.tiles_w);

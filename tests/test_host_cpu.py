@@ -382,3 +382,56 @@ def test_no_kernel_of_the_library_keeps_scratch():
                     bad.append((os.path.basename(path), name, int(m.group(1))))
     assert n >= 150, f'only {n} kernels found in the resource reports'
     assert not bad, f'kernels with scratch: {bad}'
+
+
+def _gfx950_code_objects(so_path):
+    """The device ELFs of a HIP shared library: .hip_fatbin holds one clang offload bundle per translation unit
+    (magic, entry count, then per entry offset / size / triple)."""
+    import struct
+    data = open(so_path, 'rb').read()
+    magic, out, pos = b'__CLANG_OFFLOAD_BUNDLE__', [], 0
+    while True:
+        start = data.find(magic, pos)
+        if start < 0:
+            return out
+        n, = struct.unpack_from('<Q', data, start + len(magic))
+        q = start + len(magic) + 8
+        for _ in range(n):
+            off, size, tlen = struct.unpack_from('<QQQ', data, q)
+            triple = data[q + 24:q + 24 + tlen].decode()
+            q += 24 + tlen
+            if 'gfx950' in triple and size:
+                out.append(data[start + off:start + off + size])
+        pos = start + len(magic)
+
+
+def test_no_wide_buffer_store_of_the_library_has_a_register_soffset(tmp_path):
+    """A buffer store of more than 8 bytes whose soffset is an SGPR is exempt from LLVM's "VALU write of store data" wait
+    state; on gfx950 the store then picks up a data register that the next instruction overwrites (round 3:
+    stem_mfma1_kernel stored the next column block's channel pair in some lanes - conv3d_thin.hip, tools/stem_check.cpp).
+    Every 12 / 16-byte buffer store in the library's gfx950 code must therefore carry a literal soffset."""
+    import re
+    import shutil
+    import subprocess
+    objdump = shutil.which('llvm-objdump') or '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'fast-nnunet_amd', 'csrc', 'libfnn_hip.so')
+    if not os.path.exists(objdump) or not os.path.exists(so):
+        pytest.skip('llvm-objdump or the built library is missing')
+    objs = _gfx950_code_objects(so)
+    assert objs, 'no gfx950 code object found in the library'
+    n, bad = 0, []
+    for i, blob in enumerate(objs):
+        path = tmp_path / f'co{i}.elf'
+        path.write_bytes(blob)
+        text = subprocess.run([objdump, '-d', '--mcpu=gfx950', str(path)], capture_output=True, text=True, check=True).stdout
+        for line in text.splitlines():
+            m = re.search(r'\bbuffer_store_dwordx[34]\s+(.*?)(?://|$)', line)
+            if not m:
+                continue
+            n += 1
+            ops = [o.strip() for o in m.group(1).split(',')]            # vdata, vaddr, srsrc, "soffset [modifiers]"
+            soffset = ops[-1].split()[0]
+            if re.fullmatch(r's\d+|m0|vcc_lo|vcc_hi|ttmp\d+', soffset):
+                bad.append(line.strip())
+    assert n >= 100, f'only {n} wide buffer stores found'
+    assert not bad, bad[:5]
