@@ -63,7 +63,7 @@ class Profile(C.Structure):
 EXPORTS = ['fnn_abi_version', 'fnn_last_error', 'fnn_create', 'fnn_destroy', 'fnn_weight_count', 'fnn_load_weights',
            'fnn_set_gaussian', 'fnn_predict_volume', 'fnn_predict_volume_ensemble', 'fnn_predict_labels',
            'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_labels_box', 'fnn_feature_channels', 'fnn_patch_features', 'fnn_gather_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_export_probabilities', 'fnn_resample', 'fnn_compute_steps', 'fnn_plan_volume', 'fnn_fp8_e4m3_encode',
-           'fnn_set_profiling', 'fnn_get_profile', 'fnn_kernel_log', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d', 'fnn_op_quotient_check']
+           'fnn_set_profiling', 'fnn_get_profile', 'fnn_kernel_log', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d', 'fnn_op_quotient_check', 'fnn_op_last_kernels']
 
 _lib = None
 
@@ -129,6 +129,7 @@ def load_library() -> C.CDLL:
                                   f32p, f32p, i32, I3, I3, f32p, C.POINTER(C.c_double)]
     lib.fnn_op_conv_transpose3d.argtypes = [i32, i32, I3, f32p, i32, f32p, f32p, C.c_float, f32p, f32p, i32, I3, f32p]
     lib.fnn_op_quotient_check.argtypes = [i32, C.POINTER(C.c_uint64)]
+    lib.fnn_op_last_kernels.argtypes = [C.c_char_p, i32]
     if lib.fnn_abi_version() != 3:
         raise EngineError('libfnn_hip.so has an unexpected ABI version')
     _lib = lib
@@ -276,6 +277,14 @@ def op_conv_transpose3d(x, w, bias, stride, gamma=None, beta=None, slope=1.0, de
                                      _f32p(w), _f32p(bias), cout, ss, _f32p(y))
     check(rc, lib)
     return y
+
+
+def op_last_kernels():
+    """Kernel variants launched by this thread's last op_conv3d / op_conv_transpose3d call."""
+    lib = load_library()
+    buf = C.create_string_buffer(4096)
+    lib.fnn_op_last_kernels(buf, 4096)
+    return [k for k in buf.value.decode().split('\n') if k]
 
 
 def op_quotient_check(device=0):

@@ -893,17 +893,17 @@ static int launch_persist(const ConvParams &p, int wgs_per_cu, hipStream_t st) {
         // through scalar loads, forced to 128 VGPRs: 44-132 B of scratch): 740 -> 895 us per launch; the scalar loads alone,
         // at three workgroups: 817 us - SMEM shares lgkmcnt with the LDS reads of the k-loop and returns out of order, so every
         // wait becomes a full drain
-        static const bool mb8 = fnn_knob("FNN_THIN_MB8") != nullptr;                                             // A-B aid
+        // (the 8-deep forms of these two were reachable through an A-B knob only and are gone: round 3)
         const int ivox4 = (3 * p.sd + p.kd) * ((FNN_TILE_H - 1) * p.sh + p.kh) * ((FNN_TILE_W - 1) * p.sw + p.kw);
-        if (!mb8 && ivox4 * 2 <= 4 * 256 && persist_lds_bytes(p, 1, 4, true) * 3 <= 160 * 1024) {
+        if (ivox4 * 2 <= 4 * 256 && persist_lds_bytes(p, 1, 4, true) * 3 <= 160 * 1024) {
             if (p.chunks == 1) return launch_persist_ks<1, 4, true, 5, (NB == 1 && MB == 8 && WRES ? 1 : 0), (NB == 1 && MB == 8 && WRES ? 4 : 8)>(p, 3, st);
             return launch_persist_ks<1, 4, true, 5, (NB == 1 && MB == 8 && WRES ? 2 : 0), (NB == 1 && MB == 8 && WRES ? 4 : 8)>(p, 3, st);
         }
     }
-    if (NB == 1 && MB == 8 && WRES && p.ksteps == 5 && p.chunks == 1) return launch_persist_ks<NB, MB, WRES, (NB == 1 ? 5 : 0), (NB == 1 && MB == 8 && WRES ? 1 : 0)>(p, wgs_per_cu, st);
-    if (NB == 1 && MB == 8 && WRES && p.ksteps == 5 && p.chunks == 2) return launch_persist_ks<NB, MB, WRES, (NB == 1 ? 5 : 0), (NB == 1 && MB == 8 && WRES ? 2 : 0)>(p, wgs_per_cu, st);
     if (NB == 1 && p.ksteps == 5) return launch_persist_ks<NB, MB, WRES, (NB == 1 ? 5 : 0)>(p, wgs_per_cu, st);
-    if (NB == 1 && p.ksteps == 14) return launch_persist_ks<NB, MB, WRES, (NB == 1 ? 14 : 0)>(p, wgs_per_cu, st);
+    // 27 linear taps (a 3 x 3 x 3 layer the depth-shift kernels refuse: >= 2^23 voxels per item): 8-deep tiles never fit with
+    // resident weights, so that is the one unrolled form; whatever else turns up runs the runtime k-loop
+    if (NB == 1 && MB == 8 && !WRES && p.ksteps == 14) return launch_persist_ks<NB, MB, WRES, (NB == 1 && MB == 8 && !WRES ? 14 : 0)>(p, wgs_per_cu, st);
     return launch_persist_ks<NB, MB, WRES, 0>(p, wgs_per_cu, st);
 }
 
@@ -998,7 +998,7 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
         if (rc != -1) return rc;
     }
     int nb = conv3d_pick_nb(p.Cout / 16);
-    static const bool force_v1 = fnn_knob("FNN_CONV_V1") != nullptr;          // debugging / A-B aid
+    const bool force_v1 = fnn_knob("FNN_CONV_V1") != nullptr;   // debugging aid, read per call: the test of the generic kernel sets it
     if (!force_v1 && p.sd == 1 && p.sh == 1 && p.sw == 1) {
         // (cout blocks per workgroup, column blocks per wave): prefer the most work per staged byte,
         // but small feature maps need workgroups first - the deep layers are latency bound otherwise
@@ -1049,7 +1049,7 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
             return mbsel == 8 ? launch_ldsk<2, 8>(p, st) : launch_ldsk<2, 4>(p, st);
         }
     }
-    static const bool strided_v1 = fnn_knob("FNN_CONV_STRIDED_V1") != nullptr;   // A-B aid
+    const bool strided_v1 = fnn_knob("FNN_CONV_STRIDED_V1") != nullptr;   // A-B aid (per call)
     if (!force_v1 && !strided_v1) {
         // stride (2, 2, 2) with whole groups of 64 output channels: one staged halo per group (conv3d_s2.hip)
         const int rc = launch_conv3d_s2(p, st);

@@ -886,8 +886,10 @@ bool conv_thin_ok(const ThinParams &tp) {
         if (p.n_src != 2 || p.chunks != 2 || p.src[1].C != 16 || tp.low.C > 32 || tp.low.C % 16) return false;
         const int LD = tp.tsd == 2 ? (ID + 2) / 2 : ID, LH = tp.tsh == 2 ? 6 : 10, LW = tp.tsw == 2 ? 6 : 10;
         if (LD * LH * LW > 3 * 4 * 16) return false;
+        // two stride phases never pass the window bound above, and a 3 x 3 x 3 consumer's two double-buffered images + weights
+        // never fit twice per CU: those four instantiations could not be reached and are gone (round 3)
         const int ncls = tp.tsd * tp.tsh * tp.tsw;
-        if (ncls != 2 && ncls != 4 && ncls != 8) return false;
+        if (p.kd != 1 || (ncls != 4 && ncls != 8)) return false;
         if (tp.Dl * tp.tsd != p.Di || tp.Hl * tp.tsh != p.Hi || tp.Wl * tp.tsw != p.Wi) return false;
         if ((long long)tp.Dl * tp.Hl >= (1 << 24)) return false;
     } else {
@@ -935,10 +937,10 @@ int launch_conv_thin(const ThinParams &tp, hipStream_t st) {
     }
     const int kd = tp.c.kd;
     if (tp.fuse == FUSE_STEM) return kd == 1 ? launch_thin_t<1, 1, FUSE_STEM, 1>(tp, st) : launch_thin_t<3, 1, FUSE_STEM, 1>(tp, st);
+    // FUSE_TCONV: (1, 3, 3) consumers behind a transposed conv of stride (1, 2, 2) or (2, 2, 2) (conv_thin_ok)
     switch (tp.tsd * tp.tsh * tp.tsw) {
-        case 2: return kd == 1 ? launch_thin_t<1, 2, FUSE_TCONV, 2>(tp, st) : launch_thin_t<3, 2, FUSE_TCONV, 2>(tp, st);
-        case 4: return kd == 1 ? launch_thin_t<1, 2, FUSE_TCONV, 4>(tp, st) : launch_thin_t<3, 2, FUSE_TCONV, 4>(tp, st);
-        case 8: return kd == 1 ? launch_thin_t<1, 2, FUSE_TCONV, 8>(tp, st) : launch_thin_t<3, 2, FUSE_TCONV, 8>(tp, st);
+        case 4: return launch_thin_t<1, 2, FUSE_TCONV, 4>(tp, st);
+        case 8: return launch_thin_t<1, 2, FUSE_TCONV, 8>(tp, st);
     }
     return -1;
 }

@@ -385,13 +385,14 @@ int launch_tconv(const TconvParams &p, hipStream_t st) {
     // per SIMD, the activations are read once more - 6 % less tconv time on the benchmark net
     // (round 2, late: with the 16-byte stores four taps per wave win - 9.3 -> 7.9 ms per volume; eight taps on two column
     // blocks per wave - every activation read once - measured the same as four: not kept)
-    static const int tg_max2 = fnn_knob("FNN_TCONV_TG") ? atoi(fnn_knob("FNN_TCONV_TG")) : 4;       // A-B aid
+    if (taps < 2) return -1;                                           // kernel = stride (1, 1, 1) is not a transposed conv of a U-Net decoder
+    static const int tg_max2 = fnn_knob("FNN_TCONV_TG") && atoi(fnn_knob("FNN_TCONV_TG")) == 2 ? 2 : 4;       // A-B aid
     const int tg_cap = nbt == 2 ? tg_max2 : 4;
-    const int tg = taps >= tg_cap ? (tg_cap > 4 ? 4 : tg_cap) : taps;     // taps is 1, 2, 4 or 8
+    const int tg = taps >= tg_cap ? tg_cap : taps;                     // taps is 2, 4 or 8
     dim3 grid(p.N * ((vox_in + 255) / 256), (taps / tg) * (p.nblk / nbt));
 #define FNN_TCONV(NBTv, TGv) do { fnn_note_kernel("tconv_mfma_kernel<%d,%d>", NBTv, TGv); hipLaunchKernelGGL((tconv_mfma_kernel<NBTv, TGv>), grid, dim3(256), lds, st, p); } while (0)
-    if (nbt == 2) { if (tg == 4) FNN_TCONV(2, 4); else if (tg == 2) FNN_TCONV(2, 2); else FNN_TCONV(2, 1); }
-    else          { if (tg == 4) FNN_TCONV(1, 4); else if (tg == 2) FNN_TCONV(1, 2); else FNN_TCONV(1, 1); }
+    if (nbt == 2) { if (tg == 4) FNN_TCONV(2, 4); else FNN_TCONV(2, 2); }
+    else          { if (tg == 4) FNN_TCONV(1, 4); else FNN_TCONV(1, 2); }
 #undef FNN_TCONV
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -774,8 +775,7 @@ __global__ __launch_bounds__(256, MINB) void seg_head_acc1_kernel(const HeadPara
 // Only the vectorised accumulate kernel knows the first-visit thresholds (one k-step: <= 32 input channels).
 bool launch_head_first_visit_ok(const HeadParams &p) {
     static const bool head_v1 = fnn_knob("FNN_HEAD_V1") != nullptr;
-    static const bool rd1 = fnn_knob("FNN_HEAD_RD") && atoi(fnn_knob("FNN_HEAD_RD")) == 1;
-    return p.mode == 0 && p.ksteps == 1 && !head_v1 && !rd1 && (long long)p.PD * p.PH * p.PW <= (1 << 24);
+    return p.mode == 0 && p.ksteps == 1 && !head_v1 && (long long)p.PD * p.PH * p.PW <= (1 << 24);
 }
 
 int launch_head(const HeadParams &p, hipStream_t st) {
@@ -790,25 +790,12 @@ int launch_head(const HeadParams &p, hipStream_t st) {
         const size_t lds = (size_t)((p.src.C * 8 + 255) & ~255) + (size_t)4 * 32 * HEAD_LD * 4;
         static const bool head_v1 = fnn_knob("FNN_HEAD_V1") != nullptr;            // A-B aid
         if (p.ksteps == 1 && !head_v1 && P <= (1 << 24)) {
-            static const int head_rd = fnn_knob("FNN_HEAD_RD") ? atoi(fnn_knob("FNN_HEAD_RD")) : 2;      // A-B aid (1: one 32-voxel round per wave - faster alone, slower next to the other stream)
-            if (head_rd == 1) {
-                const dim3 g1((P + 127) / 128);
-                if (p.acc_fp32) hipLaunchKernelGGL((seg_head_acc1_kernel<true, 1>), g1, dim3(256), lds, st, p);
-                else hipLaunchKernelGGL((seg_head_acc1_kernel<false, 1>), g1, dim3(256), lds, st, p);
-            } else if (p.acc_fp32) hipLaunchKernelGGL((seg_head_acc1_kernel<true, 2>), grid, dim3(256), lds, st, p);
-            else {
-                // non-temporal accumulator traffic (each line is touched once per patch): +1.3 % on the benchmark
-                static const int nt = fnn_knob("FNN_HEAD_NT") ? atoi(fnn_knob("FNN_HEAD_NT")) : 3;      // A-B aid
-                if (nt == 1) hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 1>), grid, dim3(256), lds, st, p);
-                else if (nt == 2) hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 2>), grid, dim3(256), lds, st, p);
-                else if (nt == 3) {
-                    // two workgroups per SIMD's worth of registers asked for: 177 VGPRs instead of 214 (three: 8 spills, slower)
-                    static const int minb = fnn_knob("FNN_HEAD_MINB") ? atoi(fnn_knob("FNN_HEAD_MINB")) : 2;            // A-B aid
-                    if (minb == 2) hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 3, 2>), grid, dim3(256), lds, st, p);
-                    else hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 3>), grid, dim3(256), lds, st, p);
-                }
-                else hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2>), grid, dim3(256), lds, st, p);
-            }
+            // two 32-voxel rounds per wave (one: faster alone, slower next to the other stream); fp16 buffers: non-temporal
+            // accumulator traffic (each line is touched once per patch: +1.3 % on the round-1 benchmark) and registers for two
+            // workgroups per SIMD (177 VGPRs instead of 214).  The A-B variants of those choices (FNN_HEAD_RD / _NT / _MINB)
+            // were six more kernels that nothing but a knob selected: gone (round 3).
+            if (p.acc_fp32) hipLaunchKernelGGL((seg_head_acc1_kernel<true, 2>), grid, dim3(256), lds, st, p);
+            else hipLaunchKernelGGL((seg_head_acc1_kernel<false, 2, 3, 2>), grid, dim3(256), lds, st, p);
         } else if (p.acc_fp32) hipLaunchKernelGGL(seg_head_acc_kernel<true>, grid, dim3(256), lds, st, p);
         else hipLaunchKernelGGL(seg_head_acc_kernel<false>, grid, dim3(256), lds, st, p);
         return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -1117,24 +1104,20 @@ static void launch_labels_coop(const FinalizeParams &p, void *labels, const int 
 }
 
 int launch_labels_from_acc(const FinalizeParams &p, void *labels, int label_u16, const int *order, hipStream_t st) {
-    static const bool v1 = fnn_knob("FNN_LABELS_V1") != nullptr;                     // A-B aid
+    // uint8 labels (<= 256 classes: <= 32 lanes per voxel): the cooperative kernel; uint16 labels (what more classes need): one
+    // lane per voxel.  (Round 3: the other twelve + two combinations were kernels only a knob or a raw ABI call reached.)
     int log_g = 0;
     while ((8 << log_g) < p.HP) ++log_g;                                         // lanes per voxel: HP / 8 rounded up to 2^k
     const long long nvox = p.OX * p.OY * p.OZ;
-    if (!v1 && log_g <= 5 && (nvox << log_g) < (1LL << 39)) {
-        if (p.acc_fp32) { if (label_u16) launch_labels_coop<true, uint16_t>(p, labels, order, log_g, st); else launch_labels_coop<true, uint8_t>(p, labels, order, log_g, st); }
-        else { if (label_u16) launch_labels_coop<false, uint16_t>(p, labels, order, log_g, st); else launch_labels_coop<false, uint8_t>(p, labels, order, log_g, st); }
+    if (!label_u16) {
+        if (log_g > 5 || (nvox << log_g) >= (1LL << 39)) return -1;
+        if (p.acc_fp32) launch_labels_coop<true, uint8_t>(p, labels, order, log_g, st);
+        else launch_labels_coop<false, uint8_t>(p, labels, order, log_g, st);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
-    const long long n = p.OX * p.OY * p.OZ;
-    const dim3 grid((unsigned)((n + 255) / 256));
-    if (p.acc_fp32) {
-        if (label_u16) hipLaunchKernelGGL((labels_from_acc_kernel<true, uint16_t>), grid, dim3(256), 0, st, p, (uint16_t *)labels, order);
-        else hipLaunchKernelGGL((labels_from_acc_kernel<true, uint8_t>), grid, dim3(256), 0, st, p, (uint8_t *)labels, order);
-    } else {
-        if (label_u16) hipLaunchKernelGGL((labels_from_acc_kernel<false, uint16_t>), grid, dim3(256), 0, st, p, (uint16_t *)labels, order);
-        else hipLaunchKernelGGL((labels_from_acc_kernel<false, uint8_t>), grid, dim3(256), 0, st, p, (uint8_t *)labels, order);
-    }
+    const dim3 grid((unsigned)((nvox + 255) / 256));
+    if (p.acc_fp32) hipLaunchKernelGGL((labels_from_acc_kernel<true, uint16_t>), grid, dim3(256), 0, st, p, (uint16_t *)labels, order);
+    else hipLaunchKernelGGL((labels_from_acc_kernel<false, uint16_t>), grid, dim3(256), 0, st, p, (uint16_t *)labels, order);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -91,6 +91,13 @@ bool make_src(SrcHolder &h, const float *x, int n, int c, size_t vox, const floa
 
 }  // namespace
 
+// kernel variants of the last fnn_op_* call of this thread (fnn_note_kernel at the launch sites): fnn_op_last_kernels
+static thread_local std::vector<std::string> g_op_kernels;
+struct OpKlog {
+    OpKlog() { g_op_kernels.clear(); fnn_klog_target(&g_op_kernels); }
+    ~OpKlog() { fnn_klog_target(nullptr); }
+};
+
 extern "C" {
 
 int fnn_op_conv3d(int device, int n, const int dims[3],
@@ -100,6 +107,7 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
                   float *y, double *stats_out) {
     if (!x || !w || !y || !dims || !k || !stride || n < 1 || cin < 1 || cout < 1) return FNN_E_INVALID;
     if (hipSetDevice(device) != hipSuccess) return FNN_E_HIP;
+    OpKlog klog;
     const size_t vox = (size_t)dims[0] * dims[1] * dims[2];
     const int nsrc = x2 ? 2 : 1;
     SrcHolder s1, s2;
@@ -234,6 +242,7 @@ int fnn_op_conv_transpose3d(int device, int n, const int dims[3],
                             const float *w, const float *bias, int cout, const int stride[3], float *y) {
     if (!x || !w || !y || !dims || !stride || n < 1 || cin < 1 || cout < 1) return FNN_E_INVALID;
     if (hipSetDevice(device) != hipSuccess) return FNN_E_HIP;
+    OpKlog klog;
     const size_t vox = (size_t)dims[0] * dims[1] * dims[2];
     SrcHolder s1;
     if (!make_src(s1, x, n, cin, vox, gamma1, beta1, slope1, true)) return FNN_E_HIP;
@@ -275,6 +284,13 @@ int fnn_op_conv_transpose3d(int device, int n, const int dims[3],
                 y[((size_t)b * cout + co) * ovox + v] =
                     h2f_bits(ho[ocm ? ((size_t)b * cop / 16 + co / 16) * ovox * 16 + v * 16 + co % 16 : ((size_t)b * ovox + v) * cop + co]);
     return 0;
+}
+
+int fnn_op_last_kernels(char *buf, int cap) {
+    std::string all;
+    for (const std::string &k : g_op_kernels) { all += k; all += '\n'; }
+    if (buf && cap > 0) { strncpy(buf, all.c_str(), (size_t)cap - 1); buf[cap - 1] = 0; }
+    return (int)all.size() + 1;
 }
 
 int fnn_op_quotient_check(int device, unsigned long long counts[3]) {

@@ -358,6 +358,10 @@ int fnn_op_conv_transpose3d(int device, int n, const int dims[3],
                             const float *x, int cin, const float *gamma1, const float *beta1, float slope1,
                             const float *w, const float *bias, int cout, const int stride[3], float *y);
 
+/* The kernel variants the last fnn_op_conv3d / fnn_op_conv_transpose3d call of this thread launched, one per line (the
+ * launchers pick a variant from the layer's shape; the op tests pin which one a case exercises).  Returns the size needed. */
+int fnn_op_last_kernels(char *buf, int cap);
+
 /* Self-check of the closing division of the seg-head gather (predicted_logits /= n_predictions,
  * predict_from_raw_data.py:619): runs the kernel's shared-reciprocal quotient over every fp16 value a and every fp16
  * b with a clear sign bit and counts the pairs whose fp16 result differs from IEEE fp32 division rounded to fp16

@@ -343,7 +343,7 @@ def test_fused_stage0_producers_match_the_unfused_engine_and_the_oracle(name):
 
 
 @pytest.mark.parametrize('stem', [False, True])
-@pytest.mark.parametrize('patch', [(32, 64, 64), (12, 48, 96)])
+@pytest.mark.parametrize('patch', [(32, 64, 64), (12, 48, 96), (4, 8, 128), (4, 12, 160), (4, 8, 192)])
 def test_fused_stage0_producers_are_bit_identical_to_the_unfused_engine_in_the_row_kernels(patch, stem):
     """Rows of 64 / 96 voxels: the stage-0 convs run in conv3d_row.hip with or without the fusions (same row groups,
     same statistics order); the stand-alone transposed conv is the same arithmetic as the one computed while staging,
@@ -406,6 +406,32 @@ def test_fp8_conv_path_stays_within_its_budget_of_the_fp32_oracle(name):
     assert r8 <= FP8_RMSE and agree8 >= FP8_LABEL_AGREEMENT
     assert r8 > 2 * r16                       # the fp8 kernels really ran (an f16 fallback would sit at the f16 error)
     assert bool(torch.isfinite(got8).all())
+
+
+@pytest.mark.parametrize('features', [[16, 32], [16, 48]])
+def test_fp8_depth_shift_kernels_with_four_plane_tiles(features):
+    """conv3d_zr8_kernel<NB, 4>: a stage with fewer than 8 planes (patch depth 8, stage 1 at 4 x 64 x 64) keeps the e4m3 depth-shift
+    kernels at four-plane tiles - two cout blocks per workgroup (32 channels) and one (48: an odd block count).  Same budget as
+    the 64^3 students; the f16 engine on the same network shows that the fp8 kernels ran."""
+    spec = UNetSpec('plain', 1, 3, features, [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
+    patch = (8, 128, 128)
+    sd = synthetic_state_dict(spec, 811)
+    x = torch.randn(8, 1, *patch, generator=torch.Generator().manual_seed(82))
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    with torch.inference_mode():
+        ref = build_oracle(spec, sd)(x)
+    p8 = _fp8_predictor(spec, patch, [sd], batch=8)
+    p8._engine.set_profiling(True)
+    try:
+        got8 = p8.forward_patches(x).cpu()
+        kernels = set(p8._engine.kernel_log())
+    finally:
+        p8._engine.set_profiling(False)
+    assert f'conv3d_zr8_kernel<{2 if features[1] == 32 else 1},4>' in kernels, sorted(kernels)
+    got16 = _predictor(spec, patch, [sd], batch=8).forward_patches(x).cpu()
+    _, r16 = _report(f'{features} f16 vs fp32 oracle', got16, ref)
+    _, r8 = _report(f'{features} f8  vs fp32 oracle', got8, ref)
+    assert r8 <= FP8_RMSE and r8 > 2 * r16 and bool(torch.isfinite(got8).all())
 
 
 def test_fp8_driver_is_bit_identical_to_the_oracle_driver_on_its_own_logits():

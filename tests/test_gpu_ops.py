@@ -62,6 +62,85 @@ def test_conv3d_identity_input(n, cin, cout, dims, k, stride):
     assert np.allclose(stats[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
 
 
+# Layers large enough for the persistent / row / walking variants the launchers keep for them (the launcher picks by shape
+# and planned batch; a trace of the whole GPU suite in round 3 found these variants compiled but never launched).  Each case
+# names the variant it must run (fnn_op_last_kernels): n, cin, cin2 (second source), cout, dims, k, expected kernel.
+VARIANT_CASES = [
+    (16, 16, 0, 16, (16, 64, 80), (1, 3, 3), 'conv3d_persist_kernel<1,4,1,5,1,4,0>'),     # thin (1,3,3) layer, rows of 80: no row kernel
+    (16, 16, 16, 16, (16, 64, 80), (1, 3, 3), 'conv3d_persist_kernel<1,4,1,5,2,4,0>'),    # ... two sources
+    (16, 48, 0, 16, (16, 64, 80), (1, 3, 3), 'conv3d_persist_kernel<1,8,1,5,0,8,0>'),     # ... three chunks
+    (18, 16, 0, 16, (4, 96, 80), (1, 3, 3), 'conv3d_persist_kernel<1,4,1,5,0,8,0>'),      # ... fewer than 8 planes
+    (16, 16, 0, 16, (16, 64, 80), (3, 3, 1), 'conv3d_persist_kernel<1,4,1,5,1,4,0>'),     # nine taps the other way round
+    (16, 16, 0, 16, (16, 64, 80), (1, 1, 1), 'conv3d_persist_kernel<1,8,1,0,0,8,0>'),     # 1x1x1 (a ResEnc skip projection at full size)
+    (18, 16, 0, 16, (4, 96, 80), (1, 1, 1), 'conv3d_persist_kernel<1,4,1,0,0,8,0>'),
+    (13, 176, 0, 16, (16, 64, 80), (1, 3, 3), 'conv3d_persist_kernel<1,8,0,5,0,8,0>'),    # weights too large to stay resident
+    (18, 176, 0, 16, (4, 96, 80), (1, 3, 3), 'conv3d_persist_kernel<1,4,0,5,0,8,0>'),
+    (8, 16, 0, 16, (16, 64, 48), (1, 3, 3), 'conv3d_lds_kernel<1,8,8>'),                   # too few tiles for the persistent form
+    (2, 16, 16, 16, (8, 16, 128), (1, 3, 3), 'conv_row_kernel<8,2,0>'),                    # two-source rows of 128 / 160 voxels
+    (2, 16, 16, 16, (8, 16, 160), (1, 3, 3), 'conv_row_kernel<10,2,0>'),
+    (4, 16, 0, 32, (64, 64, 64), (3, 3, 3), 'conv3d_zrw_kernel<2>'),                       # walking depth-shift kernel, two cout blocks
+]
+
+
+@pytest.mark.parametrize('n,cin,cin2,cout,dims,k,kernel', VARIANT_CASES, ids=lambda v: str(v).replace(' ', ''))
+def test_conv3d_large_layer_variants(n, cin, cin2, cout, dims, k, kernel):
+    from fast_nnunet_amd import capi
+    g = torch.Generator().manual_seed(hash((n, cin, cin2, cout, dims, k)) % 2 ** 31)
+    x = _h(torch.randn(n, cin, *dims, generator=g) * 2 - 0.5)
+    gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+    x2 = _h(torch.randn(n, cin2, *dims, generator=g)) if cin2 else None
+    w = _h(torch.randn(cout, cin + cin2, *k, generator=g) / ((cin + cin2) * k[0] * k[1] * k[2]) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    y, stats = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), k, (1, 1, 1), gamma=gamma.numpy(), beta=beta.numpy(), slope=0.01,
+                              x2=None if x2 is None else x2.numpy(), want_stats=True)
+    assert capi.op_last_kernels() == [kernel]
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    xn = _h(F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01))
+    ref = F.conv3d(xn if x2 is None else torch.cat((xn, x2), 1), w, b, 1, [(i - 1) // 2 for i in k])
+    err = np.abs(y - ref.numpy())
+    assert err.max() <= 6e-3 * max(1.0, float(ref.abs().max())), err.max()
+    y64 = y.astype(np.float64)
+    assert np.allclose(stats[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=1e-2)
+    assert np.allclose(stats[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=1e-2)
+
+
+def test_conv3d_linear_taps_on_a_layer_too_large_for_the_depth_shift_kernels():
+    """3 x 3 x 3, stride 1, 9.4 M voxels per item: beyond the depth-shift kernels' 24-bit voxel arithmetic (conv3d_zr.hip: zr_pick),
+    so the layer keeps the linear tap order and runs the persistent kernel with 14 unrolled k-steps and travelling weights."""
+    from fast_nnunet_amd import capi
+    g = torch.Generator().manual_seed(77)
+    dims = (256, 192, 192)
+    x = _h(torch.randn(1, 16, *dims, generator=g))
+    w = _h(torch.randn(16, 16, 3, 3, 3, generator=g) / 432 ** 0.5)
+    b = torch.randn(16, generator=g)
+    y = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), (1, 1, 1))
+    assert capi.op_last_kernels() == ['conv3d_persist_kernel<1,8,0,14,0,8,0>']
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    sl = (slice(None), slice(None), slice(100, 140), slice(0, 64), slice(120, 192))       # a slab incl. two faces: the CPU conv of it all takes a minute
+    ref = F.conv3d(x[:, :, 99:141, 0:65, 119:192], w, b, 1, 1)[:, :, 1:-1, :-1, 1:]
+    _check(y[sl], ref, 'conv3d 256x192x192')
+
+
+@pytest.mark.parametrize('cout', [16, 32, 64])
+def test_conv3d_generic_kernel_behind_every_launcher(cout):
+    """conv3d_mfma_kernel<1 | 2 | 4>: the form every layer shape can fall back to when no specialised launcher takes it (no
+    BASELINE workload does: tests/test_gpu_bench_oracle.py).  FNN_CONV_V1 (read per call) sends a layer there."""
+    import os
+    from fast_nnunet_amd import capi
+    g = torch.Generator().manual_seed(5 + cout)
+    for k, stride, dims in (((3, 3, 3), (1, 1, 1), (7, 9, 20)), ((1, 3, 3), (1, 2, 2), (5, 12, 18)), ((1, 1, 1), (1, 1, 1), (3, 8, 9))):
+        x = _h(torch.randn(2, 24, *dims, generator=g))
+        w = _h(torch.randn(cout, 24, *k, generator=g) / (24 * k[0] * 9) ** 0.5)
+        b = torch.randn(cout, generator=g)
+        os.environ['FNN_CONV_V1'] = '1'
+        try:
+            y = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), k, stride)
+        finally:
+            del os.environ['FNN_CONV_V1']
+        assert capi.op_last_kernels() == [f'conv3d_mfma_kernel<{cout // 16 if cout < 64 else 4}> (generic fallback)']
+        _check(y, F.conv3d(x, w, b, stride, [(i - 1) // 2 for i in k]), f'generic conv {k} {stride}')
+
+
 @pytest.mark.parametrize('n,cin,cout,dims,k,stride', CONV_CASES[:6] + CONV_CASES[-2:])
 def test_conv3d_with_fused_instancenorm_lrelu_on_load(n, cin, cout, dims, k, stride):
     from fast_nnunet_amd import capi

@@ -248,6 +248,75 @@ def test_driver_with_61_heads_uses_the_tiled_finalize(shape, folds, accum):
         assert (got.float() - want.float()).abs().max() <= 2e-3 * float(want.abs().max()) + 1e-3
 
 
+@pytest.mark.parametrize('accum', ['fp16', 'fp32'])
+@pytest.mark.parametrize('heads,features0,shape', [(15, 16, (21, 27, 50)), (61, 16, (24, 40, 64)), (70, 16, (17, 16, 40)),
+                                                   (130, 16, (17, 16, 40)), (3, 48, (21, 27, 50))])
+def test_accumulate_path_kernels_against_the_oracle_driver(heads, features0, shape, accum):
+    """The whole-volume accumulator path (FNN_NO_GATHER; what a network whose last stage has more than 32 channels takes by
+    itself: 48 here - the multi-k-step `seg_head_acc_kernel`) against the oracle driver on the engine's logits: the
+    cooperative label kernel at 2 / 8 / 16 / 32 lanes per voxel (15 / 61 / 70 / 130 classes), the LDS-tiled finalize kernel for
+    64-channel accumulator rows with an aligned z extent (61 classes - since the gather path became the default no test
+    reached it), both buffer arithmetics, two folds through the add mode."""
+    spec = UNetSpec('plain', 1, heads, [features0, 32], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
+    patch = (16, 16, 32)
+    sds = [synthetic_state_dict(spec, 610 + f) for f in range(2)]
+    os.environ['FNN_NO_GATHER'] = '1'
+    try:
+        p, p1 = _predictor(spec, patch, sds, accumulate_in=accum), _predictor(spec, patch, sds[:1], accumulate_in=accum)
+    finally:
+        os.environ.pop('FNN_NO_GATHER', None)
+    image = torch.randn(1, *shape, generator=torch.Generator().manual_seed(43))
+
+    def net(q, fold):
+        def f(x):
+            q._active_fold = fold
+            return q.forward_patches(x).cpu()
+        return f
+
+    want1 = osw.sliding_window_logits(net(p1, 0), image, patch, heads, accum=accum)
+    want2 = osw.ensemble_logits([net(p, 0), net(p, 1)], image, patch, heads, accum=accum)
+    got1, got2 = p1.predict_sliding_window_return_logits(image).cpu(), p.predict_logits_from_preprocessed_data(image).cpu()
+    if accum == 'fp16':
+        assert (_bits(got1) == _bits(want1)).all() and (_bits(got2) == _bits(want2)).all()
+    else:
+        assert (got1.float() - want1.float()).abs().max() <= 2e-3 * float(want1.abs().max()) + 1e-3
+        assert (got2.float() - want2.float()).abs().max() <= 2e-3 * float(want2.abs().max()) + 1e-3
+    labels = p1.predict_segmentation_from_preprocessed_data(image).cpu().long()
+    if accum == 'fp16':
+        assert torch.equal(labels, osw.logits_to_labels(want1.float()).long())
+    else:                                                               # fp32 sums: only ties of the rounded logits may differ
+        assert float((labels != osw.logits_to_labels(want1.float()).long()).float().mean()) <= 2e-3
+
+
+@pytest.mark.parametrize('gather', [True, False])
+@pytest.mark.parametrize('heads,accum', [(3, 'fp32'), (61, 'fp32'), (61, 'fp16')])
+def test_fp32_logits_through_the_c_abi_round_to_the_fp16_logits(heads, accum, gather):
+    """fnn_opts.out_dtype = FNN_OUT_F32 (the Python predictor always asks for the reference's fp16 logits, so only the C ABI reaches
+    it): the quotient sum / weight sum before its rounding to fp16 (fp32 sums), or the fp16 logits widened (fp16 sums: they ARE the
+    reference's values).  Either way fp16(out32) must be the fp16 output's bits.  The gather kernel writes fp16 only: an engine on the gather
+    path takes the accumulators for such a call - the plain and the LDS-tiled (61 classes, aligned z) finalize kernels."""
+    from fast_nnunet_amd import capi
+    spec = UNetSpec('plain', 1, heads, [16, 32], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
+    patch = (16, 16, 32)
+    if not gather:
+        os.environ['FNN_NO_GATHER'] = '1'
+    try:
+        p = _predictor(spec, patch, [synthetic_state_dict(spec, 650)], accumulate_in=accum)
+    finally:
+        os.environ.pop('FNN_NO_GATHER', None)
+    image = torch.randn(1, 24, 40, 64, generator=torch.Generator().manual_seed(47))
+    want = p.predict_sliding_window_return_logits(image)
+    x = image.to('cuda', torch.float32).contiguous()
+    out = torch.empty((heads, *image.shape[1:]), dtype=torch.float32, device='cuda')
+    o = p._opts()
+    o.out_dtype = capi.FNN_OUT_F32
+    p._engine.predict_volume(x.data_ptr(), x.shape, o, out.data_ptr())
+    torch.cuda.synchronize()
+    assert (_bits(out.half()) == _bits(want)).all()
+    if accum == 'fp32':
+        assert not torch.equal(out, out.half().float())                   # really un-rounded
+
+
 @pytest.mark.parametrize('heads', [15, 16, 63, 64, 130])
 def test_driver_with_head_counts_around_a_block_boundary(heads):
     """The weight-sum channel is a seg head of its own (zero weights, bias 1) right after the last class: with 15 / 63
@@ -339,13 +408,22 @@ def test_label_rules_match_reference_golden(golden_dir):
     assert np.array_equal(got.cpu().numpy(), z['argmax_f16'])
 
 
+@pytest.mark.parametrize('path', ['gather', 'accumulate', 'accumulate_fp32'])
 @pytest.mark.parametrize('n_folds', [1, 2])
-def test_region_labels_straight_from_the_accumulators(n_folds):
+def test_region_labels_straight_from_the_accumulators(n_folds, path):
+    """Region labels (the highest head above the sigmoid threshold, mapped through regions_class_order - values above 255 make the
+    map uint16) from the gather kernel and from the whole-volume accumulators (FNN_NO_GATHER: the cooperative uint8 kernel and
+    the one-lane uint16 kernel, fp16 and fp32 sums)."""
     from golden_cases import DATASET_JSONS
     spec, patch = SPECS['toy3']
     sds = [synthetic_state_dict(spec, 3 + i) for i in range(n_folds)]
     for dj_name in ('regions', 'regions_u16'):
-        p = _predictor(spec, patch, sds, dataset_json=DATASET_JSONS[dj_name])
+        if path != 'gather':
+            os.environ['FNN_NO_GATHER'] = '1'
+        try:
+            p = _predictor(spec, patch, sds, dataset_json=DATASET_JSONS[dj_name], accumulate_in='fp32' if path == 'accumulate_fp32' else 'fp16')
+        finally:
+            os.environ.pop('FNN_NO_GATHER', None)
         image = torch.randn(1, 24, 20, 40, generator=torch.Generator().manual_seed(4))
         logits = p.predict_logits_from_preprocessed_data(image)
         want = osw.logits_to_labels(logits.cpu(), DATASET_JSONS[dj_name]['regions_class_order'])
@@ -860,6 +938,44 @@ def test_gather_path_is_bit_identical_to_the_accumulate_path(shape, heads, accum
     finally:
         os.environ.pop('FNN_NO_GATHER', None)
     assert torch.equal(g1.predict_segmentation_from_preprocessed_data(image), a1.predict_segmentation_from_preprocessed_data(image))
+
+
+@pytest.mark.parametrize('accum', ['fp16', 'fp32'])
+@pytest.mark.parametrize('heads,mirror', [(3, (0,)), (20, None), (20, (2,)), (61, (1,))])
+def test_gather_kernel_variants_against_the_accumulate_path(heads, mirror, accum):
+    """gather_head_kernel<HB, ACCM, LABELS, TTA> is 36 kernels; a trace of the whole GPU suite (round 3) showed 19 of them
+    never launched - two head blocks (17-31 classes) beyond the plain case, fp32 sums with mirroring, labels with
+    mirroring.  Logits, the fold ensemble's add mode and the labels of the gather path against the accumulate path
+    (FNN_NO_GATHER: per-patch buffers, `seg_head_acc*` / `patch_acc_kernel` / `labels_from_acc*` - variants of their own
+    that the same trace had not seen either) for 1 / 2 / 4 head blocks, both buffer arithmetics, with mirroring."""
+    spec = UNetSpec('plain', 1, heads, [16, 32], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
+    patch = (16, 16, 32)
+    sds = [synthetic_state_dict(spec, 520 + f) for f in range(2)]
+    image = torch.randn(1, 21, 27, 50, generator=torch.Generator().manual_seed(37))
+    os.environ.pop('FNN_NO_GATHER', None)
+    g, g1 = _predictor(spec, patch, sds, mirror=mirror, accumulate_in=accum), _predictor(spec, patch, sds[:1], mirror=mirror, accumulate_in=accum)
+    os.environ['FNN_NO_GATHER'] = '1'
+    try:
+        a, a1 = _predictor(spec, patch, sds, mirror=mirror, accumulate_in=accum), _predictor(spec, patch, sds[:1], mirror=mirror, accumulate_in=accum)
+    finally:
+        os.environ.pop('FNN_NO_GATHER', None)
+    assert torch.equal(g1.predict_sliding_window_return_logits(image), a1.predict_sliding_window_return_logits(image))
+    assert torch.equal(g.predict_logits_from_preprocessed_data(image), a.predict_logits_from_preprocessed_data(image))
+    assert torch.equal(g1.predict_segmentation_from_preprocessed_data(image), a1.predict_segmentation_from_preprocessed_data(image))
+
+
+@pytest.mark.parametrize('heads,mirror', [(20, None), (20, (0,)), (61, (2,))])
+def test_gather_kernel_variants_in_the_autocast_arithmetic(heads, mirror):
+    """The same variants for FNN_ACC_FP16_AUTOCAST (packed fp16 sums; served by the gather path only): logits and labels
+    against the oracle driver on the engine's own fp16 network output."""
+    spec = UNetSpec('plain', 1, heads, [16, 32], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
+    patch = (16, 16, 32)
+    p = _predictor(spec, patch, [synthetic_state_dict(spec, 530)], mirror=mirror, accumulate_in='fp16_autocast')
+    image = torch.randn(1, 21, 27, 50, generator=torch.Generator().manual_seed(41))
+    want = osw.sliding_window_logits(lambda x: p.forward_patches(x).cpu().half(), image, patch, heads, step=0.5, use_gaussian=True,
+                                     mirror_axes=mirror, accum='fp16')
+    assert np.array_equal(_bits(p.predict_sliding_window_return_logits(image)), _bits(want))
+    assert torch.equal(p.predict_segmentation_from_preprocessed_data(image).long().cpu(), osw.logits_to_labels(want).long())
 
 
 @pytest.mark.parametrize('mirror', [None, (0, 1, 2), (1,)])
