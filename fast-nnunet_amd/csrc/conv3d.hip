@@ -907,6 +907,14 @@ static int launch_persist(const ConvParams &p, int wgs_per_cu, hipStream_t st) {
     return launch_persist_ks<NB, MB, WRES, 0>(p, wgs_per_cu, st);
 }
 
+// travelling weights (WRES = false): ksteps is 5 or 14 here (launch_conv3d)
+template <int NB, int MB>
+static int launch_persist_ktaps(const ConvParams &p, int wgs_per_cu, hipStream_t st) {
+    if (p.ksteps == 5) return launch_persist_ks<NB, MB, false, 5>(p, wgs_per_cu, st);
+    if (MB == 8) return launch_persist_ks<NB, MB, false, (MB == 8 ? 14 : 5)>(p, wgs_per_cu, st);
+    return -1;                                                          // 27 taps at four planes fit with resident weights: not reached
+}
+
 size_t conv3d_lds_bytes(const ConvParams &p, int nb) {
     const int ID = (FNN_TILE_D - 1) * p.sd + p.kd;
     const int IH = (FNN_TILE_H - 1) * p.sh + p.kh;
@@ -1034,11 +1042,15 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
                 if (tiles < 256LL * 2 * 4) continue;
                 static const int persist_wres = fnn_knob("FNN_PERSIST_WRES") ? atoi(fnn_knob("FNN_PERSIST_WRES")) : 1;
                 for (int wres = persist_wres; wres >= 0; --wres) {
+                    // travelling weights only for the unrolled forms (9 taps; 27 taps at 8 planes): a 1x1x1 (or 3-tap) layer whose
+                    // weights do not fit - more than 800 input channels - takes the one-tile-per-workgroup kernels below (round 3:
+                    // instantiations that no shape short of that reached)
+                    if (!wres && !(p.ksteps == 5 || (p.ksteps == 14 && mb == 8))) continue;
                     const size_t lds = persist_lds_bytes(p, nb, mb, wres != 0);
                     const int per_cu = (int)((160 * 1024) / lds);
                     if (per_cu < 2) continue;
                     const int wpc = per_cu > persist_wpc ? persist_wpc : per_cu;
-#define FNN_PERSIST(NBv, MBv) (wres ? launch_persist<NBv, MBv, true>(p, wpc, st) : launch_persist<NBv, MBv, false>(p, wpc, st))
+#define FNN_PERSIST(NBv, MBv) (wres ? launch_persist<NBv, MBv, true>(p, wpc, st) : launch_persist_ktaps<NBv, MBv>(p, wpc, st))
                     return mb == 8 ? FNN_PERSIST(1, 8) : FNN_PERSIST(1, 4);
 #undef FNN_PERSIST
                 }

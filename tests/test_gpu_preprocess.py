@@ -230,6 +230,11 @@ def test_export_probabilities_match_reference_golden(golden_dir, half):
         capi.export_probabilities(lg.data_ptr(), half, H, dj.get('regions_class_order'), case['bbox'], case['before'], tb,
                                   probs.data_ptr(), labels.data_ptr(), False, torch.cuda.current_stream().cuda_stream)
         got_p, got_l = probs.cpu().numpy(), labels.cpu().numpy()
+        # the uint16 label map (class values above 255: fnn_export_probabilities(..., FNN_LABEL_U16)) must hold the same labels
+        probs16, labels16 = torch.empty_like(probs), torch.empty(grid, dtype=torch.int16, device='cuda')
+        capi.export_probabilities(lg.data_ptr(), half, H, dj.get('regions_class_order'), case['bbox'], case['before'], tb,
+                                  probs16.data_ptr(), labels16.data_ptr(), True, torch.cuda.current_stream().cuda_stream)
+        assert torch.equal(probs16, probs) and np.array_equal(labels16.cpu().numpy().view(np.uint16), got_l.astype(np.uint16)), case['name']
         ref_p, ref_l = z[case['name'] + '__probs'], z[case['name'] + '__seg']
         assert np.abs(got_p - ref_p).max() <= 5e-7, case['name']
         if dj.get('regions_class_order') is None:
