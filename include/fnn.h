@@ -61,7 +61,9 @@ enum { FNN_PREC_F16 = 0, FNN_PREC_F8 = 1 };
  *                           mirror sum, the division by the number of evaluations, the product with the Gaussian and
  *                           the sum are each rounded to fp16.  Pinned by tests/golden/sliding_window_half.npz (made by
  *                           the reference's own predictor through networks that return fp16).  Served by the gather
- *                           path only (<= 63 classes; FNN_E_UNSUPPORTED otherwise and for the accumulate_* entry points). */
+ *                           path only (any number of classes: passes of 63 heads; FNN_E_UNSUPPORTED where that path
+ *                           cannot run - a last stage of more than 32 channels, fp32 output - and for the
+ *                           accumulate_* entry points). */
 enum { FNN_ACC_FP16_REFERENCE = 0, FNN_ACC_FP32 = 1, FNN_ACC_FP16_AUTOCAST = 2 };
 enum { FNN_OUT_F16 = 0, FNN_OUT_F32 = 1 };
 
