@@ -34,7 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16, MI355X_MICROARCH.md "Chip-level parameters"
-TRAFFIC_FILE = 'r03_traffic.json'  # per-launch HBM bytes of the conv family from separate rocprofv3 --pmc passes, per workload, keyed by csrc_sha256()
+TRAFFIC_FILE = 'r04_traffic.json'  # per-launch HBM bytes of the conv family from separate rocprofv3 --pmc passes, per workload, keyed by csrc_sha256()
 
 WORKLOADS = {
     # name: (spacing, patch, heads, reduction)
@@ -152,7 +152,7 @@ def synthetic_resenc_checkpoint(features, kernels, strides, blocks, in_ch, heads
     return sd
 
 
-def build_predictor(workload, device, batch, accumulate_in, compute_dtype='f16', mirror=False):
+def build_predictor(workload, device, batch, accumulate_in, compute_dtype='f16', mirror=False, folds=1):
     from fast_nnunet_amd import nnUNetPredictor
     from fast_nnunet_amd.plans import PlansManager
     spacing, patch, heads, r = WORKLOADS[workload]
@@ -161,7 +161,7 @@ def build_predictor(workload, device, batch, accumulate_in, compute_dtype='f16',
     features = [max(min(320, 32 * 2 ** i) // r, 8) for i in range(n)]
     resenc = workload.startswith('resenc')
     if resenc:
-        sd = synthetic_resenc_checkpoint(features, kernels, strides, RESENC_BLOCKS[:n], 1, heads)
+        sds = [synthetic_resenc_checkpoint(features, kernels, strides, RESENC_BLOCKS[:n], 1, heads, seed=1234 + f) for f in range(folds)]
         arch = {'network_class_name': 'dynamic_network_architectures.architectures.unet.ResidualEncoderUNet',
                 'arch_kwargs': {'n_stages': n, 'features_per_stage': [min(320, 32 * 2 ** i) for i in range(n)],
                                 'kernel_sizes': kernels, 'strides': strides, 'n_blocks_per_stage': list(RESENC_BLOCKS[:n]),
@@ -169,7 +169,7 @@ def build_predictor(workload, device, batch, accumulate_in, compute_dtype='f16',
                                 'norm_op_kwargs': {'eps': 1e-5, 'affine': True}},
                 '_kw_requires_import': []}
     else:
-        sd = synthetic_checkpoint(features, kernels, strides, 1, heads)
+        sds = [synthetic_checkpoint(features, kernels, strides, 1, heads, seed=1234 + f) for f in range(folds)]
         arch = {'network_class_name': 'dynamic_network_architectures.architectures.unet.PlainConvUNet',
                 'arch_kwargs': {'n_stages': n, 'features_per_stage': [min(320, 32 * 2 ** i) for i in range(n)],
                                 'kernel_sizes': kernels, 'strides': strides, 'n_conv_per_stage': [2] * n,
@@ -185,9 +185,9 @@ def build_predictor(workload, device, batch, accumulate_in, compute_dtype='f16',
                         device=device, allow_tqdm=False, accumulate_in=accumulate_in, patches_per_forward=batch,
                         compute_dtype=compute_dtype)
     p._reduction = None
-    p.manual_initialization(None, pm, pm.get_configuration('3d_fullres'), [sd], dj, 'nnUNetDistillationTrainer',
+    p.manual_initialization(None, pm, pm.get_configuration('3d_fullres'), sds, dj, 'nnUNetDistillationTrainer',
                             (0, 1, 2) if mirror else None)
-    return p, sd, dict(features=features, kernels=kernels, strides=strides, patch=patch, heads=heads, r=r, resenc=resenc)
+    return p, sds[0], dict(features=features, kernels=kernels, strides=strides, patch=patch, heads=heads, r=r, resenc=resenc)
 
 
 def synthetic_volume(size, device):
@@ -210,8 +210,12 @@ def cpu_baseline(sd, info, seconds_budget=60.0):
     from oracle.topology import UNetSpec
     from oracle.unet import build as build_oracle
     n = len(info['features'])
-    spec = UNetSpec('plain', 1, info['heads'], info['features'], [tuple(k) for k in info['kernels']],
-                    [tuple(s) for s in info['strides']], [2] * n, [2] * (n - 1))
+    if info['resenc']:
+        spec = UNetSpec('resenc', 1, info['heads'], info['features'], [tuple(k) for k in info['kernels']],
+                        [tuple(s) for s in info['strides']], list(RESENC_BLOCKS[:n]), [1] * (n - 1))
+    else:
+        spec = UNetSpec('plain', 1, info['heads'], info['features'], [tuple(k) for k in info['kernels']],
+                        [tuple(s) for s in info['strides']], [2] * n, [2] * (n - 1))
     net = build_oracle(spec, sd)
     patch = info['patch']
     all_threads = torch.get_num_threads()
@@ -305,9 +309,14 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-sharded', action='store_true', help='run the multi-GPU code path even with one rank')
-    ap.add_argument('--gather', default='labels', choices=['labels', 'logits', 'none'],
-                    help='multi-GPU: what every rank holds when the step ends (labels: argmax on the owner, then '
-                         'all_gather of the uint8 slabs; logits: all_gather of the fp16 logits; none: owned boxes only)')
+    ap.add_argument('--gather', default='none', choices=['labels', 'logits', 'none'],
+                    help='multi-GPU: what the timed step ends with.  none (default): the N = 1 step sharded - every rank holds '
+                         'the fp16 logits of the box it owns in its HBM, nothing is assembled; labels: argmax on the owner, '
+                         'then all_gather of the uint8 slabs; logits: all_gather of the fp16 logits.  The assembled-labels '
+                         'step is always timed too and reported as ms_per_step_labels_assembled')
+    ap.add_argument('--folds', type=int, default=1,
+                    help='fold ensemble (BASELINE configs[3]: 5 folds of the teacher): the folds stay resident, their logits are '
+                         'averaged on the device (fnn_predict_volume_ensemble); one step = one volume through ALL folds')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -332,7 +341,7 @@ def main():
     torch.cuda.set_device(device)
 
     accumulate_in = args.accum                                  # halo sums travel in the accumulator dtype
-    predictor, sd, info = build_predictor(args.workload, device, args.batch, accumulate_in, args.dtype, args.mirror)
+    predictor, sd, info = build_predictor(args.workload, device, args.batch, accumulate_in, args.dtype, args.mirror, args.folds)
     vol = synthetic_volume(args.volume, device)
     from fast_nnunet_amd import capi
     n_patches = capi.plan_volume(info['patch'], vol.shape[1:], 0.5)[2].shape[0]
@@ -353,17 +362,20 @@ def main():
             dt = float(t.item())
         return dt
 
-    dt_nogather = None
+    dt_labels = None
+    fold_list = list(range(args.folds)) if args.folds > 1 else None
     if distributed:
         from fast_nnunet_amd.dist import ShardedPredictor
         runner = ShardedPredictor(predictor, dist.group.WORLD)
         if args.gather == 'labels':
             step_fn = lambda: runner.predict_segmentation_from_preprocessed_data(vol)
-            bare_fn = lambda: runner.predict_segmentation_from_preprocessed_data(vol, gather=False)
         else:
-            step_fn = lambda: runner.predict_sliding_window_return_logits(vol, gather=args.gather == 'logits')
-            bare_fn = lambda: runner.predict_sliding_window_return_logits(vol)
+            step_fn = lambda: runner.predict_sliding_window_return_logits(vol, gather=args.gather == 'logits', folds=fold_list)
+        labels_fn = lambda: runner.predict_segmentation_from_preprocessed_data(vol)
         barrier = lambda: dist.barrier()
+    elif args.folds > 1:
+        step_fn = lambda: predictor.predict_logits_from_preprocessed_data(vol, on_device=True)
+        barrier = lambda: None
     else:
         step_fn = lambda: predictor.predict_sliding_window_return_logits(vol)
         barrier = lambda: None
@@ -372,19 +384,21 @@ def main():
         out = step_fn()
         del out
     dt = timed(step_fn, barrier, args.steps)
-    if distributed and args.gather != 'none':
-        out = bare_fn()                                          # (one untimed call: first-use allocations of this entry point)
+    if distributed and args.gather != 'labels':
+        out = labels_fn()                                        # (one untimed call: first-use allocations of this entry point)
         del out
-        dt_nogather = timed(bare_fn, barrier, args.steps)        # the same step without the assembly: compute + halo
+        dt_labels = timed(labels_fn, barrier, max(1, min(args.steps, 5)))   # the step that ends with the label map on every rank
 
     flops_patch, act_bytes_patch = predictor._engine.patch_work()
     assembly = {'labels': 'labels on the owner of each box, all_gather of the uint8 slabs: the label map on every rank',
                 'logits': 'all_gather of the fp16 logits of the owned boxes: the logits on every rank',
-                'none': 'every rank keeps the logits of the box it owns'}[args.gather] if distributed else \
+                'none': 'fp16 logits in HBM, every rank holds the box of the volume it owns (the N = 1 step sharded; nothing assembled)'}[args.gather] if distributed else \
         'fp16 logits [heads, X, Y, Z] in HBM (predict_sliding_window_return_logits)'
+    out_kind = {'labels': 'label map assembled on every rank', 'logits': 'fp16 logits assembled on every rank',
+                'none': 'fp16 logits resident in HBM'}[args.gather] if distributed else 'fp16 logits resident in HBM'
     result = {
-        'metric': '3d_fullres patches/sec (distilled r=2 student, sliding window, one 512^3 CT)',
-        'value': round(n_patches * args.steps / dt, 3),
+        'metric': f'3d_fullres patches/sec (distilled r=2 student, sliding window, one 512^3 CT; step ends with: {out_kind})',
+        'value': round(n_patches * args.folds * args.steps / dt, 3),
         'unit': 'patches/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(dt / args.steps * 1e3, 3),
@@ -401,13 +415,18 @@ def main():
                                f'{args.volume}^3 volume, tile_step_size 0.5, Gaussian on, mirroring {"(0, 1, 2)" if args.mirror else "off"}, '
                                f'{n_patches} patches/volume',
                    'patches_per_forward': args.batch,
+                   'folds': args.folds,
                    'accumulators': accumulate_in,
                    'gflop_per_patch': round(flops_patch / 1e9, 2),
                    'step_output': assembly,
                    'parallelism': f'patch-sharded x{world}, patch-activation exchange + slab gather over RCCL' if distributed else 'single GPU'},
     }
-    if dt_nogather is not None:
-        result['ms_per_step_compute_and_halo_only'] = round(dt_nogather / args.steps * 1e3, 3)
+    if args.folds > 1:
+        result['sec_per_volume_per_fold'] = round(dt / args.steps / args.folds, 4)
+        result['config']['ensemble'] = (f'{args.folds} resident folds, logits averaged on the device; value counts one patch forward per fold '
+                                        f'({n_patches} x {args.folds} per volume), sec_per_volume is the whole ensemble')
+    if dt_labels is not None:
+        result['ms_per_step_labels_assembled'] = round(dt_labels / max(1, min(args.steps, 5)) * 1e3, 3)
     if distributed:
         # one extra, profiled step (the device is synchronised at every phase boundary, so it is slower than the timed
         # ones): where a rank's time goes and what it exchanges - per phase the MAX over ranks, bytes per rank as a list
@@ -424,27 +443,31 @@ def main():
             'note': 'wall ms per phase of one extra step with a device synchronisation at every phase boundary; max over ranks',
             **{k: round(float(allv[:, i].max()), 3) for i, k in enumerate(keys) if k.endswith('_ms')},
             'per_rank': {k: [int(v) for v in allv[:, i]] for i, k in enumerate(keys) if not k.endswith('_ms')},
-            'mode': 'gather' if runner._use_gather() else 'accumulate',
+            'mode': runner.last_mode,
             'rccl_ranks': dist.get_world_size()}
         assert dist.get_world_size() == args.gpus, 'the process group does not have one rank per requested GPU'
 
-    if rank == 0 and not distributed and not args.no_roofline:
+    if not args.no_roofline:
         # one extra, identical step with HIP events around every launch (recorded by the engine on the
-        # launch stream) -> duration of the dominant kernel family (the MFMA convs)
+        # launch stream) -> duration of the dominant kernel family (the MFMA convs).  N > 1: every rank runs the step (it is
+        # collective), rank 0's profile is quoted - of its last fnn_patch_features call, i.e. its interior patches
         predictor._engine.set_profiling(True)
         out = step_fn()
         del out
         torch.cuda.synchronize()
         pr = predictor._engine.profile()
         import collections
-        kernel_counts = dict(collections.Counter(predictor._engine.kernel_log()))   # which variant served every launch of that volume
+        kernel_counts = dict(collections.Counter(predictor._engine.kernel_log()))   # which variant served every launch of that volume (N > 1: of the last engine call)
         predictor._engine.set_profiling(False)
+    if rank == 0 and not args.no_roofline:
         achieved = pr.conv_flops / (pr.conv_ms * 1e-3) / 1e12 if pr.conv_ms > 0 else 0.0
         launches = max(1, pr.conv_launches)
         algo_bytes = pr.conv_bytes / launches
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, 'profiles', TRAFFIC_FILE)
-        if os.path.isfile(tpath):
+        if distributed:
+            traffic_src = 'counter traffic is captured for the single-GPU step only'
+        elif os.path.isfile(tpath):
             try:                                  # HBM bytes per launch of the same kernel family from separate PMC passes
                 tj = json.load(open(tpath))
                 if tj.get('csrc_sha256') != csrc_sha256():
@@ -474,10 +497,11 @@ def main():
             'time_share_ms': {'conv3d_mfma': round(pr.conv_ms, 2), 'stem': round(pr.stem_ms, 2),
                               'tconv': round(pr.tconv_ms, 2), 'seg_head_accumulate': round(pr.head_ms, 2),
                               'finalize': round(pr.finalize_ms, 2)},
-            'whole_net_tflops': round(flops_patch * n_patches / (dt / args.steps) / 1e12, 2),
+            'whole_net_tflops': round(flops_patch * n_patches * args.folds / (dt / args.steps) / 1e12, 2),
+            'profiled': 'rank 0, its interior patches (the last fnn_patch_features call of one extra step)' if distributed else 'one extra volume on one stream',
             'launches_by_kernel': kernel_counts,
         }
-    if rank == 0 and not distributed and not args.no_cpu_baseline and not info['resenc']:
+    if rank == 0 and not distributed and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(sd, info)
     if distributed:
         dist.barrier()

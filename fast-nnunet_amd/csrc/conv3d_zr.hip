@@ -46,7 +46,11 @@ static bool zr_pick(const ConvParams &p, int &nb, int &td) {
     static const int min_cout = fnn_knob("FNN_ZR_MIN_COUT") ? atoi(fnn_knob("FNN_ZR_MIN_COUT")) : 0;
     if (off || p.kd != 3 || p.kh != 3 || p.kw != 3 || p.sd != 1 || p.sh != 1 || p.sw != 1) return false;
     if (p.Cout > max_cout || p.Cout < min_cout) return false;
-    if ((long long)p.Di * p.Hi * p.Wi >= (1 << 23)) return false;                 // 24-bit voxel index arithmetic in the kernels
+    const long long vox = (long long)p.Do * p.Ho * p.Wo;                            // (stride 1: the input's size too; the plan's probe sets only the output's)
+    if (vox >= (1 << 23)) return false;                                             // 24-bit voxel index arithmetic in the kernels
+    // the staging's zero padding is a buffer offset of 0x80000000 that the range check must refuse: every source's batch
+    // item (and the output's) stays below 2^31 bytes - bounded here by all input channels together
+    if (vox * 32 * (p.chunks > 0 ? p.chunks : 1) >= (1ll << 31) || vox * 2 * p.Cout >= (1ll << 31)) return false;
     const int nblk = p.Cout / 16;
     nb = nblk % 2 == 0 ? 2 : 1;
     const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;

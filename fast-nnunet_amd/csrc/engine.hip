@@ -110,6 +110,7 @@ struct fnn_engine {
     int label_mode = FNN_LABELS_ARGMAX, label_u16 = 0;
     int *label_order = nullptr;             // device: regions_class_order[num_heads]
     int *origins = nullptr; size_t origins_cap = 0;
+    int *origins_host = nullptr; size_t origins_host_cap = 0; hipEvent_t origins_ev = nullptr;   // pinned staging, as for steps_dev below
     void *acc = nullptr; size_t acc_bytes = 0;
     float *vol_tmp = nullptr; size_t vol_tmp_bytes = 0;
     float *vol_pad = nullptr; size_t vol_pad_bytes = 0;
@@ -118,7 +119,10 @@ struct fnn_engine {
     // gather path (gather.hip): the last conv's raw output and InstanceNorm of every patch of the volume
     void *feat = nullptr; size_t feat_bytes = 0;
     void *featss = nullptr; size_t featss_bytes = 0;
+    void *featssh = nullptr; size_t featssh_bytes = 0;   // the same rows in fp16, staging layout (GatherParams::fssh)
     int *steps_dev = nullptr; size_t steps_cap = 0;
+    int *steps_host = nullptr; size_t steps_host_cap = 0;   // pinned staging of the tile-start / slot tables (no stream sync for a host temporary)
+    hipEvent_t steps_ev = nullptr;                          // the previous upload from steps_host has been read
     std::vector<std::string> klog;          // kernel variants of the last profiled call, one entry per launch (fnn_kernel_log)
     bool gather_enabled = true;             // FNN_NO_GATHER (read when the engine is created): always accumulate in HBM
     double head_flops = 0, patch_flops = 0, patch_act_bytes = 0;
@@ -163,6 +167,31 @@ int ensure(fnn_engine *e, void **p, size_t *have, size_t need) {
     *p = nullptr; *have = 0;
     HIPCHK(e, hipMalloc(p, need));
     *have = need;
+    return 0;
+}
+
+// Small integer tables (patch origins, tile starts, a sharded caller's slot table) -> device without a stream
+// synchronisation: the host copy lives in a pinned buffer the engine owns; the only wait is for the PREVIOUS upload from
+// that buffer to have been read (an event that has long fired by the next call).
+int upload_ints(fnn_engine *e, const int *src, size_t n, int **dev, size_t *dev_cap, int **host, size_t *host_cap,
+                hipEvent_t *ev, hipStream_t st) {
+    const size_t bytes = n * sizeof(int) + 64;
+    {
+        void *t = *dev;
+        if (int rc = ensure(e, &t, dev_cap, bytes)) return rc;
+        *dev = (int *)t;
+    }
+    if (!*ev) HIPCHK(e, hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    else HIPCHK(e, hipEventSynchronize(*ev));
+    if (*host_cap < bytes) {
+        if (*host) (void)hipHostFree(*host);
+        *host = nullptr; *host_cap = 0;
+        HIPCHK(e, hipHostMalloc((void **)host, bytes, hipHostMallocDefault));
+        *host_cap = bytes;
+    }
+    memcpy(*host, src, n * sizeof(int));
+    HIPCHK(e, hipMemcpyAsync(*dev, *host, n * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipEventRecord(*ev, st));
     return 0;
 }
 
@@ -401,7 +430,7 @@ int build_plan(fnn_engine *e) {
             L.chunks = (L.cin_pad[0] + (L.n_src > 1 ? L.cin_pad[1] : 0)) / 16;
             {
                 ConvParams q{};                               // the shape facts the launcher's variant choice looks at
-                q.plan_N = e->max_batch; q.N = e->max_batch; q.Cout = L.cout_pad;
+                q.plan_N = e->max_batch; q.N = e->max_batch; q.Cout = L.cout_pad; q.chunks = L.chunks;
                 q.Do = L.out_dims[0]; q.Ho = L.out_dims[1]; q.Wo = L.out_dims[2];
                 q.kd = L.k[0]; q.kh = L.k[1]; q.kw = L.k[2]; q.sd = L.s[0]; q.sh = L.s[1]; q.sw = L.s[2];
                 L.packing = L.fuse ? FNN_PACK_LINEAR : conv3d_packing(q);
@@ -429,7 +458,7 @@ int build_plan(fnn_engine *e) {
         else if (L.type == Layer::CONV && L.fuse) L.stats_slots = FNN_STAT_REPL;
         else if (L.type == Layer::CONV) {
             ConvParams q{};
-            q.plan_N = e->max_batch; q.N = e->max_batch; q.Cout = L.cout_pad;
+            q.plan_N = e->max_batch; q.N = e->max_batch; q.Cout = L.cout_pad; q.chunks = L.chunks;
             q.Do = L.out_dims[0]; q.Ho = L.out_dims[1]; q.Wo = L.out_dims[2];
             q.kd = L.k[0]; q.kh = L.k[1]; q.kw = L.k[2]; q.sd = L.s[0]; q.sh = L.s[1]; q.sw = L.s[2];
             L.stats_slots = conv3d_stats_slots(q);
@@ -642,7 +671,7 @@ SrcDesc make_src(fnn_engine *e, const FoldWeights &fw, int layer, int nb) {
 // arena (the gather path keeps them per patch)
 int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch_stride, const long long vdim[3],
                   const int *origins_dev, int nb, const int flip[3], hipStream_t st, f16 *head_out = nullptr,
-                  float *head_ss = nullptr) {
+                  float *head_ss = nullptr, unsigned short *head_ssh = nullptr) {
     const FoldWeights &fw = e->folds[fold];
     HIPCHK(e, hipMemsetAsync(e->stats, 0, e->stats_doubles * e->max_batch * sizeof(double), st));
     for (size_t li = 0; li < e->layers.size(); ++li) {
@@ -745,6 +774,7 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             q.ss = e->ss + L.ss_off * e->max_batch * 2; q.C = L.cout_pad; q.nrep = L.stats_slots;
             q.ssh = ssh_rows(e) + L.ss_off * e->max_batch * 2;
             if (head_ss && (int)li == e->head_src) q.ss = head_ss;
+            if (head_ssh && (int)li == e->head_src) q.ssh = head_ssh;
             q.inv_count = 1.f / ((float)L.out_dims[0] * L.out_dims[1] * L.out_dims[2]); q.eps = e->arch.eps;
             if (launch_stats_finalize(q, nb, st) != 0) return fail(e, FNN_E_HIP, "stats finalize launch failed");
         }
@@ -953,7 +983,8 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
                 const size_t item = (size_t)ci * n_slots + slot0 + p0;
                 if (int rc = forward_batch(e, fold, vol_dev, 0, vdim, org, nb, flip, st,
                                            (f16 *)(feat_ext ? feat_ext : e->feat) + item * P * featC,
-                                           (fss_ext ? fss_ext : (float *)e->featss) + item * 2 * featC)) return rc;
+                                           (fss_ext ? fss_ext : (float *)e->featss) + item * 2 * featC,
+                                           feat_ext ? nullptr : (unsigned short *)e->featssh + item * 2 * featC)) return rc;
                 continue;
             }
             if (int rc = forward_batch(e, fold, vol_dev, 0, vdim, org, nb, flip, st)) return rc;
@@ -1033,13 +1064,7 @@ int upload_origins(fnn_engine *e, const VolPlan &vp, const std::vector<int64_t> 
     std::vector<int> host(ids.size() * 3);
     for (size_t i = 0; i < ids.size(); ++i)
         for (int d = 0; d < 3; ++d) host[i * 3 + d] = vp.origins[ids[i] * 3 + d];
-    const size_t need = host.size() * sizeof(int) + 64;
-    void *t = e->origins;
-    if (int rc = ensure(e, &t, &e->origins_cap, need)) return rc;
-    e->origins = (int *)t;
-    HIPCHK(e, hipMemcpyAsync(e->origins, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCHK(e, hipStreamSynchronize(st));       // `host` is a temporary
-    return 0;
+    return upload_ints(e, host.data(), host.size(), &e->origins, &e->origins_cap, &e->origins_host, &e->origins_host_cap, &e->origins_ev, st);
 }
 
 FinalizeParams make_finalize(fnn_engine *e, const void *acc, const Box &box, const int64_t out_lo[3],
@@ -1086,16 +1111,17 @@ struct GatherPlan { bool ok = false; int n_eval = 1, ring = 0, cover = 1; size_t
 // No gather when the head does not fit the kernel's registers or when not even the layers that cover one output slab fit
 // next to what is already allocated; otherwise the whole volume's patches when they fit (one launch at the end), else
 // a ring of `cover` layers with one launch per output slab.
-GatherPlan gather_plan(fnn_engine *e, const VolPlan &vp, const fnn_opts &o) {
+GatherPlan gather_plan(fnn_engine *e, const VolPlan &vp, const fnn_opts &o, size_t pending_bytes = 0) {
     GatherPlan gp;
     gp.why = "FNN_NO_GATHER is set or the output is not fp16";
     if (!e->gather_enabled || o.out_dtype != FNN_OUT_F16) return gp;
     const Layer &H = e->layers[e->head_src];
     GatherParams g{};
     g.heads = e->arch.num_heads; g.C = H.cout_pad; g.PD = e->arch.patch[0]; g.PH = e->arch.patch[1]; g.PW = e->arch.patch[2];
+    g.nx = (int)vp.steps[0].size(); g.ny = (int)vp.steps[1].size(); g.nz = (int)vp.steps[2].size();
     gp.n_eval = 1 + (int)mirror_combos(o).size();
     g.n_eval = gp.n_eval; g.n_pass = e->n_gpass;
-    gp.why = "the network's head does not fit the gather kernel (a normalised last layer of <= 32 channels, <= 8 evaluations per patch)";
+    gp.why = "the network's head does not fit the gather kernel (a normalised last layer of <= 32 channels, <= 8 evaluations per patch, <= 64 tile positions per axis)";
     if (!H.has_norm || e->head_ksteps != 1 || !gather_ok(g)) return gp;
     gp.why = "not enough free HBM for the patch activations that cover one output slab";
     const auto &sx = vp.steps[0];
@@ -1113,7 +1139,8 @@ GatherPlan gather_plan(fnn_engine *e, const VolPlan &vp, const fnn_opts &o) {
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return gp;
     const double frac = fnn_knob("FNN_GATHER_MEM_FRACTION") ? atof(fnn_knob("FNN_GATHER_MEM_FRACTION")) : 0.6;
     const int force_ring = fnn_knob("FNN_GATHER_RING") ? atoi(fnn_knob("FNN_GATHER_RING")) : 0;     // tests: a ring although all fits
-    const double budget = frac * (double)(free_b + e->feat_bytes + e->acc_bytes);       // the accumulators are not needed then
+    // (the accumulators are not needed then; `pending_bytes`: what the caller still allocates after this plan - output / label staging)
+    const double budget = frac * ((double)(free_b + e->feat_bytes + e->acc_bytes) - (double)pending_bytes);
     if (!force_ring && (double)layer_bytes * nx <= budget) gp.ring = nx;
     else if ((double)layer_bytes * gp.cover <= budget) gp.ring = std::min(nx, std::max(gp.cover, force_ring));
     else return gp;
@@ -1131,20 +1158,15 @@ int gather_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const Vol
     if (int rc = ensure(e, &e->feat, &e->feat_bytes, gp.feat_bytes)) return rc;
     const int64_t n_slots = (int64_t)gp.layer_items * gp.ring;
     if (int rc = ensure(e, &e->featss, &e->featss_bytes, (size_t)n_slots * gp.n_eval * 2 * H.cout_pad * sizeof(float))) return rc;
+    if (int rc = ensure(e, &e->featssh, &e->featssh_bytes, (size_t)n_slots * gp.n_eval * 2 * H.cout_pad * sizeof(f16))) return rc;
     std::vector<int> steps;
     for (int d = 0; d < 3; ++d) for (int64_t v : vp.steps[d]) steps.push_back((int)v);
-    {
-        void *t = e->steps_dev;
-        if (int rc = ensure(e, &t, &e->steps_cap, steps.size() * sizeof(int) + 64)) return rc;
-        e->steps_dev = (int *)t;
-    }
-    HIPCHK(e, hipMemcpyAsync(e->steps_dev, steps.data(), steps.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCHK(e, hipStreamSynchronize(st));                       // `steps` is a temporary
+    if (int rc = upload_ints(e, steps.data(), steps.size(), &e->steps_dev, &e->steps_cap, &e->steps_host, &e->steps_host_cap, &e->steps_ev, st)) return rc;
     Box box;
     for (int d = 0; d < 3; ++d) { box.lo[d] = 0; box.hi[d] = vp.padded[d]; }
     const FoldWeights &fw = e->folds[fold];
     GatherParams g{};
-    g.feat = (const f16 *)e->feat; g.fss = (const float *)e->featss; g.C = H.cout_pad;
+    g.feat = (const f16 *)e->feat; g.fss = (const float *)e->featss; g.fssh = (const unsigned short *)e->featssh; g.C = H.cout_pad;
     g.n_eval = gp.n_eval; g.n_slots = (int)n_slots; g.ring = gp.ring;
     {
         const auto combos = mirror_combos(o);
@@ -1215,23 +1237,33 @@ int predict_impl(fnn_engine *e, int fold0, int n_folds, const float *vol, const 
     const size_t nout = (size_t)a.num_heads * nvox_out;
     const size_t osz = o->out_dtype == FNN_OUT_F32 ? 4 : 2;
     const bool want_logits = out != nullptr;
-    // (the plan first: nothing is allocated yet when it refuses the request, and it decides how labels are formed)
-    const GatherPlan gp = gather_plan(e, vp, *o);
+    const bool out_on_dev = out && is_device_ptr(out);
+    const bool lab_on_dev = labels && is_device_ptr(labels);
+    const size_t lab_bytes = nvox_out * (e->label_u16 ? 2 : 1);
+    // (the plan first: nothing is allocated yet when it refuses the request, and it decides how labels are formed; the
+    // staging buffers that ARE allocated afterwards - fp16 / fp32 logits when the caller's are on the host or the labels
+    // come from materialised logits, the label map of a host caller - come out of its budget)
+    size_t pending = 0;
+    {
+        const bool maybe_direct = labels && !want_logits && n_folds == 1 && e->n_gpass == 1;
+        if (!maybe_direct && !out_on_dev && nout * osz > e->out_tmp_bytes) pending += nout * osz - e->out_tmp_bytes;
+        if (labels && !lab_on_dev) pending += lab_bytes;
+    }
+    const GatherPlan gp = gather_plan(e, vp, *o, pending);
     if (!gp.ok && o->accum == FNN_ACC_FP16_AUTOCAST)
         return fail(e, FNN_E_UNSUPPORTED, "FNN_ACC_FP16_AUTOCAST needs the gather path: %s", gp.why);
     // argmax straight from the accumulators / the gather kernel's registers; with more than 63 classes the gather kernel
     // runs in passes over the heads, so the labels come from its logits
-    const bool labels_direct = labels && !want_logits && n_folds == 1 && !(gp.ok && e->n_gpass > 1);
+    // (accumulate path: labels_from_acc_coop_kernel covers up to 32 lanes of 8 channels per voxel - 254 classes; beyond, the
+    // labels come from the logits like an ensemble's)
+    const bool labels_direct = labels && !want_logits && n_folds == 1 && !(gp.ok && e->n_gpass > 1) && (gp.ok || acc_hp(a) <= 256);
     void *out_dev = out;
-    const bool out_on_dev = out && is_device_ptr(out);
     if (!labels_direct && !out_on_dev) {
         if (int rc = ensure(e, &e->out_tmp, &e->out_tmp_bytes, nout * osz)) return rc;
         out_dev = e->out_tmp;
     }
     void *lab_dev = labels;
-    const bool lab_on_dev = labels && is_device_ptr(labels);
     void *lab_tmp = nullptr;
-    const size_t lab_bytes = nvox_out * (e->label_u16 ? 2 : 1);
     const int *lab_order = e->label_mode == FNN_LABELS_REGIONS ? e->label_order : nullptr;
     if (labels && !e->label_u16 && e->label_mode == FNN_LABELS_ARGMAX && a.num_heads > 256)
         return fail(e, FNN_E_INVALID, "%d classes do not fit uint8 labels: fnn_set_label_rule(..., FNN_LABEL_U16)", a.num_heads);
@@ -1337,7 +1369,11 @@ void fnn_destroy(fnn_engine *e) {
         if (k > 0) { (void)hipFree(e->actp[k]); (void)hipFree(e->statsp[k]); (void)hipFree(e->ssp[k]); }
     }
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
-    void *ptrs[] = {e->feat, e->featss, e->steps_dev, e->ones, e->label_order, e->act, e->stats, e->ss, e->gauss, e->inf_flag, e->origins, e->acc, e->vol_tmp, e->vol_pad, e->out_tmp, e->patch_buf};
+    if (e->steps_ev) (void)hipEventDestroy(e->steps_ev);
+    if (e->origins_ev) (void)hipEventDestroy(e->origins_ev);
+    if (e->steps_host) (void)hipHostFree(e->steps_host);
+    if (e->origins_host) (void)hipHostFree(e->origins_host);
+    void *ptrs[] = {e->feat, e->featss, e->featssh, e->steps_dev, e->ones, e->label_order, e->act, e->stats, e->ss, e->gauss, e->inf_flag, e->origins, e->acc, e->vol_tmp, e->vol_pad, e->out_tmp, e->patch_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ev : e->evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     delete e;
@@ -1501,6 +1537,8 @@ int fnn_labels_box(fnn_engine *e, const void *acc, const int64_t shape[4], const
     if (int rc = no_autocast(e, opts, "fnn_labels_box")) return rc;
     if (!acc || !labels || !box_lo || !box_hi || !out_lo || !out_hi) return fail(e, FNN_E_INVALID, "NULL argument");
     if (!is_device_ptr(acc) || !is_device_ptr(labels)) return fail(e, FNN_E_INVALID, "fnn_labels_box needs device pointers");
+    if (acc_hp(e->arch) > 256)
+        return fail(e, FNN_E_UNSUPPORTED, "fnn_labels_box serves up to 254 classes (%d here): take the logits (fnn_normalize_box) and fnn_argmax_labels", e->arch.num_heads);
     if (!e->label_u16 && e->label_mode == FNN_LABELS_ARGMAX && e->arch.num_heads > 256)
         return fail(e, FNN_E_INVALID, "%d classes do not fit uint8 labels: fnn_set_label_rule(..., FNN_LABEL_U16)", e->arch.num_heads);
     HIPCHK(e, hipSetDevice(e->device));
@@ -1573,6 +1611,7 @@ int fnn_gather_box(fnn_engine *e, int fold, const void *feat, const float *fss, 
     GatherParams g{};
     g.heads = a.num_heads; g.C = H.cout_pad; g.PD = a.patch[0]; g.PH = a.patch[1]; g.PW = a.patch[2]; g.n_eval = 1 + (int)combos.size();
     g.n_pass = e->n_gpass;
+    g.nx = (int)vp.steps[0].size(); g.ny = (int)vp.steps[1].size(); g.nz = (int)vp.steps[2].size();
     if (labels && e->n_gpass > 1)
         return fail(e, FNN_E_UNSUPPORTED, "fnn_gather_box writes labels for <= 63 classes; with %d take the logits and fnn_argmax_labels", a.num_heads);
     if (!H.has_norm || e->head_ksteps != 1 || !gather_ok(g)) return fail(e, FNN_E_UNSUPPORTED, "this network's head does not fit the gather kernel");
@@ -1583,16 +1622,15 @@ int fnn_gather_box(fnn_engine *e, int fold, const void *feat, const float *fss, 
     for (int d = 0; d < 3; ++d) for (int64_t v : vp.steps[d]) tab.push_back((int)v);
     const size_t n_steps = tab.size();
     for (int64_t i = 0; i < vp.n_patches; ++i) tab.push_back(slot_of_patch[i]);
-    {
-        void *t = e->steps_dev;
-        if (int rc = ensure(e, &t, &e->steps_cap, tab.size() * sizeof(int) + 64)) return rc;
-        e->steps_dev = (int *)t;
-    }
-    HIPCHK(e, hipMemcpyAsync(e->steps_dev, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCHK(e, hipStreamSynchronize(st));                       // `tab` is a temporary
+    if (int rc = upload_ints(e, tab.data(), tab.size(), &e->steps_dev, &e->steps_cap, &e->steps_host, &e->steps_host_cap, &e->steps_ev, st)) return rc;
     HIPCHK(e, hipMemsetAsync(e->inf_flag, 0, sizeof(int), st));
     const FoldWeights &fw = e->folds[fold];
-    g.feat = (const f16 *)feat; g.fss = fss;
+    {   // the kernel reads the InstanceNorm rows in the conv kernels' fp16 staging layout: converted from the caller's fp32 rows
+        const size_t items = (size_t)n_slots * g.n_eval;
+        if (int rc = ensure(e, &e->featssh, &e->featssh_bytes, items * 2 * H.cout_pad * sizeof(f16))) return rc;
+        if (launch_fss_to_ssh(fss, (unsigned short *)e->featssh, (long long)items, H.cout_pad, st) != 0) return fail(e, FNN_E_HIP, "row conversion launch failed");
+    }
+    g.feat = (const f16 *)feat; g.fss = fss; g.fssh = (const unsigned short *)e->featssh;
     g.n_slots = (int)n_slots; g.ring = 1; g.flipmask[0] = 0;       // evaluation f of slot s: item f * n_slots + s (fnn_patch_features)
     for (size_t ci = 0; ci < combos.size() && ci + 1 < 8; ++ci) {
         int m = 0;

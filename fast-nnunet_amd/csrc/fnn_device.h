@@ -183,6 +183,7 @@ struct GatherParams {
     const f16 *feat;             // [n_eval][n_slots][PD][PH][PW][C]: raw output of the network's last conv per (mirrored
                                  // evaluation, patch slot); patch (ix, iy, iz) sits in slot ((ix % ring) * ny + iy) * nz + iz
     const float *fss;            // [n_eval][n_slots][2][C]: scale row, shift row of its InstanceNorm
+    const unsigned short *fssh;  // the same rows as fp16 in the staging layout of SrcDesc::ssh: [n_eval][n_slots][C / 8][16] (8 scales, 8 shifts)
     int n_eval;                  // 1, or 1 + the number of mirror-axis subsets (test-time mirroring)
     int flipmask[8];             // per evaluation: bit 0 / 1 / 2 = the network input was flipped along d / h / w
     int n_slots, ring;           // ring = x layers of patches kept (nx: the whole volume)
@@ -319,6 +320,7 @@ struct StatsFinalizeParams {
 
 // launchers (implemented in the .hip files)
 int launch_stats_finalize(const StatsFinalizeParams &p, int N, hipStream_t st);
+int launch_fss_to_ssh(const float *fss, unsigned short *ssh, long long items, int C, hipStream_t st);   // [items][2][C] fp32 rows -> [items][C / 8][16] fp16 (SrcDesc::ssh)
 int launch_avgpool(const PoolParams &p, hipStream_t st);
 int launch_combine(const CombineParams &p, hipStream_t st);
 int launch_conv3d(const ConvParams &p, hipStream_t st);

@@ -105,6 +105,25 @@ int launch_stats_finalize(const StatsFinalizeParams &p, int N, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// (scale, shift) rows of kept patch activations, fp32 [items][2][C] as the C ABI hands them over (fnn_patch_features) ->
+// the fp16 staging layout stats_finalize_kernel writes next to its fp32 rows (SrcDesc::ssh): the same roundings
+__global__ __launch_bounds__(256) void fss_to_ssh_kernel(const float *fss, unsigned short *ssh, long long n, int C) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // (item, channel)
+    if (i >= n) return;
+    const long long item = i / C;
+    const int c = (int)(i - item * C);
+    f16 *h = (f16 *)ssh + (item * C + (c & ~7)) * 2 + (c & 7);
+    h[0] = (f16)fss[item * 2 * C + c];
+    h[8] = (f16)fss[item * 2 * C + C + c];
+}
+
+int launch_fss_to_ssh(const float *fss, unsigned short *ssh, long long items, int C, hipStream_t st) {
+    const long long n = items * C;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(fss_to_ssh_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fss, ssh, n, C);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // Normalise + LeakyReLU of a raw fragment of 8 channels starting at c0 (zero beyond the source's channels).
 static __device__ __forceinline__ f16x8 norm_act_frag(const SrcDesc &s, const f16x8 &x, int c0, const float2 *sSS) {
     const bool live = c0 < s.C;

@@ -370,34 +370,41 @@ class ShardedPredictor:
         p = self.p
         return mirror_flips(p.allowed_mirroring_axes if p.use_mirroring else None)
 
-    def _use_gather(self, n_slots: Optional[int] = None) -> bool:
-        """The gather path applies where the engine's gather kernel does (<= 32 channels at full resolution, <= 8
-        evaluations per patch; more than 63 classes run as passes over the heads) AND the kept activations fit: `n_slots` patch slots per evaluation
-        against 80 % of the free HBM (the single-GPU engine bounds the same buffers, csrc/engine.hip gather_plan).
-        'auto' falls back to the accumulate path; 'gather' raises."""
+    def _gather_fits(self, n_slots: Optional[int] = None, counts: Optional[Sequence[int]] = None) -> Tuple[bool, str]:
+        """Does the gather path apply on THIS rank: the engine's gather kernel does (<= 32 channels at full resolution,
+        <= 8 evaluations per patch, <= 64 tile positions per axis; more than 63 classes run as passes over the heads) AND
+        the kept activations fit - `n_slots` patch slots per evaluation against 80 % of the free HBM (the single-GPU engine
+        bounds the same buffers, csrc/engine.hip gather_plan).  Never raises: the decision is a collective one."""
         p = self.p
         n_eval = len(self._flips())
-        ok = n_eval <= 8 and p._spec.features[0] <= 32
-        why = 'the gather path needs <= 32 channels at full resolution and <= 8 evaluations per patch'
-        if ok and n_slots is not None and p.device.type == 'cuda':
+        if not (n_eval <= 8 and p._spec.features[0] <= 32 and (counts is None or max(counts) <= 64)):
+            return False, ('the gather path needs <= 32 channels at full resolution, <= 8 evaluations per patch and <= 64 tile '
+                           'positions per axis')
+        if n_slots is not None and p.device.type == 'cuda':
             C = p._engine.feature_channels
             need = n_eval * n_slots * (int(np.prod(p._spec.patch)) * C * 2 + 2 * C * 4)
             free = torch.cuda.mem_get_info(p.device)[0]
             if need > 0.8 * free:
-                ok, why = False, f'the kept patch activations need {need / 2 ** 30:.1f} GiB, {free / 2 ** 30:.1f} GiB are free'
-        if self.mode == 'gather' and not ok:
-            raise NotImplementedError(why)
-        return ok and self.mode != 'accumulate'
+                return False, f'the kept patch activations need {need / 2 ** 30:.1f} GiB, {free / 2 ** 30:.1f} GiB are free'
+        return True, ''
 
-    def _use_gather_all(self, slots) -> bool:
+    last_mode = None                                # 'gather' | 'accumulate': the path the last step really took
+
+    def _use_gather_all(self, slots, counts=None) -> bool:
         """The same path on every rank: a rank whose activations do not fit sends the whole group to the accumulate path
-        (the two exchanges do not pair up)."""
-        local = self._use_gather(None if slots is None else len(slots[2]))
-        if self.world == 1:
-            return local
-        flag = torch.tensor([1 if local else 0], dtype=torch.int32, device=self.p.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        return bool(int(flag.item()))
+        (the two exchanges do not pair up).  mode='gather' raises - on EVERY rank, after the collective, so that no rank is
+        left waiting in it - when one rank cannot."""
+        local, why = self._gather_fits(None if slots is None else len(slots[2]), counts)
+        flag_all = local
+        if self.world > 1:
+            flag = torch.tensor([1 if local else 0], dtype=torch.int32, device=self.p.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            flag_all = bool(int(flag.item()))
+        if self.mode == 'gather' and not flag_all:
+            raise NotImplementedError(why or 'another rank of the group cannot take the gather path')
+        use = flag_all and self.mode != 'accumulate'
+        self.last_mode = 'gather' if use else 'accumulate'
+        return use
 
     def _slots(self, dec, origins):
         """(boundary, interior, slot_of) of this rank: own patches first (boundary, then interior), then the foreign ones."""
@@ -520,7 +527,7 @@ class ShardedPredictor:
             box, own = dec.boxes[self.rank], owns[self.rank]
             part = None
             slots = self._slots(dec, origins) if dec.owned[self.rank] is not None else None
-            use_gather = self._use_gather_all(slots)
+            use_gather = self._use_gather_all(slots, [len(set(int(v) for v in origins[:, d])) for d in range(3)])
             for i, f in enumerate(folds):
                 if use_gather:
                     got = self._features_fold(x, dec, origins, opts, f, slots)
@@ -577,7 +584,7 @@ class ShardedPredictor:
                 opts = p._opts()
                 box, own = dec.boxes[self.rank], owns[self.rank]
                 slots = self._slots(dec, origins) if dec.owned[self.rank] is not None else None
-                if self._use_gather_all(slots):
+                if self._use_gather_all(slots, [len(set(int(v) for v in origins[:, d])) for d in range(3)]):
                     got = self._features_fold(x, dec, origins, opts, p._active_fold, slots)
                     if own is not None:
                         t0 = self._tick()

@@ -236,8 +236,9 @@ class nnUNetPredictor(object):
         return out if self.perform_everything_on_device else out.cpu()
 
     @torch.inference_mode()
-    def predict_logits_from_preprocessed_data(self, data: torch.Tensor) -> torch.Tensor:
-        """Mean over the folds; returned on the CPU like the reference (:471-504)."""
+    def predict_logits_from_preprocessed_data(self, data: torch.Tensor, on_device: bool = False) -> torch.Tensor:
+        """Mean over the folds; returned on the CPU like the reference (:471-504) unless ``on_device`` (not in the
+        reference: skips its 15 GiB device-to-host copy of a 61-class 512^3 volume)."""
         self._check_input(data)
         with torch.cuda.device(self.device):
             x = data.to(device=self.device, dtype=torch.float32).contiguous()
@@ -245,7 +246,7 @@ class nnUNetPredictor(object):
             self._engine.predict_volume(x.data_ptr(), x.shape, self._opts(), out.data_ptr(), n_folds=self._n_folds)
         if self.verbose:
             print('Prediction done')
-        return out.to('cpu')
+        return out if on_device else out.to('cpu')
 
     @torch.inference_mode()
     def predict_single_npy_array(self, input_image: np.ndarray, image_properties: dict,

@@ -36,20 +36,36 @@ def _patches(j):
 
 
 def test_bench_force_sharded_single_rank_runs_the_multi_gpu_path():
-    """`--gpus 1 --force-sharded`: the rank-sharded code path (RCCL process group, patch-activation exchange, labels on the owner,
-    all_gather of the label slabs) on one GPU - the line the driver would get from every rank 0 at N > 1."""
+    """`--gpus 1 --force-sharded`: the rank-sharded code path (RCCL process group, patch-activation exchange, the owner's box
+    formed by fnn_gather_box) on one GPU - the line the driver would get from every rank 0 at N > 1.  Round 4: the timed
+    step is the N = 1 step sharded (fp16 logits of the owned box resident in HBM; the metric string says so), the
+    assembled-labels step is a named extra key, and the line carries rank 0's roofline block."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--volume', '192', '--steps', '1', '--warmup', '1',
                           '--gpus', '1', '--force-sharded'], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
     j = json.loads(lines[0])
-    assert j['n_gpus'] == 1 and 'patch-sharded x1' in j['config']['parallelism'] and 'all_gather' in j['config']['step_output']
+    assert j['n_gpus'] == 1 and 'patch-sharded x1' in j['config']['parallelism']
+    assert 'nothing assembled' in j['config']['step_output'] and 'fp16 logits resident in HBM' in j['metric']
     # (single-step timings of a 7 ms step on a shared box: the same order of magnitude is all that can be asserted)
-    assert j['value'] > 0 and 0 < j['ms_per_step_compute_and_halo_only'] <= j['ms_per_step'] * 3 + 50
+    assert j['value'] > 0 and 0 < j['ms_per_step_labels_assembled'] <= j['ms_per_step'] * 3 + 50
     ph = j['phases_profiled_step']
     assert ph['rccl_ranks'] == 1 and ph['mode'] == 'gather' and ph['gather_box_ms'] > 0 and ph['per_rank']['n_interior_patches'][0] > 0
-    assert 'roofline' not in j and 'cpu_baseline' not in j
+    r = j['roofline']
+    assert r['bound'] == 'mfma' and r['achieved'] > 0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and r['traffic'] is None
+    assert 'cpu_baseline' not in j
+
+
+def test_bench_fold_ensemble_line():
+    """`--folds 2`: BASELINE configs[3] is a fold ENSEMBLE (predict_from_raw_data.py:483-500); the folds stay resident and
+    one step is one volume through all of them."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--volume', '192', '--steps', '1', '--warmup', '1',
+                          '--workload', 'iso128_r2', '--folds', '2', '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+    assert j['config']['folds'] == 2 and abs(j['sec_per_volume_per_fold'] * 2 - j['sec_per_volume']) < 2e-4
+    assert abs(j['value'] - 1000.0 * 2 * _patches(j) / j['ms_per_step']) / j['value'] < 1e-3
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():

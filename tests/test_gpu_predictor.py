@@ -978,6 +978,34 @@ def test_gather_kernel_variants_in_the_autocast_arithmetic(heads, mirror):
     assert torch.equal(p.predict_segmentation_from_preprocessed_data(image).long().cpu(), osw.logits_to_labels(want).long())
 
 
+@pytest.mark.parametrize('accum', ['fp16', 'fp16_autocast'])
+@pytest.mark.parametrize('heads', [3, 20, 61])
+def test_gather_k16_head_is_the_k32_head_bit_for_bit(heads, accum):
+    """Round 4: a last layer of 16 channels runs the gather kernel's head as v_mfma_f32_16x16x16_f16 (a lane holds 4
+    channels of its voxel) instead of a K = 32 operand whose upper half is zero.  tools/hw_probe.cpp found the two MFMA
+    forms bit-identical on 16.8 M random values; here the whole driver: logits and labels with the K = 32 kernels forced
+    (FNN_GATHER_K32, which also keeps those 12 variants - what 32-channel networks run - under test on small volumes)."""
+    spec = UNetSpec('plain', 1, heads, [16, 32], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
+    patch = (16, 16, 32)
+    p = _predictor(spec, patch, [synthetic_state_dict(spec, 540)], accumulate_in=accum)
+    image = torch.randn(1, 37, 30, 70, generator=torch.Generator().manual_seed(43))
+    os.environ.pop('FNN_GATHER_K32', None)
+    logits, labels = p.predict_sliding_window_return_logits(image), p.predict_segmentation_from_preprocessed_data(image)
+    p._engine.set_profiling(True)
+    p.predict_sliding_window_return_logits(image)
+    assert any(k.startswith('gather_head_kernel') and k.endswith(',1>') for k in p._engine.kernel_log())
+    os.environ['FNN_GATHER_K32'] = '1'
+    try:
+        p.predict_sliding_window_return_logits(image)
+        assert any(k.startswith('gather_head_kernel') and k.endswith(',0>') for k in p._engine.kernel_log())
+        p._engine.set_profiling(False)
+        assert np.array_equal(_bits(p.predict_sliding_window_return_logits(image)), _bits(logits))
+        assert torch.equal(p.predict_segmentation_from_preprocessed_data(image), labels)
+    finally:
+        os.environ.pop('FNN_GATHER_K32', None)
+        p._engine.set_profiling(False)
+
+
 @pytest.mark.parametrize('mirror', [None, (0, 1, 2), (1,)])
 def test_gather_ring_and_mirroring_are_bit_identical_to_the_accumulate_path(mirror):
     """The gather path with test-time mirroring (the 2^k evaluations' logits summed per visit, predict_from_raw_data.py:

@@ -435,3 +435,19 @@ def test_no_wide_buffer_store_of_the_library_has_a_register_soffset(tmp_path):
                 bad.append(line.strip())
     assert n >= 100, f'only {n} wide buffer stores found'
     assert not bad, bad[:5]
+
+
+def test_committed_counter_traffic_belongs_to_the_kernel_sources_in_the_tree():
+    """bench.py quotes `roofline.traffic` from profiles/<round>_traffic.json only while its csrc_sha256 matches the HIP
+    sources; a later kernel edit silently turns the figure into `traffic: null`.  This fails instead: re-capture
+    (tools/capture.sh) after the last kernel change of a round, or delete the file."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    path = os.path.join(ROOT, 'profiles', bench.TRAFFIC_FILE)
+    if not os.path.isfile(path):
+        pytest.skip(f'no profiles/{bench.TRAFFIC_FILE} yet')
+    doc = json.load(open(path))
+    assert doc.get('csrc_sha256') == bench.csrc_sha256(), \
+        f'profiles/{bench.TRAFFIC_FILE} was captured on other kernel sources: re-run tools/capture.sh (FNN_ROUND) and commit it'
+    assert any(k.startswith('bone_turbo_r2|f16|mirror=0|fp16|') for k in doc.get('workloads', {}))

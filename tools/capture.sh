@@ -4,7 +4,7 @@
 # (separate runs, no trace domains next to --pmc), the MFMA-busy pass, and the plain bench line.  Every pass under `timeout`.
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
-round=${FNN_ROUND:-r03}
+round=${FNN_ROUND:-r04}
 out=$root/gpurun_out/cap_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): FNN_ROUND=r03 bash tools/capture_all.sh   - every workload DESIGN.md quotes, each with tools/capture.sh
+# usage (GPU box, repo root): FNN_ROUND=r04 bash tools/capture_all.sh   - every workload DESIGN.md quotes, each with tools/capture.sh
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root
 run() { tag=$1; shift; echo "######## $tag: $*"; bash tools/capture.sh $tag "$@" 2>&1 | tail -28; }
