@@ -62,7 +62,7 @@ class Profile(C.Structure):
 
 EXPORTS = ['fnn_abi_version', 'fnn_last_error', 'fnn_create', 'fnn_destroy', 'fnn_weight_count', 'fnn_load_weights',
            'fnn_set_gaussian', 'fnn_predict_volume', 'fnn_predict_volume_ensemble', 'fnn_predict_labels',
-           'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_labels_box', 'fnn_feature_channels', 'fnn_patch_features', 'fnn_gather_box', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_export_probabilities', 'fnn_resample', 'fnn_compute_steps', 'fnn_plan_volume', 'fnn_fp8_e4m3_encode',
+           'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_labels_box', 'fnn_feature_channels', 'fnn_patch_features', 'fnn_gather_box', 'fnn_pack_regions', 'fnn_unpack_regions', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_export_probabilities', 'fnn_resample', 'fnn_compute_steps', 'fnn_plan_volume', 'fnn_fp8_e4m3_encode',
            'fnn_set_profiling', 'fnn_get_profile', 'fnn_kernel_log', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d', 'fnn_op_quotient_check', 'fnn_op_last_kernels']
 
 _lib = None
@@ -107,6 +107,8 @@ def load_library() -> C.CDLL:
     lib.fnn_feature_channels.restype = i64
     lib.fnn_patch_features.argtypes = [vp, i32, vp, P64, C.POINTER(Opts), P64, i64, vp, vp, i64, i64]
     lib.fnn_gather_box.argtypes = [vp, i32, vp, vp, C.POINTER(C.c_int32), i64, P64, C.POINTER(Opts), P64, P64, vp, vp]
+    lib.fnn_pack_regions.argtypes = [vp, vp, i64, vp, i64, vp, vp]
+    lib.fnn_unpack_regions.argtypes = [vp, vp, i64, vp, i64, vp, vp]
     lib.fnn_forward_patches.argtypes = [vp, i32, vp, i32, vp, vp]
     lib.fnn_argmax_labels.argtypes = [vp, vp, i32, i32, i64, vp, vp]
     lib.fnn_nonzero_bbox.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64), vp]
@@ -130,7 +132,7 @@ def load_library() -> C.CDLL:
     lib.fnn_op_conv_transpose3d.argtypes = [i32, i32, I3, f32p, i32, f32p, f32p, C.c_float, f32p, f32p, i32, I3, f32p]
     lib.fnn_op_quotient_check.argtypes = [i32, C.POINTER(C.c_uint64)]
     lib.fnn_op_last_kernels.argtypes = [C.c_char_p, i32]
-    if lib.fnn_abi_version() != 3:
+    if lib.fnn_abi_version() != 4:
         raise EngineError('libfnn_hip.so has an unexpected ABI version')
     _lib = lib
     return lib
@@ -399,6 +401,15 @@ class Engine:
         lo, hi = (C.c_int64 * 3)(*[int(i) for i in out_lo]), (C.c_int64 * 3)(*[int(i) for i in out_hi])
         check(self.lib.fnn_gather_box(self.handle, fold, feat_ptr, fss_ptr, tab.ctypes.data_as(C.POINTER(C.c_int32)),
                                       C.c_int64(max(1, n_slots)), shp, C.byref(opts), lo, hi, logits_ptr, labels_ptr),
+              self.lib, self.handle)
+
+    def pack_regions(self, feat_ptr, n_slots, regions_ptr, n, message_ptr, stream=0):
+        """`n` sub-blocks of the kept activations (device table of fnn_region records, include/fnn.h) -> one message buffer."""
+        check(self.lib.fnn_pack_regions(self.handle, feat_ptr, C.c_int64(n_slots), regions_ptr, C.c_int64(n), message_ptr, stream),
+              self.lib, self.handle)
+
+    def unpack_regions(self, feat_ptr, n_slots, regions_ptr, n, message_ptr, stream=0):
+        check(self.lib.fnn_unpack_regions(self.handle, feat_ptr, C.c_int64(n_slots), regions_ptr, C.c_int64(n), message_ptr, stream),
               self.lib, self.handle)
 
     def labels_box(self, acc_ptr, shape, opts, box_lo, box_hi, out_lo, out_hi, labels_ptr):

@@ -192,6 +192,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
     fnn_u32x4v ssv[2];                                        // this thread's 8 scales and 8 shifts in fp16 (SrcDesc::ssh): two 16-byte loads
 #endif
     float slope_next = 1.f;
+#ifdef FNN_TMODE
+    bool first_chunk = true;
+#endif
 
     // The chunk's loads in five slices, one per tap pair of the k-loop: issued in one block the 18 wave-wide loads of
     // every wave of the CU queue up in the texture-address path and the MFMAs behind them cannot issue (in-order waves).
@@ -239,6 +242,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
             gd = gd < 0 ? 0 : (gd >= p.Di ? p.Di - 1 : gd);   // scalar; a clamped plane's image is zeroed in commit()
             xr[u] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, (unsigned)gd * plane_bytes, 0));
         }
+#ifdef FNN_TMODE
+        if ((p.tmode & 8) && !first_chunk) return;            // proxy: no weight traffic after the first chunk
+#endif
 #pragma unroll
         for (int e = 0; e < NB * WPB; ++e) {                  // element tid + 256 u of block nb; beyond the block: range check, zeros, no traffic
             if (e * SL / (NB * WPB) != part) continue;
@@ -285,6 +291,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
                     if (!((pm >> u) & 1)) *(f16x8 *)(sA + ldso0 + u * PS) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
             }
         }
+#ifdef FNN_TMODE
+        if ((p.tmode & 8) && !first_chunk) return;
+#endif
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -345,6 +354,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
     }
 
     commit();
+#ifdef FNN_TMODE
+    first_chunk = false;
+#endif
     __syncthreads();
     FNN_STAMP();                                              // 2: first chunk staged
     // the last chunk is peeled off so that the wait for the prefetch sits on an unconditional path (see conv3d_lds_kernel)
@@ -1281,6 +1293,263 @@ __global__ __launch_bounds__(256, 2) void conv3d_zsp_kernel(const ConvParams p, 
 #undef ZSP_REL
 }
 
+// The single-chunk strided layer WALKING along d (round 4; conv3d_zrw_kernel's walk with conv3d_zs_kernel's tile).
+// conv3d_zsp_kernel re-staged its whole 10 x 9 x 17 halo for every 8 x 4 x 8 tile: 1.49 input voxels read per input voxel
+// of the layer.  A workgroup here owns one 4 x 8 in-plane window (9 x 17 input columns) and walks `tps` consecutive
+// d-tiles: the image is a RING of ten planes - a tile brings eight new ones (1.20 voxels per voxel), the next tile's
+// planes are in flight during the k-loop - the weights are staged once, and the staging is the column walk of the ZR
+// kernels: a thread owns one (row, column, channel half) of the window (306 of them: threads 0 .. 49 own a second one),
+// its address is one constant + a scalar per plane, columns outside the tensor read zeros through the buffer's range
+// check.  Same image layout, operand offsets, k-loop, epilogue and statistics row per tile as conv3d_zsp_kernel:
+// bit-identical results.
+__global__ __launch_bounds__(256, 2) void conv3d_zsw_kernel(const ConvParams p, const int segs, const int tps) {
+    constexpr int NB = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int TD = 8, TH = 4, TDW = 4;
+    constexpr int ID = TD + 2, IH = 2 * TH + 1, IW = 17, PW = 17;
+    constexpr int PS = IH * PW * 32;
+    constexpr int ABYTES = (ID * PS + 1023) & ~1023;
+    constexpr int KS = 15, WB = KS * 64, WPB = (WB + 255) / 256;
+    constexpr int NCOL = IH * IW * 2;                         // 306 (row, column, half) elements per plane
+    const int hp = wave & 1, dh = wave >> 1;
+
+    int t;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        t = __builtin_amdgcn_readfirstlane((xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx);
+    }
+    const int tw = __builtin_amdgcn_readfirstlane(t % p.tiles_w); t = __builtin_amdgcn_readfirstlane(t / p.tiles_w);
+    const int th = __builtin_amdgcn_readfirstlane(t % p.tiles_h); t = __builtin_amdgcn_readfirstlane(t / p.tiles_h);
+    const int seg = __builtin_amdgcn_readfirstlane(t % segs);
+    const int n = __builtin_amdgcn_readfirstlane(t / segs);
+    const int td0 = seg * tps, td1 = td0 + tps < p.tiles_d ? td0 + tps : p.tiles_d;
+    if (td0 >= td1) return;
+    const int cb0 = blockIdx.y * NB;
+    const int oh0 = th * TH, ow0 = tw * 8;
+
+    char *sA = smem;                                          // ring of ID halo planes: plane 8 td0 - 1 + k sits in slot k % ID
+    char *sW = smem + ABYTES;                                 // [NB][15][64 lanes][16 B], resident
+    float *sRed = (float *)(sW + NB * KS * 1024);             // [4 waves][32][2]
+
+    // ---- this thread's one or two elements of a plane
+    const int sC = p.src[0].C, vs = FNN_VS(p.src[0]);
+    const unsigned item_bytes = (unsigned)p.Di * p.Hi * p.Wi * sC * 2;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(p.src[0].ptr + (size_t)n * (item_bytes >> 1)), 0, item_bytes, 0x00020000);
+    const unsigned plane_bytes = (unsigned)p.Hi * p.Wi * vs * 2;
+    const int cg = tid & 1;
+    unsigned voff[2];
+    int ldso[2];
+    bool has[2], okc[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = tid + 256 * k;
+        has[k] = e < NCOL;
+        const int col = (has[k] ? e : 0) >> 1;
+        const int zh = (col * 241) >> 12, zw = col - zh * IW;   // col / 17 for col < 153
+        const int gh = 2 * oh0 - 1 + zh, gw = 2 * ow0 - 1 + zw;
+        okc[k] = has[k] & ((unsigned)gh < (unsigned)p.Hi) & ((unsigned)gw < (unsigned)p.Wi);
+        voff[k] = okc[k] ? (unsigned)(__mul24(gh, p.Wi) + gw) * (unsigned)(vs * 2) + cg * 16 : 0x80000000u;
+        ldso[k] = (zh * PW + zw) * 32 + cg * 16;
+    }
+    const f16 slope_h = (f16)p.src[0].slope;
+#ifdef FNN_NORM_FP32
+    float sc[8], sh[8];
+    {
+        const float *qs = p.src[0].ss ? p.src[0].ss + (size_t)(2 * n) * sC : p.ident_ss;
+        const float *qh = p.src[0].ss ? qs + sC : p.ident_ss + 512;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = qs[cg * 8 + j]; sh[j] = qh[cg * 8 + j]; }
+    }
+#else
+    f16x8 sc_h, sh_h;
+    {
+        // conv3d_zsp_kernel's arithmetic: the fp32 rows rounded to fp16 here (stats_finalize_kernel's ssh rows hold the same roundings)
+        const float *qs = p.src[0].ss ? p.src[0].ss + (size_t)(2 * n) * sC : p.ident_ss;
+        const float *qh = p.src[0].ss ? qs + sC : p.ident_ss + 512;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc_h[j] = (f16)qs[cg * 8 + j]; sh_h[j] = (f16)qh[cg * 8 + j]; }
+    }
+#endif
+
+    fnn_u32x4v xr[2][ID];
+    auto load_planes = [&](int td, int u0) {                  // the planes u0 .. 9 of tile td: 8 td - 1 + u, clamped (see stage())
+#pragma unroll
+        for (int u = 0; u < ID; ++u) {
+            if (u < u0) continue;
+            int gd = td * TD - 1 + u;
+            gd = gd < 0 ? 0 : (gd >= p.Di ? p.Di - 1 : gd);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                xr[k][u] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rx, voff[k], (unsigned)gd * plane_bytes, 0));
+        }
+    };
+    auto stage = [&](int td, int u0) {                        // normalise + LeakyReLU, into the planes' ring slots; outside the tensor: zeros
+        const int k0 = (td - td0) * TD;
+#pragma unroll
+        for (int u = 0; u < ID; ++u) {
+            if (u < u0) continue;
+            const int gd = td * TD - 1 + u;                   // (scalar)
+            const bool plane_ok = (unsigned)gd < (unsigned)p.Di;
+            char *dst = sA + ((k0 + u) % ID) * PS;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const f16x8 x = __builtin_bit_cast(f16x8, xr[k][u]);
+#ifdef FNN_NORM_FP32
+                f16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)x[j], sc[j], sh[j]);
+#else
+                f16x8 o = x * sc_h + sh_h;
+#endif
+                o = __builtin_elementwise_max(o, o * slope_h);
+                if (!okc[k] || !plane_ok) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};     // the conv's zero padding
+                if (has[k]) *(f16x8 *)(dst + ldso[k]) = o;
+            }
+        }
+    };
+    int toff[5];
+    {
+        const int r = lane & 15, hl = lane >> 5, kh = (lane >> 4) & 1;
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const int tp = 2 * pr + hl < 9 ? 2 * pr + hl : 8;
+            const int row = 2 * (2 * hp + (r >> 3)) + tp / 3, col = 2 * (r & 7) + tp % 3;
+            toff[pr] = (row * PW + col) * 32 + kh * 16;
+        }
+    }
+    const int q = lane >> 4, r = lane & 15;
+    float4 bv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bv[nb] = *(const float4 *)(p.bias + cb0 * 16 + q * 8 + nb * 4);
+    f32x4 acc[TDW][NB];
+    auto kloop = [&](int td) {
+        const int k0 = (td - td0) * TD + TDW * dh;            // the wave's first plane of the tile's ten
+        int roff[TDW + 2];                                    // (scalars) where its six planes sit in the ring
+#pragma unroll
+        for (int pl = 0; pl < TDW + 2; ++pl) roff[pl] = ((k0 + pl) % ID) * PS;
+#pragma unroll
+        for (int j = 0; j < TDW; ++j)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[j][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const char *bp = sA + toff[pr];
+            f16x8 xf[TDW + 2];
+#pragma unroll
+            for (int pl = 0; pl < TDW + 2; ++pl) xf[pl] = *(const f16x8 *)(bp + roff[pl]);
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                f16x8 wf[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wf[nb] = *(const f16x8 *)(sW + ((nb * KS + pr * 3 + dz) * 64 + lane) * 16);
+#pragma unroll
+                for (int j = 0; j < TDW; ++j)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nb], xf[j + dz], acc[j][nb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const f16x2 ones = {(f16)1.f, (f16)1.f};
+    auto finish = [&](int td) {                               // conv3d_zsp_kernel's epilogue: bias, 16-byte stores, statistics row (+ a barrier)
+        const int od0 = td * TD;
+        float t1[NB][4], t2[NB][4];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
+        {
+            const unsigned ob = (unsigned)p.Do * p.Ho * p.Wo * p.Cout * 2;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)n * (ob >> 1), 0, ob, 0x00020000);
+            const unsigned ovs2 = (unsigned)FNN_OVS(p) * 2;
+            const unsigned coff = (unsigned)(cb0 + (q >> 1)) * (unsigned)(FNN_OCS(p) * 2) + (unsigned)(q & 1) * 16;   // output layout: fnn_device.h
+            const int oh = oh0 + 2 * hp + (r >> 3), ow = ow0 + (r & 7);
+            const bool ok_hw = oh < p.Ho && ow < p.Wo;
+#pragma unroll
+            for (int mb = 0; mb < TDW; mb += 2) {
+                f16x8 o[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int od = od0 + TDW * dh + mb + h;
+                    const bool ok = ok_hw && od < p.Do;
+                    const unsigned vo = ok ? (unsigned)((od * p.Ho + oh) * p.Wo + ow) * ovs2 + coff : 0x80000000u;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        o[h][nb * 4 + 0] = (f16)(acc[mb + h][nb][0] + bv[nb].x);
+                        o[h][nb * 4 + 1] = (f16)(acc[mb + h][nb][1] + bv[nb].y);
+                        o[h][nb * 4 + 2] = (f16)(acc[mb + h][nb][2] + bv[nb].z);
+                        o[h][nb * 4 + 3] = (f16)(acc[mb + h][nb][3] + bv[nb].w);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fnn_i32x4, o[h]), rsrc, vo, 0, 0);
+                    if (!ok) o[h] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f16x2 pr = {o[0][nb * 4 + j], o[1][nb * 4 + j]};
+                        t1[nb][j] = __builtin_amdgcn_fdot2(pr, ones, t1[nb][j], false);
+                        t2[nb][j] = __builtin_amdgcn_fdot2(pr, pr, t2[nb][j], false);
+                    }
+            }
+        }
+        if (p.stats_out) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = row16_sum(t1[nb][j]), b = row16_sum(t2[nb][j]);
+                    if (r == 0) {
+                        const int c = q * 8 + nb * 4 + j;              // the interleaved cout order (conv3d_pack_cout)
+                        sRed[(wave * 32 + c) * 2] = a;
+                        sRed[(wave * 32 + c) * 2 + 1] = b;
+                    }
+                }
+        }
+        __syncthreads();                                      // sRed complete (and the planes staged before this call are published)
+        if (p.stats_out && tid < 64) {
+            const int c = tid >> 1, which = tid & 1;
+            double v = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += (double)sRed[(w * 32 + c) * 2 + which];
+            p.stats_out[(((size_t)n * p.stats_slots + (td * p.tiles_h + th) * p.tiles_w + tw) * p.Cout + cb0 * 16 + c) * 2 + which] = v;
+        }
+    };
+
+    // ---- prologue: the first tile's ten planes and the weights
+    load_planes(td0, 0);
+    fnn_u32x4v wr[NB][WPB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const f16 *wp = p.wpk + ((size_t)((cb0 + nb) * p.chunks) * WB) * 8;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, WB * 16, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < WPB; ++u) wr[nb][u] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw, tid * 16, u * 4096, 0));
+    }
+    stage(td0, 0);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int u = 0; u < WPB; ++u)
+            if (u + 1 < WPB || wave < 3) *(fnn_u32x4v *)(sW + ((nb * WB + u * 256) + tid) * 16) = wr[nb][u];
+    __syncthreads();
+
+    // ---- the walk: the last tile is peeled off (nothing to prefetch behind it)
+    for (int td = td0; td + 1 < td1; ++td) {
+        load_planes(td + 1, 2);                               // eight new planes, in flight during the MFMAs
+        kloop(td);
+        __syncthreads();                                      // every wave is done with this tile's planes (and with sRed of the previous tile)
+        stage(td + 1, 2);                                     // over the slots of this tile's first eight planes
+        finish(td);                                           // (its barrier also publishes the staged planes)
+    }
+    kloop(td1 - 1);
+    __syncthreads();
+    finish(td1 - 1);
+}
+
 static int launch_zs(ConvParams p, hipStream_t st) {
     p.tile_d = 8;
     p.tiles_d = (p.Do + 7) / 8;
@@ -1297,6 +1566,25 @@ static int launch_zs(ConvParams p, hipStream_t st) {
     const int total = p.N * p.tiles_d * p.tiles_h * p.tiles_w, groups = (p.Cout / 16) / 2;
     static const bool no_zsp = fnn_knob("FNN_NO_ZSP") != nullptr;                  // A-B aid
     const int plan_total = (p.plan_N > 0 ? p.plan_N : p.N) * p.tiles_d * p.tiles_h * p.tiles_w;   // the variant is a property of the layer, not of the batch
+    const bool no_zsw = fnn_knob("FNN_NO_ZSW") != nullptr;                         // A-B aid, read per call: a test compares the two kernels in one process
+    if (!no_zsp && !no_zsw && p.chunks == 1 && p.n_src == 1 && plan_total >= 512 * 8 && p.tiles_d >= 4) {
+        // single-chunk layers with at least four tiles along d: the walking form (round 4)
+        const size_t ldsw = lds - (size_t)2 * 64 + 4 * 32 * 2 * 4;
+        static bool attr_w = false;
+        if (!attr_w) {
+            (void)hipFuncSetAttribute((const void *)conv3d_zsw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_w = true;
+        }
+        const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;
+        const long long cols = (long long)plan_n * p.tiles_h * p.tiles_w * groups;
+        int segs = 1;                                         // enough workgroups for several rounds of the chip's 512 slots, tiles permitting
+        while (cols * segs < 8 * 512 && segs * 2 <= p.tiles_d / 2) segs *= 2;
+        const int tps = (p.tiles_d + segs - 1) / segs;
+        segs = (p.tiles_d + tps - 1) / tps;
+        fnn_note_kernel("conv3d_zsw_kernel");
+        hipLaunchKernelGGL(conv3d_zsw_kernel, dim3(p.N * p.tiles_h * p.tiles_w * segs, groups), dim3(256), ldsw, st, p, segs, tps);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     if (!no_zsp && p.chunks == 1 && p.n_src == 1 && plan_total >= 512 * 8) {
         // single-chunk layers: the persistent form (two workgroups per CU over all cout groups)
         const size_t ldsp = lds - (size_t)2 * 64 + 4 * 32 * 2 * 4;
@@ -1558,6 +1846,9 @@ static int launch_zr(ConvParams p, hipStream_t st) {
     p.ident_ssh = conv3d_identity_ssh();
     if (!p.ident_ss || !p.ident_ssh) return -2;
     dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
+#ifdef FNN_TMODE
+    p.tmode = getenv("FNN_ZR_TMODE") ? atoi(getenv("FNN_ZR_TMODE")) : 0;     // timing-only proxies (wrong results): tools/zr_tmode.py
+#endif
     fnn_note_kernel("conv3d_zr_kernel<%d,%d>", NB, TD);
     hipLaunchKernelGGL((conv3d_zr_kernel<NB, TD>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -1670,6 +1670,31 @@ int fnn_gather_box(fnn_engine *e, int fold, const void *feat, const float *fss, 
     return 0;
 }
 
+static int region_copy(fnn_engine *e, void *feat, int64_t n_slots, const fnn_region *regions, int64_t n, void *message,
+                       void *stream, bool pack) {
+    if (!e) return FNN_E_INVALID;
+    if (n == 0) return 0;
+    if (!feat || !regions || !message || n < 0 || n_slots < 1) return fail(e, FNN_E_INVALID, "bad argument");
+    if (!is_device_ptr(feat) || !is_device_ptr(regions) || !is_device_ptr(message))
+        return fail(e, FNN_E_INVALID, "fnn_pack_regions / fnn_unpack_regions need device pointers (the region table too)");
+    if (n > 65535) return fail(e, FNN_E_INVALID, "more than 65535 regions in one message");
+    static_assert(sizeof(fnn_region) == 40, "fnn_region is ten 32-bit words");
+    HIPCHK(e, hipSetDevice(e->device));
+    const fnn_arch_desc &a = e->arch;
+    if (launch_region_copy(feat, n_slots, (const int *)regions, (int)n, message, a.patch[0], a.patch[1], a.patch[2],
+                           e->layers[e->head_src].cout_pad, pack, (hipStream_t)stream) != 0)
+        return fail(e, FNN_E_HIP, "region copy launch failed");
+    return 0;
+}
+
+int fnn_pack_regions(fnn_engine *e, const void *feat, int64_t n_slots, const fnn_region *regions, int64_t n, void *message, void *stream) {
+    return region_copy(e, const_cast<void *>(feat), n_slots, regions, n, message, stream, true);
+}
+
+int fnn_unpack_regions(fnn_engine *e, void *feat, int64_t n_slots, const fnn_region *regions, int64_t n, const void *message, void *stream) {
+    return region_copy(e, feat, n_slots, regions, n, const_cast<void *>(message), stream, false);
+}
+
 int fnn_forward_patches(fnn_engine *e, int fold, const float *x, int n, float *logits, void *stream) {
     if (!e) return FNN_E_INVALID;
     if (fold < 0 || fold >= (int)e->folds.size() || !e->folds[fold].loaded) return fail(e, FNN_E_STATE, "weights of fold %d are not loaded", fold);

@@ -320,6 +320,7 @@ struct StatsFinalizeParams {
 
 // launchers (implemented in the .hip files)
 int launch_stats_finalize(const StatsFinalizeParams &p, int N, hipStream_t st);
+int launch_region_copy(void *feat, long long n_slots, const int *regions, int n, void *message, int PD, int PH, int PW, int C, bool pack, hipStream_t st);   // fnn_pack_regions / fnn_unpack_regions
 int launch_fss_to_ssh(const float *fss, unsigned short *ssh, long long items, int C, hipStream_t st);   // [items][2][C] fp32 rows -> [items][C / 8][16] fp16 (SrcDesc::ssh)
 int launch_avgpool(const PoolParams &p, hipStream_t st);
 int launch_combine(const CombineParams &p, hipStream_t st);

@@ -142,6 +142,11 @@ struct GatherGeo { int slot, dx, dy, oz; };                     // wave-uniform:
 // running sum and its add are one v_fma_mix_f32.
 // Kept from rounds 2 / 3: 64-voxel runs, sums as fp16 pairs at four waves per SIMD, untouched 16-voxel groups skipped,
 // the shared-reciprocal quotient.
+// Measured on the 512^3 x 61 benchmark volume (tools/gather_ab.py, bits equal in every arm): round 3's kernel 18.3 ms;
+// tables + pinned buffer loads + v_fma_mix 17.1; + the next visit prefetched 16.8 (K = 32, three waves per SIMD);
+// + the K = 16 head 14.7 (four waves per SIMD WITH the prefetch: 119 registers; without it, five waves: 17.2);
+// autocast arithmetic 17.3 -> 13.5.  Dropped: a head's four 128-byte row pieces of a workgroup stored as one 512-byte
+// segment behind a workgroup barrier (14.73 vs 14.75 ms: the scattered stores are not what it waits for).
 template <int HB, int ACCM, bool LABELS, bool TTA, bool K16>
 __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void gather_head_kernel(const GatherParams p) {
     constexpr bool PF = !TTA && ACCM != 1;                     // the next visit's loads in flight during this visit's arithmetic
@@ -550,10 +555,10 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
     if (bad) atomicOr(p.inf_flag, 1);
     if (LABELS) return;
 
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
     const size_t plane = (size_t)p.OX * p.OY * p.OZ;
     const size_t rowoff = ((size_t)x * p.OY + y) * p.OZ + z0;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
     const int nz = (int)(p.z_hi - z0 < ZW ? p.z_hi - z0 : ZW);
     const bool vec = p.out_vec && nz == ZW && (p.z_lo & 7) == 0;   // 16-byte aligned rows
     if (!p.out_fp32 && vec) {

@@ -117,6 +117,40 @@ __global__ __launch_bounds__(256) void fss_to_ssh_kernel(const float *fss, unsig
     h[8] = (f16)fss[item * 2 * C + C + c];
 }
 
+// fnn_pack_regions / fnn_unpack_regions (include/fnn.h): the sub-blocks of kept patch activations that one neighbour
+// needs <-> one contiguous message, a launch per peer and direction instead of a strided torch copy per sub-block.
+// blockIdx.y = region, the region's 16-byte vectors grid-strided over blockIdx.x; a voxel record is C / 8 vectors.
+template <bool PACK>
+__global__ __launch_bounds__(256) void region_copy_kernel(char *feat, const int *regions, char *message, long long n_slots,
+                                                          int PH, int PW, long long slot_bytes, int vpv) {
+    const int *rc = regions + (size_t)blockIdx.y * 10;
+    const int ev = rc[0], slot = rc[1], l0 = rc[2], l1 = rc[3], l2 = rc[4];
+    const int d0 = rc[5] - l0, d1 = rc[6] - l1, d2 = rc[7] - l2;
+    const long long nvec = (long long)d0 * d1 * d2 * vpv;
+    char *sp = feat + ((long long)ev * n_slots + slot) * slot_bytes;
+    char *mp = message + (long long)rc[8] * 16;
+    const int row = d2 * vpv;                                            // vectors per w row of the block: contiguous in both
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const long long rw = i / row;
+        const int c = (int)(i - rw * row);
+        const int h = (int)(rw % d1), dd = (int)(rw / d1);
+        char *fp = sp + ((((long long)(l0 + dd) * PH + (l1 + h)) * PW + l2) * vpv + c) * 16;
+        if (PACK) *(fnn_u32x4r *)(mp + i * 16) = *(const fnn_u32x4r *)fp;
+        else *(fnn_u32x4r *)fp = *(const fnn_u32x4r *)(mp + i * 16);
+    }
+}
+
+int launch_region_copy(void *feat, long long n_slots, const int *regions, int n, void *message, int PD, int PH, int PW, int C,
+                       bool pack, hipStream_t st) {
+    if (n <= 0) return 0;
+    const int vpv = C / 8;                                               // 16-byte vectors per voxel record
+    const long long slot_bytes = (long long)PD * PH * PW * C * 2;
+    const dim3 grid(128, (unsigned)n);                                   // (a face region of a 160 x 96 x 96 patch: ~10^5 vectors)
+    if (pack) hipLaunchKernelGGL(region_copy_kernel<true>, grid, dim3(256), 0, st, (char *)feat, regions, (char *)message, n_slots, PH, PW, slot_bytes, vpv);
+    else hipLaunchKernelGGL(region_copy_kernel<false>, grid, dim3(256), 0, st, (char *)feat, regions, (char *)message, n_slots, PH, PW, slot_bytes, vpv);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int launch_fss_to_ssh(const float *fss, unsigned short *ssh, long long items, int C, hipStream_t st) {
     const long long n = items * C;
     if (n <= 0) return 0;

@@ -229,6 +229,45 @@ def mirror_flips(mirror_axes) -> List[Tuple[int, ...]]:
     return [()] + [c for k in range(len(axes)) for c in itertools.combinations(axes, k + 1)]
 
 
+class ExchangePlan:
+    """What ``FeatureExchange`` moves, derived ONCE per decomposition (the lists depend on the volume's shape and the rank
+    grid only, not on its values): per peer and direction the (evaluation, slot, sub-block) records - as the device tables
+    of ``fnn_pack_regions`` / ``fnn_unpack_regions`` (include/fnn.h) on a GPU - the message sizes, and the row numbers of
+    the InstanceNorm rows that travel with the blocks.  Both sides derive the same lists, so no metadata travels."""
+
+    def __init__(self, dec: Decomposition, rank: int, patch, origins, slot_of, flips, channels: int, device, n_slots: int):
+        self.patch, self.flips, self.C, self.n_slots = tuple(patch), [tuple(f) for f in flips], int(channels), int(n_slots)
+        self.origins, self.slot_of = origins, slot_of
+        sends, recvs = dec.feature_transfers(rank, patch, origins)
+        self.send, self.recv = self._tables(sends, device), self._tables(recvs, device)
+
+    def local(self, pid: int, region: Box, flip=()):
+        """The block of `region` in the slot's own coordinates: [P - hi, P - lo) along every flipped axis."""
+        o = [int(v) for v in self.origins[pid]]
+        lo = [region[0][d] - o[d] for d in range(3)]
+        hi = [region[1][d] - o[d] for d in range(3)]
+        return tuple((self.patch[d] - hi[d], self.patch[d] - lo[d]) if d in flip else (lo[d], hi[d]) for d in range(3))
+
+    def _tables(self, items, device):
+        per = {}
+        for peer, pid, reg in items:
+            per.setdefault(peer, []).append((pid, reg))
+        out = []
+        for peer, lst in sorted(per.items()):
+            recs, rows, off = [], [], 0                             # off: elements; the device table wants 16-byte units (C % 8 == 0 there)
+            for f, fl in enumerate(self.flips):                     # evaluation-major, then the (patch, region) list: both sides alike
+                for pid, reg in lst:
+                    loc = self.local(pid, reg, fl)
+                    recs.append([f, self.slot_of[pid], loc[0][0], loc[1][0], loc[2][0], loc[0][1], loc[1][1], loc[2][1], off // 8, 0])
+                    rows.append(f * self.n_slots + self.slot_of[pid])
+                    off += int(np.prod([b - a for a, b in loc])) * self.C
+            table = torch.tensor(recs, dtype=torch.int32).reshape(-1, 10)
+            out.append(dict(peer=peer, items=lst, recs=recs, numel=off,
+                            table=table.to(device) if device is not None and torch.device(device).type == 'cuda' else table,
+                            rows=torch.tensor(rows, dtype=torch.int64, device=device)))
+        return out
+
+
 class FeatureExchange:
     """Gather-path exchange (SURVEY.md 8e with csrc/gather.hip): `feat` is [n_eval, n_slots, PD, PH, PW, C] (fp16 on the
     GPUs; a 5-D tensor is taken as n_eval = 1), `fss` [n_eval, n_slots, 2, C]; `slot_of[pid]` says where a patch sits.
@@ -236,71 +275,78 @@ class FeatureExchange:
     are computed), ``finish()`` lands the foreign regions in their slots.  One packed buffer per peer and direction; both
     sides derive the same (peer, patch, region) lists from the decomposition, so no metadata travels.  `flips`: the
     evaluations under test-time mirroring (``mirror_flips``): the activation of a mirrored evaluation is stored in the
-    network's coordinates, so the block of a region sits at [P - hi, P - lo) along every flipped axis - on both sides."""
+    network's coordinates, so the block of a region sits at [P - hi, P - lo) along every flipped axis - on both sides.
+    Round 4: on a GPU the packing and the landing are ONE launch per peer and direction (``fnn_pack_regions`` /
+    ``fnn_unpack_regions`` through `engine`, tables from a cached ``ExchangePlan``) instead of a strided torch copy per
+    (evaluation, patch, region); host tensors (the gloo tests of this logic) take the torch copies."""
 
     def __init__(self, feat: torch.Tensor, fss: torch.Tensor, dec: Decomposition, rank: int, patch, origins, slot_of, group=None,
-                 flips=((),)):
+                 flips=((),), engine=None, plan: Optional[ExchangePlan] = None):
         if feat.ndim == 5:
             feat, fss = feat[None], fss[None]
-        self.feat, self.fss, self.dec, self.rank, self.patch, self.origins, self.slot_of, self.group = \
-            feat, fss, dec, rank, tuple(patch), origins, slot_of, group
-        self.flips = [tuple(f) for f in flips]
-        assert feat.shape[0] == len(self.flips)
-        self.sends, self.recvs = dec.feature_transfers(rank, patch, origins)
+        self.feat, self.fss, self.group, self.engine = feat, fss, group, engine
+        assert feat.shape[0] == len(flips)
+        if feat.is_cuda and engine is None:
+            raise RuntimeError('FeatureExchange on device tensors needs the engine (fnn_pack_regions / fnn_unpack_regions): no torch fallback on a GPU')
+        self.plan = plan if plan is not None else ExchangePlan(dec, rank, patch, origins, slot_of, flips, feat.shape[-1],
+                                                               feat.device if feat.is_cuda else None, feat.shape[1])
         self.reqs, self.landing, self.keep = [], [], []
         self.bytes_sent = self.bytes_received = 0
 
-    def _local(self, pid: int, region: Box, flip=()):
-        o = [int(v) for v in self.origins[pid]]
-        lo = [region[0][d] - o[d] for d in range(3)]
-        hi = [region[1][d] - o[d] for d in range(3)]
-        return tuple(slice(self.patch[d] - hi[d], self.patch[d] - lo[d]) if d in flip else slice(lo[d], hi[d]) for d in range(3))
-
-    def _peers(self, items):
-        out = {}
-        for peer, pid, reg in items:
-            out.setdefault(peer, []).append((pid, reg))
-        return out
+    def _block(self, rec):
+        f, slot, l0, l1, l2, h0, h1, h2 = rec[:8]
+        return (f, slot, slice(l0, h0), slice(l1, h1), slice(l2, h2))
 
     def start(self) -> 'FeatureExchange':
-        if not self.sends and not self.recvs:
+        pl = self.plan
+        if not pl.send and not pl.recv:
             return self
         g = self.group
         dst = (lambda r: dist.get_global_rank(g, r)) if g is not None else (lambda r: r)
         ops = []
-        C, E = self.feat.shape[-1], len(self.flips)
-        for peer, items in sorted(self._peers(self.sends).items()):
-            blocks = [self.feat[(f, self.slot_of[pid], *self._local(pid, reg, fl))].reshape(-1)
-                      for f, fl in enumerate(self.flips) for pid, reg in items]
-            rows = torch.stack([self.fss[f, self.slot_of[pid]] for f in range(E) for pid, _ in items])
-            buf = torch.cat(blocks)
+        C = self.feat.shape[-1]
+        rows2d = self.fss.reshape(-1, 2, C)
+        for m in pl.send:
+            buf = torch.empty(m['numel'], dtype=self.feat.dtype, device=self.feat.device)
+            if self.feat.is_cuda:
+                self.engine.pack_regions(self.feat.data_ptr(), pl.n_slots, m['table'].data_ptr(), len(m['recs']), buf.data_ptr(),
+                                         torch.cuda.current_stream(self.feat.device).cuda_stream)
+            else:
+                off = 0
+                for rec in m['recs']:
+                    blk = self.feat[self._block(rec)].reshape(-1)
+                    buf[off:off + blk.numel()] = blk
+                    off += blk.numel()
+            rows = rows2d.index_select(0, m['rows'])
             self.keep += [buf, rows]
             self.bytes_sent += buf.numel() * buf.element_size() + rows.numel() * rows.element_size()
-            ops += [dist.P2POp(dist.isend, buf, dst(peer), g), dist.P2POp(dist.isend, rows, dst(peer), g)]
-        for peer, items in sorted(self._peers(self.recvs).items()):
-            n = E * sum(int(np.prod([reg[1][d] - reg[0][d] for d in range(3)])) * C for _, reg in items)
-            buf = torch.empty(n, dtype=self.feat.dtype, device=self.feat.device)
-            rows = torch.empty((E * len(items), 2, C), dtype=self.fss.dtype, device=self.fss.device)
+            ops += [dist.P2POp(dist.isend, buf, dst(m['peer']), g), dist.P2POp(dist.isend, rows, dst(m['peer']), g)]
+        for m in pl.recv:
+            buf = torch.empty(m['numel'], dtype=self.feat.dtype, device=self.feat.device)
+            rows = torch.empty((len(m['recs']), 2, C), dtype=self.fss.dtype, device=self.fss.device)
             self.bytes_received += buf.numel() * buf.element_size() + rows.numel() * rows.element_size()
-            ops += [dist.P2POp(dist.irecv, buf, dst(peer), g), dist.P2POp(dist.irecv, rows, dst(peer), g)]
-            self.landing.append((items, buf, rows))
+            ops += [dist.P2POp(dist.irecv, buf, dst(m['peer']), g), dist.P2POp(dist.irecv, rows, dst(m['peer']), g)]
+            self.landing.append((m, buf, rows))
         self.reqs = dist.batch_isend_irecv(ops)
         return self
 
     def finish(self) -> None:
         for req in self.reqs:
             req.wait()
+        pl = self.plan
         C = self.feat.shape[-1]
-        for items, buf, rows in self.landing:
-            off, k = 0, 0
-            for f, fl in enumerate(self.flips):
-                for pid, reg in items:
-                    shape = tuple(reg[1][d] - reg[0][d] for d in range(3)) + (C,)
-                    n = int(np.prod(shape))
-                    self.feat[(f, self.slot_of[pid], *self._local(pid, reg, fl))] = buf[off:off + n].view(shape)
-                    self.fss[f, self.slot_of[pid]] = rows[k]
-                    off += n
-                    k += 1
+        rows2d = self.fss.reshape(-1, 2, C)
+        for m, buf, rows in self.landing:
+            if self.feat.is_cuda:
+                self.engine.unpack_regions(self.feat.data_ptr(), pl.n_slots, m['table'].data_ptr(), len(m['recs']), buf.data_ptr(),
+                                           torch.cuda.current_stream(self.feat.device).cuda_stream)
+            else:
+                off = 0
+                for rec in m['recs']:
+                    tgt = self.feat[self._block(rec)]
+                    self.feat[self._block(rec)] = buf[off:off + tgt.numel()].view(tgt.shape)
+                    off += tgt.numel()
+            rows2d.index_copy_(0, m['rows'], rows)
         self.reqs, self.landing, self.keep = [], [], []
 
 
@@ -365,6 +411,7 @@ class ShardedPredictor:
         self.world = dist.get_world_size(group)
         assert mode in ('auto', 'gather', 'accumulate')
         self.mode = mode
+        self._plans, self._cur = {}, None           # per volume shape: decomposition, slots, exchange tables
 
     def _flips(self):
         p = self.p
@@ -408,6 +455,14 @@ class ShardedPredictor:
 
     def _slots(self, dec, origins):
         """(boundary, interior, slot_of) of this rank: own patches first (boundary, then interior), then the foreign ones."""
+        if self._cur is not None and self._cur['dec'] is dec and self._cur['slots'] is not None:
+            return self._cur['slots']
+        out = self._slots_uncached(dec, origins)
+        if self._cur is not None and self._cur['dec'] is dec:
+            self._cur['slots'] = out
+        return out
+
+    def _slots_uncached(self, dec, origins):
         patch = self.p._spec.patch
         boundary, interior = dec.split_patches_for_features(self.rank, patch, origins)
         _, recvs = dec.feature_transfers(self.rank, patch, origins)
@@ -434,7 +489,13 @@ class ShardedPredictor:
         # rank's owned box - the only part of it fnn_gather_box reads
         feat = torch.empty((len(flips), n_slots, *patch, C), dtype=torch.half, device=p.device)
         fss = torch.empty((len(flips), n_slots, 2, C), dtype=torch.float32, device=p.device)
-        fx = FeatureExchange(feat, fss, dec, self.rank, patch, origins, slot_of, self.group, flips)
+        xplan = None
+        if self._cur is not None and self._cur['dec'] is dec:
+            xkey = (tuple(flips), C, n_slots)
+            xplan = self._cur['xplan'].get(xkey)
+            if xplan is None:
+                xplan = self._cur['xplan'][xkey] = ExchangePlan(dec, self.rank, patch, origins, slot_of, flips, C, p.device, n_slots)
+        fx = FeatureExchange(feat, fss, dec, self.rank, patch, origins, slot_of, self.group, flips, engine=eng, plan=xplan)
         t0 = self._tick()
         if boundary:
             eng.patch_features(x.data_ptr(), x.shape, opts, boundary, feat.data_ptr(), fss.data_ptr(), fold=fold, slot0=0, n_slots=n_slots)
@@ -481,14 +542,21 @@ class ShardedPredictor:
         return time.perf_counter()
 
     def _plan(self, x):
+        """(decomposition, patch origins, un-padded owned boxes) of a volume shape - cached: the Python geometry (every
+        patch against every rank's box) is milliseconds per step at 8 ranks and does not depend on the voxels."""
         from . import capi
         p = self.p
-        patch = p._spec.patch
-        padded, pad_lo, origins = capi.plan_volume(patch[3 - p._spec.spatial_dims:], x.shape[1:], p.tile_step_size)
-        steps = [sorted(set(int(v) for v in origins[:, d])) for d in range(3)]
-        dec = Decomposition.build(patch, padded, steps, self.world)
-        owns = [None if b is None else unpadded(b, pad_lo, x.shape[1:]) for b in dec.owned]
-        return dec, origins, owns
+        key = (tuple(int(v) for v in x.shape[1:]), float(p.tile_step_size), self.world)
+        hit = self._plans.get(key)
+        if hit is None:
+            patch = p._spec.patch
+            padded, pad_lo, origins = capi.plan_volume(patch[3 - p._spec.spatial_dims:], x.shape[1:], p.tile_step_size)
+            steps = [sorted(set(int(v) for v in origins[:, d])) for d in range(3)]
+            dec = Decomposition.build(patch, padded, steps, self.world)
+            owns = [None if b is None else unpadded(b, pad_lo, x.shape[1:]) for b in dec.owned]
+            hit = self._plans[key] = dict(dec=dec, origins=origins, owns=owns, counts=[len(st) for st in steps], slots=None, xplan={})
+        self._cur = hit
+        return hit['dec'], hit['origins'], hit['owns']
 
     def _accumulate_fold(self, x, dec, origins, opts, fold):
         """This rank's accumulator box with every contribution to the part it owns (its own patches + the halos)."""
@@ -527,7 +595,7 @@ class ShardedPredictor:
             box, own = dec.boxes[self.rank], owns[self.rank]
             part = None
             slots = self._slots(dec, origins) if dec.owned[self.rank] is not None else None
-            use_gather = self._use_gather_all(slots, [len(set(int(v) for v in origins[:, d])) for d in range(3)])
+            use_gather = self._use_gather_all(slots, self._cur['counts'])
             for i, f in enumerate(folds):
                 if use_gather:
                     got = self._features_fold(x, dec, origins, opts, f, slots)
@@ -584,7 +652,7 @@ class ShardedPredictor:
                 opts = p._opts()
                 box, own = dec.boxes[self.rank], owns[self.rank]
                 slots = self._slots(dec, origins) if dec.owned[self.rank] is not None else None
-                if self._use_gather_all(slots, [len(set(int(v) for v in origins[:, d])) for d in range(3)]):
+                if self._use_gather_all(slots, self._cur['counts']):
                     got = self._features_fold(x, dec, origins, opts, p._active_fold, slots)
                     if own is not None:
                         t0 = self._tick()

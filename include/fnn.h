@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define FNN_MAX_STAGES 8
-#define FNN_ABI_VERSION 3
+#define FNN_ABI_VERSION 4
 
 enum {
     FNN_OK = 0,
@@ -227,6 +227,26 @@ int fnn_patch_features(fnn_engine *e, int fold, const float *vol, const int64_t 
 int fnn_gather_box(fnn_engine *e, int fold, const void *feat, const float *fss, const int32_t *slot_of_patch,
                    int64_t n_slots, const int64_t shape[4], const fnn_opts *opts, const int64_t out_lo[3],
                    const int64_t out_hi[3], void *out_logits, void *labels);
+
+/* The exchange between fnn_patch_features and fnn_gather_box as ONE launch per peer and direction (ABI 4; not in the
+ * reference, whose only inference parallelism is case level: predict_from_raw_data.py:918-925).  A rank
+ * sends each neighbour the sub-blocks of its kept activations that reach into the neighbour's owned box:
+ * fnn_pack_regions copies `n` sub-blocks of feat ([n_eval][n_slots][PD][PH][PW][C] fp16, C = fnn_feature_channels) into
+ * one contiguous message buffer, fnn_unpack_regions lands a received message in the slots of the foreign patches.
+ * `regions`: a DEVICE table (built once per decomposition, it does not change from volume to volume of one shape) of
+ * fnn_region records - evaluation, slot, the sub-block [lo, hi) in the slot's own (stored, i.e. flipped for a mirrored
+ * evaluation) voxel coordinates, and where the block sits in the message in units of 16 bytes; blocks are [d][h][w][C]
+ * contiguous.  Both run on `stream` without synchronising it; every pointer is device memory. */
+typedef struct fnn_region {
+    int32_t eval, slot;
+    int32_t lo[3], hi[3];
+    int32_t off16;                  /* block start in the message buffer, 16-byte units */
+    int32_t reserved;
+} fnn_region;
+int fnn_pack_regions(fnn_engine *e, const void *feat, int64_t n_slots, const fnn_region *regions, int64_t n,
+                     void *message, void *stream);
+int fnn_unpack_regions(fnn_engine *e, void *feat, int64_t n_slots, const fnn_region *regions, int64_t n,
+                       const void *message, void *stream);
 
 /* LabelManager.convert_logits_to_segmentation on resident logits with the
  * engine's label rule: logits [heads, n_vox] f16/f32 -> labels uint8/uint16. */

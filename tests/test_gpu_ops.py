@@ -3,6 +3,8 @@
 operands.  Tolerances: the kernels compute fp16 x fp16 products exactly and
 accumulate in fp32, the only other error is the final fp16 store, so
 |err| <= 2^-10 * |ref| + small absolute slack."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -440,6 +442,14 @@ def test_conv3d_persistent_depth_shift_kernel_with_two_cout_groups():
     w = _h(torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5)
     b = torch.randn(cout, generator=g)
     y, stats = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), stride, want_stats=True)
+    assert 'conv3d_zsw_kernel' in capi.op_last_kernels()              # round 4: eight tiles along d -> the walking form ...
+    os.environ['FNN_NO_ZSW'] = '1'
+    try:                                                              # ... whose per-tile arithmetic is conv3d_zsp_kernel's: the same bits
+        y_p, stats_p = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), stride, want_stats=True)
+        assert 'conv3d_zsp_kernel' in capi.op_last_kernels()
+    finally:
+        os.environ.pop('FNN_NO_ZSW', None)
+    assert np.array_equal(y, y_p) and np.array_equal(stats, stats_p)
     _check(y, F.conv3d(x, w, b, stride, 1), 'conv3d zsp two groups')
     y64 = y.astype(np.float64)
     assert np.allclose(stats[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=1e-3)

@@ -1143,3 +1143,52 @@ def test_sharded_gather_path_through_c_abi_is_bit_identical_to_single_gpu(heads,
     torch.cuda.synchronize()
     assert torch.equal(got, want)
     assert torch.equal(labels, want_labels) if heads <= 63 else torch.equal(want_labels.long(), got.float().argmax(0))
+
+
+@pytest.mark.parametrize('mirror', [None, (0, 2)])
+def test_pack_and_unpack_regions_are_the_strided_copies_they_replace(mirror):
+    """fnn_pack_regions / fnn_unpack_regions (ABI 4): one launch per peer and direction instead of a torch slice per
+    (evaluation, patch, region).  For every rank of an 8-rank decomposition: the packed message equals the concatenation of
+    the sub-blocks FeatureExchange's host path would send, and unpacking a message into zeroed slots writes exactly those
+    sub-blocks - with mirrored evaluations (blocks at [P - hi, P - lo) along a flipped axis) too."""
+    from fast_nnunet_amd import capi
+    from fast_nnunet_amd.dist import Decomposition, ExchangePlan, mirror_flips
+    spec = UNetSpec('plain', 1, 3, [16, 32], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
+    patch = (16, 16, 32)
+    p = _predictor(spec, patch, [synthetic_state_dict(spec, 35)], mirror=mirror)
+    eng = p._engine
+    C = eng.feature_channels
+    padded, pad_lo, origins = capi.plan_volume(patch, (37, 30, 70), 0.5)
+    steps = [sorted(set(int(v) for v in origins[:, d])) for d in range(3)]
+    dec = Decomposition.build(patch, padded, steps, 8)
+    flips = mirror_flips(mirror)
+    g = torch.Generator().manual_seed(5)
+    checked = 0
+    for r in range(8):
+        if dec.owned[r] is None:
+            continue
+        boundary, interior = dec.split_patches_for_features(r, patch, origins)
+        slot_of = {pid: i for i, pid in enumerate(boundary + interior)}
+        for _, pid, _ in dec.feature_transfers(r, patch, origins)[1]:
+            slot_of.setdefault(pid, len(slot_of))
+        n_slots = len(slot_of)
+        feat = torch.randn((len(flips), n_slots, *patch, C), generator=g).half().cuda()
+        plan = ExchangePlan(dec, r, patch, origins, slot_of, flips, C, feat.device, n_slots)
+        for m in plan.send + plan.recv:
+            want = torch.cat([feat[(rec[0], rec[1], slice(rec[2], rec[5]), slice(rec[3], rec[6]), slice(rec[4], rec[7]))].reshape(-1)
+                              for rec in m['recs']])
+            assert want.numel() == m['numel']
+            buf = torch.full((m['numel'],), float('nan'), dtype=torch.half, device='cuda')
+            eng.pack_regions(feat.data_ptr(), n_slots, m['table'].data_ptr(), len(m['recs']), buf.data_ptr(),
+                             torch.cuda.current_stream().cuda_stream)
+            assert torch.equal(buf, want)
+            land = torch.zeros_like(feat)
+            eng.unpack_regions(land.data_ptr(), n_slots, m['table'].data_ptr(), len(m['recs']), buf.data_ptr(),
+                               torch.cuda.current_stream().cuda_stream)
+            ref = torch.zeros_like(feat)
+            for rec in m['recs']:
+                sl = (rec[0], rec[1], slice(rec[2], rec[5]), slice(rec[3], rec[6]), slice(rec[4], rec[7]))
+                ref[sl] = feat[sl]
+            assert torch.equal(land, ref)
+            checked += 1
+    assert checked >= 8

@@ -34,7 +34,7 @@ def test_library_exports_every_symbol_in_header(capi):
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/fnn.h but not exported'
     assert declared == set(capi.EXPORTS)
-    assert lib.fnn_abi_version() == 3
+    assert lib.fnn_abi_version() == 4
 
 
 def test_opts_carry_the_step_size_as_a_double(capi):

@@ -17,7 +17,7 @@ kw = {}
 if cin2:
     kw = dict(x2=rng.standard_normal((n, cin2, d, h, w), dtype=np.float32), gamma2=np.ones(cin2, np.float32),
               beta2=np.zeros(cin2, np.float32), slope2=0.01)
-for mode in (0, 1, 2, 3, 4, 8, 7, 15):
+for mode in (0, 8, 4, 12, 0, 8):
     os.environ['FNN_ZR_TMODE'] = str(mode)
     sys.stderr.write(f'mode {mode:2d}: ')
     sys.stderr.flush()
