@@ -139,6 +139,7 @@ struct TconvParams {
     long long out_cs;
     int ksteps;                  // ceil(Cin / 32)
     int nblk;                    // Cout / 16
+    int row_store;               // set by launch_tconv: pairs of w-phase taps stored as contiguous rows
 };
 
 struct HeadParams {

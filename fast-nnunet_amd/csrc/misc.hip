@@ -405,6 +405,41 @@ __global__ __launch_bounds__(256, 2) void tconv_mfma_kernel(const TconvParams p)
         const int row = recip_div(v, p.Wi, rcp_wi), iw = v - (int)__umul24(row, p.Wi);
         const int id = recip_div(row, p.Hi, rcp_hi), ih = row - (int)__umul24(id, p.Hi);
         const unsigned ob = ((unsigned)(id * p.sd * Ho + ih * p.sh) * (unsigned)Wo + (unsigned)(iw * p.sw)) * ovs;
+        if constexpr (NBT == 2 && TG % 2 == 0) {
+            // Taps 2 t, 2 t + 1 are the two w phases of one (d, h) phase (stride 2 along w: the launcher's `row_store`): the
+            // 16 input voxels of a column block then make ONE contiguous run of 32 output voxels per cout block.  A second
+            // v_permlane16_swap stage sorts the two taps' 16-byte pieces by cout block - lane (r, q) ends with tap q & 1,
+            // channel half q >> 1 of voxel r - so that a store instruction writes 1 KB of consecutive bytes (8 whole cache
+            // lines) instead of 16 half lines whose other halves arrive with the next instruction (round 4).
+            if (p.row_store) {
+#pragma unroll
+                for (int tg = 0; tg < TG; tg += 2) {
+                    fnn_u32x4r pk[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        f16x4 o[2];
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) {
+                            o[nb][0] = (f16)(acc[mb][tg + t][nb][0] + bv[nb].x);
+                            o[nb][1] = (f16)(acc[mb][tg + t][nb][1] + bv[nb].y);
+                            o[nb][2] = (f16)(acc[mb][tg + t][nb][2] + bv[nb].z);
+                            o[nb][3] = (f16)(acc[mb][tg + t][nb][3] + bv[nb].w);
+                        }
+                        pk[t] = pair_to_b128(o[0], o[1]);                 // lane (r, q): block q & 1, channels 8 (q >> 1) .. of voxel r, tap tg + t
+                    }
+                    fnn_u32x4r blk[2];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {                        // odd rows of tap 0 <-> even rows of tap 1: [block][lane] with tap = q & 1
+                        const auto sw = __builtin_amdgcn_permlane16_swap((unsigned)pk[0][d], (unsigned)pk[1][d], false, false);
+                        blk[0][d] = (int)sw[0]; blk[1][d] = (int)sw[1];
+                    }
+                    const unsigned ov = ob + toff[tg] + (unsigned)(q & 1) * ovs + (unsigned)(q >> 1) * 8u;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) *(fnn_u32x4r *)(outi + (cb0 + nb) * ocs + ov) = blk[nb];
+                }
+                continue;
+            }
+        }
 #pragma unroll
         for (int tg = 0; tg < TG; ++tg) {
             const unsigned ov = ob + toff[tg];
@@ -443,7 +478,12 @@ int launch_tconv(const TconvParams &p, hipStream_t st) {
     const int tg_cap = nbt == 2 ? tg_max2 : 4;
     const int tg = taps >= tg_cap ? tg_cap : taps;                     // taps is 2, 4 or 8
     dim3 grid(p.N * ((vox_in + 255) / 256), (taps / tg) * (p.nblk / nbt));
-#define FNN_TCONV(NBTv, TGv) do { fnn_note_kernel("tconv_mfma_kernel<%d,%d>", NBTv, TGv); hipLaunchKernelGGL((tconv_mfma_kernel<NBTv, TGv>), grid, dim3(256), lds, st, p); } while (0)
+    TconvParams pp = p;
+    // whole-row stores (see the kernel): the taps of a workgroup come in pairs that differ in the w phase only.  Measured
+    // (FNN_TCONV_NO_ROWSTORE: A-B aid): transposed convs 8.1 -> 7.7 ms per benchmark volume, teacher 26.7 -> 25.6; two column
+    // blocks per wave at four waves per SIMD (98 registers) next to it: 8.35 - dropped
+    pp.row_store = p.sw == 2 && nbt == 2 && tg % 2 == 0 && fnn_knob("FNN_TCONV_NO_ROWSTORE") == nullptr;
+#define FNN_TCONV(NBTv, TGv) do { fnn_note_kernel("tconv_mfma_kernel<%d,%d>", NBTv, TGv); hipLaunchKernelGGL((tconv_mfma_kernel<NBTv, TGv>), grid, dim3(256), lds, st, pp); } while (0)
     if (nbt == 2) { if (tg == 4) FNN_TCONV(2, 4); else FNN_TCONV(2, 2); }
     else          { if (tg == 4) FNN_TCONV(1, 4); else FNN_TCONV(1, 2); }
 #undef FNN_TCONV
