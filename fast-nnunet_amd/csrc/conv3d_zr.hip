@@ -1836,7 +1836,8 @@ static int launch_zr(ConvParams p, hipStream_t st) {
     p.tiles_d = (p.Do + TD - 1) / TD;
     p.tiles_h = (p.Ho + 7) / 8;
     p.tiles_w = (p.Wo + 7) / 8;
-    const size_t lds = (size_t)((TD + 2) * 10 * 12 * 32) + (size_t)NB * 15 * 1024;
+    size_t lds = (size_t)((TD + 2) * 10 * 12 * 32) + (size_t)NB * 15 * 1024;
+    if (const char *pad = fnn_knob("FNN_ZR_LDS_PAD")) lds += (size_t)atoi(pad);      // A-B aid: fewer ZR workgroups per CU (room for another stream's kernels)
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)conv3d_zr_kernel<NB, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
