@@ -392,6 +392,264 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
 }
 
 // ----------------------------------------------------------------------------
+// ONE workgroup per CU that pipelines its own stages (round 4, experiment: FNN_ZRP=1)
+// ----------------------------------------------------------------------------
+// Measured this round: conv3d_zr_kernel at one workgroup per CU keeps 88 % of its two-workgroup throughput - the two
+// co-resident workgroups run nearly in sum, a lone one spends 7.7 k of its 16.6 k cycles per two-chunk tile in MFMAs and the
+// rest where nothing of its own can overlap: the first chunk's round trip, the commit between chunks, the epilogue, the
+// store drain, the next workgroup's launch.  This kernel removes those from the critical path inside ONE workgroup:
+//   * persistent: a workgroup walks (tile, chunk) STAGES; the LDS holds TWO chunk images (2 x 69 KB of the CU's 160);
+//   * during the k-loop of stage s the loads of stage s + 2 are issued (second register set) and the data of stage s + 1
+//     - loaded during the k-loop of stage s - 1 - are normalised and written into the other image, sliced over the five
+//     tap pairs: ~1 vector / LDS instruction per MFMA gap from the SAME wave (no second wave competes for the SIMD);
+//   * one barrier per stage; the epilogue of a tile runs after its last k-loop (not overlapped in this version).
+// Same staging, image layout, k-loop, epilogue and statistics row per tile as conv3d_zr_kernel<2, 8>: bit-identical.
+struct ZrpStage { int n, od0, oh0, ow0, cb0, slot, ch; };
+template <int TD>
+__global__ __launch_bounds__(256, 1) void conv3d_zrp_kernel(const ConvParams p, const int total_units, const int groups) {
+    constexpr int NB = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int IH = 10, IW = 10, PW = 12, ID = TD + 2;
+    constexpr int PS = IH * PW * 32, ABYTES = ID * PS;
+    constexpr int KS = 15, WB = KS * 64, WPB = (WB + 255) / 256;
+    constexpr int IMG = ABYTES + NB * KS * 1024;                  // one chunk image: halo + the two cout blocks' fragments
+    float *sRed = (float *)(smem + 2 * IMG);                      // [4 waves][32][2]: the statistics' reduction
+
+    // this workgroup's units (tile, cout group): u = first + i * stride inside its XCD's contiguous range (conv3d_zsp_kernel)
+    int u_first, u_stride, u_end;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        const int wg_lo = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd;
+        const int wg_n = xcd < rm ? qd + 1 : qd;
+        const int r_lo = (int)((long long)total_units * wg_lo / nwg), r_hi = (int)((long long)total_units * (wg_lo + wg_n) / nwg);
+        u_first = r_lo + idx; u_stride = wg_n; u_end = r_hi;
+    }
+    if (u_first >= u_end) return;
+    const int n_units = (u_end - u_first + u_stride - 1) / u_stride;
+    const int n_stages = n_units * p.chunks;
+
+    // ---- this thread's halo column (tile independent parts)
+    const int col = tid >> 1, cg = tid & 1;
+    const int zh = (col * 205) >> 11, zw = col - zh * IW;
+    const bool has_col = tid < 2 * IH * IW;
+    const int ldso0 = (zh * PW + zw) * 32 + ((cg ^ (zh & 1)) * 16);
+    const int wlds = ABYTES + tid * 16;
+    int toff[5];
+    {
+        const int r = lane & 15, hl = lane >> 5, kh = (lane >> 4) & 1;
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            const int tp = 2 * pr + hl < 9 ? 2 * pr + hl : 8;
+            const int row = 2 * wave + (r >> 3) + tp / 3, col2 = (r & 7) + tp % 3;
+            toff[pr] = (row * PW + col2) * 32 + ((kh ^ (row & 1)) * 16);
+        }
+    }
+
+    auto stage_at = [&](int s) -> ZrpStage {                     // (scalar arithmetic)
+        ZrpStage g;
+        const int ui = s / p.chunks;
+        g.ch = s - ui * p.chunks;
+        int u = u_first + ui * u_stride;
+        const int grp = u % groups; u /= groups;
+        const int tw = u % p.tiles_w; u /= p.tiles_w;
+        const int th = u % p.tiles_h; u /= p.tiles_h;
+        const int td = u % p.tiles_d;
+        g.n = u / p.tiles_d;
+        g.od0 = td * TD; g.oh0 = th * 8; g.ow0 = tw * 8; g.cb0 = grp * NB;
+        g.slot = (td * p.tiles_h + th) * p.tiles_w + tw;
+        return g;
+    };
+
+    // ---- a stage's data on their way from HBM to LDS
+    struct Loads {
+        fnn_u32x4v xr[ID], wr[NB][WPB], ssv[2];
+        bool ok_hw;
+        unsigned pmask;
+        float slope;
+    };
+    auto issue = [&](Loads &L, const ZrpStage &g, int part) {    // part 0 .. 4 of the stage's 18 loads (+ the set-up in part 0)
+        const int c_glob = g.ch * 16;
+        const int sidx = (c_glob < p.src[0].C) ? 0 : 1;
+        const int c_uni = c_glob - (sidx ? p.src[0].C : 0);
+        const int sC = p.src[sidx].C, vs = FNN_VS(p.src[sidx]);
+        const unsigned item_bytes = (unsigned)p.Di * p.Hi * p.Wi * sC * 2;
+        const f16 *sp = p.src[sidx].ptr + (size_t)g.n * (item_bytes >> 1) + (c_uni >> 4) * FNN_CS(p.src[sidx]);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)sp, 0, item_bytes, 0x00020000);
+        const int gh = g.oh0 - 1 + zh, gw = g.ow0 - 1 + zw;
+        const bool ok_hw = has_col & ((unsigned)gh < (unsigned)p.Hi) & ((unsigned)gw < (unsigned)p.Wi);
+        const unsigned voff = ok_hw ? (unsigned)(__mul24(gh, p.Wi) + gw) * (unsigned)(vs * 2) + cg * 16 : 0x80000000u;
+        const unsigned plane_bytes = (unsigned)p.Hi * p.Wi * vs * 2;
+        if (part == 0) {
+            L.ok_hw = ok_hw;
+            L.slope = p.src[sidx].slope;
+            unsigned pm = (1u << ID) - 1;
+            if (g.od0 == 0) pm &= ~1u;
+            const int over = g.od0 + TD + 1 - p.Di;
+            if (over > 0) pm &= (1u << (ID - over)) - 1;
+            L.pmask = pm;
+            const unsigned short *q = p.src[sidx].ssh ? p.src[sidx].ssh + ((size_t)g.n * sC + c_uni) * 2 : p.ident_ssh + c_uni * 2;
+            const fnn_u32x4v *qv = (const fnn_u32x4v *)(q + cg * 16);
+            L.ssv[0] = qv[0]; L.ssv[1] = qv[1];
+        }
+#pragma unroll
+        for (int u = 0; u < ID; ++u) {
+            if (u * 5 / ID != part) continue;
+            int gd = g.od0 - 1 + u;
+            gd = gd < 0 ? 0 : (gd >= p.Di ? p.Di - 1 : gd);
+            L.xr[u] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, (unsigned)gd * plane_bytes, 0));
+        }
+#pragma unroll
+        for (int e = 0; e < NB * WPB; ++e) {
+            if (e * 5 / (NB * WPB) != part) continue;
+            const int nb = e / WPB, u = e % WPB;
+            const f16 *wp = p.wpk + ((size_t)((g.cb0 + nb) * p.chunks + g.ch) * WB) * 8;
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, WB * 16, 0x00020000);
+            L.wr[nb][u] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw, tid * 16, u * 4096, 0));
+        }
+    };
+    auto commit = [&](const Loads &L, char *img, int part) {     // conv3d_zr_kernel's commit(), the same five slices
+        const f16 slope_h = (f16)L.slope;
+        const fnn_u32x4v zero4 = {0u, 0u, 0u, 0u};
+        const f16x8 sc_h = __builtin_bit_cast(f16x8, L.ok_hw ? L.ssv[0] : zero4), sh_h = __builtin_bit_cast(f16x8, L.ok_hw ? L.ssv[1] : zero4);
+        if (has_col) {
+#pragma unroll
+            for (int u = 0; u < ID; ++u) {
+                if (u * 5 / ID != part) continue;
+                const f16x8 x = __builtin_bit_cast(f16x8, L.xr[u]);
+                f16x8 o = x * sc_h + sh_h;
+                o = __builtin_elementwise_max(o, o * slope_h);
+                if (!((L.pmask >> u) & 1)) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};     // a plane outside the tensor (uniform)
+                *(f16x8 *)(img + ldso0 + u * PS) = o;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NB * WPB; ++e) {
+            if (e * 5 / (NB * WPB) != part) continue;
+            const int nb = e / WPB, u = e % WPB;
+            if (u + 1 < WPB || wave < 3) *(fnn_u32x4v *)(img + wlds + (nb * WB + u * 256) * 16) = L.wr[nb][u];
+        }
+    };
+
+    f32x4 acc[TD][NB];
+    // one stage: the k-loop on `img`, with the next stage's commit into `img_n` (from Ln) and the loads of the stage after
+    // it (into Ll) riding along its five tap pairs
+    // (the loads are unconditional - behind the last stage they re-read it - a load in a conditional block makes hipcc's next wait a vmcnt(0))
+    auto run_stage = [&](const char *img, char *img_n, Loads &Ln, bool have_n, Loads &Ll, const ZrpStage &gl) {
+        const char *sA = img, *sW = img + ABYTES;
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {
+            issue(Ll, gl, pr);
+            const char *bp = sA + toff[pr];
+            f16x8 xf[ID];
+#pragma unroll
+            for (int pl = 0; pl < ID; ++pl) xf[pl] = *(const f16x8 *)(bp + pl * PS);
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                f16x8 wf[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wf[nb] = *(const f16x8 *)(sW + ((nb * KS + pr * 3 + dz) * 64 + lane) * 16);
+#pragma unroll
+                for (int j = 0; j < TD; ++j)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nb], xf[j + dz], acc[j][nb], 0, 0, 0);
+            }
+            if (have_n) commit(Ln, img_n, pr);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto begin_tile = [&](const ZrpStage &g) {
+        f32x4 b0[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b0[nb] = *(const f32x4 *)(p.bias + g.cb0 * 16 + (lane >> 4) * 8 + nb * 4);
+#pragma unroll
+        for (int j = 0; j < TD; ++j)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[j][nb] = b0[nb];
+    };
+    auto end_tile = [&](const ZrpStage &g) {                      // fp16 stores + the tile's statistics row (two barriers inside)
+        float4 bv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float t1[NB][4], t2[NB][4];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
+        zr_epilogue_pair<TD, false>(p, acc, bv, g.n, g.od0, g.oh0, g.ow0, g.cb0, wave, lane, t1, t2);
+        if (p.stats_out) {
+            stats_to_global<NB, true, true>(p, t1, t2, sRed, g.n, g.cb0, wave, lane, tid, g.slot);
+            __syncthreads();                                      // sRed is free again
+        }
+    };
+
+    // ---- the stage stream, two stages per turn so that both register sets and both images are named
+    Loads L0, L1;
+    char *imgA = smem, *imgB = smem + IMG;
+    ZrpStage g0 = stage_at(0);
+#pragma unroll
+    for (int part = 0; part < 5; ++part) issue(L0, g0, part);
+    ZrpStage g1 = g0;
+    if (n_stages > 1) {
+        g1 = stage_at(1);
+#pragma unroll
+        for (int part = 0; part < 5; ++part) issue(L1, g1, part);
+    }
+#pragma unroll
+    for (int part = 0; part < 5; ++part) commit(L0, imgA, part);
+    __syncthreads();
+    for (int s = 0; s < n_stages; s += 2) {
+        // stage s on image A; stage s + 1 (loads in L1) is committed into B; the loads of stage s + 2 go into L0
+        {
+            const bool have_n = s + 1 < n_stages, have_l = s + 2 < n_stages;
+            const ZrpStage gl = have_l ? stage_at(s + 2) : g0;
+            if (g0.ch == 0) begin_tile(g0);
+            run_stage(imgA, imgB, L1, have_n, L0, gl);
+            if (g0.ch == p.chunks - 1) end_tile(g0);
+            __syncthreads();
+            g0 = gl;
+        }
+        if (s + 1 >= n_stages) break;
+        // stage s + 1 on image B; stage s + 2 (loads in L0) is committed into A; the loads of stage s + 3 go into L1
+        {
+            const bool have_n = s + 2 < n_stages, have_l = s + 3 < n_stages;
+            const ZrpStage gl = have_l ? stage_at(s + 3) : g1;
+            if (g1.ch == 0) begin_tile(g1);
+            run_stage(imgB, imgA, L0, have_n, L1, gl);
+            if (g1.ch == p.chunks - 1) end_tile(g1);
+            __syncthreads();
+            g1 = gl;
+        }
+    }
+}
+
+template <int TD>
+static int launch_zrp(ConvParams p, hipStream_t st) {
+    p.tile_d = TD;
+    p.tiles_d = (p.Do + TD - 1) / TD;
+    p.tiles_h = (p.Ho + 7) / 8;
+    p.tiles_w = (p.Wo + 7) / 8;
+    const size_t img = (size_t)((TD + 2) * 10 * 12 * 32) + (size_t)2 * 15 * 1024;
+    const size_t lds = 2 * img + 4 * 32 * 2 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)conv3d_zrp_kernel<TD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    p.ident_ss = conv3d_identity_ss();
+    p.ident_ssh = conv3d_identity_ssh();
+    if (!p.ident_ss || !p.ident_ssh) return -2;
+    const int groups = (p.Cout / 16) / 2;
+    const int total = p.N * p.tiles_d * p.tiles_h * p.tiles_w * groups;
+    const int gx = total < 256 ? total : 256;
+    fnn_note_kernel("conv3d_zrp_kernel<%d>", TD);
+    hipLaunchKernelGGL((conv3d_zrp_kernel<TD>), dim3(gx), dim3(256), lds, st, p, total, groups);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ----------------------------------------------------------------------------
 // single-chunk layers (Cin <= 16): the same kernel WALKING along d (round 3)
 // ----------------------------------------------------------------------------
 // A 16 -> 16 (or 16 -> 32) 3x3x3 layer at full resolution - stage 0 of every isotropic network: 38 % of the 128^3
@@ -1950,6 +2208,7 @@ int launch_conv3d_zr(const ConvParams &p, hipStream_t st) {
         static const bool no_walk = fnn_knob("FNN_NO_ZRW") != nullptr;                        // A-B aid
         if (!no_walk && p.chunks == 1 && td == 8 && (p.Do + 7) / 8 >= 4) return nb == 2 ? launch_zrw<2>(p, st) : launch_zrw<1>(p, st);
     }
+    if (nb == 2 && td == 8 && fnn_knob("FNN_ZRP")) return launch_zrp<8>(p, st);          // round 4 experiment: one self-pipelined workgroup per CU
     if (nb == 2) return td == 8 ? launch_zr<2, 8>(p, st) : launch_zr<2, 4>(p, st);
     return td == 8 ? launch_zr<1, 8>(p, st) : launch_zr<1, 4>(p, st);
 }

@@ -332,3 +332,49 @@ def test_feature_exchange_matches_single_process_gloo(world, mirror):
     want = want + 100.0 * (n_eval - 1) / 2                       # evaluation f carries toy + 100 f: the mean over f
     for _, got in results:
         assert not np.isnan(got).any() and np.allclose(got, want, rtol=1e-4, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------- the path decision is a collective one
+def _decision_worker(rank, world, port, mode, q):
+    """ShardedPredictor._use_gather_all with a stand-in predictor (no engine: the decision is host logic): rank 1 sees a
+    volume with 70 tile positions along one axis (beyond the gather kernel's 64)."""
+    import types
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from fast_nnunet_amd.dist import ShardedPredictor
+        p = types.SimpleNamespace(_spec=types.SimpleNamespace(features=[16, 32], patch=(16, 16, 16)), use_mirroring=False,
+                                  allowed_mirroring_axes=None, device=torch.device('cpu'))
+        sp = ShardedPredictor(p, None, mode=mode)
+        counts = [70, 3, 3] if rank == 1 else [6, 3, 3]
+        try:
+            use = sp._use_gather_all(None, counts)
+            q.put((rank, 'ok', use, sp.last_mode))
+        except NotImplementedError as ex:
+            q.put((rank, 'raised', str(ex), None))
+        dist.barrier()                                        # every rank got here: nobody was left waiting in the all-reduce
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('mode', ['auto', 'gather'])
+def test_gather_path_decision_is_taken_by_every_rank_together(mode):
+    """a rank that cannot take the gather path used to raise BEFORE the group's all-reduce and left the others
+    waiting in it.  Now every rank reduces first: 'auto' falls back to the accumulate path everywhere (and says so in
+    `last_mode`, what bench.py prints), 'gather' raises on every rank."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_decision_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    if mode == 'auto':
+        assert [g[1:] for g in got] == [('ok', False, 'accumulate')] * 2
+    else:
+        assert all(g[1] == 'raised' for g in got)
+        assert 'tile positions' in got[1][2]                  # the rank that cannot says why; the other one reports the group's verdict
