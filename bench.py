@@ -34,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16, MI355X_MICROARCH.md "Chip-level parameters"
+MFMA_PEAK_CLOCK_GHZ = 2.4          # the clock that peak is quoted at (same table: max clock 2400 MHz)
 TRAFFIC_FILE = 'r04_traffic.json'  # per-launch HBM bytes of the conv family from separate rocprofv3 --pmc passes, per workload, keyed by csrc_sha256()
 
 WORKLOADS = {
@@ -346,16 +347,21 @@ def main():
     from fast_nnunet_amd import capi
     n_patches = capi.plan_volume(info['patch'], vol.shape[1:], 0.5)[2].shape[0]
 
-    def timed(step_fn, barrier, steps):
+    clock = {}
+
+    def timed(step_fn, barrier, steps, probe_seconds=None):
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        probe = capi.clock_probe_start(local_rank, probe_seconds) if probe_seconds else None   # one sleeping wave: the shader clock under this load
         for _ in range(steps):
             out = step_fn()
             del out
         barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if probe is not None:
+            clock['ghz'], clock['seconds'] = capi.clock_probe_stop(probe)
         if distributed:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -380,10 +386,16 @@ def main():
         step_fn = lambda: predictor.predict_sliding_window_return_logits(vol)
         barrier = lambda: None
 
+    step_est = None
     for _ in range(args.warmup):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         out = step_fn()
         del out
-    dt = timed(step_fn, barrier, args.steps)
+        torch.cuda.synchronize()
+        step_est = time.perf_counter() - t0
+    # the clock probe samples the first half of the timed region (it must end by itself before the closing synchronisation)
+    dt = timed(step_fn, barrier, args.steps, probe_seconds=min(30.0, 0.5 * args.steps * step_est) if step_est and not args.no_roofline else None)
     if distributed and args.gather != 'labels':
         out = labels_fn()                                        # (one untimed call: first-use allocations of this entry point)
         del out
@@ -452,9 +464,12 @@ def main():
         # launch stream) -> duration of the dominant kernel family (the MFMA convs).  N > 1: every rank runs the step (it is
         # collective), rank 0's profile is quoted - of its last fnn_patch_features call, i.e. its interior patches
         predictor._engine.set_profiling(True)
+        probe = capi.clock_probe_start(local_rank, min(30.0, 0.6 * step_est)) if step_est else None
         out = step_fn()
         del out
         torch.cuda.synchronize()
+        if probe is not None:
+            clock['profiled_ghz'], _ = capi.clock_probe_stop(probe)
         pr = predictor._engine.profile()
         import collections
         kernel_counts = dict(collections.Counter(predictor._engine.kernel_log()))   # which variant served every launch of that volume (N > 1: of the last engine call)
@@ -485,6 +500,12 @@ def main():
             'kernel': 'MFMA conv family: conv3d_zr / zsp / s2 / lds / persist kernels, conv_row_kernel and conv_row_stem_kernel', 'bound': 'mfma',
             'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
+            # the shader clock the device held during the first half of the timed steps (fnn_clock_probe_*: s_memtime over
+            # s_memrealtime on one sleeping wave); `peak` assumes 2.4 GHz, `frac_at_clock` prices the same work at the clock held
+            'clock_ghz': round(clock['ghz'], 3) if clock.get('ghz') else None,
+            'clock_sampled_s': round(clock['seconds'], 3) if clock.get('seconds') else None,
+            'clock_ghz_profiled_step': round(clock['profiled_ghz'], 3) if clock.get('profiled_ghz') else None,   # the step `achieved` comes from
+            'frac_at_clock': round(achieved / (MFMA_PEAK_TFLOPS * clock['profiled_ghz'] / MFMA_PEAK_CLOCK_GHZ), 4) if clock.get('profiled_ghz') else None,
             'traffic': traffic, 'traffic_source': traffic_src,
             'algorithmic_bytes': int(algo_bytes),
             'traffic_over_algorithmic': round(traffic / algo_bytes, 3) if traffic and algo_bytes else None,

@@ -63,7 +63,7 @@ class Profile(C.Structure):
 EXPORTS = ['fnn_abi_version', 'fnn_last_error', 'fnn_create', 'fnn_destroy', 'fnn_weight_count', 'fnn_load_weights',
            'fnn_set_gaussian', 'fnn_predict_volume', 'fnn_predict_volume_ensemble', 'fnn_predict_labels',
            'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_labels_box', 'fnn_feature_channels', 'fnn_patch_features', 'fnn_gather_box', 'fnn_pack_regions', 'fnn_unpack_regions', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_export_probabilities', 'fnn_resample', 'fnn_compute_steps', 'fnn_plan_volume', 'fnn_fp8_e4m3_encode',
-           'fnn_set_profiling', 'fnn_get_profile', 'fnn_kernel_log', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d', 'fnn_op_quotient_check', 'fnn_op_last_kernels']
+           'fnn_set_profiling', 'fnn_get_profile', 'fnn_kernel_log', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d', 'fnn_op_quotient_check', 'fnn_op_last_kernels', 'fnn_clock_probe_start', 'fnn_clock_probe_stop']
 
 _lib = None
 
@@ -132,6 +132,8 @@ def load_library() -> C.CDLL:
     lib.fnn_op_conv_transpose3d.argtypes = [i32, i32, I3, f32p, i32, f32p, f32p, C.c_float, f32p, f32p, i32, I3, f32p]
     lib.fnn_op_quotient_check.argtypes = [i32, C.POINTER(C.c_uint64)]
     lib.fnn_op_last_kernels.argtypes = [C.c_char_p, i32]
+    lib.fnn_clock_probe_start.argtypes = [i32, C.c_double, C.POINTER(C.c_void_p)]
+    lib.fnn_clock_probe_stop.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if lib.fnn_abi_version() != 4:
         raise EngineError('libfnn_hip.so has an unexpected ABI version')
     _lib = lib
@@ -287,6 +289,22 @@ def op_last_kernels():
     buf = C.create_string_buffer(4096)
     lib.fnn_op_last_kernels(buf, 4096)
     return [k for k in buf.value.decode().split('\n') if k]
+
+
+def clock_probe_start(device=0, max_seconds=1.0):
+    """One sleeping wave that reads the shader-clock and the 100 MHz counters for max_seconds or until clock_probe_stop (include/fnn.h)."""
+    lib = load_library()
+    h = C.c_void_p()
+    check(lib.fnn_clock_probe_start(device, float(max_seconds), C.byref(h)), lib)
+    return h
+
+
+def clock_probe_stop(handle):
+    """(GHz the device held since clock_probe_start, seconds covered)."""
+    lib = load_library()
+    ghz, sec = C.c_double(), C.c_double()
+    check(lib.fnn_clock_probe_stop(handle, C.byref(ghz), C.byref(sec)), lib)
+    return ghz.value, sec.value
 
 
 def op_quotient_check(device=0):

@@ -1436,7 +1436,7 @@ int fnn_load_weights(fnn_engine *e, int fold, const float *blob, int64_t count) 
         for (int h = 0; h < cnt; ++h) fp[e->gpass_bias_off + (size_t)k * 64 + h] = blob[e->blob_head_b + h0 + h];
         fp[e->gpass_bias_off + (size_t)k * 64 + cnt] = 1.f;
     }
-    if (!fw.wpk) HIPCHK(e, hipMalloc((void **)&fw.wpk, wpk.size() * 2));
+    if (!fw.wpk) HIPCHK(e, hipMalloc((void **)&fw.wpk, wpk.size() * 2 + 1024));   // (+ 1 KB: see fnn_op_conv3d)
     if (!fw.fparam) HIPCHK(e, hipMalloc((void **)&fw.fparam, fp.size() * 4));
     HIPCHK(e, hipMemcpy(fw.wpk, wpk.data(), wpk.size() * 2, hipMemcpyHostToDevice));
     HIPCHK(e, hipMemcpy(fw.fparam, fp.data(), fp.size() * 4, hipMemcpyHostToDevice));

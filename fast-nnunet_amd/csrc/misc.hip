@@ -1273,3 +1273,4 @@ int launch_pad_volume(const float *src, float *dst, int C, const long long s[3],
                        d[0], d[1], d[2], lo[0], lo[1], lo[2]);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+

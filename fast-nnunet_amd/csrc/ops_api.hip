@@ -149,7 +149,8 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
     if (bias) for (int i = 0; i < cout; ++i) bp[i] = bias[i];
     const size_t ovox = (size_t)p.Do * p.Ho * p.Wo;
     DevBuf dw, db, dout, dst;
-    if (!dw.alloc(wp.size() * 2) || !db.alloc(cop * 4) || !dout.alloc((size_t)n * ovox * cop * 2) ||
+    // (+ 1 KB: the ZR kernels' last weight load of a block reads one wave past it - the bytes are dropped, the address must exist)
+    if (!dw.alloc(wp.size() * 2 + 1024) || !db.alloc(cop * 4) || !dout.alloc((size_t)n * ovox * cop * 2) ||
         !dst.alloc((size_t)n * slots * cop * 16)) return FNN_E_HIP;
     (void)hipMemcpy(dw.p, wp.data(), wp.size() * 2, hipMemcpyHostToDevice);
     (void)hipMemcpy(db.p, bp.data(), cop * 4, hipMemcpyHostToDevice);
@@ -306,3 +307,66 @@ int fnn_op_quotient_check(int device, unsigned long long counts[3]) {
 }
 
 }  // extern "C"
+
+// ----------------------------------------------------------------------------
+// fnn_clock_probe_*: the shader clock under load (include/fnn.h)
+// ----------------------------------------------------------------------------
+namespace {
+__global__ void clock_probe_kernel(unsigned long long *out, const int *flag, unsigned long long max_ticks) {
+    if (threadIdx.x) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long i = 0;
+    for (;; ++i) {                                            // ~16 us per turn
+        __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+        if (__builtin_amdgcn_s_memrealtime() - r0 >= max_ticks) break;
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[0] = t1 - t0; out[1] = r1 - r0; out[2] = i;
+}
+struct ClockProbe {
+    int device = 0;
+    hipStream_t st = nullptr;
+    unsigned long long *out = nullptr;
+    int *flag = nullptr;                                      // mapped host memory
+};
+}  // namespace
+
+int fnn_clock_probe_start(int device, double max_seconds, void **probe) {
+    if (!probe || !(max_seconds > 0) || max_seconds > 60) return FNN_E_INVALID;
+    *probe = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return FNN_E_HIP;
+    ClockProbe *c = new ClockProbe;
+    c->device = device;
+    int *dflag = nullptr;
+    if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&c->out, 32) != hipSuccess ||
+        hipHostMalloc((void **)&c->flag, sizeof(int), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&dflag, c->flag, 0) != hipSuccess) {
+        if (c->flag) (void)hipHostFree(c->flag);
+        if (c->out) (void)hipFree(c->out);
+        if (c->st) (void)hipStreamDestroy(c->st);
+        delete c;
+        return FNN_E_HIP;
+    }
+    *c->flag = 0;
+    (void)hipMemsetAsync(c->out, 0, 32, c->st);
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, c->st, c->out, dflag, (unsigned long long)(max_seconds * 1e8));
+    if (hipGetLastError() != hipSuccess) { (void)hipHostFree(c->flag); (void)hipFree(c->out); (void)hipStreamDestroy(c->st); delete c; return FNN_E_HIP; }
+    *probe = c;
+    return FNN_OK;
+}
+
+int fnn_clock_probe_stop(void *probe, double *ghz, double *seconds) {
+    ClockProbe *c = (ClockProbe *)probe;
+    if (!c) return FNN_E_INVALID;
+    (void)hipSetDevice(c->device);
+    __atomic_store_n(c->flag, 1, __ATOMIC_RELEASE);
+    unsigned long long h[4] = {0, 0, 0, 0};
+    const bool ok = hipStreamSynchronize(c->st) == hipSuccess && hipMemcpy(h, c->out, 32, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipHostFree(c->flag); (void)hipFree(c->out); (void)hipStreamDestroy(c->st);
+    delete c;
+    if (!ok || h[1] == 0) return FNN_E_HIP;
+    if (ghz) *ghz = (double)h[0] / (double)h[1] * 0.1;        // s_memrealtime: 100 MHz
+    if (seconds) *seconds = (double)h[1] * 1e-8;
+    return FNN_OK;
+}

@@ -384,6 +384,17 @@ int fnn_op_conv_transpose3d(int device, int n, const int dims[3],
  * launchers pick a variant from the layer's shape; the op tests pin which one a case exercises).  Returns the size needed. */
 int fnn_op_last_kernels(char *buf, int cap);
 
+/* The shader clock the device holds while other work runs (measurement aid, no counterpart in the reference; additive in
+ * ABI 4): fnn_clock_probe_start launches ONE wave on a stream of its own that sleeps between reads of the shader-clock
+ * counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) until max_seconds have passed on the latter or
+ * fnn_clock_probe_stop raises a flag in mapped host memory; stop waits for it and returns elapsed shader cycles / elapsed
+ * time in GHz.  (A device-wide synchronisation waits for the probe like for any kernel: give it less time than the
+ * region it samples.)  bench.py samples the first half of its timed region: under sustained MFMA load the chip lowers its
+ * clock, and a roofline fraction priced at 2.4 GHz does not say how much of what the clock allows a
+ * kernel uses. */
+int fnn_clock_probe_start(int device, double max_seconds, void **probe);
+int fnn_clock_probe_stop(void *probe, double *ghz, double *seconds);
+
 /* Self-check of the closing division of the seg-head gather (predicted_logits /= n_predictions,
  * predict_from_raw_data.py:619): runs the kernel's shared-reciprocal quotient over every fp16 value a and every fp16
  * b with a clear sign bit and counts the pairs whose fp16 result differs from IEEE fp32 division rounded to fp16

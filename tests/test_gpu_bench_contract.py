@@ -28,6 +28,24 @@ def test_bench_json_line_contract():
         assert k in r, k
     assert r['bound'] in ('hbm', 'mfma') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
     assert j['value'] > 0 and abs(j['value'] - 1000.0 * _patches(j) / j['ms_per_step']) / j['value'] < 1e-3
+    # round 4: the shader clock the device held (fnn_clock_probe_*: one sleeping wave, s_memtime over s_memrealtime)
+    assert 0.5 < r['clock_ghz'] < 3.2 and 0.5 < r['clock_ghz_profiled_step'] < 3.2 and r['clock_sampled_s'] > 0
+    assert abs(r['frac_at_clock'] - r['achieved'] / (r['peak'] * r['clock_ghz_profiled_step'] / 2.4)) < 2e-3
+
+
+def test_clock_probe_ends_by_itself_and_reads_a_plausible_clock():
+    """fnn_clock_probe_start / _stop (include/fnn.h): the probe stops after max_seconds of the 100 MHz counter without a
+    flag from the host, and on request earlier; an idle device reads its idle or boost clock."""
+    import time
+    from fast_nnunet_amd import capi
+    h = capi.clock_probe_start(0, 0.05)
+    time.sleep(0.2)
+    ghz, sec = capi.clock_probe_stop(h)
+    assert 0.045 < sec < 0.08 and 0.05 < ghz < 3.5, (ghz, sec)
+    h = capi.clock_probe_start(0, 20.0)
+    t0 = time.perf_counter()
+    ghz, sec = capi.clock_probe_stop(h)                          # the flag in mapped host memory ends it
+    assert time.perf_counter() - t0 < 5.0 and sec < 5.0 and 0.05 < ghz < 3.5, (ghz, sec)
 
 
 def _patches(j):
