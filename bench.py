@@ -292,6 +292,11 @@ def spawn_ranks(n):
 
 
 def main():
+    # The clock probe is a kernel that runs for a sizeable part of a step on a stream of its own: with HIP's default of four
+    # hardware queues it shares one with a stream of the engine and everything behind it waits (2490 instead of 3440
+    # patches/s, measured); with eight the step is the same with and without it (3440 / 3424-3440).  Read at HIP's
+    # initialisation, i.e. before the first torch.cuda call below.
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
@@ -309,6 +314,9 @@ def main():
                          'bone_turbo .ini and in the bench line)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--clock-probe', action='store_true',
+                    help='sample the shader clock during the TIMED steps too (fnn_clock_probe_*: one sleeping wave on a stream of its '
+                         'own; costs ~0.5 %% of the step).  The profiled extra step is always sampled')
     ap.add_argument('--force-sharded', action='store_true', help='run the multi-GPU code path even with one rank')
     ap.add_argument('--gather', default='none', choices=['labels', 'logits', 'none'],
                     help='multi-GPU: what the timed step ends with.  none (default): the N = 1 step sharded - every rank holds '
@@ -395,7 +403,7 @@ def main():
         torch.cuda.synchronize()
         step_est = time.perf_counter() - t0
     # the clock probe samples the first half of the timed region (it must end by itself before the closing synchronisation)
-    dt = timed(step_fn, barrier, args.steps, probe_seconds=min(30.0, 0.5 * args.steps * step_est) if step_est and not args.no_roofline else None)
+    dt = timed(step_fn, barrier, args.steps, probe_seconds=min(30.0, 0.5 * args.steps * step_est) if step_est and args.clock_probe else None)
     if distributed and args.gather != 'labels':
         out = labels_fn()                                        # (one untimed call: first-use allocations of this entry point)
         del out
@@ -464,7 +472,7 @@ def main():
         # launch stream) -> duration of the dominant kernel family (the MFMA convs).  N > 1: every rank runs the step (it is
         # collective), rank 0's profile is quoted - of its last fnn_patch_features call, i.e. its interior patches
         predictor._engine.set_profiling(True)
-        probe = capi.clock_probe_start(local_rank, min(30.0, 0.6 * step_est)) if step_est else None
+        probe = capi.clock_probe_start(local_rank, min(30.0, 0.6 * step_est)) if step_est else None   # (outside the timed region)
         out = step_fn()
         del out
         torch.cuda.synchronize()
