@@ -292,10 +292,11 @@ def spawn_ranks(n):
 
 
 def main():
-    # The clock probe is a kernel that runs for a sizeable part of a step on a stream of its own: with HIP's default of four
-    # hardware queues it shares one with a stream of the engine and everything behind it waits (2490 instead of 3440
-    # patches/s, measured); with eight the step is the same with and without it (3440 / 3424-3440).  Read at HIP's
-    # initialisation, i.e. before the first torch.cuda call below.
+    # The clock probe (one extra untimed step, below) is a kernel that runs for most of a step on a stream of its own: with
+    # HIP's default of four hardware queues it shares one with a stream of the engine and everything behind it waits (2490
+    # instead of 3440 patches/s next to it, measured); with eight the step is the same with and without it (3440 / 3424).
+    # The timed steps themselves do not care (3440 / 3440, 3347 / 3357 on two boxes).  Read at HIP's initialisation, i.e.
+    # before the first torch.cuda call below.
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -314,9 +315,7 @@ def main():
                          'bone_turbo .ini and in the bench line)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--clock-probe', action='store_true',
-                    help='sample the shader clock during the TIMED steps too (fnn_clock_probe_*: one sleeping wave on a stream of its '
-                         'own; costs ~0.5 %% of the step).  The profiled extra step is always sampled')
+    ap.add_argument('--no-clock-probe', action='store_true', help='skip the extra step that samples the shader clock (fnn_clock_probe_*)')
     ap.add_argument('--force-sharded', action='store_true', help='run the multi-GPU code path even with one rank')
     ap.add_argument('--gather', default='none', choices=['labels', 'logits', 'none'],
                     help='multi-GPU: what the timed step ends with.  none (default): the N = 1 step sharded - every rank holds '
@@ -357,19 +356,16 @@ def main():
 
     clock = {}
 
-    def timed(step_fn, barrier, steps, probe_seconds=None):
+    def timed(step_fn, barrier, steps):
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        probe = capi.clock_probe_start(local_rank, probe_seconds) if probe_seconds else None   # one sleeping wave: the shader clock under this load
         for _ in range(steps):
             out = step_fn()
             del out
         barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if probe is not None:
-            clock['ghz'], clock['seconds'] = capi.clock_probe_stop(probe)
         if distributed:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -402,8 +398,18 @@ def main():
         del out
         torch.cuda.synchronize()
         step_est = time.perf_counter() - t0
-    # the clock probe samples the first half of the timed region (it must end by itself before the closing synchronisation)
-    dt = timed(step_fn, barrier, args.steps, probe_seconds=min(30.0, 0.5 * args.steps * step_est) if step_est and args.clock_probe else None)
+    dt = timed(step_fn, barrier, args.steps)
+    if step_est and not args.no_clock_probe and not args.no_roofline:
+        # one extra, identical, UNTIMED step beside the clock probe (one sleeping wave, fnn_clock_probe_*): the shader clock the
+        # device holds under this step.  Not in the timed region (it costs ~0.5 % there) and not in the profiled step below
+        # (it stretches the per-launch durations by ~4 %, measured: 734 -> 700 TFLOP/s)
+        barrier()
+        torch.cuda.synchronize()
+        probe = capi.clock_probe_start(local_rank, min(30.0, 0.8 * step_est))   # (ends by itself before the step's closing synchronisation)
+        out = step_fn()
+        del out
+        torch.cuda.synchronize()
+        clock['ghz'], clock['seconds'] = capi.clock_probe_stop(probe)
     if distributed and args.gather != 'labels':
         out = labels_fn()                                        # (one untimed call: first-use allocations of this entry point)
         del out
@@ -472,12 +478,9 @@ def main():
         # launch stream) -> duration of the dominant kernel family (the MFMA convs).  N > 1: every rank runs the step (it is
         # collective), rank 0's profile is quoted - of its last fnn_patch_features call, i.e. its interior patches
         predictor._engine.set_profiling(True)
-        probe = capi.clock_probe_start(local_rank, min(30.0, 0.6 * step_est)) if step_est else None   # (outside the timed region)
         out = step_fn()
         del out
         torch.cuda.synchronize()
-        if probe is not None:
-            clock['profiled_ghz'], _ = capi.clock_probe_stop(probe)
         pr = predictor._engine.profile()
         import collections
         kernel_counts = dict(collections.Counter(predictor._engine.kernel_log()))   # which variant served every launch of that volume (N > 1: of the last engine call)
@@ -508,12 +511,12 @@ def main():
             'kernel': 'MFMA conv family: conv3d_zr / zsp / s2 / lds / persist kernels, conv_row_kernel and conv_row_stem_kernel', 'bound': 'mfma',
             'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
-            # the shader clock the device held during the first half of the timed steps (fnn_clock_probe_*: s_memtime over
-            # s_memrealtime on one sleeping wave); `peak` assumes 2.4 GHz, `frac_at_clock` prices the same work at the clock held
+            # the shader clock the device held during most of one extra step identical to the timed ones (fnn_clock_probe_*:
+            # s_memtime over s_memrealtime on one sleeping wave); `peak` assumes 2.4 GHz, `frac_at_clock` prices the same work
+            # at the clock held (the profiled step that `achieved` comes from runs one stream and may hold a slightly other one)
             'clock_ghz': round(clock['ghz'], 3) if clock.get('ghz') else None,
             'clock_sampled_s': round(clock['seconds'], 3) if clock.get('seconds') else None,
-            'clock_ghz_profiled_step': round(clock['profiled_ghz'], 3) if clock.get('profiled_ghz') else None,   # the step `achieved` comes from
-            'frac_at_clock': round(achieved / (MFMA_PEAK_TFLOPS * clock['profiled_ghz'] / MFMA_PEAK_CLOCK_GHZ), 4) if clock.get('profiled_ghz') else None,
+            'frac_at_clock': round(achieved / (MFMA_PEAK_TFLOPS * clock['ghz'] / MFMA_PEAK_CLOCK_GHZ), 4) if clock.get('ghz') else None,
             'traffic': traffic, 'traffic_source': traffic_src,
             'algorithmic_bytes': int(algo_bytes),
             'traffic_over_algorithmic': round(traffic / algo_bytes, 3) if traffic and algo_bytes else None,

@@ -389,9 +389,10 @@ int fnn_op_last_kernels(char *buf, int cap);
  * counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) until max_seconds have passed on the latter or
  * fnn_clock_probe_stop raises a flag in mapped host memory; stop waits for it and returns elapsed shader cycles / elapsed
  * time in GHz.  (A device-wide synchronisation waits for the probe like for any kernel: give it less time than the
- * region it samples.)  bench.py samples the first half of its timed region: under sustained MFMA load the chip lowers its
+ * region it samples.)  bench.py runs one extra, untimed step beside it: under sustained MFMA load the chip lowers its
  * clock, and a roofline fraction priced at 2.4 GHz does not say how much of what the clock allows a
- * kernel uses. */
+ * kernel uses.  The probe is not free: next to it per-launch durations stretch by ~4 %, and with HIP's default of four
+ * hardware queues it can share a queue with a caller's stream, whose work then waits for it (GPU_MAX_HW_QUEUES=8). */
 int fnn_clock_probe_start(int device, double max_seconds, void **probe);
 int fnn_clock_probe_stop(void *probe, double *ghz, double *seconds);
 
