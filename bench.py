@@ -405,11 +405,11 @@ def main():
         # (it stretches the per-launch durations by ~4 %, measured: 734 -> 700 TFLOP/s)
         barrier()
         torch.cuda.synchronize()
-        probe = capi.clock_probe_start(local_rank, min(30.0, 0.8 * step_est))   # (ends by itself before the step's closing synchronisation)
-        out = step_fn()
+        probe = capi.clock_probe_start(local_rank, min(30.0, 4.0 * step_est))
+        out = step_fn()                                          # (returns when the volume is done: the engine's entry points are synchronous)
+        clock['ghz'], clock['seconds'] = capi.clock_probe_stop(probe)   # raises the probe's flag and waits for ITS stream only
         del out
         torch.cuda.synchronize()
-        clock['ghz'], clock['seconds'] = capi.clock_probe_stop(probe)
     if distributed and args.gather != 'labels':
         out = labels_fn()                                        # (one untimed call: first-use allocations of this entry point)
         del out
