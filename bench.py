@@ -410,6 +410,13 @@ def main():
         clock['ghz'], clock['seconds'] = capi.clock_probe_stop(probe)   # raises the probe's flag and waits for ITS stream only
         del out
         torch.cuda.synchronize()
+        # the sample only counts when the probed step ran like the timed ones: with fewer hardware queues than streams (HIP
+        # initialised before main() set GPU_MAX_HW_QUEUES - a profiler's preload, an embedding process) the probe shares a queue
+        # with an engine stream and the step waits behind it; then the clock is that of a stalled device
+        step_timed = dt / args.steps
+        if not (0.85 * step_timed <= clock['seconds'] <= 1.15 * step_timed):
+            clock = {'rejected': f"probed step took {clock['seconds']:.3f} s against {step_timed:.3f} s timed: the probe disturbed the step "
+                                 f"(GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}), sample dropped"}
     if distributed and args.gather != 'labels':
         out = labels_fn()                                        # (one untimed call: first-use allocations of this entry point)
         del out
@@ -445,6 +452,7 @@ def main():
                    'accumulators': accumulate_in,
                    'gflop_per_patch': round(flops_patch / 1e9, 2),
                    'step_output': assembly,
+                   'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                    'parallelism': f'patch-sharded x{world}, patch-activation exchange + slab gather over RCCL' if distributed else 'single GPU'},
     }
     if args.folds > 1:
@@ -453,6 +461,10 @@ def main():
                                         f'({n_patches} x {args.folds} per volume), sec_per_volume is the whole ensemble')
     if dt_labels is not None:
         result['ms_per_step_labels_assembled'] = round(dt_labels / max(1, min(args.steps, 5)) * 1e3, 3)
+        result['value_labels_assembled'] = round(n_patches * args.folds / (dt_labels / max(1, min(args.steps, 5))), 3)
+        result['series_note'] = ('rounds 1-3 timed the N > 1 step with the label map assembled on every rank (--gather labels); since round 4 '
+                                 '`value` is the N = 1 step sharded (--gather none: each rank ends with the fp16 logits of its box) and the '
+                                 'assembled step is `value_labels_assembled` / `ms_per_step_labels_assembled`: compare like with like')
     if distributed:
         # one extra, profiled step (the device is synchronised at every phase boundary, so it is slower than the timed
         # ones): where a rank's time goes and what it exchanges - per phase the MAX over ranks, bytes per rank as a list
@@ -515,6 +527,7 @@ def main():
             # s_memtime over s_memrealtime on one sleeping wave); `peak` assumes 2.4 GHz, `frac_at_clock` prices the same work
             # at the clock held (the profiled step that `achieved` comes from runs one stream and may hold a slightly other one)
             'clock_ghz': round(clock['ghz'], 3) if clock.get('ghz') else None,
+            'clock_note': clock.get('rejected'),
             'clock_sampled_s': round(clock['seconds'], 3) if clock.get('seconds') else None,
             'frac_at_clock': round(achieved / (MFMA_PEAK_TFLOPS * clock['ghz'] / MFMA_PEAK_CLOCK_GHZ), 4) if clock.get('ghz') else None,
             'traffic': traffic, 'traffic_source': traffic_src,
@@ -530,6 +543,12 @@ def main():
                               'tconv': round(pr.tconv_ms, 2), 'seg_head_accumulate': round(pr.head_ms, 2),
                               'finalize': round(pr.finalize_ms, 2)},
             'whole_net_tflops': round(flops_patch * n_patches * args.folds / (dt / args.steps) / 1e12, 2),
+            # `achieved` / `frac` describe the PROFILED step (one stream, events around every launch); `value` the timed steps
+            # (three batches in flight on the engine's streams).  Both schedules side by side:
+            'schedules': {'profiled_step_kernel_ms_sum': round(pr.total_ms, 2), 'profiled_step_family_ms': round(pr.conv_ms, 2),
+                          'timed_step_ms': round(dt / args.steps * 1e3, 2),
+                          'hidden_by_batches_in_flight': round(1.0 - (dt / args.steps * 1e3) / pr.total_ms, 4) if pr.total_ms > 0 else None,
+                          'family_tflops_if_scaled_to_timed_step': round(achieved * pr.total_ms / (dt / args.steps * 1e3), 2) if pr.total_ms > 0 else None},
             'profiled': 'rank 0, its interior patches (the last fnn_patch_features call of one extra step)' if distributed else 'one extra volume on one stream',
             'launches_by_kernel': kernel_counts,
         }

@@ -103,6 +103,14 @@ struct fnn_engine {
     f16 *actp[MAXP] = {}; double *statsp[MAXP] = {}; float *ssp[MAXP] = {};      // [0] aliases act / stats / ss
     hipStream_t pipe[MAXP] = {};
     hipEvent_t ev_start = nullptr, ev_head[MAXP] = {}, ev_done[MAXP] = {};
+    // CU-masked co-scheduling experiment (FNN_CUMASK = "<thin CUs>[,a]", off by default): the full-resolution,
+    // HBM-bound layers of a batch go to a stream whose queue may only use `cus_thin` CUs, the rest of the network to a
+    // stream on the complementary CUs (",a": on all of them), so that one batch's level-0 kernels run BESIDE another
+    // batch's matrix-bound layers instead of behind them.
+    int cus_thin = 0, cus_heavy = 0;
+    hipStream_t pipe_thin[MAXP] = {};
+    hipEvent_t ev_sw[MAXP] = {};
+    hipStream_t st_thin = nullptr; hipEvent_t ev_switch = nullptr;       // of the batch forward_batch is working on
     f16 *gauss = nullptr;
     f16 *ones = nullptr;                    // weight map of use_gaussian = 0 (the kernels load the map unconditionally)
     int *inf_flag = nullptr;
@@ -674,8 +682,30 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
                   float *head_ss = nullptr, unsigned short *head_ssh = nullptr) {
     const FoldWeights &fw = e->folds[fold];
     HIPCHK(e, hipMemsetAsync(e->stats, 0, e->stats_doubles * e->max_batch * sizeof(double), st));
+    hipStream_t const st_main = st, st_thin = e->st_thin;
+    static const int thin_set = fnn_knob("FNN_CUMASK_SET") ? atoi(fnn_knob("FNN_CUMASK_SET")) : 0;
+    struct Rejoin {                                           // whatever path leaves this function, `st_main` ends behind the work
+        fnn_engine *e; hipStream_t main; hipStream_t *cur;
+        ~Rejoin() {
+            if (*cur != main) { (void)hipEventRecord(e->ev_switch, *cur); (void)hipStreamWaitEvent(main, e->ev_switch, 0); }
+            fnn_set_cu_hint(0);
+        }
+    } rejoin{e, st_main, &st};
     for (size_t li = 0; li < e->layers.size(); ++li) {
         const Layer &L = e->layers[li];
+        if (st_thin) {
+            // level 0 = output at the patch's resolution (FNN_CUMASK_SET=1: also the layers that READ level 0)
+            bool thin = L.out_dims[0] == e->arch.patch[0] && L.out_dims[1] == e->arch.patch[1] && L.out_dims[2] == e->arch.patch[2];
+            if (!thin && thin_set >= 1 && L.type != Layer::STEM)
+                thin = L.in_dims[0] == e->arch.patch[0] && L.in_dims[1] == e->arch.patch[1] && L.in_dims[2] == e->arch.patch[2];
+            hipStream_t want = thin ? st_thin : st_main;
+            if (want != st) {
+                HIPCHK(e, hipEventRecord(e->ev_switch, st));
+                HIPCHK(e, hipStreamWaitEvent(want, e->ev_switch, 0));
+                st = want;
+            }
+            fnn_set_cu_hint(thin ? e->cus_thin : e->cus_heavy);
+        }
         f16 *out = e->act + L.out_off * e->max_batch;
         if (head_out && (int)li == e->head_src) out = head_out;
         double *stats_out = L.has_norm ? e->stats + L.stats_off * e->max_batch : nullptr;
@@ -937,6 +967,17 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
                     HIPCHK(e, hipMalloc((void **)&e->statsp[k], e->stats_doubles * e->max_batch * sizeof(double)));
                     HIPCHK(e, hipMalloc((void **)&e->ssp[k], (e->ss_count * e->max_batch * 3 + 8) * sizeof(float)));   // fp32 rows + fp16 rows (ssh_rows)
                 }
+                if (e->cus_thin > 0) {
+                    // bit i of the mask = CU i of the queue's CU list; thin = the first cus_thin bits, heavy = the rest (or all)
+                    uint32_t m_thin[8] = {}, m_heavy[8] = {};
+                    for (int c = 0; c < 256; ++c) {
+                        if (c < e->cus_thin) m_thin[c >> 5] |= 1u << (c & 31);
+                        if (c >= e->cus_thin || e->cus_heavy == 256) m_heavy[c >> 5] |= 1u << (c & 31);
+                    }
+                    HIPCHK(e, hipExtStreamCreateWithCUMask(&e->pipe[k], 8, m_heavy));
+                    HIPCHK(e, hipExtStreamCreateWithCUMask(&e->pipe_thin[k], 8, m_thin));
+                    HIPCHK(e, hipEventCreateWithFlags(&e->ev_sw[k], hipEventDisableTiming));
+                } else
                 HIPCHK(e, hipStreamCreateWithFlags(&e->pipe[k], hipStreamNonBlocking));
                 HIPCHK(e, hipEventCreateWithFlags(&e->ev_head[k], hipEventDisableTiming));
                 HIPCHK(e, hipEventCreateWithFlags(&e->ev_done[k], hipEventDisableTiming));
@@ -964,7 +1005,7 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
     };
     struct Restore {                                      // whatever happens, the engine ends on its first arena
         fnn_engine *e; f16 *a; double *s; float *ss;
-        ~Restore() { e->act = a; e->stats = s; e->ss = ss; }
+        ~Restore() { e->act = a; e->stats = s; e->ss = ss; e->st_thin = nullptr; e->ev_switch = nullptr; }
     } restore{e, act0, stats0, ss0};
     hipStream_t user_st = st;
     int64_t bi = 0;
@@ -975,6 +1016,7 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
         if (pipelined) {
             st = e->pipe[k];
             e->act = e->actp[k]; e->stats = e->statsp[k]; e->ss = e->ssp[k];
+            e->st_thin = e->pipe_thin[k]; e->ev_switch = e->ev_sw[k];
         }
         for (size_t ci = 0; ci <= (tta ? combos.size() : 0); ++ci) {
             int flip[3] = {0, 0, 0};
@@ -1105,6 +1147,24 @@ int accumulate_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const
     return run_patches(e, fold, vol_dev, vp, o, ids, e->origins, box, e->acc, acc_fp32, st, fresh);
 }
 
+// The gather kernel's integer tables for a volume: tile starts (+ window bases of axes with more than 64 positions,
+// gather.hip gather_tile_windows).  false: an axis has more than 64 tiles over one voxel.
+bool gather_tables(const fnn_arch_desc &a, const VolPlan &vp, std::vector<int> *tab, int off[3]) {
+    const long long *st[3] = {(const long long *)vp.steps[0].data(), (const long long *)vp.steps[1].data(), (const long long *)vp.steps[2].data()};
+    const int n[3] = {(int)vp.steps[0].size(), (int)vp.steps[1].size(), (int)vp.steps[2].size()};
+    const int ext[3] = {a.patch[0], a.patch[1], a.patch[2]};
+    const long long pad[3] = {(long long)vp.padded[0], (long long)vp.padded[1], (long long)vp.padded[2]};
+    size_t count = 0;
+    if (!gather_tile_windows(st, n, ext, pad, nullptr, off, &count)) return false;
+    if (tab) { tab->assign(count, 0); (void)gather_tile_windows(st, n, ext, pad, tab->data(), off, &count); }
+    return true;
+}
+void gather_set_tables(GatherParams &g, const int *dev, const int off[3]) {
+    g.steps = dev;
+    g.base_x = off[0] >= 0 ? dev + off[0] : nullptr; g.base_y = off[1] >= 0 ? dev + off[1] : nullptr; g.base_z = off[2] >= 0 ? dev + off[2] : nullptr;
+    g.windowed = 1;
+}
+
 // Plan of the gather path (gather.hip) for a volume: how many x layers of patches are kept at a time.
 struct GatherPlan { bool ok = false; int n_eval = 1, ring = 0, cover = 1; size_t layer_items = 0, feat_bytes = 0; const char *why = ""; };
 
@@ -1121,7 +1181,8 @@ GatherPlan gather_plan(fnn_engine *e, const VolPlan &vp, const fnn_opts &o, size
     g.nx = (int)vp.steps[0].size(); g.ny = (int)vp.steps[1].size(); g.nz = (int)vp.steps[2].size();
     gp.n_eval = 1 + (int)mirror_combos(o).size();
     g.n_eval = gp.n_eval; g.n_pass = e->n_gpass;
-    gp.why = "the network's head does not fit the gather kernel (a normalised last layer of <= 32 channels, <= 8 evaluations per patch, <= 64 tile positions per axis)";
+    { int off[3]; g.windowed = gather_tables(e->arch, vp, nullptr, off) ? 1 : 0; }
+    gp.why = "the network's head does not fit the gather kernel (a normalised last layer of <= 32 channels, <= 8 evaluations per patch, <= 64 tiles of one axis over a voxel)";
     if (!H.has_norm || e->head_ksteps != 1 || !gather_ok(g)) return gp;
     gp.why = "not enough free HBM for the patch activations that cover one output slab";
     const auto &sx = vp.steps[0];
@@ -1160,7 +1221,8 @@ int gather_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const Vol
     if (int rc = ensure(e, &e->featss, &e->featss_bytes, (size_t)n_slots * gp.n_eval * 2 * H.cout_pad * sizeof(float))) return rc;
     if (int rc = ensure(e, &e->featssh, &e->featssh_bytes, (size_t)n_slots * gp.n_eval * 2 * H.cout_pad * sizeof(f16))) return rc;
     std::vector<int> steps;
-    for (int d = 0; d < 3; ++d) for (int64_t v : vp.steps[d]) steps.push_back((int)v);
+    int win_off[3];
+    if (!gather_tables(a, vp, &steps, win_off)) return fail(e, FNN_E_UNSUPPORTED, "more than 64 tiles of one axis over a voxel");
     if (int rc = upload_ints(e, steps.data(), steps.size(), &e->steps_dev, &e->steps_cap, &e->steps_host, &e->steps_host_cap, &e->steps_ev, st)) return rc;
     Box box;
     for (int d = 0; d < 3; ++d) { box.lo[d] = 0; box.hi[d] = vp.padded[d]; }
@@ -1178,7 +1240,8 @@ int gather_whole_volume(fnn_engine *e, int fold, const float *vol_dev, const Vol
         }
     }
     g.slope = H.act ? a.slope : 1.f;
-    g.steps = e->steps_dev; g.nx = (int)vp.steps[0].size(); g.ny = (int)vp.steps[1].size(); g.nz = (int)vp.steps[2].size();
+    gather_set_tables(g, e->steps_dev, win_off);
+    g.nx = (int)vp.steps[0].size(); g.ny = (int)vp.steps[1].size(); g.nz = (int)vp.steps[2].size();
     g.PD = a.patch[0]; g.PH = a.patch[1]; g.PW = a.patch[2];
     g.wpk = fw.wpk + e->head_w_off; g.bias = fw.fparam + e->head_bias_off; g.heads = a.num_heads; g.hblocks = e->hblocks;
     g.n_pass = e->n_gpass; g.pass_wpk = fw.wpk + e->gpass_w_off; g.pass_bias = fw.fparam + e->gpass_bias_off;
@@ -1331,6 +1394,10 @@ int fnn_create(const fnn_arch_desc *arch, int device, int max_batch, fnn_engine 
     fnn_engine *e = new fnn_engine();
     e->arch = *arch; e->device = device; e->max_batch = max_batch;
     e->fuse_enabled = fnn_knob("FNN_NO_FUSE") == nullptr;
+    if (const char *cm = fnn_knob("FNN_CUMASK")) {
+        const int n = atoi(cm);
+        if (n >= 8 && n <= 248) { e->cus_thin = n; e->cus_heavy = strstr(cm, ",a") ? 256 : 256 - n; }
+    }
     if (const char *v = fnn_knob("FNN_FUSE_STEM")) e->fuse_stem = atoi(v) != 0 ? 1 : 0;
     if (const char *v = fnn_knob("FNN_FUSE_TCONV")) e->fuse_tconv = atoi(v) != 0;
     e->gather_enabled = fnn_knob("FNN_NO_GATHER") == nullptr;
@@ -1364,6 +1431,8 @@ void fnn_destroy(fnn_engine *e) {
     for (auto &f : e->folds) { if (f.wpk) (void)hipFree(f.wpk); if (f.fparam) (void)hipFree(f.fparam); }
     for (int k = 0; k < fnn_engine::MAXP; ++k) {
         if (e->pipe[k]) (void)hipStreamDestroy(e->pipe[k]);
+        if (e->pipe_thin[k]) (void)hipStreamDestroy(e->pipe_thin[k]);
+        if (e->ev_sw[k]) (void)hipEventDestroy(e->ev_sw[k]);
         if (e->ev_head[k]) (void)hipEventDestroy(e->ev_head[k]);
         if (e->ev_done[k]) (void)hipEventDestroy(e->ev_done[k]);
         if (k > 0) { (void)hipFree(e->actp[k]); (void)hipFree(e->statsp[k]); (void)hipFree(e->ssp[k]); }
@@ -1612,14 +1681,15 @@ int fnn_gather_box(fnn_engine *e, int fold, const void *feat, const float *fss, 
     g.heads = a.num_heads; g.C = H.cout_pad; g.PD = a.patch[0]; g.PH = a.patch[1]; g.PW = a.patch[2]; g.n_eval = 1 + (int)combos.size();
     g.n_pass = e->n_gpass;
     g.nx = (int)vp.steps[0].size(); g.ny = (int)vp.steps[1].size(); g.nz = (int)vp.steps[2].size();
+    std::vector<int> tab;
+    int win_off[3];
+    g.windowed = gather_tables(a, vp, &tab, win_off) ? 1 : 0;
     if (labels && e->n_gpass > 1)
         return fail(e, FNN_E_UNSUPPORTED, "fnn_gather_box writes labels for <= 63 classes; with %d take the logits and fnn_argmax_labels", a.num_heads);
     if (!H.has_norm || e->head_ksteps != 1 || !gather_ok(g)) return fail(e, FNN_E_UNSUPPORTED, "this network's head does not fit the gather kernel");
     for (int64_t i = 0; i < vp.n_patches; ++i)
         if (slot_of_patch[i] >= n_slots) return fail(e, FNN_E_INVALID, "slot %d of patch %lld is beyond the %lld slots", slot_of_patch[i], (long long)i, (long long)n_slots);
-    // tile starts, then the slot table, in one device buffer
-    std::vector<int> tab;
-    for (int d = 0; d < 3; ++d) for (int64_t v : vp.steps[d]) tab.push_back((int)v);
+    // tile starts (+ window bases), then the slot table, in one device buffer
     const size_t n_steps = tab.size();
     for (int64_t i = 0; i < vp.n_patches; ++i) tab.push_back(slot_of_patch[i]);
     if (int rc = upload_ints(e, tab.data(), tab.size(), &e->steps_dev, &e->steps_cap, &e->steps_host, &e->steps_host_cap, &e->steps_ev, st)) return rc;
@@ -1638,8 +1708,8 @@ int fnn_gather_box(fnn_engine *e, int fold, const void *feat, const float *fss, 
         g.flipmask[ci + 1] = m;
     }
     g.slope = H.act ? a.slope : 1.f;
-    g.steps = e->steps_dev; g.slot_tab = e->steps_dev + n_steps;
-    g.nx = (int)vp.steps[0].size(); g.ny = (int)vp.steps[1].size(); g.nz = (int)vp.steps[2].size();
+    gather_set_tables(g, e->steps_dev, win_off);
+    g.slot_tab = e->steps_dev + n_steps;
     g.wpk = fw.wpk + e->head_w_off; g.bias = fw.fparam + e->head_bias_off; g.hblocks = e->hblocks;
     g.pass_wpk = fw.wpk + e->gpass_w_off; g.pass_bias = fw.fparam + e->gpass_bias_off;
     g.gauss = opts->use_gaussian ? e->gauss : e->ones;

@@ -195,6 +195,12 @@ struct GatherParams {
     float slope;
     const int *steps;            // device: tile starts per axis, x then y then z (ascending)
     int nx, ny, nz;
+    // an axis with more than 64 tile positions (a 2-D configuration's slices, a small patch in a long volume): per padded
+    // coordinate c the index of the first tile that reaches it (start + extent > c); the tiles that can cover c - or meet
+    // the 64-voxel run that starts at c, along z - are the 64 from there (gather_tile_windows checks that on the host).
+    // nullptr: the axis has <= 64 positions, window base 0
+    const int *base_x, *base_y, *base_z;
+    int windowed;                // host check passed: axes with more than 64 positions come with their base tables
     int PD, PH, PW;
     const f16 *wpk;              // seg head [hblock][64][8] (one k-step)
     const float *bias;           // [hblocks * 16], bias[heads] = 1 (the weight-sum channel)
@@ -218,6 +224,11 @@ struct GatherParams {
     int ieee_div;                    // A-B aid (FNN_GATHER_IEEE): IEEE division per value in the epilogue
 };
 
+// tile starts of the three axes + (for an axis with more than 64 positions) its window-base table, ready for upload:
+// tab = [steps x | steps y | steps z | base tables ...]; off[d] = offset of axis d's base table in tab or -1.
+// false: some coordinate is covered by more than 64 tiles of one axis (the accumulate path serves that)
+bool gather_tile_windows(const long long *const steps[3], const int n[3], const int extent[3], const long long padded[3],
+                         int *tab, int off[3], size_t *count);
 struct FinalizeParams {
     const void *acc;             // [AX][Y][Z][HP]
     long long AX, Y, Z;
@@ -248,6 +259,9 @@ struct FinalizeParams {
 // variables that are honoured ONLY when FNN_KNOBS=1 is set as well - a production process does not change behaviour
 // because of a stray variable; the tests and tools/ set it.
 const char *fnn_knob(const char *name);
+// CUs the stream of the next launches may use (0 = the whole device): kernels whose grid is "one workgroup per CU" size it by this
+void fnn_set_cu_hint(int cus);
+int fnn_cu_hint();
 // Which kernel variant a launcher picked: recorded per launch while the engine profiles (fnn_kernel_log), a no-op otherwise.
 void fnn_note_kernel(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 void fnn_klog_target(void *vector_of_strings);          // where this thread's notes go (nullptr: nowhere)

@@ -279,7 +279,9 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
     // (the reference's).  Lane i holds tile start i of each axis (<= 64 per axis: gather_ok); the covering sets are three
     // ballots, a patch's start a v_readlane: no memory access between visits apart from a sharded caller's slot table.
     constexpr int NEVER = 0x3fffffff;                          // a tile start no coordinate reaches
-    const int tx = lane < p.nx ? sx[lane] : NEVER, ty = lane < p.ny ? sy[lane] : NEVER, tz = lane < p.nz ? sz[lane] : NEVER;
+    // (an axis with more than 64 positions: the 64 from the first tile that reaches this coordinate - GatherParams::base_x)
+    const int bx = p.base_x ? p.base_x[xp] : 0, by = p.base_y ? p.base_y[yp] : 0, bz = p.base_z ? p.base_z[zp0] : 0;
+    const int tx = bx + lane < p.nx ? sx[bx + lane] : NEVER, ty = by + lane < p.ny ? sy[by + lane] : NEVER, tz = bz + lane < p.nz ? sz[bz + lane] : NEVER;
     const unsigned long long MX = __builtin_amdgcn_ballot_w64(tx <= xp && xp - tx < p.PD);
     const unsigned long long MY = __builtin_amdgcn_ballot_w64(ty <= yp && yp - ty < p.PH);
     const unsigned long long MZ = __builtin_amdgcn_ballot_w64(tz < zp0 + ZW && zp0 - tz < p.PW);
@@ -288,8 +290,9 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
         const int jx = __builtin_ctzll(c.rx), jy = __builtin_ctzll(c.ry), jz = __builtin_ctzll(c.rz);
         GatherGeo e;
         e.dx = xp - __builtin_amdgcn_readlane(tx, jx); e.dy = yp - __builtin_amdgcn_readlane(ty, jy); e.oz = __builtin_amdgcn_readlane(tz, jz);
-        const int pid = (jx * p.ny + jy) * p.nz + jz;
-        e.slot = p.slot_tab ? p.slot_tab[pid] : ((jx % p.ring) * p.ny + jy) * p.nz + jz;   // -1: not held here (a sharded caller's table)
+        const int gx = jx + bx, gy = jy + by, gz = jz + bz;    // tile indices on the whole axes
+        const int pid = (gx * p.ny + gy) * p.nz + gz;
+        e.slot = p.slot_tab ? p.slot_tab[pid] : ((gx % p.ring) * p.ny + gy) * p.nz + gz;   // -1: not held here (a sharded caller's table)
         return e;
     };
     const auto advance = [&](Cur &c) -> bool {                 // z fastest; false = past the last visit
@@ -624,7 +627,28 @@ int launch_quotient_check(unsigned long long *counts, hipStream_t st) {         
 bool gather_ok(const GatherParams &p) {
     const int hblocks = (p.heads + 1 + 15) / 16;
     return (hblocks <= 4 || p.n_pass > 1) && p.C <= 32 && p.C % 8 == 0 && (long long)p.PD * p.PH * p.PW < (1LL << 31) / 32 && p.n_eval <= 8 &&
-           p.nx <= 64 && p.ny <= 64 && p.nz <= 64;          // a wave holds an axis' tile starts one per lane
+           ((p.nx <= 64 && p.ny <= 64 && p.nz <= 64) || p.windowed);   // a wave holds 64 of an axis' tile starts one per lane
+}
+
+bool gather_tile_windows(const long long *const steps[3], const int n[3], const int extent[3], const long long padded[3],
+                         int *tab, int off[3], size_t *count) {
+    size_t k = 0;
+    for (int d = 0; d < 3; ++d)
+        for (int i = 0; i < n[d]; ++i, ++k) if (tab) tab[k] = (int)steps[d][i];
+    for (int d = 0; d < 3; ++d) {
+        off[d] = -1;
+        if (n[d] <= 64) continue;
+        off[d] = (int)k;
+        const int run = d == 2 ? 64 : 1;                       // a wave owns one (x, y) and 64 consecutive z
+        int b = 0;
+        for (long long c = 0; c < padded[d]; ++c, ++k) {
+            while (b < n[d] && steps[d][b] + extent[d] <= c) ++b;          // first tile that reaches c (starts ascend)
+            if (b + 64 < n[d] && steps[d][b + 64] < c + run) return false; // a 65th tile meets [c, c + run)
+            if (tab) tab[k] = b;
+        }
+    }
+    *count = k;
+    return true;
 }
 
 template <int HB, bool TTA, bool K16>

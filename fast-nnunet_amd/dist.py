@@ -25,6 +25,7 @@ import itertools
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence, Tuple
 
+import collections
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -35,6 +36,28 @@ Box = Tuple[Tuple[int, int, int], Tuple[int, int, int]]          # (lo, hi) in p
 def _split(n: int, parts: int) -> List[Tuple[int, int]]:
     """`n` items into `parts` contiguous, balanced ranges."""
     return [(n * i // parts, n * (i + 1) // parts) for i in range(parts)]
+
+
+def tile_cover(steps: Sequence[Sequence[int]], patch: Sequence[int]) -> List[int]:
+    """Per axis: the largest number of tiles that reach one coordinate (along the last axis: one 64-voxel run of the gather
+    kernel) - what csrc/gather.hip gather_tile_windows bounds by 64.  An axis with <= 64 tile positions is its count."""
+    out = []
+    patch3 = [1] * (3 - len(patch)) + [int(v) for v in patch]
+    for d in range(3):
+        st, ext, run = list(steps[d]), patch3[d], (64 if d == 2 else 1)
+        if len(st) <= 64:
+            out.append(len(st))
+            continue
+        worst, b = 0, 0
+        for c in range(st[-1] + ext):
+            while b < len(st) and st[b] + ext <= c:
+                b += 1
+            e = b
+            while e < len(st) and st[e] < c + run:
+                e += 1
+            worst = max(worst, e - b)
+        out.append(worst)
+    return out
 
 
 def rank_grid(world: int, counts: Sequence[int]) -> Tuple[int, int, int]:
@@ -411,7 +434,16 @@ class ShardedPredictor:
         self.world = dist.get_world_size(group)
         assert mode in ('auto', 'gather', 'accumulate')
         self.mode = mode
-        self._plans, self._cur = {}, None           # per volume shape: decomposition, slots, exchange tables
+        # per (volume shape, patch, step size, world): decomposition, slots, exchange tables - the 8 most recently used
+        # (real datasets have another shape for nearly every case: an unbounded cache grows for ever); `_cur` = the entry of
+        # the volume being predicted, only ever used through an identity check against the decomposition in hand
+        self._plans, self._cur = collections.OrderedDict(), None
+    PLAN_CACHE = 8
+
+    def reset_plans(self):
+        """Drop the cached decompositions (the predictor was re-initialised with another network)."""
+        self._plans.clear()
+        self._cur = None
 
     def _flips(self):
         p = self.p
@@ -419,14 +451,15 @@ class ShardedPredictor:
 
     def _gather_fits(self, n_slots: Optional[int] = None, counts: Optional[Sequence[int]] = None) -> Tuple[bool, str]:
         """Does the gather path apply on THIS rank: the engine's gather kernel does (<= 32 channels at full resolution,
-        <= 8 evaluations per patch, <= 64 tile positions per axis; more than 63 classes run as passes over the heads) AND
+        <= 8 evaluations per patch, <= 64 tiles of one axis over a voxel (`counts`: tile_cover); more than 63 classes run as
+        passes over the heads) AND
         the kept activations fit - `n_slots` patch slots per evaluation against 80 % of the free HBM (the single-GPU engine
         bounds the same buffers, csrc/engine.hip gather_plan).  Never raises: the decision is a collective one."""
         p = self.p
         n_eval = len(self._flips())
         if not (n_eval <= 8 and p._spec.features[0] <= 32 and (counts is None or max(counts) <= 64)):
-            return False, ('the gather path needs <= 32 channels at full resolution, <= 8 evaluations per patch and <= 64 tile '
-                           'positions per axis')
+            return False, ('the gather path needs <= 32 channels at full resolution, <= 8 evaluations per patch and <= 64 tiles '
+                           'of one axis over a voxel')
         if n_slots is not None and p.device.type == 'cuda':
             C = p._engine.feature_channels
             need = n_eval * n_slots * (int(np.prod(p._spec.patch)) * C * 2 + 2 * C * 4)
@@ -546,15 +579,20 @@ class ShardedPredictor:
         patch against every rank's box) is milliseconds per step at 8 ranks and does not depend on the voxels."""
         from . import capi
         p = self.p
-        key = (tuple(int(v) for v in x.shape[1:]), float(p.tile_step_size), self.world)
+        key = (tuple(int(v) for v in x.shape[1:]), float(p.tile_step_size), self.world,
+               tuple(int(v) for v in p._spec.patch), int(p._spec.spatial_dims), id(p._spec))
         hit = self._plans.get(key)
+        if hit is not None:
+            self._plans.move_to_end(key)
         if hit is None:
             patch = p._spec.patch
             padded, pad_lo, origins = capi.plan_volume(patch[3 - p._spec.spatial_dims:], x.shape[1:], p.tile_step_size)
             steps = [sorted(set(int(v) for v in origins[:, d])) for d in range(3)]
             dec = Decomposition.build(patch, padded, steps, self.world)
             owns = [None if b is None else unpadded(b, pad_lo, x.shape[1:]) for b in dec.owned]
-            hit = self._plans[key] = dict(dec=dec, origins=origins, owns=owns, counts=[len(st) for st in steps], slots=None, xplan={})
+            hit = self._plans[key] = dict(dec=dec, origins=origins, owns=owns, counts=tile_cover(steps, patch), slots=None, xplan={})
+            while len(self._plans) > self.PLAN_CACHE:
+                self._plans.popitem(last=False)
         self._cur = hit
         return hit['dec'], hit['origins'], hit['owns']
 

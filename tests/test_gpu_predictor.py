@@ -30,7 +30,8 @@ from oracle.unet import build as build_oracle, synthetic_state_dict
 
 pytestmark = pytest.mark.gpu
 
-MAX_REL, RMSE_REL = 1e-2, 5e-3
+# measured on the BASELINE configurations at full patch size: max ratio 2.2-3.4e-3, relative RMSE 1.7-2.4e-3
+MAX_REL, RMSE_REL = 6e-3, 3.5e-3
 
 
 def _bits(t):
@@ -938,6 +939,37 @@ def test_gather_path_is_bit_identical_to_the_accumulate_path(shape, heads, accum
     finally:
         os.environ.pop('FNN_NO_GATHER', None)
     assert torch.equal(g1.predict_segmentation_from_preprocessed_data(image), a1.predict_segmentation_from_preprocessed_data(image))
+
+
+@pytest.mark.parametrize('kind,shape', [('3d_x', (530, 16, 40)), ('3d_z', (16, 20, 1070)), ('2d', (70, 20, 40))])
+def test_gather_path_with_more_than_64_tile_positions_on_an_axis(kind, shape):
+    """the gather kernel holds 64 tile starts of an axis, one per lane; an axis with more positions - every
+    slice of a 2-D configuration, a small patch in a long volume - used to drop to the accumulate path (and the autocast
+    arithmetic to FNN_E_UNSUPPORTED).  Now the 64 starts are a WINDOW from the first tile that reaches the wave's
+    coordinate (GatherParams::base_x, csrc/gather.hip gather_tile_windows): 66 positions along x, 65 along z (the axis
+    of the 64-voxel runs), 70 slices.  The gather kernel must run and agree bit for bit with the accumulate path
+    (logits, labels), and in the autocast arithmetic with the oracle driver."""
+    if kind == '2d':
+        spec, patch = toy_unet_spec_2d(1, 3), (16, 32)
+    else:
+        spec, patch = UNetSpec('plain', 1, 3, [16, 32], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2]), (16, 16, 32)
+    sds = [synthetic_state_dict(spec, 610)]
+    image = torch.randn(1, *shape, generator=torch.Generator().manual_seed(61))
+    os.environ.pop('FNN_NO_GATHER', None)
+    g = _predictor(spec, patch, sds, batch=8)
+    got = g.predict_sliding_window_return_logits(image)
+    assert any(k.startswith('gather_head_kernel') for k in g._engine.kernel_log()), g._engine.kernel_log()
+    os.environ['FNN_NO_GATHER'] = '1'
+    try:
+        a = _predictor(spec, patch, sds, batch=8)
+    finally:
+        os.environ.pop('FNN_NO_GATHER', None)
+    assert torch.equal(got, a.predict_sliding_window_return_logits(image))
+    assert torch.equal(g.predict_segmentation_from_preprocessed_data(image), a.predict_segmentation_from_preprocessed_data(image))
+    pa = _predictor(spec, patch, sds, batch=8, accumulate_in='fp16_autocast')
+    want = osw.sliding_window_logits(lambda x: pa.forward_patches(x).cpu().half(), image, patch, spec.num_heads, step=0.5,
+                                     use_gaussian=True, mirror_axes=None, accum='fp16')
+    assert np.array_equal(_bits(pa.predict_sliding_window_return_logits(image)), _bits(want))
 
 
 @pytest.mark.parametrize('accum', ['fp16', 'fp32'])
