@@ -35,7 +35,7 @@ if ROOT not in sys.path:
 
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16, MI355X_MICROARCH.md "Chip-level parameters"
 MFMA_PEAK_CLOCK_GHZ = 2.4          # the clock that peak is quoted at (same table: max clock 2400 MHz)
-TRAFFIC_FILE = 'r04_traffic.json'  # per-launch HBM bytes of the conv family from separate rocprofv3 --pmc passes, per workload, keyed by csrc_sha256()
+TRAFFIC_FILE = 'r05_traffic.json'  # per-launch HBM bytes of the conv family from separate rocprofv3 --pmc passes, per workload, keyed by csrc_sha256()
 
 WORKLOADS = {
     # name: (spacing, patch, heads, reduction)

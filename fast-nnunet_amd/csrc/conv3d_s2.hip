@@ -351,8 +351,7 @@ int launch_conv3d_s2(ConvParams p, hipStream_t st) {
         (void)hipFuncSetAttribute((const void *)conv3d_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const int ncu = fnn_cu_hint();
-    const int gx = total < ncu ? total : ncu;
+    const int gx = total < 256 ? total : 256;
     fnn_note_kernel("conv3d_s2_kernel");
     hipLaunchKernelGGL(conv3d_s2_kernel, dim3(gx), dim3(512), lds, st, p, total, groups);
     return hipGetLastError() == hipSuccess ? 0 : -2;

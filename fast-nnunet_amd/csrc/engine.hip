@@ -103,14 +103,6 @@ struct fnn_engine {
     f16 *actp[MAXP] = {}; double *statsp[MAXP] = {}; float *ssp[MAXP] = {};      // [0] aliases act / stats / ss
     hipStream_t pipe[MAXP] = {};
     hipEvent_t ev_start = nullptr, ev_head[MAXP] = {}, ev_done[MAXP] = {};
-    // CU-masked co-scheduling experiment (FNN_CUMASK = "<thin CUs>[,a]", off by default): the full-resolution,
-    // HBM-bound layers of a batch go to a stream whose queue may only use `cus_thin` CUs, the rest of the network to a
-    // stream on the complementary CUs (",a": on all of them), so that one batch's level-0 kernels run BESIDE another
-    // batch's matrix-bound layers instead of behind them.
-    int cus_thin = 0, cus_heavy = 0;
-    hipStream_t pipe_thin[MAXP] = {};
-    hipEvent_t ev_sw[MAXP] = {};
-    hipStream_t st_thin = nullptr; hipEvent_t ev_switch = nullptr;       // of the batch forward_batch is working on
     f16 *gauss = nullptr;
     f16 *ones = nullptr;                    // weight map of use_gaussian = 0 (the kernels load the map unconditionally)
     int *inf_flag = nullptr;
@@ -682,30 +674,8 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
                   float *head_ss = nullptr, unsigned short *head_ssh = nullptr) {
     const FoldWeights &fw = e->folds[fold];
     HIPCHK(e, hipMemsetAsync(e->stats, 0, e->stats_doubles * e->max_batch * sizeof(double), st));
-    hipStream_t const st_main = st, st_thin = e->st_thin;
-    static const int thin_set = fnn_knob("FNN_CUMASK_SET") ? atoi(fnn_knob("FNN_CUMASK_SET")) : 0;
-    struct Rejoin {                                           // whatever path leaves this function, `st_main` ends behind the work
-        fnn_engine *e; hipStream_t main; hipStream_t *cur;
-        ~Rejoin() {
-            if (*cur != main) { (void)hipEventRecord(e->ev_switch, *cur); (void)hipStreamWaitEvent(main, e->ev_switch, 0); }
-            fnn_set_cu_hint(0);
-        }
-    } rejoin{e, st_main, &st};
     for (size_t li = 0; li < e->layers.size(); ++li) {
         const Layer &L = e->layers[li];
-        if (st_thin) {
-            // level 0 = output at the patch's resolution (FNN_CUMASK_SET=1: also the layers that READ level 0)
-            bool thin = L.out_dims[0] == e->arch.patch[0] && L.out_dims[1] == e->arch.patch[1] && L.out_dims[2] == e->arch.patch[2];
-            if (!thin && thin_set >= 1 && L.type != Layer::STEM)
-                thin = L.in_dims[0] == e->arch.patch[0] && L.in_dims[1] == e->arch.patch[1] && L.in_dims[2] == e->arch.patch[2];
-            hipStream_t want = thin ? st_thin : st_main;
-            if (want != st) {
-                HIPCHK(e, hipEventRecord(e->ev_switch, st));
-                HIPCHK(e, hipStreamWaitEvent(want, e->ev_switch, 0));
-                st = want;
-            }
-            fnn_set_cu_hint(thin ? e->cus_thin : e->cus_heavy);
-        }
         f16 *out = e->act + L.out_off * e->max_batch;
         if (head_out && (int)li == e->head_src) out = head_out;
         double *stats_out = L.has_norm ? e->stats + L.stats_off * e->max_batch : nullptr;
@@ -967,17 +937,6 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
                     HIPCHK(e, hipMalloc((void **)&e->statsp[k], e->stats_doubles * e->max_batch * sizeof(double)));
                     HIPCHK(e, hipMalloc((void **)&e->ssp[k], (e->ss_count * e->max_batch * 3 + 8) * sizeof(float)));   // fp32 rows + fp16 rows (ssh_rows)
                 }
-                if (e->cus_thin > 0) {
-                    // bit i of the mask = CU i of the queue's CU list; thin = the first cus_thin bits, heavy = the rest (or all)
-                    uint32_t m_thin[8] = {}, m_heavy[8] = {};
-                    for (int c = 0; c < 256; ++c) {
-                        if (c < e->cus_thin) m_thin[c >> 5] |= 1u << (c & 31);
-                        if (c >= e->cus_thin || e->cus_heavy == 256) m_heavy[c >> 5] |= 1u << (c & 31);
-                    }
-                    HIPCHK(e, hipExtStreamCreateWithCUMask(&e->pipe[k], 8, m_heavy));
-                    HIPCHK(e, hipExtStreamCreateWithCUMask(&e->pipe_thin[k], 8, m_thin));
-                    HIPCHK(e, hipEventCreateWithFlags(&e->ev_sw[k], hipEventDisableTiming));
-                } else
                 HIPCHK(e, hipStreamCreateWithFlags(&e->pipe[k], hipStreamNonBlocking));
                 HIPCHK(e, hipEventCreateWithFlags(&e->ev_head[k], hipEventDisableTiming));
                 HIPCHK(e, hipEventCreateWithFlags(&e->ev_done[k], hipEventDisableTiming));
@@ -1005,7 +964,7 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
     };
     struct Restore {                                      // whatever happens, the engine ends on its first arena
         fnn_engine *e; f16 *a; double *s; float *ss;
-        ~Restore() { e->act = a; e->stats = s; e->ss = ss; e->st_thin = nullptr; e->ev_switch = nullptr; }
+        ~Restore() { e->act = a; e->stats = s; e->ss = ss; }
     } restore{e, act0, stats0, ss0};
     hipStream_t user_st = st;
     int64_t bi = 0;
@@ -1016,7 +975,6 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
         if (pipelined) {
             st = e->pipe[k];
             e->act = e->actp[k]; e->stats = e->statsp[k]; e->ss = e->ssp[k];
-            e->st_thin = e->pipe_thin[k]; e->ev_switch = e->ev_sw[k];
         }
         for (size_t ci = 0; ci <= (tta ? combos.size() : 0); ++ci) {
             int flip[3] = {0, 0, 0};
@@ -1394,10 +1352,6 @@ int fnn_create(const fnn_arch_desc *arch, int device, int max_batch, fnn_engine 
     fnn_engine *e = new fnn_engine();
     e->arch = *arch; e->device = device; e->max_batch = max_batch;
     e->fuse_enabled = fnn_knob("FNN_NO_FUSE") == nullptr;
-    if (const char *cm = fnn_knob("FNN_CUMASK")) {
-        const int n = atoi(cm);
-        if (n >= 8 && n <= 248) { e->cus_thin = n; e->cus_heavy = strstr(cm, ",a") ? 256 : 256 - n; }
-    }
     if (const char *v = fnn_knob("FNN_FUSE_STEM")) e->fuse_stem = atoi(v) != 0 ? 1 : 0;
     if (const char *v = fnn_knob("FNN_FUSE_TCONV")) e->fuse_tconv = atoi(v) != 0;
     e->gather_enabled = fnn_knob("FNN_NO_GATHER") == nullptr;
@@ -1431,8 +1385,6 @@ void fnn_destroy(fnn_engine *e) {
     for (auto &f : e->folds) { if (f.wpk) (void)hipFree(f.wpk); if (f.fparam) (void)hipFree(f.fparam); }
     for (int k = 0; k < fnn_engine::MAXP; ++k) {
         if (e->pipe[k]) (void)hipStreamDestroy(e->pipe[k]);
-        if (e->pipe_thin[k]) (void)hipStreamDestroy(e->pipe_thin[k]);
-        if (e->ev_sw[k]) (void)hipEventDestroy(e->ev_sw[k]);
         if (e->ev_head[k]) (void)hipEventDestroy(e->ev_head[k]);
         if (e->ev_done[k]) (void)hipEventDestroy(e->ev_done[k]);
         if (k > 0) { (void)hipFree(e->actp[k]); (void)hipFree(e->statsp[k]); (void)hipFree(e->ssp[k]); }

@@ -259,9 +259,6 @@ struct FinalizeParams {
 // variables that are honoured ONLY when FNN_KNOBS=1 is set as well - a production process does not change behaviour
 // because of a stray variable; the tests and tools/ set it.
 const char *fnn_knob(const char *name);
-// CUs the stream of the next launches may use (0 = the whole device): kernels whose grid is "one workgroup per CU" size it by this
-void fnn_set_cu_hint(int cus);
-int fnn_cu_hint();
 // Which kernel variant a launcher picked: recorded per launch while the engine profiles (fnn_kernel_log), a no-op otherwise.
 void fnn_note_kernel(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 void fnn_klog_target(void *vector_of_strings);          // where this thread's notes go (nullptr: nowhere)

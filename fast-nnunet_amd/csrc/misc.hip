@@ -13,10 +13,6 @@
 #include <cstdlib>
 #include <cstring>
 
-static thread_local int g_cu_hint = 0;
-void fnn_set_cu_hint(int cus) { g_cu_hint = cus; }
-int fnn_cu_hint() { return g_cu_hint > 0 ? g_cu_hint : 256; }
-
 const char *fnn_knob(const char *name) {
     static const bool on = [] { const char *v = getenv("FNN_KNOBS"); return v && strcmp(v, "0") != 0; }();
     return on ? getenv(name) : nullptr;

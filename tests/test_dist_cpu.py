@@ -337,7 +337,8 @@ def test_feature_exchange_matches_single_process_gloo(world, mirror):
 # ------------------------------------------------------------------------------- the path decision is a collective one
 def _decision_worker(rank, world, port, mode, q):
     """ShardedPredictor._use_gather_all with a stand-in predictor (no engine: the decision is host logic): rank 1 sees a
-    volume with 70 tile positions along one axis (beyond the gather kernel's 64)."""
+    volume where 70 tiles of one axis lie over one voxel (beyond the 64 a wave of the gather kernel holds; `counts` is what
+    dist.tile_cover returns - an axis with more than 64 POSITIONS is fine since round 5 as long as 64 consecutive ones reach)."""
     import types
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -377,4 +378,4 @@ def test_gather_path_decision_is_taken_by_every_rank_together(mode):
         assert [g[1:] for g in got] == [('ok', False, 'accumulate')] * 2
     else:
         assert all(g[1] == 'raised' for g in got)
-        assert 'tile positions' in got[1][2]                  # the rank that cannot says why; the other one reports the group's verdict
+        assert 'tiles of one axis' in got[1][2]                  # the rank that cannot says why; the other one reports the group's verdict
