@@ -2402,6 +2402,7 @@ int launch_conv3d_zr(const ConvParams &p, hipStream_t st) {
     {
         // planes of 9 .. 12 x 9 .. 12 voxels (two half-empty 8 x 8 tiles per axis): whole planes per tile
         static const bool no_zr12 = fnn_knob("FNN_NO_ZR12") != nullptr;                       // A-B aid
+        if (!no_zr12 && nb == 2 && conv3d_zq12_ok(p)) return launch_conv3d_zq12(p, st);   // round 5: 8 x 12 x 12 tiles, eight balanced waves (conv3d_zq.hip)
         if (!no_zr12 && nb == 2 && p.Ho > 8 && p.Ho <= 12 && p.Wo > 8 && p.Wo <= 12 && conv3d_stats_slots(p) >= (p.Do + 3) / 4)
             return launch_zr12<4>(p, st);                                            // (TD = 6: 60 B of scratch, -1.5 %; TD = 8: 140-224 B, -3 %)
     }

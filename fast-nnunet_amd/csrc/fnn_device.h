@@ -347,6 +347,8 @@ int conv3d_ksteps(int packing, int taps);
 int conv3d_kstep_tap(int packing, int ks, int half, int taps);     // linear tap index, or -1 = zero padding
 int conv3d_pack_cout(int packing, int nblk, int cb, int m);        // output channel in row m of cout block cb of the packed weights
 int launch_conv3d_zr(const ConvParams &p, hipStream_t st);
+bool conv3d_zq12_ok(const ConvParams &p);                               // conv3d_zq.hip: 3x3x3 stride 1 over planes of 9 .. 12 voxels per axis
+int launch_conv3d_zq12(ConvParams p, hipStream_t st);                  // -1 = not this kernel's layer
 bool conv3d_s2_ok(const ConvParams &p);                                  // conv3d_s2.hip: 3x3x3 stride (2,2,2), Cout % 64 == 0
 int launch_conv3d_s2(ConvParams p, hipStream_t st);                     // -1 = not this kernel's layer
 int conv3d_stats_slots(const ConvParams &p);                           // rows per item the layer's kernel writes into stats_out

@@ -493,12 +493,16 @@ def test_conv3d_role_split_kernel_is_the_zr_kernel_bit_for_bit(n, cin, cin2, cou
     assert np.allclose(stats_s[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
 
 
-@pytest.mark.parametrize('n,cin,cout,dims', [(8, 128, 128, (40, 12, 12)), (16, 48, 64, (21, 11, 9)), (32, 32, 32, (17, 12, 10))])
-def test_conv3d_zr_whole_plane_tiles(n, cin, cout, dims):
-    """conv3d_zr12_kernel (planes of 9 .. 12 voxels per axis: nine waves, one 4 x 4 column block each, whole planes per
-    tile): full and ragged planes, ragged depth, 2 - 8 chunks, 1 - 4 cout groups; identity input with statistics, then
-    fused InstanceNorm + LeakyReLU on load."""
+@pytest.mark.parametrize('n,cin,cout,dims', [(8, 128, 128, (40, 12, 12)), (16, 48, 64, (21, 11, 9)), (32, 32, 32, (17, 12, 10)),
+                                             (64, 32, 32, (6, 12, 10))])
+def test_conv3d_zr_whole_plane_tiles(n, cin, cout, dims, monkeypatch):
+    """Planes of 9 .. 12 voxels per axis, whole planes per tile: conv3d_zq12_kernel (round 5: 8 x 12 x 12 tiles, eight waves
+    with 5 + 4 column blocks per SIMD) where the layer is at least 8 deep, conv3d_zr12_kernel (4 x 12 x 12, nine one-block
+    waves) below that.  Full and ragged planes, ragged depth, 2 - 8 chunks, 1 - 4 cout groups; identity input with
+    statistics, then fused InstanceNorm + LeakyReLU on load; the two kernels' OUTPUT BITS must be equal."""
     from fast_nnunet_amd import capi
+    monkeypatch.delenv('FNN_NO_ZQ12', raising=False)
+    want_kernel = 'conv3d_zq12_kernel' if dims[0] >= 8 else 'conv3d_zr12_kernel<4>'
     g = torch.Generator().manual_seed(91 + cin + dims[1])
     x = _h(torch.randn(n, cin, *dims, generator=g) * 2 + 0.5)
     gamma = torch.rand(cin, generator=g) + 0.5
@@ -506,14 +510,23 @@ def test_conv3d_zr_whole_plane_tiles(n, cin, cout, dims):
     w = _h(torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5)
     b = torch.randn(cout, generator=g)
     y, stats = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), (1, 1, 1), want_stats=True)
+    assert capi.op_last_kernels() == [want_kernel], capi.op_last_kernels()
     _check(y, F.conv3d(x, w, b, 1, 1), 'conv3d zr12')
     y64 = y.astype(np.float64)
     assert np.allclose(stats[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
     assert np.allclose(stats[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
-    y = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), (1, 1, 1), gamma=gamma.numpy(), beta=beta.numpy(), slope=0.01)
+    yn = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), (1, 1, 1), gamma=gamma.numpy(), beta=beta.numpy(), slope=0.01)
     xn = _h(F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01))
     ref = F.conv3d(xn, w, b, 1, 1)
-    assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
+    assert np.abs(yn - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
+    if dims[0] >= 8:
+        monkeypatch.setenv('FNN_NO_ZQ12', '1')
+        y_old, stats_old = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), (1, 1, 1), want_stats=True)
+        assert capi.op_last_kernels() == ['conv3d_zr12_kernel<4>'], capi.op_last_kernels()
+        yn_old = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), (1, 1, 1), gamma=gamma.numpy(), beta=beta.numpy(), slope=0.01)
+        monkeypatch.delenv('FNN_NO_ZQ12')
+        assert np.array_equal(y.view(np.uint16), y_old.view(np.uint16)) and np.array_equal(yn.view(np.uint16), yn_old.view(np.uint16))
+        assert np.allclose(stats, stats_old, rtol=2e-6, atol=1e-3)
 
 
 def test_conv3d_zr_whole_plane_operand_map_with_exact_integers():
@@ -542,7 +555,7 @@ def test_conv_ops_with_chunk_major_tensors(monkeypatch):
     test_conv3d_with_fused_instancenorm_lrelu_on_load(*CONV_CASES[5])
     test_conv3d_zr_variants(*ZR_CASES[-1])
     test_conv3d_zr_two_sources()
-    test_conv3d_zr_whole_plane_tiles(16, 48, 64, (21, 11, 9))
+    test_conv3d_zr_whole_plane_tiles(16, 48, 64, (21, 11, 9), monkeypatch)
     test_conv3d_stride2_grouped_kernel(64, 128)
     test_conv3d_persistent_depth_shift_kernel_with_two_cout_groups()
     for case in TCONV_CASES[:3] + TCONV_CASES[4:]:
