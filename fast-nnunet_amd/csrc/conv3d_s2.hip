@@ -31,16 +31,20 @@ namespace {
 
 constexpr int S2_ID = 9, S2_IH = 17, S2_IW = 17;
 constexpr int S2_PW = 18;                                               // LDS row pitch (voxels): see the bank note below
-constexpr int S2_IVOX = S2_ID * S2_IH * S2_IW;                          // 2601 halo voxels per chunk
 constexpr int S2_ABYTES = S2_ID * S2_IH * S2_PW * 32;                   // 88128
 constexpr int S2_KS = 14, S2_NB = 4;
 constexpr int S2_WBYTES = S2_NB * S2_KS * 1024;                         // 57344
-constexpr int S2_PF = (S2_IVOX * 2 + 511) / 512;                        // 11 halo elements per thread and chunk
 constexpr int S2_WPF = (S2_NB * S2_KS * 64) / 512;                      // 7 weight elements
 
 static __device__ __forceinline__ int s2_pos(int zw) { return (zw & 1) ? 9 + (zw >> 1) : (zw >> 1); }
 
+// SH: rows / columns of a halo plane that are STAGED (17: a full 8 x 8 output tile; 13: a layer whose output plane is at most
+// 6 x 6 - one tile per plane whose rows and columns 13 .. 16 nobody needs); MBV: the column blocks (pairs of output rows) of a
+// depth slice that hold output rows of the layer (4, or 3 for planes of at most 6 rows).  The LDS image keeps its geometry.
+template <int SH, int MBV>
 __global__ __launch_bounds__(512, 1) void conv3d_s2_kernel(const ConvParams p, const int total_units, const int groups) {
+    constexpr int S2_IVOX = S2_ID * SH * SH;                             // staged halo voxels per chunk (2601 / 1521)
+    constexpr int S2_PF = (S2_IVOX * 2 + 511) / 512;                     // 11 / 6 halo elements per thread and chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4, hl = lane >> 5, kh = q & 1;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_s2_kernel(const ConvParams p, c
 #pragma unroll
     for (int u = 0; u < S2_PF; ++u) {
         const int idx = tid + u * 512, v = (idx < S2_IVOX * 2 ? idx : S2_IVOX * 2 - 1) >> 1;
-        const int zd = v / (S2_IH * S2_IW), rem = v - zd * (S2_IH * S2_IW), zh = rem / S2_IW, zw = rem - zh * S2_IW;
+        const int zd = v / (SH * SH), rem = v - zd * (SH * SH), zh = rem / SH, zw = rem - zh * SH;
         const unsigned t = (unsigned)((zd << 10) | (zh << 5) | zw);
         if (u & 1) relp[u >> 1] |= t << 16; else relp[u >> 1] = t;
     }
@@ -124,8 +128,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_s2_kernel(const ConvParams p, c
     const char *i_sp = nullptr;
     const f16x8 *i_wp = nullptr;
     const float *i_qs = nullptr, *i_qh = nullptr;
-    int i_sc2 = 0;
+    int i_sc2 = 0, i_nbv = S2_NB;
+    const int nblk_all = p.Cout >> 4;
     auto issue_setup = [&](int n, int grp, int ch) {
+        i_nbv = nblk_all - grp * S2_NB < S2_NB ? nblk_all - grp * S2_NB : S2_NB;
         const int c_glob = ch * 16;
         const int s = (c_glob < p.src[0].C) ? 0 : 1;
         const int c_loc = c_glob - (s ? p.src[0].C : 0) + cg * 8;
@@ -137,23 +143,24 @@ __global__ __launch_bounds__(512, 1) void conv3d_s2_kernel(const ConvParams p, c
         i_qh = p.src[s].ss ? i_qs + sC : p.ident_ss + 512 + c_loc;
         i_wp = (const f16x8 *)p.wpk + (size_t)(grp * S2_NB * p.chunks + ch) * per_cb;
     };
-    auto issue_part = [&](int ks) {                                      // k-step 0: scale / shift; 1 .. 11: halo element ks - 1 (+ weight element)
+    auto issue_part = [&](int ks) {                                      // k-step 0: scale / shift; 1 ..: halo element ks - 1 and weight element ks - 1
         if (ks == 0) {
             scr[0] = *(const float4 *)i_qs; scr[1] = *(const float4 *)(i_qs + 4);
             shr[0] = *(const float4 *)i_qh; shr[1] = *(const float4 *)(i_qh + 4);
-        } else if (ks <= S2_PF) {
+        } else {
             const int u = ks - 1;                                        // unconditional: branches around loads make hipcc drain vmcnt
-            xr[u] = *(const f16x8 *)(i_sp + __umul24((unsigned)(offv[u] >= 0 ? offv[u] : 0), (unsigned)i_sc2));   // voxels < 2^24 (launcher)
+            if (u < S2_PF) xr[u] = *(const f16x8 *)(i_sp + __umul24((unsigned)(offv[u] >= 0 ? offv[u] : 0), (unsigned)i_sc2));   // voxels < 2^24 (launcher)
             if (u < S2_WPF) {
                 const int idx = tid + u * 512, cbl = (idx * 74899) >> 26;  // idx / 896 for idx < 3584
-                wr[u] = i_wp[idx + cbl * wskip];
+                // (a last group of fewer than four cout blocks: the missing blocks re-read block 0 - finite values nobody stores)
+                wr[u] = i_wp[cbl < i_nbv ? idx + cbl * wskip : idx - cbl * per_cb];
             }
         }
     };
     auto issue = [&](int n, int grp, int ch) {                          // all at once (prologue)
         issue_setup(n, grp, ch);
 #pragma unroll
-        for (int ks = 0; ks <= S2_PF; ++ks) issue_part(ks);
+        for (int ks = 0; ks <= (S2_PF > S2_WPF ? S2_PF : S2_WPF); ++ks) issue_part(ks);
     };
     auto commit = [&]() {
         const f16 slope_h = (f16)slope_next;
@@ -191,13 +198,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_s2_kernel(const ConvParams p, c
     // two waves per SIMD did not cover each other
     auto read_frags = [&](int ks, f16x8 (&xf)[4], f16x8 (&wf)[2]) {
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) xf[mb] = *(const f16x8 *)(sA + lanec[ks] + mb * MB_STEP);
+        for (int mb = 0; mb < MBV; ++mb) xf[mb] = *(const f16x8 *)(sA + lanec[ks] + mb * MB_STEP);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) wf[nb] = *(const f16x8 *)(sW + (((2 * cp + nb) * S2_KS + ks) * 64 + lane) * 16);
     };
     auto mfmas = [&](const f16x8 (&xf)[4], const f16x8 (&wf)[2]) {
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+        for (int mb = 0; mb < MBV; ++mb)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
@@ -245,6 +252,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_s2_kernel(const ConvParams p, c
     auto flush_stats = [&](int n, int grp) {                            // the tid < 128 threads own sAcc[tid]: no barrier needed
         if (p.stats_out && tid < 128) {
             const int c = tid >> 1, which = tid & 1;
+            if (grp * 64 + c < p.Cout)
             unsafeAtomicAdd(p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout + grp * 64 + c) * 2 + which, sAcc[tid]);
             sAcc[tid] = 0.0;
         }
@@ -286,15 +294,17 @@ __global__ __launch_bounds__(512, 1) void conv3d_s2_kernel(const ConvParams p, c
             if (stamp_it) FNN_STAMP();                                   // k-loop done
 #endif
             if (last) {
-                float4 bv[2];
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) bv[nb] = *(const float4 *)(p.bias + (grp * 4 + 2 * cp + nb) * 16 + q * 4);
                 float t1[2][4], t2[2][4];
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
-                tile_epilogue<2, 4>(p, acc, bv, n_cur, od0, oh0, ow0, grp * 4 + 2 * cp, bg, lane, t1, t2);
+                if (grp * 4 + 2 * cp < nblk_all) {                       // (a short last group: this wave's pair of cout blocks may not exist)
+                    float4 bv[2];
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) bv[nb] = *(const float4 *)(p.bias + (grp * 4 + 2 * cp + nb) * 16 + q * 4);
+                    tile_epilogue<2, 4>(p, acc, bv, n_cur, od0, oh0, ow0, grp * 4 + 2 * cp, bg, lane, t1, t2);
+                }
                 unit_stats(t1, t2);
             }
             __syncthreads();                                             // every wave is done reading this item; sRed complete
@@ -325,7 +335,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_s2_kernel(const ConvParams p, c
 bool conv3d_s2_ok(const ConvParams &p) {
     static const bool off = fnn_knob("FNN_NO_S2") != nullptr;                        // A-B aid
     if (off || p.kd != 3 || p.kh != 3 || p.kw != 3 || p.sd != 2 || p.sh != 2 || p.sw != 2 || p.fp8) return false;
-    if (p.packing != FNN_PACK_LINEAR || p.ksteps != S2_KS || p.Cout % 64 != 0) return false;
+    // whole groups of 64 output channels, or (round 5) a last group of 32: 160 = 64 + 64 + 32
+    if (p.packing != FNN_PACK_LINEAR || p.ksteps != S2_KS || p.Cout % 32 != 0 || p.Cout < 64) return false;
     if (p.stats_out && p.stats_slots != FNN_STAT_REPL) return false;
     if ((long long)p.Di * p.Hi * p.Wi >= (1 << 24)) return false;                  // 24-bit voxel index arithmetic in the kernel
     for (int i = 0; i < p.n_src; ++i)
@@ -333,8 +344,10 @@ bool conv3d_s2_ok(const ConvParams &p) {
     if (2ull * p.Do * p.Ho * p.Wo * p.Cout >= (1ull << 31)) return false;
     // enough units to give every CU a few: below that the 2 x 8 x 8 kernels' many small workgroups win
     const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;
-    const long long units = (long long)plan_n * ((p.Do + 3) / 4) * ((p.Ho + 7) / 8) * ((p.Wo + 7) / 8) * (p.Cout / 64);
-    return units >= 256 * 3;
+    const long long units = (long long)plan_n * ((p.Do + 3) / 4) * ((p.Ho + 7) / 8) * ((p.Wo + 7) / 8) * ((p.Cout + 63) / 64);
+    // (round 5: 384 instead of 768 - the 128 -> 160 layer at 20 x 6 x 6, 480 units, 170 -> 96 us against the 2 x 8 x 8 kernel)
+    static const int min_units = fnn_knob("FNN_S2_MIN_UNITS") ? atoi(fnn_knob("FNN_S2_MIN_UNITS")) : 384;       // A-B aid
+    return units >= min_units;
 }
 
 int launch_conv3d_s2(ConvParams p, hipStream_t st) {
@@ -343,16 +356,19 @@ int launch_conv3d_s2(ConvParams p, hipStream_t st) {
     p.tiles_d = (p.Do + 3) / 4; p.tiles_h = (p.Ho + 7) / 8; p.tiles_w = (p.Wo + 7) / 8;
     p.ident_ss = conv3d_identity_ss();
     if (!p.ident_ss) return -2;
-    const int groups = p.Cout / 64;
+    const int groups = (p.Cout + 63) / 64;                              // the last group may hold two cout blocks instead of four
     const int total = p.N * p.tiles_d * p.tiles_h * p.tiles_w * groups;
     const size_t lds = (size_t)S2_ABYTES + S2_WBYTES + 128 * 8 + 8 * 32 * 2 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)conv3d_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
     const int gx = total < 256 ? total : 256;
-    fnn_note_kernel("conv3d_s2_kernel");
-    hipLaunchKernelGGL(conv3d_s2_kernel, dim3(gx), dim3(512), lds, st, p, total, groups);
+    const bool small = p.Ho <= 6 && p.Wo <= 6;                         // one tile per plane, input planes of at most 13 x 13 (with the padding)
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[small]) {
+        if (small) (void)hipFuncSetAttribute((const void *)conv3d_s2_kernel<13, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        else (void)hipFuncSetAttribute((const void *)conv3d_s2_kernel<17, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set[small] = true;
+    }
+    fnn_note_kernel(small ? "conv3d_s2_kernel<13,3>" : "conv3d_s2_kernel");
+    if (small) hipLaunchKernelGGL((conv3d_s2_kernel<13, 3>), dim3(gx), dim3(512), lds, st, p, total, groups);
+    else hipLaunchKernelGGL((conv3d_s2_kernel<17, 4>), dim3(gx), dim3(512), lds, st, p, total, groups);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -406,20 +406,25 @@ def test_conv3d_row_operand_map_with_exact_integers():
     assert np.array_equal(y, F.conv3d(x, w, None, 1, (0, 1, 1)).numpy())
 
 
-@pytest.mark.parametrize('cin,cout', [(32, 64), (64, 128), (48, 192)])
-def test_conv3d_stride2_grouped_kernel(cin, cout):
+@pytest.mark.parametrize('cin,cout,n,dims', [(32, 64, 8, (45, 61, 58)), (64, 128, 8, (45, 61, 58)), (48, 192, 8, (45, 61, 58)),
+                                             (48, 160, 8, (45, 61, 58)), (32, 96, 8, (45, 61, 58)),
+                                             (128, 160, 32, (40, 12, 12)), (48, 160, 32, (38, 11, 9))])
+def test_conv3d_stride2_grouped_kernel(cin, cout, n, dims):
     """conv3d_s2.hip (3x3x3, stride (2,2,2), whole groups of 64 output channels per staged halo, 512-thread persistent
     workgroups): ragged 4 x 8 x 8 tiles on every axis, 2 - 4 chunks, 1 - 3 cout groups, InstanceNorm + LeakyReLU on load,
-    statistics across units and batch items."""
+    statistics across units and batch items.  Round 5: a last group of two cout blocks (160 = 64 + 64 + 32 channels), and the
+    <13, 3> form for output planes of at most 6 x 6 (13 x 13 of the 17 x 17 halo staged, three of the four column blocks)."""
     from fast_nnunet_amd import capi
     g = torch.Generator().manual_seed(41 + cin)
-    n, dims, stride = 8, (45, 61, 58), (2, 2, 2)
+    stride = (2, 2, 2)
+    kernel = 'conv3d_s2_kernel<13,3>' if dims[1] <= 12 else 'conv3d_s2_kernel'
     x = _h(torch.randn(n, cin, *dims, generator=g) * 2 + 0.5)
     gamma = torch.rand(cin, generator=g) + 0.5
     beta = torch.randn(cin, generator=g) * 0.1
     w = _h(torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5)
     b = torch.randn(cout, generator=g)
     y, stats = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), stride, want_stats=True)
+    assert capi.op_last_kernels() == [kernel], capi.op_last_kernels()
     _check(y, F.conv3d(x, w, b, stride, 1), 'conv3d s2')
     y64 = y.astype(np.float64)
     assert np.allclose(stats[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=1e-3)

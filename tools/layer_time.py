@@ -1,5 +1,5 @@
 """Diagnostic: mean launch time of one conv layer shape (FNN_OP_TIME: 10 launches after 2 warm-ups, HIP events).
-usage: [FNN_LIB=.../libfnn_exp.so] python tools/layer_time.py N CIN COUT D H W [cin2]   (3x3x3, stride 1, fused-norm inputs)"""
+usage: [FNN_LIB=.../libfnn_exp.so] [LT_STRIDE=2] python tools/layer_time.py N CIN COUT D H W [cin2]   (3x3x3, stride 1 (LT_STRIDE: 2,2,2), fused-norm inputs; D H W = the INPUT size)"""
 import os
 os.environ.setdefault('FNN_KNOBS', '1')
 os.environ['FNN_OP_TIME'] = '1'
@@ -19,5 +19,6 @@ if cin2:
               beta2=np.zeros(cin2, np.float32), slope2=0.01)
 sys.stderr.write(f'{os.path.basename(os.environ.get("FNN_LIB", "libfnn_hip.so"))}: ')
 sys.stderr.flush()
-capi.op_conv3d(x, wt, np.zeros(cout, np.float32), (3, 3, 3), (1, 1, 1), gamma=np.ones(cin, np.float32),
+st = int(os.environ.get('LT_STRIDE', '1'))
+capi.op_conv3d(x, wt, np.zeros(cout, np.float32), (3, 3, 3), (st, st, st), gamma=np.ones(cin, np.float32),
                beta=np.zeros(cin, np.float32), slope=0.01, want_stats=True, **kw)
