@@ -308,6 +308,9 @@ bool conv3d_zq12_ok(const ConvParams &p) {
     if (off || p.fp8 || p.packing != FNN_PACK_ZR || p.ksteps != ZQ_KS) return false;
     if (p.kd != 3 || p.kh != 3 || p.kw != 3 || p.sd != 1 || p.sh != 1 || p.sw != 1) return false;
     if ((p.Cout / 16) % 2 != 0 || p.Ho <= 8 || p.Ho > 12 || p.Wo <= 8 || p.Wo > 12 || p.Do < ZQ_TD) return false;
+    // depth-8 tiles must not waste much more of the layer's depth than conv3d_zr12_kernel's depth-4 tiles do (Do = 10: 16
+    // computed slices against 12, and 2 instead of 3 tiles per item to spread over the CUs)
+    if (((p.Do + 7) / 8) * 8 * 10 > ((p.Do + 3) / 4) * 4 * 11) return false;
     return !p.stats_out || p.stats_slots >= (p.Do + ZQ_TD - 1) / ZQ_TD;
 }
 

@@ -392,464 +392,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
     FNN_STAMP_FLUSH(p.dbg);
 }
 
-// ----------------------------------------------------------------------------
-// ONE 512-thread workgroup per CU with two ROLES (round 4): conv3d_zrs_kernel
-// ----------------------------------------------------------------------------
-// Measured this round (in-kernel stamps, 32 -> 32 at 160x48x48): conv3d_zr_kernel's two co-resident workgroups take 17.6 k
-// cycles of their CU per two-chunk tile against 7.7 k cycles of MFMAs; one workgroup per CU that interleaves its own
-// staging into its k-loop (every order tried, down to a hand-placed one) is SLOWER, 18.5 k: a lone wave issues in order,
-// every scalar / vector-memory / LDS instruction of the staging sits in the stream its MFMAs need, and an LDS read that the
-// compiler sinks next to its use exposes a round trip (22 cycles per MFMA in a bare loop instead of 16).  What the two
-// workgroups get right by accident - another wave's scalar, memory and LDS instructions go through other issue ports -
-// this kernel does on purpose:
-//   * waves 0 .. 3 (one per SIMD) only multiply: per (tile, chunk) STAGE 240 MFMAs and the 80 fragment reads they need,
-//     hand-ordered (each read ~8 MFMAs ahead of its use); the bias is the C operand of a tile's first 16 MFMAs; at the end
-//     of a tile: accumulators -> fp16 -> global stores, nothing else;
-//   * waves 4 .. 7 (their partners on the SIMDs) stage: during stage s they load the halo of stage s + 2 (two register
-//     sets), normalise and write stage s + 1 into the OTHER chunk image (2 x 69 KB of the CU's 160 KB LDS), stream the
-//     weights of stage s + 1 through registers - and read the tile that finished two stages ago back from L2 for its
-//     InstanceNorm statistics row (no LDS left for a hand-over; the stores have left the CU by then: vmcnt(0));
-//   * one barrier per stage.
-// Same staging arithmetic, image layout, k-loop order and output bits as conv3d_zr_kernel<2, 8>; the statistics are the
-// same sums in another order (fp32 per lane over the tile's 8 planes, fp64 across lanes and waves).
-struct ZrsStage { int n, od0, oh0, ow0, cb0, slot, ch; };
-template <int TD>
-__global__ __launch_bounds__(768, 1) void conv3d_zrs_kernel(const ConvParams p, const int total_units, const int groups) {
-    constexpr int NB = 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    FNN_STAMP_DECL
-    FNN_STAMP();                                                  // 0: entry
-    constexpr int IH = 10, IW = 10, PW = 12, ID = TD + 2;
-    constexpr int PS = IH * PW * 32, ABYTES = ID * PS;
-    constexpr int KS = 15, WB = KS * 64, WPB = (WB + 255) / 256;
-    constexpr int IMG = ABYTES + NB * KS * 1024;                  // one chunk image: halo + the two cout blocks' fragments
-    float *sRed = (float *)(smem + 2 * IMG);                      // [2 tile parities][8 waves][4 rows][4][16]: the statistics' partial sums
-    char *dump0 = smem + 2 * IMG + 16384;                         // [64] 16-byte slots: where the staging's masked-out writes go
-    float *sBias = (float *)(smem + 2 * IMG + 16384 + 1024);      // [Cout]
-
-    // this workgroup's units (tile, cout group): u = first + i * stride inside its XCD's contiguous range (conv3d_zsp_kernel)
-    int u_first, u_stride, u_end;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        const int wg_lo = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd;
-        const int wg_n = xcd < rm ? qd + 1 : qd;
-        const int r_lo = (int)((long long)total_units * wg_lo / nwg), r_hi = (int)((long long)total_units * (wg_lo + wg_n) / nwg);
-        u_first = r_lo + idx; u_stride = wg_n; u_end = r_hi;
-    }
-    if (u_first >= u_end) return;
-    const int n_units = (u_end - u_first + u_stride - 1) / u_stride;
-    const int n_stages = n_units * p.chunks;
-    for (int i = tid; i < p.Cout; i += 768) sBias[i] = p.bias[i];
-
-    // A role walks its own copy of the stage stream: (tile digits, chunk).  The next tile is u_stride units on - added
-    // digit by digit in the mixed radix (groups, tiles_w, tiles_h, tiles_d) with one conditional subtraction per digit:
-    // six integer divisions per stage (~200 scalar and vector instructions in a stream that has 16 cycles per MFMA) were
-    // a sixth of the multiplying waves' time.
-    struct StageIt { int grp, tw, th, td, n, ch; };
-    StageIt it0;
-    int dgt[5];
-    {
-        auto digits = [&](int u, int (&d)[5]) {
-            d[0] = u % groups; u /= groups;
-            d[1] = u % p.tiles_w; u /= p.tiles_w;
-            d[2] = u % p.tiles_h; u /= p.tiles_h;
-            d[3] = u % p.tiles_d; d[4] = u / p.tiles_d;
-        };
-        int f[5];
-        digits(u_first, f);
-        digits(u_stride, dgt);
-        it0.grp = f[0]; it0.tw = f[1]; it0.th = f[2]; it0.td = f[3]; it0.n = f[4]; it0.ch = 0;
-    }
-    auto next_stage = [&](StageIt &t) {
-        if (++t.ch < p.chunks) return;
-        t.ch = 0;
-        int c;
-        t.grp += dgt[0];     c = t.grp >= groups;    t.grp -= c ? groups : 0;
-        t.tw += dgt[1] + c;  c = t.tw >= p.tiles_w;  t.tw -= c ? p.tiles_w : 0;
-        t.th += dgt[2] + c;  c = t.th >= p.tiles_h;  t.th -= c ? p.tiles_h : 0;
-        t.td += dgt[3] + c;  c = t.td >= p.tiles_d;  t.td -= c ? p.tiles_d : 0;
-        t.n += dgt[4] + c;
-    };
-    auto stage_of = [&](const StageIt &t) -> ZrsStage {
-        ZrsStage g;
-        g.n = t.n; g.ch = t.ch;
-        g.od0 = t.td * TD; g.oh0 = t.th * 8; g.ow0 = t.tw * 8; g.cb0 = t.grp * NB;
-        g.slot = (t.td * p.tiles_h + t.th) * p.tiles_w + t.tw;
-        return g;
-    };
-
-    if (wave < 4) {
-        // ================= the multiplying waves =================
-        int toff[5];
-        {
-            const int r = lane & 15, hl = lane >> 5, kh = (lane >> 4) & 1;
-#pragma unroll
-            for (int pr = 0; pr < 5; ++pr) {
-                const int tp = 2 * pr + hl < 9 ? 2 * pr + hl : 8;
-                const int row = 2 * wave + (r >> 3) + tp / 3, col2 = (r & 7) + tp % 3;
-                toff[pr] = (row * PW + col2) * 32 + ((kh ^ (row & 1)) * 16);
-            }
-        }
-        f32x4 acc[TD][NB];
-        // One stage's k-loop, the order spelled out slot by slot (one slot = one MFMA pair, fenced): left alone hipcc sinks
-        // every LDS read to just before its first use.  The weight fragments of k-step k + 1 are read at the start of step
-        // k; after an MFMA pair the halo fragment of the NEXT tap pair goes into the register whose last use it was.
-        auto k_loop = [&](const char *img, auto first_tag, const f32x4 (&b0)[NB]) {
-            constexpr bool FIRST = decltype(first_tag)::value;
-            const char *sA = img, *sW = img + ABYTES;
-            f16x8 xf[ID], wf[NB], wfn[NB];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) wf[nb] = *(const f16x8 *)(sW + (nb * KS * 64 + lane) * 16);
-#pragma unroll
-            for (int pl = 0; pl < ID; ++pl) xf[pl] = *(const f16x8 *)(sA + toff[0] + pl * PS);
-#pragma unroll
-            for (int pr = 0; pr < 5; ++pr) {
-                const char *bn = sA + toff[pr + 1 < 5 ? pr + 1 : 4];
-#pragma unroll
-                for (int i = 0; i < 24; ++i) {
-                    const int dz = i / 8, j = i % 8, k = pr * 3 + dz;
-                    if (j == 0 && k + 1 < KS) {
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) wfn[nb] = *(const f16x8 *)(sW + ((nb * KS + k + 1) * 64 + lane) * 16);
-                    }
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nb], xf[j + dz], (FIRST && k == 0) ? b0[nb] : acc[j][nb], 0, 0, 0);
-                    if (pr + 1 < 5) {
-                        if (dz < 2 && j == 0) xf[dz] = *(const f16x8 *)(bn + dz * PS);
-                        if (dz == 2) xf[j + 2] = *(const f16x8 *)(bn + (j + 2) * PS);
-                    }
-                    if (j == 7 && k + 1 < KS) {
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) wf[nb] = wfn[nb];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        };
-        __syncthreads();                                          // stage 0 is staged, the bias is in LDS
-#ifndef FNN_ZRS_STAMP_FROM
-#define FNN_ZRS_STAMP_FROM 0
-#endif
-#ifdef FNN_ZRS_STAMP_L
-#define FNN_MSTAMP() do {} while (0)
-#define FNN_LSTAMP(s) do { if ((s) >= FNN_ZRS_STAMP_FROM) FNN_STAMP(); } while (0)
-#else
-#define FNN_MSTAMP() FNN_STAMP()
-#define FNN_LSTAMP(s) __builtin_amdgcn_sched_barrier(0)          // (the staging steps stay in their order: measured, 16 % of the kernel)
-#endif
-        StageIt tm = it0;
-        for (int s = 0; s < n_stages; ++s) {
-            const ZrsStage g = stage_of(tm);
-            next_stage(tm);
-            const char *img = smem + (s & 1) * IMG;
-            if (g.ch == 0) {
-                f32x4 b0[NB];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) b0[nb] = *(const f32x4 *)(sBias + g.cb0 * 16 + (lane >> 4) * 8 + nb * 4);
-                k_loop(img, std::true_type{}, b0);
-            } else {
-                const f32x4 none[NB] = {};
-                k_loop(img, std::false_type{}, none);
-            }
-            if (s >= FNN_ZRS_STAMP_FROM) FNN_MSTAMP();
-            if (g.ch == p.chunks - 1) {                           // the tile is complete: fp16 stores (the statistics: the staging waves, two stages on)
-                float4 bv[NB];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) bv[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
-                float t1[NB][4] = {}, t2[NB][4] = {};
-                zr_epilogue_pair<TD, false>(p, acc, bv, g.n, g.od0, g.oh0, g.ow0, g.cb0, wave, lane, t1, t2);
-            } else {
-                __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the previous tile's stores have left the CU
-            }
-            if (s >= FNN_ZRS_STAMP_FROM) FNN_MSTAMP();
-            __syncthreads();
-            if (s >= FNN_ZRS_STAMP_FROM) FNN_MSTAMP();
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();                                          // (1) the last tile's stores are out: its statistics can be read back
-        __syncthreads();                                          // (2), (3): the staging waves' last partial sums
-        __syncthreads();
-#ifndef FNN_ZRS_STAMP_L
-        FNN_STAMP_FLUSH(p.dbg);
-#endif
-        return;
-    }
-
-    // ================= the staging waves =================
-    // Eight of them, two per SIMD: a lone in-order wave per SIMD needed ~1000 instructions per stage beside a partner that
-    // takes most issue slots - longer than the stage's 240 MFMAs.  Waves 4 .. 7 (half 0) stage halo planes 0 .. 4, cout block 0
-    // of the weights and read back output planes 0 .. 3; waves 8 .. 11 (half 1) the other halves.
-    const int lt = (tid - 256) & 255, lw = wave - 4;              // lw 0 .. 7
-    const int hf = __builtin_amdgcn_readfirstlane(lw >> 2);
-    // The parameters are re-read from the kernel argument segment in every stage (scalar loads): kept in registers across
-    // the stages they overflowed the scalar file, and every spilled scalar is a VALU instruction (v_readlane / v_writelane:
-    // 85 of a staging wave's ~300 per stage) - the unit whose issue slots the MFMAs leave only half of.
-    typedef const ConvParams __attribute__((address_space(4))) *KP;
-    KP q = (KP)__builtin_amdgcn_kernarg_segment_ptr();
-    auto fresh_params = [&]() { q = (KP)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(q)); };
-    constexpr int HP = ID / 2, HD = TD / 2;
-    char *dump = dump0 + lane * 16;                               // (shared by the waves: nobody reads it)
-    const int col = lt >> 1, cg = lt & 1;
-    const int zh = (col * 205) >> 11, zw = col - zh * IW;         // col / 10 for col < 128
-    const bool has_col = lt < 2 * IH * IW;
-    const int ldso0 = (zh * PW + zw) * 32 + ((cg ^ (zh & 1)) * 16) + hf * HP * PS;
-    const int wlds = ABYTES + (hf * WB + lt) * 16;
-
-    struct Halo {
-        fnn_u32x4v xr[HP], ssv[2];                                // ssv: 8 scales, 8 shifts (fp16); zeros for a column outside the tensor
-        unsigned voff;                                            // this thread's column in the stage's source (0x80000000: outside)
-        unsigned pmask;                                           // this half's planes inside the tensor (bit i: plane hf * 5 + i)
-        float slope;
-    };
-    auto issue_x = [&](Halo &L, const ZrsStage &g) {
-        const int c_glob = g.ch * 16;
-        const int sidx = (c_glob < q->src[0].C) ? 0 : 1;
-        const int c_uni = c_glob - (sidx ? q->src[0].C : 0);
-        const int sC = q->src[sidx].C, vs = FNN_VS(q->src[sidx]);
-        const unsigned item_bytes = (unsigned)q->Di * q->Hi * q->Wi * sC * 2;
-        const f16 *sp = q->src[sidx].ptr + (size_t)g.n * (item_bytes >> 1) + (c_uni >> 4) * FNN_CS(q->src[sidx]);
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)sp, 0, item_bytes, 0x00020000);
-        const unsigned plane_bytes = (unsigned)q->Hi * q->Wi * vs * 2;
-        const int gh = g.oh0 - 1 + zh, gw = g.ow0 - 1 + zw;
-        const bool ok_hw = has_col & ((unsigned)gh < (unsigned)q->Hi) & ((unsigned)gw < (unsigned)q->Wi);
-        L.voff = ok_hw ? (unsigned)(__mul24(gh, q->Wi) + gw) * (unsigned)(vs * 2) + cg * 16 : 0x80000000u;
-        L.slope = q->src[sidx].slope;
-        unsigned pm = (1u << ID) - 1;
-        if (g.od0 == 0) pm &= ~1u;
-        const int over = g.od0 + TD + 1 - q->Di;
-        if (over > 0) pm &= (1u << (ID - over)) - 1;
-        L.pmask = (pm >> (hf * HP)) & ((1u << HP) - 1);
-        // a column outside the tensor gets scale = shift = 0 from the range check: 0 * 0 + 0 = the conv's zero padding
-        const unsigned short *qs = q->src[sidx].ssh ? q->src[sidx].ssh + ((size_t)g.n * sC + c_uni) * 2 : q->ident_ssh + c_uni * 2;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)qs, 0, 64, 0x00020000);
-        const unsigned so = ok_hw ? (unsigned)cg * 32 : 0x80000000u;
-        L.ssv[0] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, so, 0, 0));
-        L.ssv[1] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, so, 16, 0));
-        const int d0 = g.od0 - 1 + hf * HP;
-#pragma unroll
-        for (int i = 0; i < HP; ++i) {                            // a clamped plane's image is zeroed in commit_x()
-            const int gd = d0 + i < 0 ? 0 : (d0 + i < q->Di ? d0 + i : q->Di - 1);
-            L.xr[i] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rx, L.voff, (unsigned)gd * plane_bytes, 0));
-        }
-    };
-    auto commit_x = [&](const Halo &L, char *img) {              // conv3d_zr_kernel's commit(): x * scale + shift, LeakyReLU, into the image
-        const f16 slope_h = (f16)L.slope;
-        const f16x8 sc_h = __builtin_bit_cast(f16x8, L.ssv[0]), sh_h = __builtin_bit_cast(f16x8, L.ssv[1]);
-        const bool all_in = L.pmask == (1u << HP) - 1;            // (uniform; border tiles along d only)
-        if (has_col) {
-#pragma unroll
-            for (int i = 0; i < HP; ++i) {
-                const f16x8 x = __builtin_bit_cast(f16x8, L.xr[i]);
-                f16x8 o = x * sc_h + sh_h;
-                o = __builtin_elementwise_max(o, o * slope_h);
-                *(f16x8 *)(img + ldso0 + i * PS) = o;
-            }
-            if (!all_in) {
-#pragma unroll
-                for (int i = 0; i < HP; ++i)
-                    if (!((L.pmask >> i) & 1)) *(f16x8 *)(img + ldso0 + i * PS) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            }
-        }
-    };
-    fnn_u32x4v wr[WPB];
-    auto issue_w = [&](const ZrsStage &g) {                      // this half's cout block
-        const f16 *wp = q->wpk + ((size_t)((g.cb0 + hf) * q->chunks + g.ch) * WB) * 8;
-        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, WB * 16, 0x00020000);
-#pragma unroll
-        for (int u = 0; u < WPB; ++u)                             // element lt + 256 u of the block; beyond it: range check, zeros, no traffic
-            wr[u] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw, lt * 16, u * 4096, 0));
-    };
-    auto commit_w = [&](char *img) {
-#pragma unroll
-        for (int u = 0; u < WPB; ++u) {
-            char *dst = img + wlds + u * 256 * 16;
-            if (u + 1 == WPB) dst = (lw & 3) < 3 ? dst : dump;    // (the half's fourth wave: its share of the last group lies beyond the block)
-            *(fnn_u32x4v *)dst = wr[u];
-        }
-    };
-    // The statistics row of a finished tile, read back from L2 one stage after its stores have left the CU and summed one
-    // stage after that (the loads of a stage are never waited for inside it: under this kernel's traffic a load takes
-    // ~3 us): lane = (voxel of an 8 x 8 plane, cout block, 16-byte half), 4 planes per half; fp32 sums and sums of squares of
-    // the lane's 8 channels; lanes of one 16-lane row that hold the same channels are added with two DPP rotations; every
-    // (wave, row) leaves its 4 x 16 partial sums in LDS; after the next barrier waves 4 .. 7 add the 32 partial sums per value.
-    // The loads are issued every stage (a stage that ends no tile: all lanes out of range - zeros, no traffic): a load in a
-    // conditional block makes hipcc's next wait a vmcnt(0).
-    fnn_u32x4v rb[HD];
-    int rb_n = 0, rb_cb0 = 0, rb_slot = -1;                       // the tile whose outputs are on their way (slot < 0: none)
-    int tile_par = 0, fin_n = 0, fin_cb0 = 0, fin_slot = -1;      // the tile whose partial sums are in LDS
-    auto readback_issue = [&](const ZrsStage &g, bool tile_end) {
-        const unsigned item_bytes = (unsigned)q->Do * q->Ho * q->Wo * q->Cout * 2;
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(q->out + (size_t)g.n * (item_bytes >> 1), 0, item_bytes, 0x00020000);
-        const int vp = lt >> 2, blk = (lt >> 1) & 1, half = lt & 1;
-        const int oh = g.oh0 + (vp >> 3), ow = g.ow0 + (vp & 7);
-        const bool ok_hw = tile_end && oh < q->Ho && ow < q->Wo;
-        const unsigned ovs2 = (unsigned)FNN_OVS(p) * 2;
-        const unsigned coff = (unsigned)(g.cb0 + blk) * (unsigned)(FNN_OCS(p) * 2) + (unsigned)half * 16;
-        // (no branches around the loads: the lane's offset in the half's first plane once, the plane as the scalar offset -
-        // which the range check does not see - and a plane beyond the tensor by a uniform select of the out-of-range offset)
-        const int od_first = g.od0 + hf * HD;
-        unsigned voff0 = (unsigned)((od_first * q->Ho + oh) * q->Wo + ow) * ovs2 + coff;
-        voff0 = ok_hw ? voff0 : 0x80000000u;
-        asm volatile("" : "+v"(voff0));
-        const unsigned plane_bytes = (unsigned)q->Ho * q->Wo * ovs2;
-#pragma unroll
-        for (int d = 0; d < HD; ++d) {
-            const unsigned voff = od_first + d < q->Do ? voff0 : 0x80000000u;
-            rb[d] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(ro, voff, (unsigned)d * plane_bytes, 0));
-        }
-        rb_n = g.n; rb_cb0 = g.cb0; rb_slot = tile_end ? g.slot : -1;
-    };
-    auto readback_sum = [&]() {
-        fnn_u32x4v v[HD];
-#pragma unroll
-        for (int d = 0; d < HD; ++d) { v[d] = rb[d]; asm volatile("" : "+v"(v[d])); }     // (the wait for the loads: outside the branch)
-        if (rb_slot >= 0) {
-            float s1[8], s2[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {                         // v_fma_mix_f32: the fp16 -> fp32 conversions inside the fma (exact)
-                const unsigned w = v[0][e];
-                asm("v_fma_mix_f32 %0, %1, 1.0, 0 op_sel_hi:[1,0,0]" : "=v"(s1[2 * e]) : "v"(w));
-                asm("v_fma_mix_f32 %0, %1, 1.0, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(s1[2 * e + 1]) : "v"(w));
-                asm("v_fma_mix_f32 %0, %1, %1, 0 op_sel_hi:[1,1,0]" : "=v"(s2[2 * e]) : "v"(w));
-                asm("v_fma_mix_f32 %0, %1, %1, 0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(s2[2 * e + 1]) : "v"(w));
-            }
-#pragma unroll
-            for (int d = 1; d < HD; ++d)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned w = v[d][e];
-                    asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(s1[2 * e]) : "v"(w));
-                    asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(s1[2 * e + 1]) : "v"(w));
-                    asm("v_fma_mix_f32 %0, %1, %1, %0 op_sel_hi:[1,1,0]" : "+v"(s2[2 * e]) : "v"(w));
-                    asm("v_fma_mix_f32 %0, %1, %1, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(s2[2 * e + 1]) : "v"(w));
-                }
-            float *red = sRed + tile_par * 2048 + ((lw * 4 + (lane >> 4)) * 4 + (lane & 3)) * 16;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {                         // (one v_add_f32_dpp per step: hipcc fuses only every other one)
-                float a = s1[e], b = s2[e], a2, b2;
-                asm("v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(a2) : "v"(a));
-                asm("v_add_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(a) : "v"(a2));
-                asm("v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(b2) : "v"(b));
-                asm("v_add_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(b) : "v"(b2));
-                if ((lane & 15) < 4) { red[e] = a; red[8 + e] = b; }
-            }
-            fin_n = rb_n; fin_cb0 = rb_cb0; fin_slot = rb_slot;
-            rb_slot = -1;
-        }
-    };
-    // after a barrier: the 32 partial sums per value (8 waves x 4 rows) - lane = (value, quarter): 8 of them in fp32, the
-    // quarters with two DPP quad permutes, the row entry in fp64
-    auto flush_stats = [&]() {
-        if (fin_slot >= 0) {
-            if (hf == 0) {
-                const int val = lt >> 2, qt = lt & 3;             // value = (channel c of the pair in memory order, which)
-                const int c = val >> 1, which = val & 1;
-                const float *red = sRed + tile_par * 2048 + qt * 8 * 64 + ((c >> 3) & 3) * 16 + which * 8 + (c & 7);
-                float v = 0.f;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) v += red[w * 64];
-                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm:[1,0,3,2]
-                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm:[2,3,0,1]
-                if (qt == 0) q->stats_out[(((size_t)fin_n * q->stats_slots + fin_slot) * q->Cout + fin_cb0 * 16 + c) * 2 + which] = (double)v;
-            }
-            fin_slot = -1;
-            tile_par ^= 1;
-        }
-    };
-
-    // ---- the stage stream, two stages per turn so that both register sets are named
-    Halo L0, L1;
-    char *imgA = smem, *imgB = smem + IMG;
-    StageIt tl = it0, tr = it0;                                   // the stage whose halo is being loaded; the stage whose tile is read back
-    const ZrsStage g0 = stage_of(tl);
-    issue_x(L0, g0);
-    issue_w(g0);
-    if (n_stages > 1) next_stage(tl);                             // (a lone stage is loaded twice: no conditional loads)
-    const ZrsStage g1 = stage_of(tl);
-    issue_x(L1, g1);
-    commit_x(L0, imgA);
-    commit_w(imgA);
-    issue_w(g1);
-    readback_issue(g0, false);
-    __syncthreads();
-    // During stage s: the halo loads of stage s + 2; the commit of stage s + 1 (halo loaded during stage s - 1, weights at
-    // its end); the sums of the tile whose outputs were requested at the end of stage s - 1; then the weight loads of stage
-    // s + 2 and the request for the outputs of the tile that ended with stage s - 2.
-    auto stage_work = [&](int s, char *img_n, Halo &Ln, Halo &Ll) {
-        fresh_params();
-        flush_stats();
-        if (s + 2 < n_stages) next_stage(tl);                     // (behind the last stage: that one again)
-        const ZrsStage gl = stage_of(tl);
-        issue_x(Ll, gl);
-        FNN_LSTAMP(s);
-        commit_x(Ln, img_n);
-        FNN_LSTAMP(s);
-        commit_w(img_n);
-        FNN_LSTAMP(s);
-        readback_sum();
-        issue_w(gl);
-        if (s >= 3) next_stage(tr);                               // tr = stage s - 2
-        {
-            const ZrsStage gf = stage_of(tr);
-            readback_issue(gf, q->stats_out && s >= 2 && gf.ch == q->chunks - 1);
-        }
-        FNN_LSTAMP(s);
-    };
-    for (int s = 0; s < n_stages; s += 2) {
-        stage_work(s, imgB, L1, L0);
-        __syncthreads();
-        FNN_LSTAMP(s);
-        if (s + 1 >= n_stages) break;
-        stage_work(s + 1, imgA, L0, L1);
-        __syncthreads();
-        FNN_LSTAMP(s + 1);
-    }
-    // the tail: the tile whose outputs were requested in the last stage, then the tiles that ended with the last two stages
-    // (chunks >= 2: the last one), two barriers each for the sums in LDS
-    __syncthreads();                                              // (1) the multiplying waves' last stores are out
-    flush_stats();
-    readback_sum();
-    __syncthreads();                                              // (2)
-    flush_stats();
-    {
-        for (int s = n_stages >= 3 ? n_stages - 3 : 0; s < n_stages - 1; ++s) next_stage(tr);      // tr = the last stage
-        readback_issue(stage_of(tr), q->stats_out != nullptr);
-    }
-    readback_sum();
-    __syncthreads();                                              // (3)
-    flush_stats();
-#if defined(FNN_STAMPS) && defined(FNN_ZRS_STAMP_L)
-    if (q->dbg && tid == 256) for (int i = 0; i < 12; ++i) q->dbg[(size_t)blockIdx.x * 12 + i] = i < _si ? _st[i] : 0ull;
-#endif
-}
-
-template <int TD>
-static int launch_zrs(ConvParams p, hipStream_t st) {
-    p.tile_d = TD;
-    p.tiles_d = (p.Do + TD - 1) / TD;
-    p.tiles_h = (p.Ho + 7) / 8;
-    p.tiles_w = (p.Wo + 7) / 8;
-    const size_t img = (size_t)((TD + 2) * 10 * 12 * 32) + (size_t)2 * 15 * 1024;
-    const size_t lds = 2 * img + 16384 + 1024 + (size_t)p.Cout * 4;
-    if (lds > 160 * 1024) return -1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)conv3d_zrs_kernel<TD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    p.ident_ss = conv3d_identity_ss();
-    p.ident_ssh = conv3d_identity_ssh();
-    if (!p.ident_ss || !p.ident_ssh) return -2;
-    const int groups = (p.Cout / 16) / 2;
-    const int total = p.N * p.tiles_d * p.tiles_h * p.tiles_w * groups;
-    const int gx = total < 256 ? total : 256;
-    fnn_note_kernel("conv3d_zrs_kernel<%d>", TD);
-    hipLaunchKernelGGL((conv3d_zrs_kernel<TD>), dim3(gx), dim3(768), lds, st, p, total, groups);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
-}
+// (Round 4's role-split form of this kernel - conv3d_zrs_kernel: one 768-thread workgroup per CU, four multiplying and eight
+// staging waves, -10.6 % cycles per tile at -9 % clock - was an opt-in experiment behind FNN_ZRS; its last step-level A-B in
+// round 5 (3516 / 3512 vs 3507 / 3500 patches/s) confirmed 0 +- 0.4 %, and it is gone: DESIGN.md 7.0 keeps the finding, the
+// source is in the history at commit "conv3d_zq12_kernel" and before.)
 
 // ----------------------------------------------------------------------------
 // single-chunk layers (Cin <= 16): the same kernel WALKING along d (round 3)
@@ -2411,7 +1957,6 @@ int launch_conv3d_zr(const ConvParams &p, hipStream_t st) {
         static const bool no_walk = fnn_knob("FNN_NO_ZRW") != nullptr;                        // A-B aid
         if (!no_walk && p.chunks == 1 && td == 8 && (p.Do + 7) / 8 >= 4) return nb == 2 ? launch_zrw<2>(p, st) : launch_zrw<1>(p, st);
     }
-    if (nb == 2 && td == 8 && p.chunks >= 2 && fnn_knob("FNN_ZRS")) return launch_zrs<8>(p, st);          // round 4 experiment: one self-pipelined workgroup per CU
     if (nb == 2) return td == 8 ? launch_zr<2, 8>(p, st) : launch_zr<2, 4>(p, st);
     return td == 8 ? launch_zr<1, 8>(p, st) : launch_zr<1, 4>(p, st);
 }

@@ -46,6 +46,8 @@ struct Layer {
     // conv3d_thin.hip: the stem as one MFMA per 16 voxels (w_off2 = its weight fragment in wpk); a CONV that recomputes
     // its producer while staging (fuse = FUSE_STEM / FUSE_TCONV); a producer whose output is never written (virtual)
     bool mfma_stem = false, virtual_out = false;
+    int pool_layer = -1;              // COMBINE: the POOL layer (the next stage's skip path) whose output this launch writes too; that POOL has pool_fused
+    bool pool_fused = false;
     bool chunk_major = false;         // output stored [C / 16][voxels][16] (fnn_device.h, SrcDesc): convs / transposed convs whose consumers are convs
     bool fp8 = false;                 // conv3d_zr8_kernel: e4m3 operands; oscale_off = per-cout output scales (floats)
     size_t oscale_off = 0;
@@ -298,7 +300,15 @@ int build_plan(fnn_engine *e) {
                 const int c2 = add_conv(Layer::CONV, 1, cin2, src2, F, a.kernels[s], one, dims[s], dims[s]);
                 next_act = true;
                 int skip = prev;
-                if (strided) skip = add_aux(Layer::POOL, prev, -1, prev_c, st, in_d, dims[s]);
+                if (strided) {
+                    skip = add_aux(Layer::POOL, prev, -1, prev_c, st, in_d, dims[s]);
+                    // the pooled tensor is written by the launch that forms the block output it pools (combine_pool_kernel)
+                    Layer &Cb = e->layers[prev];
+                    if (e->fuse_enabled && fnn_knob("FNN_NO_POOL_FUSE") == nullptr && Cb.type == Layer::COMBINE &&
+                        combine_pool_ok(in_d[0], in_d[1], in_d[2], st[0], st[1], st[2])) {
+                        Cb.pool_layer = skip; e->layers[skip].pool_fused = true;
+                    }
+                }
                 if (prev_c != F) {
                     const int cinp[2] = {prev_c, 0}, srcp[2] = {skip, -1};
                     next_has_bias = false; next_act = false;
@@ -738,6 +748,7 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             } else
             rc = launch_conv3d(p, st);
         } else if (L.type == Layer::POOL) {
+            if (L.pool_fused) continue;                               // written by the COMBINE launch of its source
             PoolParams p{};
             p.src = make_src(e, fw, L.src_layer[0], nb);
             p.N = nb; p.Di = L.in_dims[0]; p.Hi = L.in_dims[1]; p.Wi = L.in_dims[2];
@@ -753,6 +764,13 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.vox = (long long)L.out_dims[0] * L.out_dims[1] * L.out_dims[2];
             p.N = nb; p.slope = e->arch.slope; p.out = out;
             if (L.chunk_major) { p.out_vs = 16; p.out_cs = 16LL * p.vox; }
+            if (L.pool_layer >= 0) {
+                const Layer &P = e->layers[L.pool_layer];
+                p.pool_out = e->act + P.out_off * e->max_batch;
+                p.D = L.out_dims[0]; p.H = L.out_dims[1]; p.W = L.out_dims[2];
+                p.psd = P.s[0]; p.psh = P.s[1]; p.psw = P.s[2];
+                if (P.chunk_major) { p.pool_vs = 16; p.pool_cs = 16LL * P.out_dims[0] * P.out_dims[1] * P.out_dims[2]; }
+            }
             Scope sc(e, st, FAM_TCONV, 0);
             rc = launch_combine(p, st);
         } else {

@@ -318,6 +318,14 @@ struct CombineParams {
     f16 *out;                    // [N][vox][C], final values; or chunk-major (out_vs, out_cs; 0 = channels-last)
     int out_vs;
     long long out_cs;
+    // Round 5: the block output that closes a stage is pooled by the next stage's skip path (AvgPool3d(stride) of exactly
+    // these values): combine_pool_kernel writes that tensor in the same pass instead of avgpool_kernel re-reading the one
+    // just written.  pool_out != nullptr: D, H, W = the block output's size (each a multiple of its stride), psd / psh / psw
+    // the pooling strides, pool_vs / pool_cs the pooled tensor's layout (0 = channels-last)
+    f16 *pool_out;
+    int D, H, W, psd, psh, psw;
+    int pool_vs;
+    long long pool_cs;
 };
 
 struct StatsFinalizeParams {
@@ -336,6 +344,7 @@ int launch_region_copy(void *feat, long long n_slots, const int *regions, int n,
 int launch_fss_to_ssh(const float *fss, unsigned short *ssh, long long items, int C, hipStream_t st);   // [items][2][C] fp32 rows -> [items][C / 8][16] fp16 (SrcDesc::ssh)
 int launch_avgpool(const PoolParams &p, hipStream_t st);
 int launch_combine(const CombineParams &p, hipStream_t st);
+bool combine_pool_ok(int D, int H, int W, int sd, int sh, int sw);     // can the combine launch write the pooled tensor of these strides too
 int launch_conv3d(const ConvParams &p, hipStream_t st);
 size_t conv3d_lds_bytes(const ConvParams &p, int nb);
 int conv3d_pick_nb(int nblk);

@@ -481,6 +481,104 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
             for (int j = 0; j < 4; ++j) if (hb == whb && j == wj) wsum = sum_of(hb, j);
         wsum = __shfl(wsum, wq * 16 + r, 64);
         const bool zok = z0 + 16 * g + r < p.z_hi;
+        const int lrem = wrow & 15;                            // classes in block whb (the row behind them holds the weight sum)
+        if constexpr (LABELS && PKS) {
+            // ---- argmax labels without the 64 quotients (round 5).  The logit of a head is Q(a) = fp16(fl32(a / w)) of its sum a
+            // (both fp16 values, w > 0): monotone in a.  So the winners are the heads with Q(a) = Q(A), A = the largest sum, and
+            // Q(a) >= Q(A)  <=>  fl32(a / w) > m, or = m with the tie going up (Q(A) even), m = the midpoint below Q(A)
+            // <=>  a > T or (a = T and Q(A) even), T = m w EXACTLY in fp32 (12 x 11 significant bits) - and fl32(a / w) = m only
+            // when a = T: an fp16 a != T is at least 2^-22 |T| away from the 23-bit T, a / w then 2^-22 m from m.  One quotient
+            // (the shared-reciprocal form the logits take, checked against IEEE division over all pairs), one threshold, one
+            // compare per head; the lowest winning head = torch's first maximum.  Anything unusual - a non-finite sum, w not a
+            // positive finite number, a quotient near the fp16 range's ends, regions instead of argmax - takes the chain below.
+            if (!p.order && !p.ieee_div) {
+                const f16 HINF = __builtin_bit_cast(f16, (unsigned short)0x7c00), HNINF = __builtin_bit_cast(f16, (unsigned short)0xfc00);
+                // block whb ends with the weight-sum row: vmk[k] = 0xffff per half of its pair k that is a class
+                unsigned vmk[2], xw[2] = {0u, 0u};
+#pragma unroll
+                for (int k = 0; k < 2; ++k) vmk[k] = (q * 4 + 2 * k < lrem ? 0xffffu : 0u) | (q * 4 + 2 * k + 1 < lrem ? 0xffff0000u : 0u);
+                // (v_pk_max / min_f16 through asm: the builtin quiets its operands first - three instructions per maximum)
+                const auto pkmax = [](unsigned a2, unsigned b2) { unsigned r2; asm("v_pk_max_f16 %0, %1, %2" : "=v"(r2) : "v"(a2), "v"(b2)); return r2; };
+                const auto pkmin = [](unsigned a2, unsigned b2) { unsigned r2; asm("v_pk_min_f16 %0, %1, %2" : "=v"(r2) : "v"(a2), "v"(b2)); return r2; };
+                unsigned mxu = 0xfc00fc00u, mnu = 0x7c007c00u;
+                f16x2 sm = {(f16)0.f, (f16)0.f};
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) {
+                    if (hb > whb) continue;                    // (wave-uniform)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const unsigned x2 = __builtin_bit_cast(unsigned, ah[PKS ? g : 0][hb][k]);
+                        unsigned xa = x2, xi = x2, xs = x2;
+                        if (hb == whb) {                       // (wave-uniform)
+                            xa = (x2 & vmk[k]) | (0xfc00fc00u & ~vmk[k]);
+                            xi = (x2 & vmk[k]) | (0x7c007c00u & ~vmk[k]);
+                            xs = x2 & vmk[k];
+                            xw[k] = xa;
+                        }
+                        mxu = pkmax(mxu, xa);
+                        mnu = pkmin(mnu, xi);
+                        sm = add_h2(sm, __builtin_bit_cast(f16x2, xs));   // NaN / inf among the sums end up here (the packed max ignores a NaN)
+                    }
+                }
+                const f16x2 mx = __builtin_bit_cast(f16x2, mxu), mn = __builtin_bit_cast(f16x2, mnu);
+                f16x2 P;                                       // (largest sum, largest negated sum) of the voxel's heads
+                P[0] = mx[0] > mx[1] ? mx[0] : mx[1];
+                P[1] = mn[0] < mn[1] ? -mn[0] : -mn[1];
+                if (!(__builtin_fabsf((float)sm[0]) < 65520.f) || !(__builtin_fabsf((float)sm[1]) < 65520.f)) P[0] = HINF;
+#pragma unroll
+                for (int m = 16; m < 64; m <<= 1) {
+                    const unsigned o2 = (unsigned)__shfl_xor((int)__builtin_bit_cast(unsigned, P), m, 64);
+                    P = __builtin_bit_cast(f16x2, pkmax(__builtin_bit_cast(unsigned, P), o2));
+                }
+                const float A = (float)P[0], Bm = (float)P[1];
+                const float yr = quot_rcp(wsum);
+                const float qA = quot_fast(A, wsum, yr);
+                const f16 qh = (f16)qA;
+                const unsigned qb = __builtin_bit_cast(unsigned short, qh), qmag = qb & 0x7fffu;
+                bool slow = !(A < 65520.f) || !(wsum > 0.f) || !(wsum < 65520.f) || !(__builtin_fmaxf(__builtin_fabsf(A), Bm) * yr < 32768.f) ||
+                            qmag < 0x0400u || qmag >= 0x7bffu;
+                const unsigned pb = (qb & 0x8000u) ? qb + 1u : qb - 1u;       // the fp16 value below Q(A)
+                const float mid = 0.5f * ((float)__builtin_bit_cast(f16, (unsigned short)pb) + (float)qh);
+                const float T = mul_rn(mid, wsum);
+                const f16 Tn = (f16)T;
+                const float tf = (float)Tn;
+                const unsigned tb = __builtin_bit_cast(unsigned short, Tn);
+                const bool down = tf > T || (tf == T && !(qb & 1u));         // the largest fp16 value that does NOT win: Tn itself, or the one below it
+                const unsigned tb2 = (tb & 0x8000u) ? tb + 1u : (tb == 0u ? 0x8001u : tb - 1u);
+                const unsigned tdb = down ? tb2 : tb;
+                slow |= (tdb & 0x7fffu) == 0u || (tdb & 0x7fffu) >= 0x7c00u;
+                if (__builtin_amdgcn_ballot_w64(slow) == 0) {
+                    // this lane's lowest winning head as the index hb * 4 + j of its 16: per pair two compares (the high half
+                    // through SDWA) and two selects, the pairs descending so that the lowest index is written last; two wait
+                    // states between a compare and the select that reads its mask (gfx950)
+                    int win = 16;
+#pragma unroll
+                    for (int hb = HB - 1; hb >= 0; --hb) {
+                        if (hb > whb) continue;
+#pragma unroll
+                        for (int k = 1; k >= 0; --k) {
+                            const unsigned xv = hb == whb ? xw[k] : __builtin_bit_cast(unsigned, ah[PKS ? g : 0][hb][k]);
+                            unsigned long long mh;
+                            asm("v_cmp_gt_f16_sdwa %1, %2, %3 src0_sel:WORD_1 src1_sel:WORD_0\n\t"
+                                "v_cmp_gt_f16_e32 vcc, %2, %3\n\t"
+                                "s_nop 0\n\t"
+                                "v_cndmask_b32_e64 %0, %0, %4, %1\n\t"
+                                "v_cndmask_b32_e64 %0, %0, %5, vcc"
+                                : "+v"(win), "=&s"(mh) : "v"(xv), "v"(tdb), "n"(hb * 4 + 2 * k + 1), "n"(hb * 4 + 2 * k) : "vcc");
+                        }
+                    }
+                    int lab = win < 16 ? (win >> 2) * 16 + q * 4 + (win & 3) : 0x7fff;
+#pragma unroll
+                    for (int m = 16; m < 64; m <<= 1) { const int ol = __shfl_xor(lab, m, 64); lab = ol < lab ? ol : lab; }
+                    const int z = z0 + 16 * g + r;
+                    if (q == 0 && z < p.z_hi) {
+                        const size_t o = ((size_t)x * p.OY + y) * p.OZ + z;
+                        if (p.label_u16) ((uint16_t *)p.labels)[o] = (uint16_t)lab; else ((uint8_t *)p.labels)[o] = (uint8_t)lab;
+                    }
+                    continue;
+                }
+            }
+        }
         bool odd = true;
         f16x2 qh[HB][2];                                       // the group's logits: heads 4q + {0,1}, {2,3} per block
         if (PKS) {                                             // fp16-valued sums: the shared-reciprocal quotient (above)

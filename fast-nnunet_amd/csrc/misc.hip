@@ -316,8 +316,103 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineParams p) {
     }
 }
 
+// The closing add of a stage's last block AND the next stage's skip-path pooling in one pass (round 5): thread = (pooled
+// voxel, 8-channel group) like avgpool_kernel; it forms the sd x sh x sw block outputs under its pooled voxel with
+// combine_kernel's arithmetic, stores them, and averages the fp16-ROUNDED values in avgpool_kernel's order (fp32 sum over
+// d, h, w ascending, times 1 / count, one rounding): both tensors carry the bits the two kernels wrote.
+template <int SD, int SH, int SW>
+__global__ __launch_bounds__(256) void combine_pool_kernel(const CombineParams p) {
+    const int Do = p.D / SD, Ho = p.H / SH, Wo = p.W / SW;
+    const int cg = p.a.C >> 3;
+    const long long ovox = (long long)Do * Ho * Wo;
+    const long long total = (long long)p.N * ovox * cg;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int g, n;
+    long long v;                                                          // pooled voxel inside item n
+    if (p.pool_vs) {                                                      // chunk-major pooled tensor: (n, chunk, voxel, half)
+        const int half = (int)(i & 1);
+        long long t = i >> 1;
+        v = t % ovox; t /= ovox;
+        const int chunk = (int)(t % (cg >> 1));
+        n = (int)(t / (cg >> 1));
+        g = chunk * 2 + half;
+    } else {
+        g = (int)(i % cg);
+        const long long t = i / cg;
+        v = t % ovox;
+        n = (int)(t / ovox);
+    }
+    const int ow = (int)(v % Wo), oh = (int)((v / Wo) % Ho), od = (int)(v / ((long long)Wo * Ho));
+    const int c0 = g * 8;
+    const size_t item = (size_t)n * p.vox * p.a.C;
+    const f16 *pa = p.a.ptr + item + (size_t)(c0 >> 4) * FNN_CS(p.a) + (c0 & 15);
+    const f16 *pb = p.b.ptr + item + (size_t)(c0 >> 4) * FNN_CS(p.b) + (c0 & 15);
+    f16 *po = p.out + item + (size_t)(c0 >> 4) * (p.out_vs ? p.out_cs : 16LL) + (c0 & 15);
+    const unsigned vsa = (unsigned)FNN_VS(p.a), vsb = (unsigned)FNN_VS(p.b), vso = (unsigned)(p.out_vs ? p.out_vs : p.a.C);
+    constexpr int NV = SD * SH * SW;
+    // every load of the thread leaves before the first use: 2 NV 16-byte loads in flight (the runtime-bounded loops of the
+    // first form waited for four at a time and ran at half the rate of the two kernels it replaces)
+    f16x8 xa[NV], xb[NV];
+    unsigned vin[NV];                                                     // voxel index inside the item (< 2^31 / C: launch_combine)
+#pragma unroll
+    for (int a = 0; a < SD; ++a)
+#pragma unroll
+        for (int b = 0; b < SH; ++b)
+#pragma unroll
+            for (int c = 0; c < SW; ++c) {
+                const int k = (a * SH + b) * SW + c;
+                vin[k] = (unsigned)(((od * SD + a) * p.H + oh * SH + b) * p.W + ow * SW + c);
+                xa[k] = *(const f16x8 *)(pa + (size_t)vin[k] * vsa);
+                xb[k] = *(const f16x8 *)(pb + (size_t)vin[k] * vsb);
+            }
+    float sa[8], ha[8], sb[8], hb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sa[j] = p.a.ss ? p.a.ss[(size_t)(2 * n) * p.a.C + c0 + j] : 1.f;
+        ha[j] = p.a.ss ? p.a.ss[(size_t)(2 * n + 1) * p.a.C + c0 + j] : 0.f;
+        sb[j] = p.b.ss ? p.b.ss[(size_t)(2 * n) * p.b.C + c0 + j] : 1.f;
+        hb[j] = p.b.ss ? p.b.ss[(size_t)(2 * n + 1) * p.b.C + c0 + j] : 0.f;
+    }
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {                                        // (d, h, w ascending: avgpool_kernel's order of summation)
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float ya = (float)xa[k][j], yb = (float)xb[k][j];
+            if (p.a.ss) ya = fmaf(ya, sa[j], ha[j]);
+            if (p.b.ss) yb = fmaf(yb, sb[j], hb[j]);
+            o[j] = (f16)leaky(leaky(ya, p.a.slope) + leaky(yb, p.b.slope), p.slope);
+            acc[j] += (float)o[j];
+        }
+        *(f16x8 *)(po + (size_t)vin[k] * vso) = o;
+    }
+    const float inv = 1.f / (float)NV;
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)(acc[j] * inv);
+    *(f16x8 *)(p.pool_out + (size_t)n * ovox * p.a.C + (size_t)v * (p.pool_vs ? p.pool_vs : p.a.C) + (c0 >> 4) * (p.pool_vs ? p.pool_cs : 16LL) + (c0 & 15)) = o;
+}
+
+// the fused form serves the strides the networks use: (2, 2, 2) and (1, 2, 2), sizes that are multiples of them
+bool combine_pool_ok(int D, int H, int W, int sd, int sh, int sw) {
+    return sh == 2 && sw == 2 && (sd == 1 || sd == 2) && D % sd == 0 && H % 2 == 0 && W % 2 == 0 && (long long)D * H * W < (1LL << 26);
+}
+
 int launch_combine(const CombineParams &p, hipStream_t st) {
     const int cg = p.a.C >> 3;
+    if (p.pool_out) {
+        if (!combine_pool_ok(p.D, p.H, p.W, p.psd, p.psh, p.psw) || (long long)p.D * p.H * p.W != p.vox) return -1;
+        const long long total = (long long)p.N * (p.D / p.psd) * (p.H / p.psh) * (p.W / p.psw) * cg;
+        const dim3 grid((unsigned)((total + 255) / 256));
+        fnn_note_kernel("combine_pool_kernel");
+        if (p.psd == 2) hipLaunchKernelGGL((combine_pool_kernel<2, 2, 2>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((combine_pool_kernel<1, 2, 2>), grid, dim3(256), 0, st, p);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     const long long rowlen = p.vox * (p.out_vs ? 2 : cg);
     const long long rows = (long long)p.N * (p.out_vs ? cg >> 1 : 1);
     if (rowlen >= (1LL << 32) - 256 * FNN_CMB_U || rows > 65535) return -1;

@@ -595,6 +595,35 @@ def test_resenc_sliding_window_bit_identical_and_close_to_oracle():
     assert mr <= MAX_REL and rr <= RMSE_REL
 
 
+@pytest.mark.parametrize('name', ['resenc4', 'resenc_2ch_odd'])
+def test_resenc_stage_closing_add_writes_the_pooled_skip_tensor_too(name):
+    """Round 5: the block output that closes a stage is average-pooled by the next stage's skip path; combine_pool_kernel
+    forms the block output and the pooled tensor in one pass (the pooled values from the fp16-rounded outputs, summed in
+    avgpool_kernel's order) instead of avgpool_kernel re-reading the tensor just written.  Bit-identical to the two
+    launches (FNN_NO_POOL_FUSE), and no avgpool_kernel behind a combine launch."""
+    spec, patch = SPECS[name]
+    sd = synthetic_state_dict(spec, 77)
+    x = torch.randn(3, spec.in_channels, *patch, generator=torch.Generator().manual_seed(5))
+    os.environ.pop('FNN_NO_POOL_FUSE', None)
+    p = _predictor(spec, patch, [sd])
+    p._engine.set_profiling(True)
+    fused = p.forward_patches(x).cpu()
+    log = p._engine.kernel_log()
+    p._engine.set_profiling(False)
+    # (resenc4's last stage pools with stride (2, 1, 1): not a form the fused kernel takes - that one avgpool_kernel stays)
+    assert 'combine_pool_kernel' in log and log.count('avgpool_kernel') == (1 if name == 'resenc4' else 0), log
+    os.environ['FNN_NO_POOL_FUSE'] = '1'
+    try:
+        q = _predictor(spec, patch, [sd])
+    finally:
+        os.environ.pop('FNN_NO_POOL_FUSE', None)
+    q._engine.set_profiling(True)
+    plain = q.forward_patches(x).cpu()
+    assert 'avgpool_kernel' in q._engine.kernel_log() and 'combine_pool_kernel' not in q._engine.kernel_log()
+    q._engine.set_profiling(False)
+    assert torch.equal(fused, plain)
+
+
 def test_initialize_from_trained_model_folder_distilled_student(tmp_path):
     """The reference's model-folder layout (plans.json, dataset.json, fold_k/checkpoint_*.pth with the
     nnUNetTrainer.save_checkpoint schema, nnUNetTrainer.py:1159-1169) for a DISTILLED student - which the
@@ -957,8 +986,11 @@ def test_gather_path_with_more_than_64_tile_positions_on_an_axis(kind, shape):
     image = torch.randn(1, *shape, generator=torch.Generator().manual_seed(61))
     os.environ.pop('FNN_NO_GATHER', None)
     g = _predictor(spec, patch, sds, batch=8)
+    g._engine.set_profiling(True)                             # (the kernel log is kept while profiling)
     got = g.predict_sliding_window_return_logits(image)
-    assert any(k.startswith('gather_head_kernel') for k in g._engine.kernel_log()), g._engine.kernel_log()
+    log = g._engine.kernel_log()
+    g._engine.set_profiling(False)
+    assert any(k.startswith('gather_head_kernel') for k in log), log
     os.environ['FNN_NO_GATHER'] = '1'
     try:
         a = _predictor(spec, patch, sds, batch=8)
@@ -1008,6 +1040,42 @@ def test_gather_kernel_variants_in_the_autocast_arithmetic(heads, mirror):
                                      mirror_axes=mirror, accum='fp16')
     assert np.array_equal(_bits(p.predict_sliding_window_return_logits(image)), _bits(want))
     assert torch.equal(p.predict_segmentation_from_preprocessed_data(image).long().cpu(), osw.logits_to_labels(want).long())
+
+
+@pytest.mark.parametrize('accum', ['fp16', 'fp16_autocast'])
+@pytest.mark.parametrize('heads,scale', [(61, 1.0), (61, 1e-4), (61, 300.0), (20, 1.0), (16, 1.0), (3, 30.0)])
+def test_gather_labels_without_the_quotients_on_near_ties(heads, scale, accum):
+    """Round 5: the label form of the gather kernel takes ONE quotient per voxel (the largest sum's), derives the smallest
+    sum whose logit rounds to the same fp16 value and compares every head's sum with it, instead of dividing all 64 sums
+    and running the argmax chain (gather.hip, "argmax labels without the 64 quotients").  A seg head built to tie: pairs of
+    identical classes (the first must win), classes whose biases differ by a few fp16 ulps of the logit (the division by a
+    weight sum > 1 merges them: the lower index must win exactly when the quotients are equal), a class that is the maximum
+    almost everywhere; logits scaled down to the fp16 subnormals and up towards the range's end (both leave the fast route).
+    Labels must equal (a) the chain's (FNN_GATHER_IEEE forces it), (b) the oracle's labels of the engine's own logits."""
+    spec = UNetSpec('plain', 1, heads, [16, 32], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
+    patch = (16, 16, 32)
+    sd = synthetic_state_dict(spec, 710 + heads)
+    w, b = sd['decoder.seg_layers.0.weight'].clone(), sd['decoder.seg_layers.0.bias'].clone()
+    for h in range(1, heads, 4):                              # identical to the class in front of it
+        w[h], b[h] = w[h - 1], b[h - 1]
+    for h in range(2, heads, 4):                              # the same class with a bias a hair larger / smaller
+        w[h] = w[h - 2]
+        b[h] = b[h - 2] + (1e-3 if h % 8 == 2 else -2e-4) * (1 + h % 3)
+    sd['decoder.seg_layers.0.weight'], sd['decoder.seg_layers.0.bias'] = w * scale, b * scale
+    image = torch.randn(1, 40, 36, 70, generator=torch.Generator().manual_seed(71))
+    os.environ.pop('FNN_GATHER_IEEE', None)
+    p = _predictor(spec, patch, [sd], accumulate_in=accum)
+    fast = p.predict_segmentation_from_preprocessed_data(image)
+    os.environ['FNN_GATHER_IEEE'] = '1'
+    try:
+        chain = p.predict_segmentation_from_preprocessed_data(image)
+    finally:
+        os.environ.pop('FNN_GATHER_IEEE', None)
+    assert torch.equal(fast, chain)
+    logits = p.predict_sliding_window_return_logits(image)
+    assert torch.equal(fast.long().cpu(), osw.logits_to_labels(logits.cpu()).long())
+    ties = (logits.float().topk(2, dim=0).values.diff(dim=0) == 0).float().mean().item()
+    print(f'[labels fast path] heads {heads} scale {scale}: {ties:.3f} of the voxels have equal top-2 logits')
 
 
 @pytest.mark.parametrize('accum', ['fp16', 'fp16_autocast'])
