@@ -125,6 +125,9 @@ __global__ __launch_bounds__(256, CH == 1 ? (NBLK <= 8 ? 3 : 2) : (NBLK <= 8 ? 2
     f16x8 sc_h[NPL], sh_h[NPL];
     f16 slope_h[NPL];
     float lsc[8], lsh[8];
+#ifndef FNN_NORM_FP32
+    f16x8 lsc_h = {0, 0, 0, 0, 0, 0, 0, 0}, lsh_h = lsc_h;              // the low tensor's rows rounded to fp16 once per batch item (round 5: fnn_norm8 converted them per low block)
+#endif
     int n_ss = -1;
     auto load_ss = [&](int n) {                                          // wave-uniform addresses: scalar loads
 #pragma unroll
@@ -148,6 +151,10 @@ __global__ __launch_bounds__(256, CH == 1 ? (NBLK <= 8 ? 3 : 2) : (NBLK <= 8 ? 2
                 lsc[j] = q == 0 ? qs[j] : q == 1 ? qs[8 + j] : q == 2 ? qs[16 + j] : qs[24 + j];
                 lsh[j] = q == 0 ? qh[j] : q == 1 ? qh[8 + j] : q == 2 ? qh[16 + j] : qh[24 + j];
             }
+#ifndef FNN_NORM_FP32
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { lsc_h[j] = (f16)lsc[j]; lsh_h[j] = (f16)lsh[j]; }
+#endif
         }
     };
     auto issue = [&](const RowCur &c) {
@@ -204,7 +211,11 @@ __global__ __launch_bounds__(256, CH == 1 ? (NBLK <= 8 ? 3 : 2) : (NBLK <= 8 ? 2
                     const int lr = bb / (NBLK / 2), bl = bb - lr * (NBLK / 2);
                     const int lrow = lbase + lr;
                     const bool ok = lrow >= 0 && lrow < Hl;
+#ifdef FNN_NORM_FP32
                     f16x8 o = fnn_norm8(xl[t], lsc, lsh);                // load_act_frag's arithmetic (misc.hip)
+#else
+                    f16x8 o = xl[t] * lsc_h + lsh_h;                     // fnn_norm8 = load_act_frag's arithmetic (misc.hip) on the pre-rounded rows
+#endif
                     o = __builtin_elementwise_max(o, o * lslope);
                     char *dst = smem + (slot * 4 + 2 * lr) * PB + bl * 1024;
 #pragma unroll

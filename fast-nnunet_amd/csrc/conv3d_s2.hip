@@ -68,18 +68,25 @@ __global__ __launch_bounds__(512, 1) void conv3d_s2_kernel(const ConvParams p, c
     // ---- one-time set-up
     if (tid < 128) sAcc[tid] = 0.0;
     const int cg = tid & 1;
-    // halo coordinates of this thread's elements, two 14-bit triples (zd : 4, zh : 5, zw : 5) per register; the last
-    // element exists only for idx < 2 IVOX
-    unsigned relp[(S2_PF + 1) / 2];
+    // this thread's halo elements: element u = (zd, zh, zw, half) of index tid + 512 u (the last one exists only for
+    // idx < 2 IVOX).  Kept per element: its place in the LDS image in 16-byte units, two per register (round 5: commit() used
+    // to rebuild it per item from a packed coordinate triple - 15 of the ~35 vector instructions an element cost there; the
+    // coordinates themselves are only needed once per unit, in set_offsets(), and are re-derived there from the index)
+    unsigned ldp[(S2_PF + 1) / 2];
+    const auto elem_coords = [&](int u, int &zd, int &zh, int &zw) {
+        const int idx = tid + u * 512, v = (idx < S2_IVOX * 2 ? idx : S2_IVOX * 2 - 1) >> 1;
+        zd = v / (SH * SH);
+        const int rem = v - zd * (SH * SH);
+        zh = rem / SH; zw = rem - zh * SH;
+    };
 #pragma unroll
     for (int u = 0; u < S2_PF; ++u) {
-        const int idx = tid + u * 512, v = (idx < S2_IVOX * 2 ? idx : S2_IVOX * 2 - 1) >> 1;
-        const int zd = v / (SH * SH), rem = v - zd * (SH * SH), zh = rem / SH, zw = rem - zh * SH;
-        const unsigned t = (unsigned)((zd << 10) | (zh << 5) | zw);
-        if (u & 1) relp[u >> 1] |= t << 16; else relp[u >> 1] = t;
+        int zd, zh, zw;
+        elem_coords(u, zd, zh, zw);
+        const unsigned l = (unsigned)((__mul24(__mul24(zd, S2_IH) + zh, S2_PW) + s2_pos(zw)) * 2 + (cg ^ ((zh >> 1) & 1)));
+        if (u & 1) ldp[u >> 1] |= l << 16; else ldp[u >> 1] = l;
     }
     const bool has_last = tid + (S2_PF - 1) * 512 < S2_IVOX * 2;
-#define S2_REL(u) ((relp[(u) >> 1] >> (((u) & 1) * 16)) & 0x3fffu)
     // operand reads: k-step ks = taps (2 ks, 2 ks + 1), d-major; lane (voxel r of the block's two rows, tap hl, half kh);
     // block mb = rows 2 mb, 2 mb + 1 of depth slice bg: + mb * 4 input rows
     int lanec[S2_KS];
@@ -114,10 +121,16 @@ __global__ __launch_bounds__(512, 1) void conv3d_s2_kernel(const ConvParams p, c
         const int id0 = 2 * od0 - 1, ih0 = 2 * oh0 - 1, iw0 = 2 * ow0 - 1;
 #pragma unroll
         for (int u = 0; u < S2_PF; ++u) {
-            unsigned t = S2_REL(u);
-            asm volatile("" : "+v"(t));                                  // keep the unpacked coordinates out of loop-invariant registers (they spill)
-            const unsigned gd = (unsigned)(id0 + (int)(t >> 10)), gh = (unsigned)(ih0 + (int)((t >> 5) & 31)),
-                           gw = (unsigned)(iw0 + (int)(t & 31));
+            int zd, zh, zw;
+            int tv = tid;
+            asm volatile("" : "+v"(tv));                                 // keep the coordinates out of loop-invariant registers (they spill)
+            {
+                const int idx = tv + u * 512, v = (idx < S2_IVOX * 2 ? idx : S2_IVOX * 2 - 1) >> 1;
+                zd = v / (SH * SH);
+                const int rem = v - zd * (SH * SH);
+                zh = rem / SH; zw = rem - zh * SH;
+            }
+            const unsigned gd = (unsigned)(id0 + zd), gh = (unsigned)(ih0 + zh), gw = (unsigned)(iw0 + zw);
             const bool ok = gd < (unsigned)p.Di && gh < (unsigned)p.Hi && gw < (unsigned)p.Wi;
             offv[u] = ok ? (int)(__umul24(__umul24(gd, (unsigned)p.Hi) + gh, (unsigned)p.Wi) + gw) : -1;
         }
@@ -182,10 +195,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_s2_kernel(const ConvParams p, c
 #endif
             o = __builtin_elementwise_max(o, o * slope_h);
             if (offv[u] < 0) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};       // the conv's zero padding
-            unsigned t = S2_REL(u);                                      // (an ldso[] array would cost 11 registers)
-            asm volatile("" : "+v"(t));
-            const int zd = (int)(t >> 10), zh = (int)((t >> 5) & 31), zw = (int)(t & 31);
-            const int ldso = (__mul24(__mul24(zd, S2_IH) + zh, S2_PW) + s2_pos(zw)) * 32 + ((cg ^ ((zh >> 1) & 1)) * 16);
+            const unsigned ldso = ((u & 1) ? ldp[u >> 1] >> 16 : ldp[u >> 1] & 0xffffu) << 4;
             if (u + 1 < S2_PF || has_last) *(f16x8 *)(sA + ldso) = o;
         }
 #pragma unroll
@@ -327,7 +337,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_s2_kernel(const ConvParams p, c
         n_cur = n_nx; od0 = d_nx; oh0 = h_nx; ow0 = w_nx; grp = g_nx;
     }
     FNN_STAMP_FLUSH(p.dbg);
-#undef S2_REL
 }
 
 }  // namespace

@@ -218,19 +218,28 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
         const size_t ev = (size_t)f * p.n_slots + e.slot;
         const int rowbase = (fx * p.PH + fy) * p.PW;
         const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)(p.feat + ev * P * p.C), 0, slot_bytes, 0x00020000);
+        // A 16-voxel group of the run that the patch does not reach is not fetched (round 5): its lanes' offset becomes one the
+        // buffer's range check refuses - zeros, no memory traffic.  A patch spans 96 z voxels and meets two or three 64-voxel
+        // runs, every visit used to fetch all four groups: FETCH_SIZE (x2: tools/fetch_calib.cpp finds the counter at half
+        // the bytes for 4 / 8 / 16-byte loads alike) had the kernel read 46.6 GB for 28.3 GB of kept activations, 1.64x.
+        const int zlo = zp0 - e.oz;                            // z of the run's first voxel inside the patch (wave-uniform)
         if (TTA && (fm & 4)) {
             const unsigned b = fln + (unsigned)(rowbase + p.PW - 1 + e.oz) * c2;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                if constexpr (K16) v.x[g] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b64(rf, b - (unsigned)g * 16u * c2, 0, 0));
-                else v.x[g] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b128(rf, b - (unsigned)g * 16u * c2, 0, 0));
+                const bool reach = zlo + 16 * g + 15 >= 0 && zlo + 16 * g < p.PW;
+                const unsigned vo = reach ? b - (unsigned)g * 16u * c2 : 0x80000000u;
+                if constexpr (K16) v.x[g] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b64(rf, vo, 0, 0));
+                else v.x[g] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b128(rf, vo, 0, 0));
             }
         } else {
             const unsigned b = fl + (unsigned)(rowbase - e.oz) * c2;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                if constexpr (K16) v.x[g] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b64(rf, b + (unsigned)g * 16u * c2, 0, 0));
-                else v.x[g] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b128(rf, b + (unsigned)g * 16u * c2, 0, 0));
+                const bool reach = zlo + 16 * g + 15 >= 0 && zlo + 16 * g < p.PW;
+                const unsigned vo = reach ? b + (unsigned)g * 16u * c2 : 0x80000000u;
+                if constexpr (K16) v.x[g] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b64(rf, vo, 0, 0));
+                else v.x[g] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b128(rf, vo, 0, 0));
             }
         }
 #ifdef FNN_NORM_FP32

@@ -10,5 +10,6 @@ cd $root
 f=$(find gpurun_out/lay_$tag -name "*kernel_trace.csv" | head -1)
 python tools/trace_summary.py $f > gpurun_out/lay_${tag}_summary.txt 2>&1
 python tools/trace_layers.py $f > gpurun_out/lay_${tag}_layers.txt 2>&1
+python tools/trace_gaps.py $f >> gpurun_out/lay_${tag}_layers.txt 2>&1
 rm -rf gpurun_out/lay_$tag
 cat gpurun_out/lay_${tag}_layers.txt

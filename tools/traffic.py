@@ -34,7 +34,24 @@ def load(path, counter):
     return agg
 
 
+def load_by_kernel(path, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] != counter:
+            continue
+        a = agg[(r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '')[:44], r.get('Grid_Size', ''))]
+        a[0] += 1
+        a[1] += float(r['Counter_Value'])
+    return agg
+
+
 fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
+# per kernel (name, grid): mean HBM bytes of one launch - next to a kernel's duration this is its real memory rate
+fk, wk = load_by_kernel(sys.argv[1], 'FETCH_SIZE'), load_by_kernel(sys.argv[2], 'WRITE_SIZE')
+print('# per kernel and grid: launches, mean read GB (FETCH_SIZE x 2), mean written GB per launch', file=sys.stderr)
+for k in sorted(set(fk) | set(wk), key=lambda k: -(2 * fk[k][1] + wk[k][1])):
+    n = max(fk[k][0], wk[k][0], 1)
+    print(f'# {k[0]:44s} grid {k[1]:>10s}  n={n:4d}  read {2 * fk[k][1] * 1024 / n / 1e9:8.3f} GB  written {wk[k][1] * 1024 / n / 1e9:8.3f} GB', file=sys.stderr)
 out = {}
 for fam in sorted(set(fetch) | set(write)):
     n = max(fetch[fam][0], write[fam][0])
