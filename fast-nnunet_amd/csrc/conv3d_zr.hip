@@ -41,7 +41,8 @@ int conv3d_pack_cout(int packing, int nblk, int cb, int m) {
 
 // (cout blocks per workgroup, tile depth) the ZR kernel would run with, or false when the layer keeps the
 // linear-tap kernels: not 3x3x3 / stride 1, or too few workgroups to fill the chip.
-static bool zr_pick(const ConvParams &p, int &nb, int &td) {
+static bool zr_pick(const ConvParams &p, int &nb, int &td, int *th_out = nullptr) {
+    if (th_out) *th_out = 8;
     static const bool off = fnn_knob("FNN_CONV_NO_ZR") != nullptr;                  // A-B aid
     static const int max_cout = fnn_knob("FNN_ZR_MAX_COUT") ? atoi(fnn_knob("FNN_ZR_MAX_COUT")) : 1 << 30;
     static const int min_cout = fnn_knob("FNN_ZR_MIN_COUT") ? atoi(fnn_knob("FNN_ZR_MIN_COUT")) : 0;
@@ -56,6 +57,15 @@ static bool zr_pick(const ConvParams &p, int &nb, int &td) {
     nb = nblk % 2 == 0 ? 2 : 1;
     const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;
     const long long th = (p.Ho + 7) / 8, tw = (p.Wo + 7) / 8;
+    // planes of at most 6 x 8 voxels in a layer whose depth is a multiple of 10 (the 160-channel stages of the benchmark net:
+    // 20 x 6 x 6): tiles of 10 x 6 x 8 on three waves (conv3d_zr_kernel<2, 10, 6>) - 75 % of the tile's columns and all of its
+    // depth are output voxels (8 x 8 x 8 tiles: 47 %)
+    if (nb == 2 && !p.fp8 && p.Ho <= 6 && p.Wo <= 8 && p.Do >= 10 && p.Do % 10 == 0 && fnn_knob("FNN_NO_ZR6") == nullptr &&
+        (long long)plan_n * (p.Do / 10) * (nblk / 2) >= 160) {
+        td = 10;
+        if (th_out) *th_out = 6;
+        return true;
+    }
     static const int td_max = fnn_knob("FNN_ZR_TD") ? atoi(fnn_knob("FNN_ZR_TD")) : 8;       // A-B aid
     static const int min_wgs = fnn_knob("FNN_ZR_MIN_WGS") ? atoi(fnn_knob("FNN_ZR_MIN_WGS")) : 480;   // one round of 512 slots at TD = 8 beats two of 768 at TD = 4 (stage 4: 70 -> 64 us)
     for (td = td_max; td >= 4; td -= 4) {
@@ -136,19 +146,23 @@ static __device__ __forceinline__ void zr_epilogue_pair(const ConvParams &p, con
 // immediate (LDS offsets).  The weights' two cout blocks get a buffer descriptor each whose num_records ends the block's
 // 15 k-steps: fragment element tid + 256 u needs no per-lane address either.  The bias is the accumulators' initial value.
 typedef unsigned fnn_u32x4v __attribute__((ext_vector_type(4)));
-template <int NB, int TD>
-__global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
+// TH = 8: the tile's rows, four waves.  TH = 6 (round 5, NB = 2): planes of at most 6 rows - three waves, a halo of 8 rows, the
+// depth the register file allows (TD = 10: 20-deep layers in two tiles) - for the 160-channel stages of a 96 x 96 in-plane patch
+// (20 x 6 x 6), where 8 x 8 x 8 tiles are filled to 47 % and their fourth wave multiplies rows that do not exist.
+template <int NB, int TD, int TH = 8>
+__global__ __launch_bounds__(TH * 32, 2) void conv3d_zr_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     FNN_STAMP_DECL
     FNN_STAMP();                                              // 0: entry
-    constexpr int IH = 10, IW = 10, PW = 12, ID = TD + 2;    // halo tile, row pitch 12 = 4 (mod 8) voxels
+    constexpr int NT = TH * 32;                               // threads: one wave per pair of tile rows
+    constexpr int IH = TH + 2, IW = 10, PW = 12, ID = TD + 2;   // halo tile, row pitch 12 = 4 (mod 8) voxels
     constexpr int PS = IH * PW * 32;                          // bytes per halo plane
     constexpr int ABYTES = ID * PS;                           // no rounding: at TD = 4 the workgroup is 42 LDS granules (3 per CU)
     constexpr int KS = 15;
     constexpr int WB = KS * 64;                               // 16-byte weight elements per cout block and chunk
-    constexpr int WPB = (WB + 255) / 256;                     // loads per thread and cout block (the last one: waves 0 .. 2 only)
-    static_assert(WB - (WPB - 1) * 256 == 192, "the last weight element group covers exactly waves 0 .. 2");
+    constexpr int WPB = (WB + NT - 1) / NT;                   // loads per thread and cout block (256 threads: the last one by waves 0 .. 2 only)
+    static_assert(WB - (WPB - 1) * NT == 192, "the last weight element group covers exactly waves 0 .. 2");
 
     // XCD-aware, bijective remap (blocks b and b + 8 share an XCD)
     int t;
@@ -250,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
         for (int e = 0; e < NB * WPB; ++e) {                  // element tid + 256 u of block nb; beyond the block: range check, zeros, no traffic
             if (e * SL / (NB * WPB) != part) continue;
             const int nb = e / WPB, u = e % WPB;
-            wr[nb][u] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw[nb], tid * 16, u * 4096, 0));
+            wr[nb][u] = __builtin_bit_cast(fnn_u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw[nb], tid * 16, u * (NT * 16), 0));
         }
     };
     auto commit = [&]() {
@@ -299,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int u = 0; u < WPB; ++u)
-                if (u + 1 < WPB || wave < 3) *(fnn_u32x4v *)(smem + wlds + (nb * WB + u * 256) * 16) = wr[nb][u];
+                if (u + 1 < WPB || wave < 3) *(fnn_u32x4v *)(smem + wlds + (nb * WB + u * NT) * 16) = wr[nb][u];
     };
     int toff[5];                                              // filled in after the first loads have left
     auto kloop = [&](bool prefetch) {
@@ -386,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_zr_kernel(const ConvParams p) {
             for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
         if constexpr (NB == 2) zr_epilogue_pair<TD, false>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
         else tile_epilogue<NB, TD, true, false>(p, acc, bv, n, od0, oh0, ow0, cb0, wave, lane, t1, t2);
-        if (p.stats_out) stats_to_global<NB, true, NB == 2>(p, t1, t2, (float *)smem, n, cb0, wave, lane, tid, (td * p.tiles_h + th) * p.tiles_w + tw);
+        if (p.stats_out) stats_to_global<NB, true, NB == 2, TH / 2>(p, t1, t2, (float *)smem, n, cb0, wave, lane, tid, (td * p.tiles_h + th) * p.tiles_w + tw);
     }
     FNN_STAMP();                                              // epilogue done
     FNN_STAMP_FLUSH(p.dbg);
@@ -1836,17 +1850,17 @@ static int launch_zr8(ConvParams p, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-template <int NB, int TD>
+template <int NB, int TD, int TH = 8>
 static int launch_zr(ConvParams p, hipStream_t st) {
     p.tile_d = TD;
     p.tiles_d = (p.Do + TD - 1) / TD;
     p.tiles_h = (p.Ho + 7) / 8;
     p.tiles_w = (p.Wo + 7) / 8;
-    size_t lds = (size_t)((TD + 2) * 10 * 12 * 32) + (size_t)NB * 15 * 1024;
+    size_t lds = (size_t)((TD + 2) * (TH + 2) * 12 * 32) + (size_t)NB * 15 * 1024;
     if (const char *pad = fnn_knob("FNN_ZR_LDS_PAD")) lds += (size_t)atoi(pad);      // A-B aid: fewer ZR workgroups per CU (room for another stream's kernels)
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)conv3d_zr_kernel<NB, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv3d_zr_kernel<NB, TD, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     p.ident_ss = conv3d_identity_ss();
@@ -1856,8 +1870,8 @@ static int launch_zr(ConvParams p, hipStream_t st) {
 #ifdef FNN_TMODE
     p.tmode = getenv("FNN_ZR_TMODE") ? atoi(getenv("FNN_ZR_TMODE")) : 0;     // timing-only proxies (wrong results): tools/zr_tmode.py
 #endif
-    fnn_note_kernel("conv3d_zr_kernel<%d,%d>", NB, TD);
-    hipLaunchKernelGGL((conv3d_zr_kernel<NB, TD>), grid, dim3(256), lds, st, p);
+    if (TH == 8) fnn_note_kernel("conv3d_zr_kernel<%d,%d>", NB, TD); else fnn_note_kernel("conv3d_zr_kernel<%d,%d,%d>", NB, TD, TH);
+    hipLaunchKernelGGL((conv3d_zr_kernel<NB, TD, TH>), grid, dim3(TH * 32), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -1938,9 +1952,10 @@ static int launch_zrw(ConvParams p, hipStream_t st) {
 //   48 %, matrix pipe busy 50 -> 55 %; clock under 30 back-to-back launches 1.80 GHz, inside the network 2.13 GHz.
 // Runs the layer on the ZR kernel; the weights must have been packed as FNN_PACK_ZR (p.packing).
 int launch_conv3d_zr(const ConvParams &p, hipStream_t st) {
-    int nb, td;
+    int nb, td, th;
     if (p.packing == FNN_PACK_ZR && p.ksteps == 15 && zs_pick(p)) return launch_zs(p, st);
-    if (p.packing != FNN_PACK_ZR || p.ksteps != 15 || !zr_pick(p, nb, td)) return -1;
+    if (p.packing != FNN_PACK_ZR || p.ksteps != 15 || !zr_pick(p, nb, td, &th)) return -1;
+    if (th == 6) return launch_zr<2, 10, 6>(p, st);
     if (p.fp8) {
         if (nb == 2) return td == 8 ? launch_zr8<2, 8>(p, st) : launch_zr8<2, 4>(p, st);
         return td == 8 ? launch_zr8<1, 8>(p, st) : launch_zr8<1, 4>(p, st);

@@ -113,7 +113,7 @@ static __device__ __forceinline__ void tile_epilogue(const ConvParams &p, const 
 // atomics of one-tile-per-workgroup kernels cost 5 % of the whole benchmark - 1.5 M of them per launch).
 // PERM: the ZR kernels' channel order at NB = 2 (conv3d_pack_cout): lane quarter q holds channels q * 8 + nb * 4 + j.
 // `at(i)`: where float i of the 4 * NB * 32 reduction floats lives in LDS (a plain array, or slots that a kernel has free)
-template <int NB, bool SLOT = false, bool PERM = false, typename At>
+template <int NB, bool SLOT = false, bool PERM = false, int NW = 4, typename At>
 static __device__ __forceinline__ void stats_to_global_at(const ConvParams &p, float (&t1)[NB][4], float (&t2)[NB][4], At at,
                                                           int n, int cb0, int wave, int lane, int tid, int slot = 0) {
     const int q = lane >> 4, r = lane & 15;
@@ -133,15 +133,15 @@ static __device__ __forceinline__ void stats_to_global_at(const ConvParams &p, f
         const int c = tid >> 1, which = tid & 1;
         double v = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) v += (double)*at((w * NB * 16 + c) * 2 + which);
+        for (int w = 0; w < NW; ++w) v += (double)*at((w * NB * 16 + c) * 2 + which);   // NW = the workgroup's waves
         if (SLOT) p.stats_out[(((size_t)n * p.stats_slots + slot) * p.Cout + cb0 * 16 + c) * 2 + which] = v;
         else unsafeAtomicAdd(p.stats_out + (((size_t)n * FNN_STAT_REPL + (blockIdx.x & (FNN_STAT_REPL - 1))) * p.Cout + cb0 * 16 + c) * 2 + which, v);
     }
 }
 
-template <int NB, bool SLOT = false, bool PERM = false>
+template <int NB, bool SLOT = false, bool PERM = false, int NW = 4>
 static __device__ __forceinline__ void stats_to_global(const ConvParams &p, float (&t1)[NB][4], float (&t2)[NB][4], float *sRed,
                                                        int n, int cb0, int wave, int lane, int tid, int slot = 0) {
-    stats_to_global_at<NB, SLOT, PERM>(p, t1, t2, [sRed](int i) { return sRed + i; }, n, cb0, wave, lane, tid, slot);
+    stats_to_global_at<NB, SLOT, PERM, NW>(p, t1, t2, [sRed](int i) { return sRed + i; }, n, cb0, wave, lane, tid, slot);
 }
 

@@ -319,7 +319,8 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
             // a patch that starts or ends inside the run leaves whole 16-voxel groups untouched: skip them
             // (wave-uniform; 3.5 patches intersect a 64-voxel run along z, 2 cover each voxel)
             const bool in = (unsigned)(dz0 + 16 * g) < (unsigned)p.PW;
-            if (__builtin_amdgcn_ballot_w64(in) == 0) continue;
+            const unsigned long long inm = __builtin_amdgcn_ballot_w64(in);
+            if (inm == 0) continue;
             const FV o = normed(v, g);
             const f16 gh = weight_of(v, g);
             const float gw = (float)gh;
@@ -338,6 +339,32 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
                     a2[0] = in ? n01 : a2[0];
                     a2[1] = in ? n23 : a2[1];
                 } else if (PKS) {
+#if !defined(FNN_GATHER_NOMIX) && !defined(FNN_GATHER_SELECT)
+                    // Round 5: the four sums of a head block are updated under an EXEC mask of the lanes inside the patch instead
+                    // of through one select per pair (`if (in) a = v` comes back from hipcc as v_cndmask): the up-convert + add
+                    // (v_fma_mix_f32, as add_half_lo / _hi) and the rounding to fp16 pairs of all four values in ONE asm
+                    // statement, so that nothing else is scheduled between the two writes of EXEC.  The products are formed
+                    // outside (all lanes): hipcc places the wait states between the MFMA and its first reader there.
+                    {
+                        unsigned a01 = __builtin_bit_cast(unsigned, ah[PKS ? g : 0][hb][0]), a23 = __builtin_bit_cast(unsigned, ah[PKS ? g : 0][hb][1]);
+                        float t0 = mul_rn(d[0], gw), t1 = mul_rn(d[1], gw), t2 = mul_rn(d[2], gw), t3 = mul_rn(d[3], gw);
+                        unsigned long long sv;
+                        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                                     "s_and_b64 exec, exec, %[m]\n\t"
+                                     "v_fma_mix_f32 %[t0], %[a01], 1.0, %[t0] op_sel_hi:[1,0,0]\n\t"
+                                     "v_fma_mix_f32 %[t1], %[a01], 1.0, %[t1] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                                     "v_fma_mix_f32 %[t2], %[a23], 1.0, %[t2] op_sel_hi:[1,0,0]\n\t"
+                                     "v_fma_mix_f32 %[t3], %[a23], 1.0, %[t3] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                                     "s_nop 0\n\t"
+                                     "v_cvt_pk_f16_f32 %[a01], %[t0], %[t1]\n\t"
+                                     "v_cvt_pk_f16_f32 %[a23], %[t2], %[t3]\n\t"
+                                     "s_mov_b64 exec, %[sv]"
+                                     : [a01] "+v"(a01), [a23] "+v"(a23), [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3), [sv] "=&s"(sv)
+                                     : [m] "s"(inm));
+                        ah[PKS ? g : 0][hb][0] = __builtin_bit_cast(f16x2, a01);
+                        ah[PKS ? g : 0][hb][1] = __builtin_bit_cast(f16x2, a23);
+                    }
+#else
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         f16x2 &a2 = ah[PKS ? g : 0][hb][k];
@@ -349,6 +376,7 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
 #endif
                         a2 = in ? nv : a2;
                     }
+#endif
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {

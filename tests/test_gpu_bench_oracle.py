@@ -211,7 +211,7 @@ def test_resenc_f8_step_stays_within_its_budget_at_full_patch_size():
 # the generic fallback.
 BENCH_KERNELS = {
     'stem_row_kernel<6,0>', 'conv_row_stem_kernel<6>', 'conv3d_zsw_kernel', 'conv3d_zr_kernel<2,8>', 'conv3d_s2_kernel',
-    'conv3d_zq12_kernel', 'conv3d_s2_kernel<13,3>', 'conv3d_lds_kernel<2,2,8>', 'conv3d_zr_kernel<2,4>',
+    'conv3d_zq12_kernel', 'conv3d_s2_kernel<13,3>', 'conv3d_lds_kernel<2,2,8>', 'conv3d_zr_kernel<2,10,6>',
     'tconv_mfma_kernel<2,2>', 'tconv_mfma_kernel<2,4>', 'conv_row_kernel<6,2,1>', 'conv_row_kernel<6,1,0>',
 }
 

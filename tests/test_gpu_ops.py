@@ -263,6 +263,41 @@ def test_conv3d_zr_variants(n, cin, cout, dims):
     assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize('n,cin,cin2,cout,dims', [(32, 160, 0, 160, (20, 6, 6)), (32, 48, 32, 64, (30, 5, 7)), (96, 32, 0, 64, (10, 3, 3))])
+def test_conv3d_zr_six_row_tiles(n, cin, cin2, cout, dims, monkeypatch):
+    """conv3d_zr_kernel<2, 10, 6> (round 5): planes of at most 6 x 8 voxels in layers whose depth is a multiple of 10 - the
+    160-channel stages of the benchmark net (20 x 6 x 6, 10 x 3 x 3) - as tiles of 10 x 6 x 8 on three waves.  Full and ragged
+    planes, two sources, 1 - 5 cout groups; the OUTPUT BITS must be the 8 x 8 x 8 kernel's (FNN_NO_ZR6), the statistics the
+    same sums."""
+    from fast_nnunet_amd import capi
+    monkeypatch.delenv('FNN_NO_ZR6', raising=False)
+    g = torch.Generator().manual_seed(17 + cin + dims[1])
+    x = _h(torch.randn(n, cin, *dims, generator=g) * 2 + 0.5)
+    gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+    w = _h(torch.randn(cout, cin + cin2, 3, 3, 3, generator=g) / ((cin + cin2) * 27) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    kw = dict(gamma=gamma.numpy(), beta=beta.numpy(), slope=0.01, want_stats=True)
+    x2 = None
+    if cin2:
+        x2 = _h(torch.randn(n, cin2, *dims, generator=g))
+        kw.update(x2=x2.numpy())
+    y, stats = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), (1, 1, 1), **kw)
+    assert capi.op_last_kernels() == ['conv3d_zr_kernel<2,10,6>'], capi.op_last_kernels()
+    xn = _h(F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01))
+    ref = F.conv3d(xn if x2 is None else torch.cat((xn, x2), 1), w, b, 1, 1)
+    assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
+    y64 = y.astype(np.float64)
+    assert np.allclose(stats[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    assert np.allclose(stats[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    monkeypatch.setenv('FNN_NO_ZR6', '1')
+    y_old, stats_old = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), (1, 1, 1), **kw)
+    assert capi.op_last_kernels() != ['conv3d_zr_kernel<2,10,6>']
+    monkeypatch.delenv('FNN_NO_ZR6')
+    if any(k.startswith('conv3d_zr_kernel') for k in capi.op_last_kernels()):      # the same arithmetic per output value
+        assert np.array_equal(y.view(np.uint16), y_old.view(np.uint16))
+    assert np.allclose(stats, stats_old, rtol=2e-6, atol=1e-3)
+
+
 @pytest.mark.parametrize('n,cin,cout,dims', [(1, 16, 16, (45, 16, 16)),     # few windows: three d-segments per window, the last tile ragged
                                              (2, 8, 32, (37, 24, 9)),       # two cout blocks, padded input channels, ragged everywhere
                                              (3, 16, 16, (64, 40, 40))])    # one segment of eight tiles per window
