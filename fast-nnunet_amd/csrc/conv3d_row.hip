@@ -837,7 +837,9 @@ int launch_row_t(ThinParams tp, hipStream_t st) {
         attr_set = true;
     }
     int per_cu = (int)((160 * 1024) / lds);
-    const int cap = CH == 1 ? (NBLK <= 8 ? 3 : 2) : (NBLK <= 8 ? 2 : 1);
+    int cap = CH == 1 ? (NBLK <= 8 ? 3 : 2) : (NBLK <= 8 ? 2 : 1);
+    static const int wpc_knob = fnn_knob("FNN_ROW_WPC") ? atoi(fnn_knob("FNN_ROW_WPC")) : 0;      // A-B aid: fewer persistent workgroups per CU (room for another stream's kernels)
+    if (wpc_knob > 0 && wpc_knob < cap) cap = wpc_knob;
     if (per_cu > cap) per_cu = cap;
     int gx = 256 * per_cu;
     if (gx > total) gx = total;
@@ -872,7 +874,9 @@ int launch_row_stem_t(ThinParams tp, hipStream_t st) {
         attr_set = true;
     }
     int per_cu = (int)((160 * 1024) / lds);
-    const int cap = NBLK <= 8 ? 3 : 2;
+    int cap = NBLK <= 8 ? 3 : 2;
+    static const int wpc_knob = fnn_knob("FNN_ROW_WPC") ? atoi(fnn_knob("FNN_ROW_WPC")) : 0;      // A-B aid (launch_row_t)
+    if (wpc_knob > 0 && wpc_knob < cap) cap = wpc_knob;
     if (per_cu > cap) per_cu = cap;
     int gx = 256 * per_cu;
     if (gx > total) gx = total;

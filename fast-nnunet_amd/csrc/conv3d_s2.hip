@@ -368,7 +368,8 @@ int launch_conv3d_s2(ConvParams p, hipStream_t st) {
     const int groups = (p.Cout + 63) / 64;                              // the last group may hold two cout blocks instead of four
     const int total = p.N * p.tiles_d * p.tiles_h * p.tiles_w * groups;
     const size_t lds = (size_t)S2_ABYTES + S2_WBYTES + 128 * 8 + 8 * 32 * 2 * 4;
-    const int gx = total < 256 ? total : 256;
+    static const int wgs_knob = fnn_knob("FNN_S2_WGS") ? atoi(fnn_knob("FNN_S2_WGS")) : 256;        // A-B aid: fewer persistent workgroups (CUs left to another stream's kernels)
+    const int gx = total < wgs_knob ? total : wgs_knob;
     const bool small = p.Ho <= 6 && p.Wo <= 6;                         // one tile per plane, input planes of at most 13 x 13 (with the padding)
     static bool attr_set[2] = {false, false};
     if (!attr_set[small]) {

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
     constexpr int KN = GatherK<K16>::N;                        // channels per lane
     constexpr int G = 4, ZW = 16 * G, TP = ZW + 8;             // 16-voxel groups and z voxels per wave; row pitch of the LDS transpose
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;   // (a scalar: so are the wave's x, y, z0 and what a visit derives from them)
     f16 *sT = (f16 *)smem + wave * (HB * 16 * TP);             // per wave: [HB * 16 heads][ZW z (+8 pad)] fp16
 
     // wave -> (x, y, run of 64 z) of the UN-PADDED output
@@ -227,7 +227,11 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
             const unsigned b = fln + (unsigned)(rowbase + p.PW - 1 + e.oz) * c2;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
+#ifdef FNN_GATHER_NOREACH
+                const bool reach = true;
+#else
                 const bool reach = zlo + 16 * g + 15 >= 0 && zlo + 16 * g < p.PW;
+#endif
                 const unsigned vo = reach ? b - (unsigned)g * 16u * c2 : 0x80000000u;
                 if constexpr (K16) v.x[g] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b64(rf, vo, 0, 0));
                 else v.x[g] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b128(rf, vo, 0, 0));
@@ -236,7 +240,11 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
             const unsigned b = fl + (unsigned)(rowbase - e.oz) * c2;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
+#ifdef FNN_GATHER_NOREACH
+                const bool reach = true;
+#else
                 const bool reach = zlo + 16 * g + 15 >= 0 && zlo + 16 * g < p.PW;
+#endif
                 const unsigned vo = reach ? b + (unsigned)g * 16u * c2 : 0x80000000u;
                 if constexpr (K16) v.x[g] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b64(rf, vo, 0, 0));
                 else v.x[g] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b128(rf, vo, 0, 0));
@@ -289,7 +297,15 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
     // ballots, a patch's start a v_readlane: no memory access between visits apart from a sharded caller's slot table.
     constexpr int NEVER = 0x3fffffff;                          // a tile start no coordinate reaches
     // (an axis with more than 64 positions: the 64 from the first tile that reaches this coordinate - GatherParams::base_x)
-    const int bx = p.base_x ? p.base_x[xp] : 0, by = p.base_y ? p.base_y[yp] : 0, bz = p.base_z ? p.base_z[zp0] : 0;
+#ifdef FNN_GATHER_NOWIN
+    constexpr int bx = 0, by = 0, bz = 0;
+#else
+    // (scalars: x, y, z0 come from the wave's index, which hipcc does not know to be wave-uniform - as vector values the bases
+    // made every visit's tile indices, the ring rule's modulo and the slot vector arithmetic: +2 ms on the benchmark volume)
+    const int bx = __builtin_amdgcn_readfirstlane(p.base_x ? p.base_x[__builtin_amdgcn_readfirstlane(xp)] : 0);
+    const int by = __builtin_amdgcn_readfirstlane(p.base_y ? p.base_y[__builtin_amdgcn_readfirstlane(yp)] : 0);
+    const int bz = __builtin_amdgcn_readfirstlane(p.base_z ? p.base_z[__builtin_amdgcn_readfirstlane(zp0)] : 0);
+#endif
     const int tx = bx + lane < p.nx ? sx[bx + lane] : NEVER, ty = by + lane < p.ny ? sy[by + lane] : NEVER, tz = bz + lane < p.nz ? sz[bz + lane] : NEVER;
     const unsigned long long MX = __builtin_amdgcn_ballot_w64(tx <= xp && xp - tx < p.PD);
     const unsigned long long MY = __builtin_amdgcn_ballot_w64(ty <= yp && yp - ty < p.PH);
