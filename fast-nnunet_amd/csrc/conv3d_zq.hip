@@ -331,308 +331,3 @@ int launch_conv3d_zq12(ConvParams p, hipStream_t st) {
     hipLaunchKernelGGL(conv3d_zq12_kernel, grid, dim3(ZQ_NT), ZQ_LDS, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
-
-// ----------------------------------------------------------------------------
-// 8 x 8 x 8 tiles with FOUR cout blocks per staged halo (round 5)
-// ----------------------------------------------------------------------------
-// conv3d_zr_kernel<2, 8> stages a tile's halo once per 32 output channels: a 64- / 128- / 256-channel layer re-stages it 2 / 4
-// / 8 times (the teacher's conv traffic: 1.51x algorithmic).  Here the eight-wave shape of conv3d_zq12_kernel on the ZR
-// kernel's 8 x 8 x 8 tile: ONE halo image (38.4 KB) and the weight fragments of four cout blocks (61.4 KB) per chunk, wave =
-// (depth quarter: two output slices, four halo planes) x (pair of cout blocks); a wave owns all four column blocks (row
-// pairs) of its two slices: 16 accumulators, per (chunk, tap pair) 16 activation + 6 weight fragment reads for 48 MFMAs (0.46).
-// Same image layout, weights (FNN_PACK_ZR, interleaved cout order per pair), k order and bias-as-initial-value as
-// conv3d_zr_kernel<2, 8>: the same output bits; one statistics row per tile (64 channels).
-namespace {
-
-constexpr int Z8_ID = 10, Z8_IH = 10, Z8_IW = 10, Z8_PW = 12;
-constexpr int Z8_PS = Z8_IH * Z8_PW * 32;                       // 3840
-constexpr int Z8_ABYTES = Z8_ID * Z8_PS;                        // 38400
-constexpr int Z8_NB = 4;
-constexpr int Z8_WBYTES = Z8_NB * ZQ_KS * 1024;                 // 61440
-constexpr int Z8_LDS = Z8_ABYTES + Z8_WBYTES + 8 * 32 * 2 * 4;
-
-__global__ __launch_bounds__(512, 2) void conv3d_zq8_kernel(const ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dq = wave >> 1, ch = wave & 1;                   // depth quarter; pair of cout blocks (2 ch, 2 ch + 1)
-    int t;
-    {                                                          // XCD-aware, bijective remap (conv3d_zr_kernel)
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        t = __builtin_amdgcn_readfirstlane((xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx);
-    }
-    const int tw = __builtin_amdgcn_readfirstlane(t % p.tiles_w); t = __builtin_amdgcn_readfirstlane(t / p.tiles_w);
-    const int th = __builtin_amdgcn_readfirstlane(t % p.tiles_h); t = __builtin_amdgcn_readfirstlane(t / p.tiles_h);
-    const int td = __builtin_amdgcn_readfirstlane(t % p.tiles_d);
-    const int n = __builtin_amdgcn_readfirstlane(t / p.tiles_d);
-    const int cb0 = blockIdx.y * Z8_NB;
-    const int od0 = td * 8, oh0 = th * 8, ow0 = tw * 8;
-
-    char *sA = smem;
-    char *sW = smem + Z8_ABYTES;                               // [4][15][64 lanes][16 B]
-    float *sRed = (float *)(sW + Z8_WBYTES);                   // [8 waves][32][2]
-
-    // ---- this thread's halo column (200 of the 512 threads)
-    const int col = tid >> 1, cg = tid & 1;
-    const int zh = (col * 205) >> 11, zw = col - zh * Z8_IW;   // col / 10 for col < 128 (idle threads: any value)
-    const bool has_col = tid < 2 * Z8_IH * Z8_IW;
-    const int gh = oh0 - 1 + zh, gw = ow0 - 1 + zw;
-    const bool ok_hw = has_col & ((unsigned)gh < (unsigned)p.Hi) & ((unsigned)gw < (unsigned)p.Wi);
-    const int hw_lin = __mul24(gh, p.Wi) + gw;
-    const int ldso0 = (zh * Z8_PW + zw) * 32 + ((cg ^ (zh & 1)) * 16);
-    const int wlds = Z8_ABYTES + tid * 16;
-    unsigned pmask = (1u << Z8_ID) - 1;
-    if (od0 == 0) pmask &= ~1u;
-    {
-        const int over = od0 + 8 + 1 - p.Di;
-        if (over > 0) pmask &= (1u << (Z8_ID - over)) - 1;
-    }
-    pmask = __builtin_amdgcn_readfirstlane(pmask);
-
-    f32x4 acc[4][2][2];                                        // [column block][slice][cout block of the pair]
-    zq_u32x4 xr[Z8_ID], wr[Z8_NB][2];
-    zq_u32x4 ssv[2];
-    float slope_next = 1.f;
-    __amdgpu_buffer_rsrc_t rx, rw[Z8_NB];
-    unsigned voff = 0x80000000u, plane_bytes = 0;
-    auto prep = [&](int chk) {
-        const int c_glob = chk * 16;
-        const int s = (c_glob < p.src[0].C) ? 0 : 1;
-        const int c_uni = c_glob - (s ? p.src[0].C : 0);
-        const int sC = p.src[s].C;
-        const int vs = FNN_VS(p.src[s]);
-        const unsigned item_bytes = (unsigned)p.Di * p.Hi * p.Wi * sC * 2;
-        const f16 *sp = p.src[s].ptr + (size_t)n * (item_bytes >> 1) + (c_uni >> 4) * FNN_CS(p.src[s]);
-        rx = __builtin_amdgcn_make_buffer_rsrc((void *)sp, 0, item_bytes, 0x00020000);
-        slope_next = p.src[s].slope;
-        {
-            const unsigned short *q = p.src[s].ssh ? p.src[s].ssh + ((size_t)n * sC + c_uni) * 2 : p.ident_ssh + c_uni * 2;
-            const zq_u32x4 *qv = (const zq_u32x4 *)(q + cg * 16);
-            ssv[0] = qv[0]; ssv[1] = qv[1];
-        }
-        voff = ok_hw ? (unsigned)hw_lin * (unsigned)(vs * 2) + cg * 16 : 0x80000000u;
-        plane_bytes = (unsigned)p.Hi * p.Wi * vs * 2;
-#pragma unroll
-        for (int nb = 0; nb < Z8_NB; ++nb) {
-            const f16 *wp = p.wpk + ((size_t)((cb0 + nb) * p.chunks + chk) * ZQ_WB) * 8;
-            rw[nb] = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, ZQ_WB * 16, 0x00020000);
-        }
-    };
-    auto load_part = [&](int part) {                           // 10 + 8 loads per thread in five slices along the k-loop
-#pragma unroll
-        for (int u = 0; u < Z8_ID; ++u) {
-            if (u * 5 / Z8_ID != part) continue;
-            int gd = od0 - 1 + u;
-            gd = gd < 0 ? 0 : (gd >= p.Di ? p.Di - 1 : gd);
-            xr[u] = __builtin_bit_cast(zq_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, (unsigned)gd * plane_bytes, 0));
-        }
-#pragma unroll
-        for (int e = 0; e < Z8_NB * 2; ++e) {
-            if (e * 5 / (Z8_NB * 2) != part) continue;
-            const int nb = e >> 1, u = e & 1;
-            wr[nb][u] = __builtin_bit_cast(zq_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw[nb], tid * 16, u * 8192, 0));
-        }
-    };
-    auto commit = [&]() {
-        const f16 slope_h = (f16)slope_next;
-        const zq_u32x4 zero4 = {0u, 0u, 0u, 0u};
-        const f16x8 sc_h = __builtin_bit_cast(f16x8, ok_hw ? ssv[0] : zero4), sh_h = __builtin_bit_cast(f16x8, ok_hw ? ssv[1] : zero4);
-        if (has_col) {
-#pragma unroll
-            for (int u = 0; u < Z8_ID; ++u) {
-                const f16x8 x = __builtin_bit_cast(f16x8, xr[u]);
-#ifdef FNN_NORM_FP32
-                f16x8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (f16)fmaf((float)x[j], (float)sc_h[j], (float)sh_h[j]);
-#else
-                f16x8 o = x * sc_h + sh_h;
-#endif
-                o = __builtin_elementwise_max(o, o * slope_h);
-                *(f16x8 *)(sA + ldso0 + u * Z8_PS) = o;
-            }
-            if (pmask != (1u << Z8_ID) - 1) {
-                unsigned pm = pmask;
-                asm volatile("" : "+s"(pm));
-#pragma unroll
-                for (int u = 0; u < Z8_ID; ++u)
-                    if (!((pm >> u) & 1)) *(f16x8 *)(sA + ldso0 + u * Z8_PS) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            }
-        }
-#pragma unroll
-        for (int nb = 0; nb < Z8_NB; ++nb) {
-            *(zq_u32x4 *)(smem + wlds + nb * ZQ_WB * 16) = wr[nb][0];
-            if (tid < ZQ_WB - 512) *(zq_u32x4 *)(smem + wlds + (nb * ZQ_WB + 512) * 16) = wr[nb][1];
-        }
-    };
-
-    int toff[5];                                               // column block 0 of this wave's first plane; block b: + b * 2 rows (an immediate)
-    {
-        const int r = lane & 15, hl = lane >> 5, kh = (lane >> 4) & 1;
-#pragma unroll
-        for (int pr = 0; pr < 5; ++pr) {
-            const int tp = 2 * pr + hl < 9 ? 2 * pr + hl : 8;
-            const int row = (r >> 3) + tp / 3, cl = (r & 7) + tp % 3;
-            toff[pr] = (row * Z8_PW + cl) * 32 + ((kh ^ (row & 1)) * 16) + dq * 2 * Z8_PS;
-        }
-    }
-    constexpr int BSTEP = 2 * Z8_PW * 32;                      // two rows further (an even number: the swap parity is the lane's)
-    auto read_x = [&](f16x8 (&xf)[4], int pr, int b) {
-        const char *bp = sA + toff[pr] + b * BSTEP;
-#pragma unroll
-        for (int pl = 0; pl < 4; ++pl) xf[pl] = *(const f16x8 *)(bp + pl * Z8_PS);
-    };
-    auto kloop = [&](bool prefetch) {
-#pragma unroll
-        for (int pr = 0; pr < 5; ++pr) {
-            if (prefetch) load_part(pr);
-            f16x8 wf[3][2];
-#pragma unroll
-            for (int dz = 0; dz < 3; ++dz)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) wf[dz][nb] = *(const f16x8 *)(sW + (((2 * ch + nb) * ZQ_KS + pr * 3 + dz) * 64 + lane) * 16);
-            f16x8 xa[4], xb[4];
-            read_x(xa, pr, 0);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                f16x8 (&cur)[4] = (b & 1) ? xb : xa;
-                f16x8 (&nxt)[4] = (b & 1) ? xa : xb;
-                if (b + 1 < 4) read_x(nxt, pr, b + 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int dz = 0; dz < 3; ++dz)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int nb = 0; nb < 2; ++nb)
-                            acc[b][j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[dz][nb], cur[j + dz], acc[b][j][nb], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-
-    prep(0);
-#pragma unroll
-    for (int part = 0; part < 5; ++part) load_part(part);
-    __builtin_amdgcn_sched_barrier(0);
-    {   // the bias is where the accumulators start (the interleaved order of conv3d_pack_cout: lane quarter q holds channels
-        // q * 8 + nb * 4 .. + 3 of its block pair) - conv3d_zr_kernel<2, 8>'s arithmetic
-        f32x4 b0[2];
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) b0[nb] = *(const f32x4 *)(p.bias + (cb0 + 2 * ch) * 16 + (lane >> 4) * 8 + nb * 4);
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) acc[b][j][nb] = b0[nb];
-    }
-    commit();
-    __syncthreads();
-    for (int chk = 0; chk + 1 < p.chunks; ++chk) {
-        prep(chk + 1);
-        kloop(true);
-        __syncthreads();
-        commit();
-        __syncthreads();
-    }
-    kloop(false);
-
-    // ---- epilogue: 16-byte stores (the bias is in the accumulators), statistics
-    {
-        const int q = lane >> 4, r = lane & 15;
-        float t1[2][4], t2[2][4];
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
-        const unsigned item_bytes = (unsigned)p.Do * p.Ho * p.Wo * p.Cout * 2;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)n * (item_bytes >> 1), 0, item_bytes, 0x00020000);
-        const unsigned ovs2 = (unsigned)FNN_OVS(p) * 2;
-        const unsigned coff = (unsigned)(cb0 + 2 * ch + (q >> 1)) * (unsigned)(FNN_OCS(p) * 2) + (unsigned)(q & 1) * 16;
-        const f16x2 ones = {(f16)1.f, (f16)1.f};
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int oh = oh0 + 2 * b + (r >> 3), ow = ow0 + (r & 7);
-            const bool ok_o = oh < p.Ho && ow < p.Wo;
-            f16x8 o[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int od = od0 + 2 * dq + h;
-                const bool ok = ok_o && od < p.Do;
-                const unsigned vo = ok ? (unsigned)((od * p.Ho + oh) * p.Wo + ow) * ovs2 + coff : 0x80000000u;
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    o[h][nb * 4 + 0] = (f16)acc[b][h][nb][0];
-                    o[h][nb * 4 + 1] = (f16)acc[b][h][nb][1];
-                    o[h][nb * 4 + 2] = (f16)acc[b][h][nb][2];
-                    o[h][nb * 4 + 3] = (f16)acc[b][h][nb][3];
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(zq_i32x4, o[h]), rsrc, vo, 0, 0);
-                if (!ok) o[h] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f16x2 pr2 = {o[0][nb * 4 + j], o[1][nb * 4 + j]};
-                    t1[nb][j] = __builtin_amdgcn_fdot2(pr2, ones, t1[nb][j], false);
-                    t2[nb][j] = __builtin_amdgcn_fdot2(pr2, pr2, t2[nb][j], false);
-                }
-        }
-        if (p.stats_out) {
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float a = row16_sum(t1[nb][j]), b = row16_sum(t2[nb][j]);
-                    if (r == 0) {
-                        const int c = q * 8 + nb * 4 + j;
-                        sRed[(wave * 32 + c) * 2] = a;
-                        sRed[(wave * 32 + c) * 2 + 1] = b;
-                    }
-                }
-            __syncthreads();
-            if (tid < 128) {                                   // 64 channels x (sum, sum of squares): the four waves of a cout pair
-                const int c64 = tid >> 1, which = tid & 1, chp = c64 >> 5, c = c64 & 31;
-                double v = 0;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) v += (double)sRed[((2 * w + chp) * 32 + c) * 2 + which];
-                const int slot = (td * p.tiles_h + th) * p.tiles_w + tw;
-                p.stats_out[(((size_t)n * p.stats_slots + slot) * p.Cout + (cb0 + 2 * chp) * 16 + c) * 2 + which] = v;
-            }
-        }
-    }
-}
-
-}  // namespace
-
-// opt-in this round (FNN_ZQ8=1): measured per layer and in the step against conv3d_zr_kernel<2, 8>
-bool conv3d_zq8_ok(const ConvParams &p) {
-    const bool on = fnn_knob("FNN_ZQ8") != nullptr;                                  // read per call: the tests compare the two kernels' bits
-    if (!on || p.fp8 || p.packing != FNN_PACK_ZR || p.ksteps != ZQ_KS) return false;
-    if (p.kd != 3 || p.kh != 3 || p.kw != 3 || p.sd != 1 || p.sh != 1 || p.sw != 1) return false;
-    if (p.Cout % 64 != 0 || p.Do < 8 || p.chunks < 2) return false;
-    const long long tiles = (long long)((p.Do + 7) / 8) * ((p.Ho + 7) / 8) * ((p.Wo + 7) / 8);
-    if (p.stats_out && p.stats_slots < tiles) return false;
-    const int plan_n = p.plan_N > 0 ? p.plan_N : p.N;
-    return tiles * plan_n * (p.Cout / 64) >= 512;
-}
-
-int launch_conv3d_zq8(ConvParams p, hipStream_t st) {
-    if (!conv3d_zq8_ok(p)) return -1;
-    p.tile_d = 8;
-    p.tiles_d = (p.Do + 7) / 8; p.tiles_h = (p.Ho + 7) / 8; p.tiles_w = (p.Wo + 7) / 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)conv3d_zq8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    p.ident_ss = conv3d_identity_ss();
-    p.ident_ssh = conv3d_identity_ssh();
-    if (!p.ident_ss || !p.ident_ssh) return -2;
-    dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / Z8_NB);
-    fnn_note_kernel("conv3d_zq8_kernel");
-    hipLaunchKernelGGL(conv3d_zq8_kernel, grid, dim3(512), Z8_LDS, st, p);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
-}

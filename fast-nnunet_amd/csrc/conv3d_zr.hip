@@ -1972,7 +1972,6 @@ int launch_conv3d_zr(const ConvParams &p, hipStream_t st) {
         static const bool no_walk = fnn_knob("FNN_NO_ZRW") != nullptr;                        // A-B aid
         if (!no_walk && p.chunks == 1 && td == 8 && (p.Do + 7) / 8 >= 4) return nb == 2 ? launch_zrw<2>(p, st) : launch_zrw<1>(p, st);
     }
-    if (nb == 2 && td == 8 && conv3d_zq8_ok(p)) return launch_conv3d_zq8(p, st);      // round 5 experiment (FNN_ZQ8): four cout blocks per staged halo
     if (nb == 2) return td == 8 ? launch_zr<2, 8>(p, st) : launch_zr<2, 4>(p, st);
     return td == 8 ? launch_zr<1, 8>(p, st) : launch_zr<1, 4>(p, st);
 }

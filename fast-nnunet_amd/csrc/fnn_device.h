@@ -358,8 +358,6 @@ int conv3d_pack_cout(int packing, int nblk, int cb, int m);        // output cha
 int launch_conv3d_zr(const ConvParams &p, hipStream_t st);
 bool conv3d_zq12_ok(const ConvParams &p);                               // conv3d_zq.hip: 3x3x3 stride 1 over planes of 9 .. 12 voxels per axis
 int launch_conv3d_zq12(ConvParams p, hipStream_t st);                  // -1 = not this kernel's layer
-bool conv3d_zq8_ok(const ConvParams &p);                                // conv3d_zq.hip: 8 x 8 x 8 tiles, four cout blocks per staged halo (opt-in: FNN_ZQ8)
-int launch_conv3d_zq8(ConvParams p, hipStream_t st);
 bool conv3d_s2_ok(const ConvParams &p);                                  // conv3d_s2.hip: 3x3x3 stride (2,2,2), Cout % 64 == 0
 int launch_conv3d_s2(ConvParams p, hipStream_t st);                     // -1 = not this kernel's layer
 int conv3d_stats_slots(const ConvParams &p);                           // rows per item the layer's kernel writes into stats_out

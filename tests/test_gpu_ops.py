@@ -263,34 +263,6 @@ def test_conv3d_zr_variants(n, cin, cout, dims):
     assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize('n,cin,cin2,cout,dims', [(8, 64, 0, 64, (24, 40, 40)), (16, 40, 0, 64, (21, 19, 27)), (16, 32, 32, 128, (16, 24, 24))])
-def test_conv3d_four_cout_blocks_per_staged_halo(n, cin, cin2, cout, dims, monkeypatch):
-    """conv3d_zq8_kernel (round 5, opt-in FNN_ZQ8=1): the ZR kernel's 8 x 8 x 8 tile with the halo staged once per 64 output
-    channels - eight waves, (depth quarter) x (pair of cout blocks).  Same image, weights, k order and bias handling as
-    conv3d_zr_kernel<2, 8>: the output bits must be equal; full and ragged tiles, two sources, one and two groups of 64."""
-    from fast_nnunet_amd import capi
-    monkeypatch.delenv('FNN_ZQ8', raising=False)
-    g = torch.Generator().manual_seed(23 + cin + dims[1])
-    x = _h(torch.randn(n, cin, *dims, generator=g) * 2 + 0.5)
-    gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
-    w = _h(torch.randn(cout, cin + cin2, 3, 3, 3, generator=g) / ((cin + cin2) * 27) ** 0.5)
-    b = torch.randn(cout, generator=g)
-    kw = dict(gamma=gamma.numpy(), beta=beta.numpy(), slope=0.01, want_stats=True)
-    if cin2:
-        kw.update(x2=_h(torch.randn(n, cin2, *dims, generator=g)).numpy())
-    y, stats = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), (1, 1, 1), **kw)
-    assert capi.op_last_kernels() == ['conv3d_zr_kernel<2,8>'], capi.op_last_kernels()
-    monkeypatch.setenv('FNN_ZQ8', '1')
-    y4, stats4 = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (3, 3, 3), (1, 1, 1), **kw)
-    assert capi.op_last_kernels() == ['conv3d_zq8_kernel'], capi.op_last_kernels()
-    monkeypatch.delenv('FNN_ZQ8')
-    assert np.array_equal(y.view(np.uint16), y4.view(np.uint16))
-    assert np.allclose(stats4, stats, rtol=2e-6, atol=1e-3)
-    y64 = y4.astype(np.float64)
-    assert np.allclose(stats4[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
-    assert np.allclose(stats4[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
-
-
 @pytest.mark.parametrize('n,cin,cin2,cout,dims', [(32, 160, 0, 160, (20, 6, 6)), (32, 48, 32, 64, (30, 5, 7)), (96, 32, 0, 64, (10, 3, 3))])
 def test_conv3d_zr_six_row_tiles(n, cin, cin2, cout, dims, monkeypatch):
     """conv3d_zr_kernel<2, 10, 6> (round 5): planes of at most 6 x 8 voxels in layers whose depth is a multiple of 10 - the
