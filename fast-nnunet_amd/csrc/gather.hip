@@ -420,14 +420,15 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
                 for (int g = 0; g < G; ++g) in[g] = (unsigned)(dz0 + 16 * g) < (unsigned)p.PW;
                 f32x4 tsum[TTA ? G : 1][HB];                   // running fp32 sum of the logits
                 f16x2 tsh[TTA && ACH ? G : 1][HB][2];          // ... or the running fp16 sum (autocast arithmetic)
-                GatherVisit<G, K16> v;
-                for (int f = 0; f < p.n_eval; ++f) {
-                    issue(v, e, f, p.flipmask[f]);
-                    pin(v);
+                // the evaluations two at a time (their count is 2, 4 or 8): the loads of evaluation f + 1 leave before the arithmetic of
+                // evaluation f (round 5; two register sets; unconditional loads - behind the last one the last evaluation is re-read)
+                GatherVisit<G, K16> v, vb;
+                const auto eval_body = [&](GatherVisit<G, K16> &w, int f) {
+                    pin(w);
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         if (__builtin_amdgcn_ballot_w64(in[g]) == 0) continue;
-                        const FV o = normed(v, g);
+                        const FV o = normed(w, g);
 #pragma unroll
                         for (int hb = 0; hb < HB; ++hb) {
                             const f32x4 d = head_mfma(wf[hb], o, bv[hb]);
@@ -441,8 +442,22 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
                             }
                         }
                     }
+                };
+                issue(v, e, 0, p.flipmask[0]);
+                for (int f = 0; f < p.n_eval; f += 2) {
+                    issue(vb, e, f + 1, p.flipmask[f + 1]);
+                    eval_body(v, f);
+                    const int f2 = f + 2 < p.n_eval ? f + 2 : p.n_eval - 1;
+                    issue(v, e, f2 ? f2 : 1, p.flipmask[f2 ? f2 : 1]);    // (never evaluation 0 again: that would reload the Gaussian weights' register - harmless, but a load more)
+                    eval_body(vb, f + 1);
                 }
                 const float nf = (float)p.n_eval;
+                // 2^k evaluations (every subset of k mirror axes): x / 2^k = x * 2^-k to the bit (both are the correctly rounded
+                // value of the same real number, subnormals included) - one multiply instead of the ~10 instructions of an IEEE
+                // division per value, 40 % of this path's vector instructions (round 5)
+                // (gather_ok refuses any other count: the evaluations are the subsets of the mirror axes)
+                const float rnf = 1.0f / nf;
+                const auto div_n = [&](float x) -> float { return mul_rn(x, rnf); };
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     if (__builtin_amdgcn_ballot_w64(in[g]) == 0) continue;
@@ -455,7 +470,7 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
 #pragma unroll
                             for (int k = 0; k < 2; ++k) {
                                 const f16x2 ts = tsh[TTA && ACH ? g : 0][hb][k];
-                                const f16x2 t = round_h2(__fdiv_rn((float)ts[0], nf), __fdiv_rn((float)ts[1], nf));   // half /= int
+                                const f16x2 t = round_h2(div_n((float)ts[0]), div_n((float)ts[1]));   // half /= int
                                 f16x2 &a2 = ah[PKS ? g : 0][hb][k];
                                 const f16x2 nv = acc_add_product_h2(a2, t, gw2);
                                 a2 = in[g] ? nv : a2;
@@ -466,8 +481,8 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
                     for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {
-                            const float t0 = __fdiv_rn(tsum[TTA ? g : 0][hb][2 * k], nf);         // prediction /= (len(axes_combinations) + 1)
-                            const float t1 = __fdiv_rn(tsum[TTA ? g : 0][hb][2 * k + 1], nf);
+                            const float t0 = div_n(tsum[TTA ? g : 0][hb][2 * k]);         // prediction /= (len(axes_combinations) + 1)
+                            const float t1 = div_n(tsum[TTA ? g : 0][hb][2 * k + 1]);
                             if (PKS) {
                                 f16x2 &a2 = ah[PKS ? g : 0][hb][k];
                                 const f16x2 nv = round_h2(acc_add_product_1((float)a2[0], t0, gw), acc_add_product_1((float)a2[1], t1, gw));
@@ -778,6 +793,7 @@ int launch_quotient_check(unsigned long long *counts, hipStream_t st) {         
 bool gather_ok(const GatherParams &p) {
     const int hblocks = (p.heads + 1 + 15) / 16;
     return (hblocks <= 4 || p.n_pass > 1) && p.C <= 32 && p.C % 8 == 0 && (long long)p.PD * p.PH * p.PW < (1LL << 31) / 32 && p.n_eval <= 8 &&
+           (p.n_eval & (p.n_eval - 1)) == 0 &&                 // 1, 2, 4 or 8 evaluations (the mean over them is a multiply by 2^-k)
            ((p.nx <= 64 && p.ny <= 64 && p.nz <= 64) || p.windowed);   // a wave holds 64 of an axis' tile starts one per lane
 }
 
@@ -852,7 +868,13 @@ int launch_gather(const GatherParams &p0, hipStream_t st) {
 
 static int launch_gather_one(const GatherParams &p, hipStream_t st) {
     const int hblocks = (p.heads + 1 + 15) / 16;
-    if (p.n_eval > 1) {                                             // mirrored evaluations: the K = 32 form
+    if (p.n_eval > 1) {                                             // mirrored evaluations
+        // (round 5: 16 channels take the K = 16 head here too - half the lanes of the K = 32 form load and normalise zeros)
+        if (p.C == 16 && p.acc_mode != 1 && fnn_knob("FNN_GATHER_K32") == nullptr) {
+            if (hblocks == 1) return launch_gather_hb<1, true, true>(p, st);
+            if (hblocks == 2) return launch_gather_hb<2, true, true>(p, st);
+            return launch_gather_hb<4, true, true>(p, st);
+        }
         if (hblocks == 1) return launch_gather_hb<1, true, false>(p, st);
         if (hblocks == 2) return launch_gather_hb<2, true, false>(p, st);
         return launch_gather_hb<4, true, false>(p, st);

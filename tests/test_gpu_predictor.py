@@ -1078,16 +1078,18 @@ def test_gather_labels_without_the_quotients_on_near_ties(heads, scale, accum):
     print(f'[labels fast path] heads {heads} scale {scale}: {ties:.3f} of the voxels have equal top-2 logits')
 
 
+@pytest.mark.parametrize('mirror', [None, (0, 2)])
 @pytest.mark.parametrize('accum', ['fp16', 'fp16_autocast'])
 @pytest.mark.parametrize('heads', [3, 20, 61])
-def test_gather_k16_head_is_the_k32_head_bit_for_bit(heads, accum):
+def test_gather_k16_head_is_the_k32_head_bit_for_bit(heads, accum, mirror):
     """Round 4: a last layer of 16 channels runs the gather kernel's head as v_mfma_f32_16x16x16_f16 (a lane holds 4
     channels of its voxel) instead of a K = 32 operand whose upper half is zero.  tools/hw_probe.cpp found the two MFMA
     forms bit-identical on 16.8 M random values; here the whole driver: logits and labels with the K = 32 kernels forced
-    (FNN_GATHER_K32, which also keeps those 12 variants - what 32-channel networks run - under test on small volumes)."""
+    (FNN_GATHER_K32, which also keeps those variants - what 32-channel networks run - under test on small volumes).
+    Round 5: with test-time mirroring too (the mirrored evaluations used to take the K = 32 form whatever the channels)."""
     spec = UNetSpec('plain', 1, heads, [16, 32], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
     patch = (16, 16, 32)
-    p = _predictor(spec, patch, [synthetic_state_dict(spec, 540)], accumulate_in=accum)
+    p = _predictor(spec, patch, [synthetic_state_dict(spec, 540)], accumulate_in=accum, mirror=mirror)
     image = torch.randn(1, 37, 30, 70, generator=torch.Generator().manual_seed(43))
     os.environ.pop('FNN_GATHER_K32', None)
     logits, labels = p.predict_sliding_window_return_logits(image), p.predict_segmentation_from_preprocessed_data(image)
