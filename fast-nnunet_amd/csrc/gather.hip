@@ -148,7 +148,7 @@ struct GatherGeo { int slot, dx, dy, oz; };                     // wave-uniform:
 // autocast arithmetic 17.3 -> 13.5.  Dropped: a head's four 128-byte row pieces of a workgroup stored as one 512-byte
 // segment behind a workgroup barrier (14.73 vs 14.75 ms: the scattered stores are not what it waits for).
 template <int HB, int ACCM, bool LABELS, bool TTA, bool K16>
-__global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void gather_head_kernel(const GatherParams p) {
+__global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : (TTA && K16 ? 3 : 1)) void gather_head_kernel(const GatherParams p) {
     constexpr bool PF = !TTA && ACCM != 1;                     // the next visit's loads in flight during this visit's arithmetic
     typedef typename GatherK<K16>::XV XV;
     typedef typename GatherK<K16>::FV FV;
@@ -213,7 +213,9 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
     // one evaluation's loads: the four groups' feature vectors + its InstanceNorm rows (+ the patch's Gaussian weights:
     // lane l takes the weight of z voxel l of the run, a group's 16 come back through ds_bpermute).  Lanes outside the
     // patch along z read the neighbouring row of the slot (valid memory, masked later) or fall outside num_records (zeros).
-    const auto issue = [&](GatherVisit<G, K16> &v, const GatherGeo &e, int f, int fm) {
+    // (`g0`: the run's first group that goes into v.x[0] - the mirrored path takes the run two groups at a time)
+    const auto issue = [&](auto &v, const GatherGeo &e, int f, int fm, int g0 = 0) {
+        constexpr int GV = (int)(sizeof(v.x) / sizeof(v.x[0]));
         const int fx = (fm & 1) ? p.PD - 1 - e.dx : e.dx, fy = (fm & 2) ? p.PH - 1 - e.dy : e.dy;   // output voxel of an evaluation whose input was flipped
         const size_t ev = (size_t)f * p.n_slots + e.slot;
         const int rowbase = (fx * p.PH + fy) * p.PW;
@@ -226,28 +228,30 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
         if (TTA && (fm & 4)) {
             const unsigned b = fln + (unsigned)(rowbase + p.PW - 1 + e.oz) * c2;
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
+            for (int gv = 0; gv < GV; ++gv) {
+                const int g = g0 + gv;
 #ifdef FNN_GATHER_NOREACH
                 const bool reach = true;
 #else
                 const bool reach = zlo + 16 * g + 15 >= 0 && zlo + 16 * g < p.PW;
 #endif
                 const unsigned vo = reach ? b - (unsigned)g * 16u * c2 : 0x80000000u;
-                if constexpr (K16) v.x[g] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b64(rf, vo, 0, 0));
-                else v.x[g] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b128(rf, vo, 0, 0));
+                if constexpr (K16) v.x[gv] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b64(rf, vo, 0, 0));
+                else v.x[gv] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b128(rf, vo, 0, 0));
             }
         } else {
             const unsigned b = fl + (unsigned)(rowbase - e.oz) * c2;
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
+            for (int gv = 0; gv < GV; ++gv) {
+                const int g = g0 + gv;
 #ifdef FNN_GATHER_NOREACH
                 const bool reach = true;
 #else
                 const bool reach = zlo + 16 * g + 15 >= 0 && zlo + 16 * g < p.PW;
 #endif
                 const unsigned vo = reach ? b + (unsigned)g * 16u * c2 : 0x80000000u;
-                if constexpr (K16) v.x[g] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b64(rf, vo, 0, 0));
-                else v.x[g] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b128(rf, vo, 0, 0));
+                if constexpr (K16) v.x[gv] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b64(rf, vo, 0, 0));
+                else v.x[gv] = __builtin_bit_cast(XV, __builtin_amdgcn_raw_buffer_load_b128(rf, vo, 0, 0));
             }
         }
 #ifdef FNN_NORM_FP32
@@ -268,10 +272,11 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
     };
     // the loads stay in front of the arithmetic: hipcc sinks a pure load into the branch that uses it (a group's skip
     // test), where its round trip is exposed once per group
-    const auto pin = [&](GatherVisit<G, K16> &v) {
-        asm volatile("" : "+v"(v.x[0]), "+v"(v.x[1]), "+v"(v.x[2]), "+v"(v.x[3]), "+v"(v.gall));
+    const auto pin = [&](auto &v) {
+        if constexpr (sizeof(v.x) / sizeof(v.x[0]) == 2) asm volatile("" : "+v"(v.x[0]), "+v"(v.x[1]), "+v"(v.gall));
+        else asm volatile("" : "+v"(v.x[0]), "+v"(v.x[1]), "+v"(v.x[2]), "+v"(v.x[3]), "+v"(v.gall));
     };
-    const auto normed = [&](const GatherVisit<G, K16> &v, int g) -> FV {
+    const auto normed = [&](const auto &v, int g) -> FV {
         const FV xr = __builtin_bit_cast(FV, v.x[g]);
 #ifdef FNN_NORM_FP32
         FV o;
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
         }
         return o;
     };
-    const auto weight_of = [&](const GatherVisit<G, K16> &v, int g) -> f16 {     // group g's Gaussian weight of this lane's voxel
+    const auto weight_of = [&](const auto &v, int g) -> f16 {     // group g's Gaussian weight of this lane's voxel
         const int w = __builtin_amdgcn_ds_bpermute((16 * g + r) << 2, (int)v.gall);
         return __builtin_bit_cast(f16, (unsigned short)w);
     };
@@ -418,81 +423,87 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : 1) void 
                 bool in[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) in[g] = (unsigned)(dz0 + 16 * g) < (unsigned)p.PW;
-                f32x4 tsum[TTA ? G : 1][HB];                   // running fp32 sum of the logits
-                f16x2 tsh[TTA && ACH ? G : 1][HB][2];          // ... or the running fp16 sum (autocast arithmetic)
-                // the evaluations two at a time (their count is 2, 4 or 8): the loads of evaluation f + 1 leave before the arithmetic of
-                // evaluation f (round 5; two register sets; unconditional loads - behind the last one the last evaluation is re-read)
-                GatherVisit<G, K16> v, vb;
-                const auto eval_body = [&](GatherVisit<G, K16> &w, int f) {
-                    pin(w);
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        if (__builtin_amdgcn_ballot_w64(in[g]) == 0) continue;
-                        const FV o = normed(w, g);
-#pragma unroll
-                        for (int hb = 0; hb < HB; ++hb) {
-                            const f32x4 d = head_mfma(wf[hb], o, bv[hb]);
-                            if (ACH) {
-                                const f16x2 t01 = round_h2(d[0], d[1]), t23 = round_h2(d[2], d[3]);
-                                f16x2 (&ts)[2] = tsh[TTA && ACH ? g : 0][hb];
-                                ts[0] = f == 0 ? t01 : add_h2(ts[0], t01);
-                                ts[1] = f == 0 ? t23 : add_h2(ts[1], t23);
-                            } else {
-                                tsum[TTA ? g : 0][hb] = f == 0 ? d : tsum[TTA ? g : 0][hb] + d;
-                            }
-                        }
-                    }
-                };
-                issue(v, e, 0, p.flipmask[0]);
-                for (int f = 0; f < p.n_eval; f += 2) {
-                    issue(vb, e, f + 1, p.flipmask[f + 1]);
-                    eval_body(v, f);
-                    const int f2 = f + 2 < p.n_eval ? f + 2 : p.n_eval - 1;
-                    issue(v, e, f2 ? f2 : 1, p.flipmask[f2 ? f2 : 1]);    // (never evaluation 0 again: that would reload the Gaussian weights' register - harmless, but a load more)
-                    eval_body(vb, f + 1);
-                }
+                // The run two groups at a time (round 5): the evaluations' running sums of two groups are half the registers of all
+                // four (HB = 4: 183 -> 3 waves per SIMD), a half no group of which the patch reaches is skipped; within a half the
+                // evaluations two at a time (their count is 2, 4 or 8): the loads of evaluation f + 1 leave before the arithmetic
+                // of evaluation f (two register sets; unconditional loads - behind the last one the last evaluation is re-read).
                 const float nf = (float)p.n_eval;
                 // 2^k evaluations (every subset of k mirror axes): x / 2^k = x * 2^-k to the bit (both are the correctly rounded
                 // value of the same real number, subnormals included) - one multiply instead of the ~10 instructions of an IEEE
-                // division per value, 40 % of this path's vector instructions (round 5)
-                // (gather_ok refuses any other count: the evaluations are the subsets of the mirror axes)
+                // division per value (gather_ok refuses any other count)
                 const float rnf = 1.0f / nf;
                 const auto div_n = [&](float x) -> float { return mul_rn(x, rnf); };
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    if (__builtin_amdgcn_ballot_w64(in[g]) == 0) continue;
-                    const f16 gh = weight_of(v, g);
-                    const float gw = (float)gh;
-                    if (ACH) {
-                        const f16x2 gw2 = {gh, gh};
+                for (int gh = 0; gh < G; gh += 2) {
+                    if ((__builtin_amdgcn_ballot_w64(in[gh]) | __builtin_amdgcn_ballot_w64(in[gh + 1])) == 0) continue;
+                    f32x4 tsum[2][HB];                         // running fp32 sum of the logits
+                    f16x2 tsh[ACH ? 2 : 1][HB][2];             // ... or the running fp16 sum (autocast arithmetic)
+                    GatherVisit<2, K16> v, vb;
+                    const auto eval_body = [&](GatherVisit<2, K16> &w, int f) {
+                        pin(w);
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2) {
+                            if (__builtin_amdgcn_ballot_w64(in[gh + g2]) == 0) continue;
+                            const FV o = normed(w, g2);
+#pragma unroll
+                            for (int hb = 0; hb < HB; ++hb) {
+                                const f32x4 d = head_mfma(wf[hb], o, bv[hb]);
+                                if (ACH) {
+                                    const f16x2 t01 = round_h2(d[0], d[1]), t23 = round_h2(d[2], d[3]);
+                                    f16x2 (&ts)[2] = tsh[ACH ? g2 : 0][hb];
+                                    ts[0] = f == 0 ? t01 : add_h2(ts[0], t01);
+                                    ts[1] = f == 0 ? t23 : add_h2(ts[1], t23);
+                                } else {
+                                    tsum[g2][hb] = f == 0 ? d : tsum[g2][hb] + d;
+                                }
+                            }
+                        }
+                    };
+                    issue(v, e, 0, p.flipmask[0], gh);
+                    for (int f = 0; f < p.n_eval; f += 2) {
+                        issue(vb, e, f + 1, p.flipmask[f + 1], gh);
+                        eval_body(v, f);
+                        const int f2 = f + 2 < p.n_eval ? f + 2 : p.n_eval - 1;
+                        issue(v, e, f2 ? f2 : 1, p.flipmask[f2 ? f2 : 1], gh);    // (never evaluation 0 again: that one also loads the Gaussian weights)
+                        eval_body(vb, f + 1);
+                    }
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const int g = gh + g2;
+                        if (__builtin_amdgcn_ballot_w64(in[g]) == 0) continue;
+                        const f16 gh16 = weight_of(v, g);
+                        const float gw = (float)gh16;
+                        if (ACH) {
+                            const f16x2 gw2 = {gh16, gh16};
+#pragma unroll
+                            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) {
+                                    const f16x2 ts = tsh[ACH ? g2 : 0][hb][k];
+                                    const f16x2 t = round_h2(div_n((float)ts[0]), div_n((float)ts[1]));   // half /= int
+                                    f16x2 &a2 = ah[PKS ? g : 0][hb][k];
+                                    const f16x2 nv = acc_add_product_h2(a2, t, gw2);
+                                    a2 = in[g] ? nv : a2;
+                                }
+                            continue;
+                        }
 #pragma unroll
                         for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
                             for (int k = 0; k < 2; ++k) {
-                                const f16x2 ts = tsh[TTA && ACH ? g : 0][hb][k];
-                                const f16x2 t = round_h2(div_n((float)ts[0]), div_n((float)ts[1]));   // half /= int
-                                f16x2 &a2 = ah[PKS ? g : 0][hb][k];
-                                const f16x2 nv = acc_add_product_h2(a2, t, gw2);
-                                a2 = in[g] ? nv : a2;
+                                const float t0 = div_n(tsum[g2][hb][2 * k]);         // prediction /= (len(axes_combinations) + 1)
+                                const float t1 = div_n(tsum[g2][hb][2 * k + 1]);
+                                if (PKS) {
+                                    f16x2 &a2 = ah[PKS ? g : 0][hb][k];
+                                    const f16x2 nv = round_h2(acc_add_product_1((float)a2[0], t0, gw), acc_add_product_1((float)a2[1], t1, gw));
+                                    a2 = in[g] ? nv : a2;
+                                } else {
+                                    const float s0 = acc_add_product_1(acc[g][hb][2 * k], t0, gw), s1 = acc_add_product_1(acc[g][hb][2 * k + 1], t1, gw);
+                                    acc[g][hb][2 * k] = in[g] ? s0 : acc[g][hb][2 * k];
+                                    acc[g][hb][2 * k + 1] = in[g] ? s1 : acc[g][hb][2 * k + 1];
+                                }
                             }
-                        continue;
                     }
-#pragma unroll
-                    for (int hb = 0; hb < HB; ++hb)
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const float t0 = div_n(tsum[TTA ? g : 0][hb][2 * k]);         // prediction /= (len(axes_combinations) + 1)
-                            const float t1 = div_n(tsum[TTA ? g : 0][hb][2 * k + 1]);
-                            if (PKS) {
-                                f16x2 &a2 = ah[PKS ? g : 0][hb][k];
-                                const f16x2 nv = round_h2(acc_add_product_1((float)a2[0], t0, gw), acc_add_product_1((float)a2[1], t1, gw));
-                                a2 = in[g] ? nv : a2;
-                            } else {
-                                const float s0 = acc_add_product_1(acc[g][hb][2 * k], t0, gw), s1 = acc_add_product_1(acc[g][hb][2 * k + 1], t1, gw);
-                                acc[g][hb][2 * k] = in[g] ? s0 : acc[g][hb][2 * k];
-                                acc[g][hb][2 * k + 1] = in[g] ? s1 : acc[g][hb][2 * k + 1];
-                            }
-                        }
                 }
             }
         } else if (PF) {
