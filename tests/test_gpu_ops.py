@@ -580,3 +580,118 @@ def test_gather_quotient_matches_ieee_division_on_every_fp16_pair():
     assert diff == 0, f'{diff} pairs differ, e.g. a = {example[0]:#06x}, b = {example[1]:#06x}'
     # finite a, finite b > 0 whose quotient stays below fp16's overflow boundary: ~1.78e9 of the 2^31 pairs
     assert 1.7e9 < fast < 1.85e9
+
+
+def _random_layer(seed):
+    """A conv layer of the kind an nnU-Net plans file can ask for, drawn from a seed: the shapes nobody tuned a launch rule on."""
+    rs = np.random.RandomState(1000 + seed)
+    k = [(3, 3, 3), (3, 3, 3), (3, 3, 3), (1, 3, 3), (1, 1, 1), (3, 1, 3)][rs.randint(6)]
+    stride = [(1, 1, 1), (1, 1, 1), (1, 1, 1), (2, 2, 2), (1, 2, 2), (2, 1, 1)][rs.randint(6)]
+    cin = int(rs.choice([8, 16, 21, 32, 48, 64, 96, 128, 160]))
+    two = stride == (1, 1, 1) and k == (3, 3, 3) and cin % 16 == 0 and cin <= 64 and rs.rand() < 0.4
+    cout = int(rs.choice([10, 16, 24, 32, 48, 64, 96, 128, 160, 320]))
+    n = int(rs.choice([1, 2, 3, 8, 16, 32]))
+    dims = [int(rs.randint(2, 41)), int(rs.randint(3, 35)), int(rs.randint(3, 35))]
+    macs = lambda: n * dims[0] * dims[1] * dims[2] * k[0] * k[1] * k[2] * cin * (2 if two else 1) * cout
+    while macs() > 1.5e10:                                   # what torch's CPU conv does in about a second
+        i = int(np.argmax(dims))
+        if dims[i] > 6:
+            dims[i] = dims[i] * 2 // 3
+        elif n > 1:
+            n = max(1, n // 2)
+        else:
+            cout = max(16, cout // 2)
+    return n, cin, two, cout, tuple(dims), k, stride, bool(rs.rand() < 0.5)
+
+
+@pytest.mark.parametrize('seed', range(48))
+def test_conv3d_random_layers_through_the_launch_rules(seed):
+    """Whatever kernel the launch rules pick for a layer nobody timed (odd planes, ragged tiles, channel padding, one or two
+    sources, statistics, InstanceNorm + LeakyReLU on load), the output and the statistics are torch's."""
+    from fast_nnunet_amd import capi
+    n, cin, two, cout, dims, k, stride, norm = _random_layer(seed)
+    g = torch.Generator().manual_seed(seed)
+    x = _h(torch.randn(n, cin, *dims, generator=g) * 2 + 0.5)
+    x2 = _h(torch.randn(n, cin, *dims, generator=g) - 0.25) if two else None
+    ctot = cin * (2 if two else 1)
+    w = _h(torch.randn(cout, ctot, *k, generator=g) / (ctot * k[0] * k[1] * k[2]) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    pad = [(i - 1) // 2 for i in k]
+    what = f'seed {seed}: n {n}, {cin}{"+" + str(cin) if two else ""} -> {cout}, {dims}, k {k}, stride {stride}, norm {norm}'
+    if norm:
+        gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+        kw = dict(x2=x2.numpy(), gamma2=gamma.numpy(), beta2=beta.numpy(), slope2=0.01) if two else \
+            dict(gamma=gamma.numpy(), beta=beta.numpy(), slope=0.01)
+        y = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), k, stride, **kw)
+        src = x2 if two else x
+        xn = _h(F.leaky_relu(F.instance_norm(src, weight=gamma, bias=beta, eps=1e-5), 0.01))
+        ref = F.conv3d(torch.cat((x, xn), 1) if two else xn, w, b, stride, pad)
+        print(what, '->', capi.op_last_kernels())
+        assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max())), what
+    else:
+        y, stats = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), k, stride, x2=None if x2 is None else x2.numpy(),
+                                  want_stats=True)
+        print(what, '->', capi.op_last_kernels())
+        _check(y, F.conv3d(torch.cat((x, x2), 1) if two else x, w, b, stride, pad), what)
+        y64 = y.astype(np.float64)
+        assert np.allclose(stats[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=1e-3), what
+        assert np.allclose(stats[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=1e-3), what
+
+
+def _random_big_layer(seed):
+    """A layer of a network's size at a batch of patches: the (cin, cout, kernel, stride) pairs U-Nets are made of, on planes and
+    depths drawn from a seed - enough workgroups for the depth-shift, whole-plane, stride-2, walking and row-streaming kernels."""
+    rs = np.random.RandomState(5000 + seed)
+    cin, cin2, cout, k, stride = [
+        (16, 0, 16, (3, 3, 3), (1, 1, 1)), (16, 0, 16, (1, 3, 3), (1, 1, 1)), (16, 16, 16, (1, 3, 3), (1, 1, 1)),
+        (16, 0, 32, (3, 3, 3), (1, 2, 2)), (16, 0, 32, (3, 3, 3), (2, 2, 2)), (32, 0, 32, (3, 3, 3), (1, 1, 1)),
+        (32, 32, 32, (3, 3, 3), (1, 1, 1)), (32, 0, 64, (3, 3, 3), (2, 2, 2)), (64, 0, 64, (3, 3, 3), (1, 1, 1)),
+        (64, 64, 64, (3, 3, 3), (1, 1, 1)), (64, 0, 128, (3, 3, 3), (2, 2, 2)), (128, 0, 128, (3, 3, 3), (1, 1, 1)),
+        (128, 128, 128, (3, 3, 3), (1, 1, 1)), (128, 0, 160, (3, 3, 3), (2, 2, 2)), (160, 0, 160, (3, 3, 3), (1, 1, 1)),
+        (48, 0, 96, (3, 3, 3), (1, 1, 1)), (32, 0, 48, (3, 3, 3), (2, 2, 2)), (64, 0, 320, (3, 3, 3), (1, 1, 1)),
+    ][seed % 18]
+    n = int(rs.choice([8, 16, 32]))
+    small = cin >= 128
+    dims = [int(rs.randint(6, 25 if small else 65)), int(rs.randint(5, 17 if small else 65)), int(rs.randint(5, 17 if small else 65))]
+    macs = lambda: n * dims[0] * dims[1] * dims[2] * k[0] * k[1] * k[2] * (cin + cin2) * cout / (stride[0] * stride[1] * stride[2])
+    byts = lambda: n * dims[0] * dims[1] * dims[2] * (cin + cin2 + cout) * 4
+    while macs() > 3e11 or byts() > 3e9:
+        i = int(np.argmax(dims))
+        dims[i] = dims[i] * 3 // 4
+    return n, cin, cin2, cout, tuple(dims), k, stride, bool(rs.rand() < 0.6)
+
+
+@pytest.mark.parametrize('seed', range(36))
+def test_conv3d_random_network_sized_layers_through_the_launch_rules(seed):
+    """The same for layers large enough to reach the kernels a network runs on (reference: torch's fp32 conv on the GPU, fp16-rounded
+    operands): random depths and planes - ragged tiles, planes the whole-plane and six-row forms were not written for."""
+    from fast_nnunet_amd import capi
+    n, cin, cin2, cout, dims, k, stride, norm = _random_big_layer(seed)
+    g = torch.Generator().manual_seed(100 + seed)
+    x = _h(torch.randn(n, cin, *dims, generator=g) * 2 + 0.5)
+    x2 = _h(torch.randn(n, cin2, *dims, generator=g) - 0.25) if cin2 else None
+    ctot = cin + cin2
+    w = _h(torch.randn(cout, ctot, *k, generator=g) / (ctot * k[0] * k[1] * k[2]) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    pad = [(i - 1) // 2 for i in k]
+    what = f'seed {seed}: n {n}, {cin}{"+" + str(cin2) if cin2 else ""} -> {cout}, {dims}, k {k}, stride {stride}, norm {norm}'
+    dev = torch.device('cuda:0')
+    conv = lambda t: F.conv3d(t.to(dev), w.to(dev), b.to(dev), stride, pad).cpu()
+    if norm:
+        gamma, beta = torch.rand(cin2 or cin, generator=g) + 0.5, torch.randn(cin2 or cin, generator=g) * 0.1
+        kw = dict(x2=x2.numpy(), gamma2=gamma.numpy(), beta2=beta.numpy(), slope2=0.01) if cin2 else \
+            dict(gamma=gamma.numpy(), beta=beta.numpy(), slope=0.01)
+        y = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), k, stride, **kw)
+        print(what, '->', capi.op_last_kernels())
+        src = x2 if cin2 else x
+        xn = _h(F.leaky_relu(F.instance_norm(src.to(dev), weight=gamma.to(dev), bias=beta.to(dev), eps=1e-5), 0.01).cpu())
+        ref = conv(torch.cat((x, xn), 1) if cin2 else xn)
+        assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max())), what
+    else:
+        y, stats = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), k, stride, x2=None if x2 is None else x2.numpy(),
+                                  want_stats=True)
+        print(what, '->', capi.op_last_kernels())
+        _check(y, conv(torch.cat((x, x2), 1) if cin2 else x), what)
+        y64 = y.astype(np.float64)
+        assert np.allclose(stats[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=2e-3), what
+        assert np.allclose(stats[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=2e-3), what
