@@ -13,9 +13,10 @@ the C ABI underneath it.
   to the patch, step 1.0, no Gaussian, inf detection, argument assertions.
 
 Tolerance (network in fp16 on the matrix cores vs fp32 on the CPU):
-max |err| <= 1e-2 * max|ref| and relative RMSE <= 5e-3.  Measured on MI355X
-(round 1): max ratio 0.9e-3 .. 1.9e-3, relative RMSE 0.8e-3 .. 1.8e-3 over all
-topologies below; values are printed with -s.
+max |err| <= 6e-3 * max|ref| and relative RMSE <= 3.5e-3 (MAX_REL, RMSE_REL below).
+Measured on MI355X: max ratio 0.9e-3 .. 1.9e-3, relative RMSE 0.8e-3 .. 1.8e-3 over
+the small topologies below, 2.2-3.4e-3 / 1.7-2.4e-3 on the BASELINE configurations at
+full patch size; values are printed with -s.
 """
 import os
 
@@ -106,6 +107,53 @@ def test_network_forward_matches_fp32_oracle(name):
     mr, rr = _report(name, got, ref)
     assert mr <= MAX_REL and rr <= RMSE_REL
     # batching must not change results beyond the statistics' summation order
+    single = p.forward_patches(x[3:4]).cpu()
+    assert (single - got[3:4]).abs().max() <= 1e-3 * float(ref.abs().max())
+
+
+def _random_spec(seed):
+    """A U-Net of the family the reference builds from a plans file (PlainConvUNet / ResidualEncoderUNet: get_network_from_plans),
+    drawn from a seed: stages, widths (the r = 3 / 6 students' odd ones too), anisotropic kernels and strides, convs per stage."""
+    rs = np.random.RandomState(700 + seed)
+    kind = 'resenc' if rs.rand() < 0.25 else 'plain'
+    stages = int(rs.randint(2, 6))
+    base = int(rs.choice([8, 10, 16, 16, 24, 32]))
+    cap = int(rs.choice([64, 96, 160]))
+    feats = [min(int(base * 2 ** i * (1.0 if rs.rand() < 0.7 else 1.06)), cap) for i in range(stages)]
+    strides = [(1, 1, 1)] + [[(2, 2, 2), (2, 2, 2), (1, 2, 2), (2, 1, 1)][rs.randint(4)] for _ in range(stages - 1)]
+    kernels = [(1, 3, 3) if i < 2 and rs.rand() < 0.3 else (3, 3, 3) for i in range(stages)]
+    enc = [int(rs.randint(1, 4)) for _ in range(stages)]
+    dec = [int(rs.randint(1, 3)) for _ in range(stages - 1)]
+    spec = UNetSpec(kind, int(rs.choice([1, 1, 2, 4])), int(rs.choice([2, 3, 5, 9, 17])), feats, kernels, strides, enc, dec)
+    total = [int(np.prod([s[a] for s in strides])) for a in range(3)]
+    patch = [t * int(rs.randint(2, 9)) for t in total]       # the bottleneck keeps at least 2 voxels per axis (nnU-Net's own plans: 4)
+    while patch[0] * patch[1] * patch[2] > 150000:
+        a = int(np.argmax([patch[i] / total[i] for i in range(3)]))
+        if patch[a] <= 2 * total[a]:
+            break
+        patch[a] -= total[a]
+    return spec, tuple(patch)
+
+
+@pytest.mark.parametrize('seed', range(20))
+def test_random_topologies_match_fp32_oracle(seed):
+    """Networks nobody wrote a launch rule for: whatever the plan picks per layer, the logits are the oracle's within the
+    tolerance of the fixed topologies above, and a patch's result does not depend on its batch."""
+    spec, patch = _random_spec(seed)
+    sd = synthetic_state_dict(spec, 4000 + seed)
+    net = build_oracle(spec, sd)
+    p = _predictor(spec, patch, [sd])
+    x = torch.randn(4, spec.in_channels, *patch, generator=torch.Generator().manual_seed(seed))     # batch 3 -> ragged last batch
+    got = p.forward_patches(x).cpu()
+    torch.set_num_threads(8)
+    with torch.inference_mode():
+        ref = net(x)
+    mr, rr = _report(f'seed {seed}: {spec.kind} {spec.features} k {spec.kernels} s {spec.strides} convs {spec.n_conv_enc} / '
+                     f'{spec.n_conv_dec}, {spec.in_channels} -> {spec.num_heads}, patch {patch}', got, ref)
+    # measured over the 20 seeds: max ratio 0.8-3.0e-3, relative RMSE 0.7-2.5e-3, and 4.6e-3 / 3.5e-3 for seed 13 (19 convs, three per
+    # encoder stage, over a bottleneck of 108 voxels: InstanceNorm over so few voxels amplifies the fp16 rounding of its input -
+    # nnU-Net's own plans keep 4 voxels per axis and two convs per stage): 1.5 x the tolerance of the fixed topologies
+    assert mr <= 1.5 * MAX_REL and rr <= 1.5 * RMSE_REL
     single = p.forward_patches(x[3:4]).cpu()
     assert (single - got[3:4]).abs().max() <= 1e-3 * float(ref.abs().max())
 
