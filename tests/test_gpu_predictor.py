@@ -216,29 +216,7 @@ def test_forward_is_bit_stable_while_another_engine_shares_the_gpu():
     assert bad == [0, 0]
 
 
-DRIVER_CASES = [
-    dict(shape=(40, 36, 44), mirror=None, step=0.5, gaussian=True, folds=1),
-    dict(shape=(40, 36, 44), mirror=None, step=1.0, gaussian=False, folds=1),
-    dict(shape=(11, 30, 9), mirror=None, step=0.5, gaussian=True, folds=1),        # smaller than the patch -> padded
-    dict(shape=(16, 16, 32), mirror=None, step=0.5, gaussian=True, folds=1),       # exactly one patch
-    dict(shape=(24, 33, 40), mirror=[0], step=0.5, gaussian=True, folds=1),
-    dict(shape=(20, 18, 47), mirror=[0, 1, 2], step=0.5, gaussian=True, folds=1),
-    dict(shape=(33, 20, 37), mirror=[1, 2], step=0.3, gaussian=True, folds=3),
-    # (image - patch) / (patch * step) lands on an integer: ceil() of the quotient formed with a float-rounded step
-    # gives one tile position more (72: 6 instead of 5; 44 and 88: 6 instead of 5) - fnn_opts carries a double
-    dict(shape=(72, 20, 40), mirror=None, step=0.7, gaussian=True, folds=1),
-    dict(shape=(44, 16, 88), mirror=None, step=0.35, gaussian=True, folds=1),
-]
-
-
-@pytest.mark.parametrize('mode', ['fp16', 'fp16_autocast'])
-@pytest.mark.parametrize('case', DRIVER_CASES, ids=lambda c: f"{c['shape']}-m{c['mirror']}-s{c['step']}-f{c['folds']}")
-def test_driver_bit_identical_to_oracle_driver_on_engine_logits(case, mode):
-    """'fp16': the reference without autocast (fp32 logits; pinned by tests/golden/sliding_window.npz).
-    'fp16_autocast': the reference on a GPU - the network returns fp16, so the oracle's driver (the reference's own
-    torch statements, pinned for fp16-output networks by tests/golden/sliding_window_half.npz) rounds the mirror sums,
-    the Gaussian product and the accumulation to fp16; the engine's FNN_ACC_FP16_AUTOCAST must give the same bits."""
-    spec, patch = SPECS['toy3']
+def _driver_case(case, mode, spec, patch):
     sds = [synthetic_state_dict(spec, 50 + f) for f in range(case['folds'])]
     p = _predictor(spec, patch, sds, mirror=case['mirror'], step=case['step'], gaussian=case['gaussian'], accumulate_in=mode)
     image = torch.randn(1, *case['shape'], generator=torch.Generator().manual_seed(9))
@@ -266,6 +244,51 @@ def test_driver_bit_identical_to_oracle_driver_on_engine_logits(case, mode):
     same = (gb == wb).mean()
     print(f'bit-identical fraction {same:.6f}')
     assert same == 1.0
+
+
+DRIVER_CASES = [
+    dict(shape=(40, 36, 44), mirror=None, step=0.5, gaussian=True, folds=1),
+    dict(shape=(40, 36, 44), mirror=None, step=1.0, gaussian=False, folds=1),
+    dict(shape=(11, 30, 9), mirror=None, step=0.5, gaussian=True, folds=1),        # smaller than the patch -> padded
+    dict(shape=(16, 16, 32), mirror=None, step=0.5, gaussian=True, folds=1),       # exactly one patch
+    dict(shape=(24, 33, 40), mirror=[0], step=0.5, gaussian=True, folds=1),
+    dict(shape=(20, 18, 47), mirror=[0, 1, 2], step=0.5, gaussian=True, folds=1),
+    dict(shape=(33, 20, 37), mirror=[1, 2], step=0.3, gaussian=True, folds=3),
+    # (image - patch) / (patch * step) lands on an integer: ceil() of the quotient formed with a float-rounded step
+    # gives one tile position more (72: 6 instead of 5; 44 and 88: 6 instead of 5) - fnn_opts carries a double
+    dict(shape=(72, 20, 40), mirror=None, step=0.7, gaussian=True, folds=1),
+    dict(shape=(44, 16, 88), mirror=None, step=0.35, gaussian=True, folds=1),
+]
+
+
+@pytest.mark.parametrize('mode', ['fp16', 'fp16_autocast'])
+@pytest.mark.parametrize('case', DRIVER_CASES, ids=lambda c: f"{c['shape']}-m{c['mirror']}-s{c['step']}-f{c['folds']}")
+def test_driver_bit_identical_to_oracle_driver_on_engine_logits(case, mode):
+    """'fp16': the reference without autocast (fp32 logits; pinned by tests/golden/sliding_window.npz).
+    'fp16_autocast': the reference on a GPU - the network returns fp16, so the oracle's driver (the reference's own
+    torch statements, pinned for fp16-output networks by tests/golden/sliding_window_half.npz) rounds the mirror sums,
+    the Gaussian product and the accumulation to fp16; the engine's FNN_ACC_FP16_AUTOCAST must give the same bits."""
+    _driver_case(case, mode, *SPECS['toy3'])
+
+
+def _random_driver_case(seed):
+    rs = np.random.RandomState(300 + seed)
+    name = 'heads61' if rs.rand() < 0.35 else 'toy3'
+    patch = SPECS[name][1]
+    shape = tuple(int(rs.randint(max(3, q // 2), int(3.2 * q) + 1)) for q in patch)
+    axes = [a for a in range(3) if rs.rand() < 0.5]
+    return name, dict(shape=shape, mirror=axes if axes and rs.rand() < 0.6 else None,
+                      step=float(rs.choice([0.25, 0.3, 0.4, 0.5, 0.5, 0.6, 0.75, 1.0])), gaussian=bool(rs.rand() < 0.85),
+                      folds=int(rs.choice([1, 1, 2]))), ['fp16', 'fp16_autocast'][rs.randint(2)]
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_driver_bit_identical_to_oracle_driver_on_random_volumes(seed):
+    """Volume shapes from half a patch to 3.2 patches per axis, tile steps 0.25-1.0, every subset of mirror axes, one or two
+    folds, 3 or 61 heads, both accumulation arithmetics, drawn from a seed: the same bits as the oracle's driver."""
+    name, case, mode = _random_driver_case(seed)
+    print(name, case, mode)
+    _driver_case(case, mode, *SPECS[name])
 
 
 @pytest.mark.parametrize('shape,folds,accum', [((24, 40, 64), 1, 'fp16'), ((19, 23, 72), 2, 'fp16'), ((17, 16, 40), 1, 'fp32')])
