@@ -695,3 +695,39 @@ def test_conv3d_random_network_sized_layers_through_the_launch_rules(seed):
         y64 = y.astype(np.float64)
         assert np.allclose(stats[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=2e-3), what
         assert np.allclose(stats[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=2e-3), what
+
+
+def _random_tconv(seed):
+    rs = np.random.RandomState(2000 + seed)
+    stride = [(2, 2, 2), (2, 2, 2), (1, 2, 2), (2, 1, 1)][rs.randint(4)]
+    cin = int(rs.choice([16, 21, 32, 48, 64, 96, 128, 160, 320]))
+    cout = int(rs.choice([8, 10, 16, 32, 48, 64, 128, 160]))
+    n = int(rs.choice([1, 2, 5, 16, 32]))
+    dims = [int(rs.randint(2, 33)), int(rs.randint(2, 33)), int(rs.randint(2, 33))]
+    while n * dims[0] * dims[1] * dims[2] * cin * cout * 8 > 2e10 or n * dims[0] * dims[1] * dims[2] * cout * 8 * 4 > 2e9:
+        i = int(np.argmax(dims))
+        if dims[i] > 3:
+            dims[i] = dims[i] * 2 // 3
+        else:
+            n = max(1, n // 2)
+    return n, cin, cout, tuple(dims), stride
+
+
+@pytest.mark.parametrize('seed', range(20))
+def test_conv_transpose3d_random_layers(seed):
+    """Transposed convs (kernel = stride, as in every nnU-Net decoder) on shapes drawn from a seed: both launch forms, ragged rows."""
+    from fast_nnunet_amd import capi
+    n, cin, cout, dims, stride = _random_tconv(seed)
+    g = torch.Generator().manual_seed(seed)
+    x = _h(torch.randn(n, cin, *dims, generator=g) * 2 + 0.5)
+    gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+    w = _h(torch.randn(cin, cout, *stride, generator=g) / cin ** 0.5)
+    b = torch.randn(cout, generator=g)
+    what = f'seed {seed}: n {n}, {cin} -> {cout}, {dims}, stride {stride}'
+    y = capi.op_conv_transpose3d(x.numpy(), w.numpy(), b.numpy(), stride, gamma=gamma.numpy(), beta=beta.numpy(), slope=0.01)
+    print(what, '->', capi.op_last_kernels())
+    xn = _h(F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01))
+    ref = F.conv_transpose3d(xn, w, b, stride)
+    assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max())), what
+    y2 = capi.op_conv_transpose3d(x.numpy(), w.numpy(), b.numpy(), stride)
+    _check(y2, F.conv_transpose3d(x, w, b, stride), what)

@@ -114,6 +114,27 @@ RESAMPLE_CASES = [
 
 @pytest.mark.parametrize('shape,new_shape,order,axis', RESAMPLE_CASES)
 def test_resample_matches_scipy_restatement(shape, new_shape, order, axis):
+    _resample_case(shape, new_shape, order, axis)
+
+
+def _random_resample_case(seed):
+    rs = np.random.RandomState(900 + seed)
+    shape = (int(rs.randint(1, 4)),) + tuple(int(rs.randint(3, 41)) for _ in range(3))
+    new_shape = tuple(int(max(2, round(d * rs.uniform(0.4, 2.2)))) for d in shape[1:])
+    order = int(rs.choice([0, 1, 3, 3]))
+    axis = None if rs.rand() < 0.5 else int(rs.randint(3))
+    return shape, new_shape, order, axis
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_resample_matches_scipy_restatement_on_random_shapes(seed):
+    """Up- and down-sampling by 0.4-2.2 per axis, orders 0 / 1 / 3, with and without the separate axis, drawn from a seed."""
+    case = _random_resample_case(seed)
+    print(case)
+    _resample_case(*case)
+
+
+def _resample_case(shape, new_shape, order, axis):
     from fast_nnunet_amd import capi
     from oracle import resample as ores
     rng = np.random.default_rng(hash((shape, new_shape, order)) % 2 ** 31)
