@@ -218,12 +218,19 @@ __global__ __launch_bounds__(256, CH == 1 ? (NBLK <= 8 ? 3 : 2) : (NBLK <= 8 ? 2
 #endif
                     o = __builtin_elementwise_max(o, o * lslope);
                     char *dst = smem + (slot * 4 + 2 * lr) * PB + bl * 1024;
+                    // the four phases' MFMAs back to back into their own registers (as conv_row_stem_kernel's stem rows), then
+                    // bias added behind the MFMA like tconv_mfma_kernel: the unfused engine's bits
+                    f32x4 dd[4];
+#pragma unroll
+                    for (int cls = 0; cls < 4; ++cls)
+                        dd[cls] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwf[cls], o, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#ifndef FNN_STEM_SERIAL
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                     for (int cls = 0; cls < 4; ++cls) {
-                        // bias added behind the MFMA like tconv_mfma_kernel: the unfused engine's bits
-                        const f32x4 dd = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwf[cls], o, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                         f16x4 h;
-                        h[0] = (f16)(dd[0] + fb[0]); h[1] = (f16)(dd[1] + fb[1]); h[2] = (f16)(dd[2] + fb[2]); h[3] = (f16)(dd[3] + fb[3]);
+                        h[0] = (f16)(dd[cls][0] + fb[0]); h[1] = (f16)(dd[cls][1] + fb[1]); h[2] = (f16)(dd[cls][2] + fb[2]); h[3] = (f16)(dd[cls][3] + fb[3]);
                         if (!ok) h = (f16x4){0, 0, 0, 0};                // rows outside the patch: the conv's zero padding
                         *(f16x4 *)(dst + (cls >> 1) * PB + up_lds[cls & 1]) = h;
                     }
@@ -679,6 +686,25 @@ __global__ __launch_bounds__(256, NBLK <= 8 ? 3 : 2) void conv_row_stem_kernel(c
             for (int b = 0; b < NBLK; ++b) *(f16x4 *)(dst + b * 512) = (f16x4){0, 0, 0, 0};
             return;
         }
+#ifndef FNN_STEM_SERIAL
+        // the row's MFMAs back to back into their own registers, then their commits (written per block, hipcc puts every block's
+        // result into the same four registers: MFMA, eight wait states, the commit - NBLK times in a row per step)
+        f32x4 dd[NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            const f16x4 ea = *(const f16x4 *)(pa + b * 128), eb = *(const f16x4 *)(pb + b * 128);
+            const f16x8 xb = {ea[0], ea[1], ea[2], ea[3], eb[0], eb[1], eb[2], eb[3]};
+            dd[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(swf, xb, sbv, 0, 0, 0);                // bias = the C operand: stem_row_kernel's value
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            f16x4 o = {(f16)dd[b][0], (f16)dd[b][1], (f16)dd[b][2], (f16)dd[b][3]};
+            o = o * ssc + ssh;                                           // conv_row_kernel's commit on it
+            o = __builtin_elementwise_max(o, o * sslope);
+            *(f16x4 *)(dst + b * 512) = o;
+        }
+#else
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) {
             const f16x4 ea = *(const f16x4 *)(pa + b * 128), eb = *(const f16x4 *)(pb + b * 128);
@@ -689,6 +715,7 @@ __global__ __launch_bounds__(256, NBLK <= 8 ? 3 : 2) void conv_row_stem_kernel(c
             o = __builtin_elementwise_max(o, o * sslope);
             *(f16x4 *)(dst + b * 512) = o;
         }
+#endif
     };
 
     // ---- statistics and the conv step: conv_row_kernel<NBLK, 1, false>

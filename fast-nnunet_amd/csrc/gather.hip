@@ -348,9 +348,108 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : (TTA && 
             // channel `heads` has zero weights and bias 1: its product is the weight itself; the product is rounded
             // before the sum (no fma), one rounding to fp16 per visit; lanes outside the patch keep their sums (and
             // signed zeros)
+#if !defined(FNN_GATHER_NOMIX) && !defined(FNN_GATHER_SELECT) && !defined(FNN_GATHER_EXEC_PER_BLOCK)
+            if constexpr (!ACH && PKS && HB == 4) {
+                // all four head blocks of the group under ONE EXEC window (two writes of EXEC per group visit instead of eight):
+                // the four MFMAs and the sixteen products first (all lanes), then the sixteen add + up-convert and the eight
+                // roundings of the per-block form below, in one asm statement
+                float t[4][4];
+                unsigned a[4][2];
+                f32x4 d[4];
+                // the four MFMAs back to back into their own registers (written per block with its products, hipcc puts every
+                // block's result into the same four registers: MFMA, eight wait states, four products - four times in a row)
+#pragma unroll
+                for (int hb = 0; hb < 4; ++hb) d[hb] = head_mfma(wf[hb], o, bv[hb]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int hb = 0; hb < 4; ++hb) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[hb][j] = mul_rn(d[hb][j], gw);
+                    a[hb][0] = __builtin_bit_cast(unsigned, ah[g][hb][0]);
+                    a[hb][1] = __builtin_bit_cast(unsigned, ah[g][hb][1]);
+                }
+                unsigned long long sv;
+#define FNN_MIX4(A, B, T0, T1, T2, T3)                                                             \
+                "v_fma_mix_f32 %[" #T0 "], %[" #A "], 1.0, %[" #T0 "] op_sel_hi:[1,0,0]\n\t"                  \
+                "v_fma_mix_f32 %[" #T1 "], %[" #A "], 1.0, %[" #T1 "] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"  \
+                "v_fma_mix_f32 %[" #T2 "], %[" #B "], 1.0, %[" #T2 "] op_sel_hi:[1,0,0]\n\t"                  \
+                "v_fma_mix_f32 %[" #T3 "], %[" #B "], 1.0, %[" #T3 "] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+#define FNN_CVT2(A, B, T0, T1, T2, T3)                                                             \
+                "v_cvt_pk_f16_f32 %[" #A "], %[" #T0 "], %[" #T1 "]\n\t"                                      \
+                "v_cvt_pk_f16_f32 %[" #B "], %[" #T2 "], %[" #T3 "]\n\t"
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             "s_and_b64 exec, exec, %[m]\n\t"
+                             FNN_MIX4(a00, a01, t00, t01, t02, t03) FNN_MIX4(a10, a11, t10, t11, t12, t13)
+                             FNN_MIX4(a20, a21, t20, t21, t22, t23) FNN_MIX4(a30, a31, t30, t31, t32, t33)
+                             FNN_CVT2(a00, a01, t00, t01, t02, t03) FNN_CVT2(a10, a11, t10, t11, t12, t13)
+                             FNN_CVT2(a20, a21, t20, t21, t22, t23) FNN_CVT2(a30, a31, t30, t31, t32, t33)
+                             "s_mov_b64 exec, %[sv]"
+                             : [a00] "+v"(a[0][0]), [a01] "+v"(a[0][1]), [a10] "+v"(a[1][0]), [a11] "+v"(a[1][1]),
+                               [a20] "+v"(a[2][0]), [a21] "+v"(a[2][1]), [a30] "+v"(a[3][0]), [a31] "+v"(a[3][1]),
+                               [t00] "+v"(t[0][0]), [t01] "+v"(t[0][1]), [t02] "+v"(t[0][2]), [t03] "+v"(t[0][3]),
+                               [t10] "+v"(t[1][0]), [t11] "+v"(t[1][1]), [t12] "+v"(t[1][2]), [t13] "+v"(t[1][3]),
+                               [t20] "+v"(t[2][0]), [t21] "+v"(t[2][1]), [t22] "+v"(t[2][2]), [t23] "+v"(t[2][3]),
+                               [t30] "+v"(t[3][0]), [t31] "+v"(t[3][1]), [t32] "+v"(t[3][2]), [t33] "+v"(t[3][3]), [sv] "=&s"(sv)
+                             : [m] "s"(inm));
+#undef FNN_MIX4
+#undef FNN_CVT2
+#pragma unroll
+                for (int hb = 0; hb < 4; ++hb) {
+                    ah[g][hb][0] = __builtin_bit_cast(f16x2, a[hb][0]);
+                    ah[g][hb][1] = __builtin_bit_cast(f16x2, a[hb][1]);
+                }
+                continue;
+            }
+#endif
+#if !defined(FNN_GATHER_SELECT) && !defined(FNN_GATHER_EXEC_PER_BLOCK)
+            if constexpr (ACH && HB == 4) {
+                // the autocast arithmetic the same way: the rounded logits' products and the sums' adds (v_pk_mul_f16, v_pk_add_f16: the
+                // instructions hipcc emits for acc_add_product_h2) of all four head blocks under one EXEC window - no selects
+                f32x4 d[4];
+#pragma unroll
+                for (int hb = 0; hb < 4; ++hb) d[hb] = head_mfma(wf[hb], o, bv[hb]);
+                __builtin_amdgcn_sched_barrier(0);
+                unsigned t[4][2], a[4][2];
+#pragma unroll
+                for (int hb = 0; hb < 4; ++hb) {
+                    t[hb][0] = __builtin_bit_cast(unsigned, round_h2(d[hb][0], d[hb][1]));      // the network's fp16 output
+                    t[hb][1] = __builtin_bit_cast(unsigned, round_h2(d[hb][2], d[hb][3]));
+                    a[hb][0] = __builtin_bit_cast(unsigned, ah[g][hb][0]);
+                    a[hb][1] = __builtin_bit_cast(unsigned, ah[g][hb][1]);
+                }
+                const unsigned g2 = __builtin_bit_cast(unsigned, (f16x2){gh, gh});
+                unsigned long long sv;
+#define FNN_PKMUL2(T0, T1) "v_pk_mul_f16 %[" #T0 "], %[" #T0 "], %[g2]\n\tv_pk_mul_f16 %[" #T1 "], %[" #T1 "], %[g2]\n\t"
+#define FNN_PKADD2(A0, A1, T0, T1) "v_pk_add_f16 %[" #A0 "], %[" #A0 "], %[" #T0 "]\n\tv_pk_add_f16 %[" #A1 "], %[" #A1 "], %[" #T1 "]\n\t"
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             "s_and_b64 exec, exec, %[m]\n\t"
+                             FNN_PKMUL2(t00, t01) FNN_PKMUL2(t10, t11) FNN_PKMUL2(t20, t21) FNN_PKMUL2(t30, t31)
+                             FNN_PKADD2(a00, a01, t00, t01) FNN_PKADD2(a10, a11, t10, t11)
+                             FNN_PKADD2(a20, a21, t20, t21) FNN_PKADD2(a30, a31, t30, t31)
+                             "s_mov_b64 exec, %[sv]"
+                             : [a00] "+v"(a[0][0]), [a01] "+v"(a[0][1]), [a10] "+v"(a[1][0]), [a11] "+v"(a[1][1]),
+                               [a20] "+v"(a[2][0]), [a21] "+v"(a[2][1]), [a30] "+v"(a[3][0]), [a31] "+v"(a[3][1]),
+                               [t00] "+v"(t[0][0]), [t01] "+v"(t[0][1]), [t10] "+v"(t[1][0]), [t11] "+v"(t[1][1]),
+                               [t20] "+v"(t[2][0]), [t21] "+v"(t[2][1]), [t30] "+v"(t[3][0]), [t31] "+v"(t[3][1]), [sv] "=&s"(sv)
+                             : [m] "s"(inm), [g2] "v"(g2));
+#undef FNN_PKMUL2
+#undef FNN_PKADD2
+#pragma unroll
+                for (int hb = 0; hb < 4; ++hb) {
+                    ah[g][hb][0] = __builtin_bit_cast(f16x2, a[hb][0]);
+                    ah[g][hb][1] = __builtin_bit_cast(f16x2, a[hb][1]);
+                }
+                continue;
+            }
+#endif
+            // (fewer head blocks, fp32 sums: per block; the MFMAs still back to back into their own registers)
+            f32x4 dd[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) dd[hb] = head_mfma(wf[hb], o, bv[hb]);   // logit: the bias is the C operand, as in the seg-head kernels
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb) {
-                const f32x4 d = head_mfma(wf[hb], o, bv[hb]);   // logit: the bias is the C operand, as in the seg-head kernels
+                const f32x4 d = dd[hb];
                 if (ACH) {
                     const f16x2 t01 = round_h2(d[0], d[1]);      // the network's fp16 output
                     const f16x2 t23 = round_h2(d[2], d[3]);
@@ -445,9 +544,18 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : (TTA && 
                         for (int g2 = 0; g2 < 2; ++g2) {
                             if (__builtin_amdgcn_ballot_w64(in[gh + g2]) == 0) continue;
                             const FV o = normed(w, g2);
+                            // (back to back, as in consume(), where the registers are there: the forms with fp16 running sums and
+                            // the K = 32 head would lose a wave per SIMD to them)
+                            constexpr bool B2B = K16 && !ACH;
+                            f32x4 dd[B2B ? HB : 1];
+                            if (B2B) {
+#pragma unroll
+                                for (int hb = 0; hb < HB; ++hb) dd[B2B ? hb : 0] = head_mfma(wf[hb], o, bv[hb]);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
 #pragma unroll
                             for (int hb = 0; hb < HB; ++hb) {
-                                const f32x4 d = head_mfma(wf[hb], o, bv[hb]);
+                                const f32x4 d = B2B ? dd[B2B ? hb : 0] : head_mfma(wf[hb], o, bv[hb]);
                                 if (ACH) {
                                     const f16x2 t01 = round_h2(d[0], d[1]), t23 = round_h2(d[2], d[3]);
                                     f16x2 (&ts)[2] = tsh[ACH ? g2 : 0][hb];
