@@ -335,6 +335,14 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : (TTA && 
     const auto consume = [&](GatherVisit<G, K16> &v, const GatherGeo &e) {
         pin(v);
         const int dz0 = zl - e.oz;                             // this lane's z inside the patch, group 0
+#ifndef FNN_GATHER_WEIGHT_PER_GROUP
+        // the four groups' Gaussian weights (one ds_bpermute each) requested up front: per group the request sat right in front of
+        // its wait, and the wait in front of the group's MFMAs
+        f16 ghs[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) ghs[g] = weight_of(v, g);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             // a patch that starts or ends inside the run leaves whole 16-voxel groups untouched: skip them
@@ -343,7 +351,11 @@ __global__ __launch_bounds__(256, (!TTA && ACCM != 1) ? (K16 ? 4 : 3) : (TTA && 
             const unsigned long long inm = __builtin_amdgcn_ballot_w64(in);
             if (inm == 0) continue;
             const FV o = normed(v, g);
+#ifndef FNN_GATHER_WEIGHT_PER_GROUP
+            const f16 gh = ghs[g];
+#else
             const f16 gh = weight_of(v, g);
+#endif
             const float gw = (float)gh;
             // channel `heads` has zero weights and bias 1: its product is the weight itself; the product is rounded
             // before the sum (no fma), one rounding to fp16 per visit; lanes outside the patch keep their sums (and
