@@ -1,5 +1,7 @@
-# scratch: copy the final capture from gpurun_out/ into profiles/ (round r05)
-cd /root/repo
+#!/bin/bash
+# usage (this container, after `gpurun -- 'FNN_ROUND=r05 bash tools/capture_all.sh'` has merged its output into gpurun_out/):
+#   bash tools/install_capture.sh      - copies the per-workload capture files and the counter-traffic file into profiles/ under the round's names
+cd ${GRAFT_REPO_ROOT:-/root/repo}
 for t in bone iso128_r2 iso128_teacher resenc160_r2 resenc160_r2_f8 bone_autocast bone_mirror; do
   d=gpurun_out/cap_$t
   [ -d $d ] || { echo "missing $d"; continue; }
