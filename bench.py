@@ -35,7 +35,7 @@ if ROOT not in sys.path:
 
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16, MI355X_MICROARCH.md "Chip-level parameters"
 MFMA_PEAK_CLOCK_GHZ = 2.4          # the clock that peak is quoted at (same table: max clock 2400 MHz)
-TRAFFIC_FILE = 'r05_traffic.json'  # per-launch HBM bytes of the conv family from separate rocprofv3 --pmc passes, per workload, keyed by csrc_sha256()
+TRAFFIC_FILE = 'r06_traffic.json'  # per-launch HBM bytes of the conv family from separate rocprofv3 --pmc passes, per workload, keyed by csrc_sha256()
 
 WORKLOADS = {
     # name: (spacing, patch, heads, reduction)
@@ -91,13 +91,14 @@ def synthetic_checkpoint(features, kernels, strides, in_ch, heads, seed=1234):
     gain = (2.0 / (1 + 0.01 ** 2)) ** 0.5
 
     def conv(prefix, cout, cin, k):
-        fan_in = cin * k[0] * k[1] * k[2]
+        fan_in = cin * int(np.prod(k))
         sd[prefix + '.conv.weight'] = torch.randn(cout, cin, *k, generator=g) * (gain / fan_in ** 0.5)
         sd[prefix + '.conv.bias'] = torch.randn(cout, generator=g) * 0.05
         sd[prefix + '.norm.weight'] = torch.rand(cout, generator=g) + 0.5
         sd[prefix + '.norm.bias'] = torch.randn(cout, generator=g) * 0.1
 
     n = len(features)
+    ones = [1] * len(kernels[0])                       # (Conv2d weights are 4-D: `2d` configurations)
     cin = in_ch
     for s in range(n):
         for i in range(2):
@@ -105,12 +106,12 @@ def synthetic_checkpoint(features, kernels, strides, in_ch, heads, seed=1234):
             cin = features[s]
     for d in range(n - 1):
         below, skip, st = features[-(d + 1)], features[-(d + 2)], strides[-(d + 1)]
-        fan_in = below * st[0] * st[1] * st[2]
+        fan_in = below * int(np.prod(st))
         sd[f'decoder.transpconvs.{d}.weight'] = torch.randn(below, skip, *st, generator=g) * (gain / fan_in ** 0.5)
         sd[f'decoder.transpconvs.{d}.bias'] = torch.randn(skip, generator=g) * 0.05
         conv(f'decoder.stages.{d}.convs.0', skip, 2 * skip, kernels[-(d + 2)])
         conv(f'decoder.stages.{d}.convs.1', skip, skip, kernels[-(d + 2)])
-        sd[f'decoder.seg_layers.{d}.weight'] = torch.randn(heads, skip, 1, 1, 1, generator=g) * (gain / skip ** 0.5)
+        sd[f'decoder.seg_layers.{d}.weight'] = torch.randn(heads, skip, *ones, generator=g) * (gain / skip ** 0.5)
         sd[f'decoder.seg_layers.{d}.bias'] = torch.randn(heads, generator=g) * 0.05
     return sd
 
@@ -123,7 +124,7 @@ def synthetic_resenc_checkpoint(features, kernels, strides, blocks, in_ch, heads
     gain = (2.0 / (1 + 0.01 ** 2)) ** 0.5
 
     def conv(prefix, cout, cin, k, bias=True):
-        fan_in = cin * k[0] * k[1] * k[2]
+        fan_in = cin * int(np.prod(k))
         sd[prefix + '.conv.weight'] = torch.randn(cout, cin, *k, generator=g) * (gain / fan_in ** 0.5)
         if bias:
             sd[prefix + '.conv.bias'] = torch.randn(cout, generator=g) * 0.05
@@ -131,6 +132,7 @@ def synthetic_resenc_checkpoint(features, kernels, strides, blocks, in_ch, heads
         sd[prefix + '.norm.bias'] = torch.randn(cout, generator=g) * 0.1
 
     n = len(features)
+    ones = tuple([1] * len(kernels[0]))
     conv('encoder.stem.convs.0', features[0], in_ch, kernels[0])
     cin = features[0]
     for s in range(n):
@@ -140,65 +142,93 @@ def synthetic_resenc_checkpoint(features, kernels, strides, blocks, in_ch, heads
             conv(pre + '.conv2', features[s], features[s], kernels[s])
             strided = b == 0 and any(v != 1 for v in strides[s])
             if cin != features[s]:
-                conv(f'{pre}.skip.{1 if strided else 0}', features[s], cin, (1, 1, 1), bias=False)
+                conv(f'{pre}.skip.{1 if strided else 0}', features[s], cin, ones, bias=False)
             cin = features[s]
     for d in range(n - 1):
         below, skip, st = features[-(d + 1)], features[-(d + 2)], strides[-(d + 1)]
-        fan_in = below * st[0] * st[1] * st[2]
+        fan_in = below * int(np.prod(st))
         sd[f'decoder.transpconvs.{d}.weight'] = torch.randn(below, skip, *st, generator=g) * (gain / fan_in ** 0.5)
         sd[f'decoder.transpconvs.{d}.bias'] = torch.randn(skip, generator=g) * 0.05
         conv(f'decoder.stages.{d}.convs.0', skip, 2 * skip, kernels[-(d + 2)])
-        sd[f'decoder.seg_layers.{d}.weight'] = torch.randn(heads, skip, 1, 1, 1, generator=g) * (gain / skip ** 0.5)
+        sd[f'decoder.seg_layers.{d}.weight'] = torch.randn(heads, skip, *ones, generator=g) * (gain / skip ** 0.5)
         sd[f'decoder.seg_layers.{d}.bias'] = torch.randn(heads, generator=g) * 0.05
     return sd
 
 
-def build_predictor(workload, device, batch, accumulate_in, compute_dtype='f16', mirror=False, folds=1):
+def resolve_workload(args):
+    """The workload as one dict: a named BASELINE workload (cubic --volume), or a plan file (--plan: a JSON object with
+    name, patch, spacing, in_channels, heads, r, kind 'plain' | 'resenc', volume [X, Y, Z] - a realistic nnU-Net
+    configuration off the BASELINE shapes, tools/plans/*.json)."""
+    if args.plan:
+        j = json.load(open(args.plan))
+        patch = tuple(int(v) for v in j['patch'])
+        w = dict(name=j.get('name', os.path.splitext(os.path.basename(args.plan))[0]), spacing=tuple(float(v) for v in j['spacing']),
+                 patch=patch, heads=int(j['heads']), r=int(j.get('r', 1)), in_channels=int(j.get('in_channels', 1)),
+                 resenc=j.get('kind', 'plain') == 'resenc', volume=tuple(int(v) for v in j['volume']),
+                 max_features=int(j.get('max_features', 320 if len(patch) == 3 else 512)), plan=True, note=j.get('note', ''))
+        if 'batch' in j and not args.batch_given:
+            args.batch = int(j['batch'])
+        return w
+    spacing, patch, heads, r = WORKLOADS[args.workload]
+    return dict(name=args.workload, spacing=spacing, patch=patch, heads=heads, r=r, in_channels=1,
+                resenc=args.workload.startswith('resenc'), volume=(args.volume,) * 3, max_features=320, plan=False, note='')
+
+
+def build_predictor(w, device, batch, accumulate_in, compute_dtype='f16', mirror=False, folds=1):
     from fast_nnunet_amd import nnUNetPredictor
     from fast_nnunet_amd.plans import PlansManager
-    spacing, patch, heads, r = WORKLOADS[workload]
+    spacing, patch, heads, r, in_ch = w['spacing'], w['patch'], w['heads'], w['r'], w['in_channels']
     strides, kernels = plan_topology(spacing, patch)
     n = len(strides)
-    features = [max(min(320, 32 * 2 ** i) // r, 8) for i in range(n)]
-    resenc = workload.startswith('resenc')
+    plan_features = [min(w['max_features'], 32 * 2 ** i) for i in range(n)]
+    features = [max(f // r, 8) for f in plan_features]
+    resenc = w['resenc']
+    nd = len(patch)
+    conv_op = 'torch.nn.modules.conv.Conv%dd' % nd
     if resenc:
-        sds = [synthetic_resenc_checkpoint(features, kernels, strides, RESENC_BLOCKS[:n], 1, heads, seed=1234 + f) for f in range(folds)]
+        blocks = (list(RESENC_BLOCKS) + [RESENC_BLOCKS[-1]] * n)[:n]
+        sds = [synthetic_resenc_checkpoint(features, kernels, strides, blocks, in_ch, heads, seed=1234 + f) for f in range(folds)]
         arch = {'network_class_name': 'dynamic_network_architectures.architectures.unet.ResidualEncoderUNet',
-                'arch_kwargs': {'n_stages': n, 'features_per_stage': [min(320, 32 * 2 ** i) for i in range(n)],
-                                'kernel_sizes': kernels, 'strides': strides, 'n_blocks_per_stage': list(RESENC_BLOCKS[:n]),
+                'arch_kwargs': {'n_stages': n, 'features_per_stage': plan_features,
+                                'conv_op': conv_op, 'kernel_sizes': kernels, 'strides': strides, 'n_blocks_per_stage': blocks,
                                 'n_conv_per_stage_decoder': [1] * (n - 1), 'conv_bias': True,
                                 'norm_op_kwargs': {'eps': 1e-5, 'affine': True}},
                 '_kw_requires_import': []}
     else:
-        sds = [synthetic_checkpoint(features, kernels, strides, 1, heads, seed=1234 + f) for f in range(folds)]
+        sds = [synthetic_checkpoint(features, kernels, strides, in_ch, heads, seed=1234 + f) for f in range(folds)]
         arch = {'network_class_name': 'dynamic_network_architectures.architectures.unet.PlainConvUNet',
-                'arch_kwargs': {'n_stages': n, 'features_per_stage': [min(320, 32 * 2 ** i) for i in range(n)],
-                                'kernel_sizes': kernels, 'strides': strides, 'n_conv_per_stage': [2] * n,
+                'arch_kwargs': {'n_stages': n, 'features_per_stage': plan_features,
+                                'conv_op': conv_op, 'kernel_sizes': kernels, 'strides': strides, 'n_conv_per_stage': [2] * n,
                                 'n_conv_per_stage_decoder': [2] * (n - 1), 'conv_bias': True,
                                 'norm_op_kwargs': {'eps': 1e-5, 'affine': True}},
                 '_kw_requires_import': []}
+    cfg = '3d_fullres' if nd == 3 else '2d'
     pm = PlansManager({'dataset_name': 'Dataset000_Synthetic', 'plans_name': 'nnUNetPlans',
-                       'configurations': {'3d_fullres': {'patch_size': list(patch), 'spacing': list(spacing),
-                                                         'architecture': arch}}})
+                       'configurations': {cfg: {'patch_size': list(patch), 'spacing': list(spacing),
+                                                'architecture': arch}}})
     dj = {'labels': {('background' if i == 0 else f'class_{i}'): i for i in range(heads)},
-          'channel_names': {'0': 'CT'}, 'file_ending': '.nii.gz'}
+          'channel_names': {str(c): 'CT' for c in range(in_ch)}, 'file_ending': '.nii.gz'}
     p = nnUNetPredictor(tile_step_size=0.5, use_gaussian=True, use_mirroring=mirror, perform_everything_on_device=True,
                         device=device, allow_tqdm=False, accumulate_in=accumulate_in, patches_per_forward=batch,
                         compute_dtype=compute_dtype)
     p._reduction = None
-    p.manual_initialization(None, pm, pm.get_configuration('3d_fullres'), sds, dj, 'nnUNetDistillationTrainer',
-                            (0, 1, 2) if mirror else None)
-    return p, sds[0], dict(features=features, kernels=kernels, strides=strides, patch=patch, heads=heads, r=r, resenc=resenc)
+    p.manual_initialization(None, pm, pm.get_configuration(cfg), sds, dj, 'nnUNetDistillationTrainer',
+                            tuple(range(nd)) if mirror else None)
+    return p, sds[0], dict(features=features, kernels=kernels, strides=strides, patch=patch, heads=heads, r=r, resenc=resenc,
+                           in_channels=in_ch, blocks=(blocks if resenc else None))
 
 
-def synthetic_volume(size, device):
+def synthetic_volume(size, device, channels=1):
     """Preprocessed CT-like tensor: HU ~ N(418.68, 412.19) clipped to [-60, 3068], z-scored with the
-    fast_nnunet_bone_turbo constants (engine/config/fast_nnunet_bone_turbo.ini:15-18)."""
+    fast_nnunet_bone_turbo constants (engine/config/fast_nnunet_bone_turbo.ini:15-18).  `size`: an edge (cube) or (X, Y, Z)."""
+    shape = (size,) * 3 if isinstance(size, int) else tuple(size)
     g = torch.Generator(device='cpu').manual_seed(0)
-    out = torch.empty((1, size, size, size), dtype=torch.float32)
-    for x in range(0, size, 64):                       # chunked: keeps the host working set small
-        hu = torch.randn((min(64, size - x), size, size), generator=g) * 412.1883239746094 + 418.6798400878906
+    out = torch.empty((channels, *shape), dtype=torch.float32)
+    for x in range(0, shape[0], 64):                       # chunked: keeps the host working set small
+        hu = torch.randn((min(64, shape[0] - x), shape[1], shape[2]), generator=g) * 412.1883239746094 + 418.6798400878906
         out[0, x:x + hu.shape[0]] = (hu.clamp_(-60.0, 3068.0) - 418.6798400878906) / 412.1883239746094
+    for c in range(1, channels):                           # further channels: the first one shifted by c voxels along z (cheap, distinct)
+        out[c] = out[0].roll(c, dims=2)
     return out.to(device)
 
 
@@ -212,17 +242,17 @@ def cpu_baseline(sd, info, seconds_budget=60.0):
     from oracle.unet import build as build_oracle
     n = len(info['features'])
     if info['resenc']:
-        spec = UNetSpec('resenc', 1, info['heads'], info['features'], [tuple(k) for k in info['kernels']],
-                        [tuple(s) for s in info['strides']], list(RESENC_BLOCKS[:n]), [1] * (n - 1))
+        spec = UNetSpec('resenc', info['in_channels'], info['heads'], info['features'], [tuple(k) for k in info['kernels']],
+                        [tuple(s) for s in info['strides']], list(info['blocks']), [1] * (n - 1))
     else:
-        spec = UNetSpec('plain', 1, info['heads'], info['features'], [tuple(k) for k in info['kernels']],
+        spec = UNetSpec('plain', info['in_channels'], info['heads'], info['features'], [tuple(k) for k in info['kernels']],
                         [tuple(s) for s in info['strides']], [2] * n, [2] * (n - 1))
     net = build_oracle(spec, sd)
     patch = info['patch']
     all_threads = torch.get_num_threads()
     # sub-volume that holds exactly 2 x 2 x 2 = 8 patches at step 0.5
     shape8 = tuple(int(p * 1.5) for p in patch)
-    image8 = synthetic_volume(max(shape8), torch.device('cpu'))[:, :shape8[0], :shape8[1], :shape8[2]].contiguous()
+    image8 = synthetic_volume(max(shape8), torch.device('cpu'), info['in_channels'])[:, :shape8[0], :shape8[1], :shape8[2]].contiguous()
 
     def run(threads):
         torch.set_num_threads(threads)
@@ -271,6 +301,42 @@ def traffic_key(args):
     return f'{args.workload}|{args.dtype}|mirror={int(args.mirror)}|{args.accum}|vol={args.volume}|batch={args.batch}'
 
 
+def conv_family_names(kernel_counts):
+    """The kernel templates of the conv family among a profiled step's launches (their names without template arguments)."""
+    fam = sorted({k.split('<')[0].split(' ')[0] for k in kernel_counts if k.startswith('conv')})
+    return fam or ['(none)']
+
+
+def layer_table(engine, batch):
+    """Per layer of the network: the kernel the launch rules picked and what it achieves - median microseconds per forward
+    over the profiled step's full batches (HIP events around every launch, one stream), algorithmic TFLOP/s (2*MACs) and
+    TB/s (every input read once + the output written once, fp16)."""
+    layers = {L['index']: L for L in engine.layer_table()}
+    per = {}
+    for layer, fam, ms, flops, by, kern in engine.profile_launches():
+        if layer < 0:
+            continue
+        per.setdefault(layer, []).append((flops, ms, by, kern, fam))
+    rows = []
+    for li in sorted(per):
+        full = max(f for f, *_ in per[li])
+        runs = [r for r in per[li] if r[0] == full] or per[li]          # the batches of `batch` patches (the tail batch is smaller)
+        ms = float(np.median([r[1] for r in runs]))
+        L = layers[li]
+        flops, by = runs[0][0], runs[0][2]
+        if L['type'] == 'tconv':                                        # (the engine prices transposed convs' bytes as 0: priced here)
+            vi, vo = np.prod([int(v) for v in L['in_dims'].split('x')]), np.prod([int(v) for v in L['out_dims'].split('x')])
+            by = 2.0 * (L['cin'] * vi + L['cout'] * vo) * (flops / L['flops'] if L['flops'] else batch)
+        rows.append({'layer': li, 'type': L['type'] + ('+producer' if L['fused'] == 2 else ''), 'cin': L['cin'], 'cout': L['cout'],
+                     'kernel': L['kernel'], 'stride': L['stride'], 'out': L['out_dims'], 'picked': runs[0][3], 'us': round(ms * 1e3, 1),
+                     'tflops': round(flops / (ms * 1e-3) / 1e12, 1) if ms > 0 else None,
+                     'tbps': round(by / (ms * 1e-3) / 1e12, 2) if ms > 0 and by else None})
+    tot = sum(r['us'] for r in rows) or 1.0
+    for r in rows:
+        r['share'] = round(r['us'] / tot, 4)
+    return rows
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) BEFORE anything in
     this process touches the GPU, wait for them, and leave with the worst exit code.  Rank 0 prints the JSON line."""
@@ -303,8 +369,11 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='bone_turbo_r2', choices=list(WORKLOADS))
+    ap.add_argument('--plan', default=None,
+                    help='a plan file (tools/plans/*.json: patch, spacing, input channels, classes, r, kind, volume) instead of a named '
+                         'workload: the topology comes from the planning rule (plan_topology), the line carries a per-layer table')
     ap.add_argument('--volume', type=int, default=512)
-    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--batch', type=int, default=None, help='patches per forward (default 32, or the plan file\'s)')
     ap.add_argument('--accum', default='fp16', choices=['fp16', 'fp32', 'fp16_autocast'],
                     help="accumulation arithmetic: 'fp16' = the reference without autocast (its CPU path; the oracle's "
                          "default and the bench line), 'fp16_autocast' = the reference on a GPU (fp16 network output)")
@@ -313,6 +382,7 @@ def main():
     ap.add_argument('--mirror', action='store_true',
                     help='test-time mirroring over all three axes (8 evaluations per patch; the reference default, off in the '
                          'bone_turbo .ini and in the bench line)')
+    ap.add_argument('--layers', action='store_true', help='add the per-layer table of the profiled step (always on with --plan)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-clock-probe', action='store_true', help='skip the extra step that samples the shader clock (fnn_clock_probe_*)')
@@ -326,6 +396,9 @@ def main():
                     help='fold ensemble (BASELINE configs[3]: 5 folds of the teacher): the folds stay resident, their logits are '
                          'averaged on the device (fnn_predict_volume_ensemble); one step = one volume through ALL folds')
     args = ap.parse_args()
+    args.batch_given = args.batch is not None
+    if args.batch is None:
+        args.batch = 32
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         spawn_ranks(args.gpus)                                  # does not return
@@ -349,8 +422,11 @@ def main():
     torch.cuda.set_device(device)
 
     accumulate_in = args.accum                                  # halo sums travel in the accumulator dtype
-    predictor, sd, info = build_predictor(args.workload, device, args.batch, accumulate_in, args.dtype, args.mirror, args.folds)
-    vol = synthetic_volume(args.volume, device)
+    w = resolve_workload(args)
+    if len(w['patch']) == 2 and distributed:
+        raise SystemExit('bench.py: the sharded path is 3-D only')
+    predictor, sd, info = build_predictor(w, device, args.batch, accumulate_in, args.dtype, args.mirror, args.folds)
+    vol = synthetic_volume(w['volume'], device, w['in_channels'])
     from fast_nnunet_amd import capi
     n_patches = capi.plan_volume(info['patch'], vol.shape[1:], 0.5)[2].shape[0]
 
@@ -429,8 +505,11 @@ def main():
         'fp16 logits [heads, X, Y, Z] in HBM (predict_sliding_window_return_logits)'
     out_kind = {'labels': 'label map assembled on every rank', 'logits': 'fp16 logits assembled on every rank',
                 'none': 'fp16 logits resident in HBM'}[args.gather] if distributed else 'fp16 logits resident in HBM'
+    vshape = 'x'.join(map(str, w['volume']))
+    vol_desc = f'{args.volume}^3 volume' if not w['plan'] else f'{vshape} volume'
+    what = 'distilled r=2 student, sliding window, one 512^3 CT' if not w['plan'] else f'plan {w["name"]}, sliding window, one {vshape} volume'
     result = {
-        'metric': f'3d_fullres patches/sec (distilled r=2 student, sliding window, one 512^3 CT; step ends with: {out_kind})',
+        'metric': f'3d_fullres patches/sec ({what}; volume resident in HBM at step start; step ends with: {out_kind})',
         'value': round(n_patches * args.folds * args.steps / dt, 3),
         'unit': 'patches/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -441,11 +520,11 @@ def main():
         'vs_baseline': None,
         'dtype': args.dtype,
         'data': 'synthetic',
-        'config': {'workload': f'{args.workload}: {"ResidualEncoderUNet" if info["resenc"] else "PlainConvUNet"} '
+        'config': {'workload': f'{w["name"]}: {"ResidualEncoderUNet" if info["resenc"] else "PlainConvUNet"} '
                                f'{"student" if info["r"] > 1 else "teacher"} r={info["r"]}, '
-                               f'features {info["features"]}, '
+                               f'features {info["features"]}, {info["in_channels"]} input channel{"s" if info["in_channels"] > 1 else ""}, '
                                f'patch {"x".join(map(str, info["patch"]))}, {info["heads"]} classes, '
-                               f'{args.volume}^3 volume, tile_step_size 0.5, Gaussian on, mirroring {"(0, 1, 2)" if args.mirror else "off"}, '
+                               f'{vol_desc}, tile_step_size 0.5, Gaussian on, mirroring {"on (all axes)" if args.mirror else "off"}, '
                                f'{n_patches} patches/volume',
                    'patches_per_forward': args.batch,
                    'folds': args.folds,
@@ -455,6 +534,9 @@ def main():
                    'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                    'parallelism': f'patch-sharded x{world}, patch-activation exchange + slab gather over RCCL' if distributed else 'single GPU'},
     }
+    if w['plan']:
+        result['config']['plan'] = {'file': os.path.relpath(os.path.abspath(args.plan), ROOT), 'spacing': list(w['spacing']),
+                                    'kernels': info['kernels'], 'strides': info['strides'], 'note': w['note']}
     if args.folds > 1:
         result['sec_per_volume_per_fold'] = round(dt / args.steps / args.folds, 4)
         result['config']['ensemble'] = (f'{args.folds} resident folds, logits averaged on the device; value counts one patch forward per fold '
@@ -496,6 +578,7 @@ def main():
         pr = predictor._engine.profile()
         import collections
         kernel_counts = dict(collections.Counter(predictor._engine.kernel_log()))   # which variant served every launch of that volume (N > 1: of the last engine call)
+        layer_rows = layer_table(predictor._engine, args.batch) if (w['plan'] or args.layers) else None
         predictor._engine.set_profiling(False)
     if rank == 0 and not args.no_roofline:
         achieved = pr.conv_flops / (pr.conv_ms * 1e-3) / 1e12 if pr.conv_ms > 0 else 0.0
@@ -520,7 +603,7 @@ def main():
             except Exception as ex:
                 traffic_src = f'profiles/{TRAFFIC_FILE} unreadable: {ex}'
         result['roofline'] = {
-            'kernel': 'MFMA conv family: conv3d_zr / zsp / s2 / lds / persist kernels, conv_row_kernel and conv_row_stem_kernel', 'bound': 'mfma',
+            'kernel': 'MFMA conv family, as launched in the profiled step: ' + ', '.join(conv_family_names(kernel_counts)), 'bound': 'mfma',
             'achieved': round(achieved, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / MFMA_PEAK_TFLOPS, 4),
             # the shader clock the device held during most of one extra step identical to the timed ones (fnn_clock_probe_*:
@@ -552,6 +635,8 @@ def main():
             'profiled': 'rank 0, its interior patches (the last fnn_patch_features call of one extra step)' if distributed else 'one extra volume on one stream',
             'launches_by_kernel': kernel_counts,
         }
+        if layer_rows is not None:
+            result['layers'] = layer_rows
     if rank == 0 and not distributed and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(sd, info)
     if distributed:

@@ -63,7 +63,7 @@ class Profile(C.Structure):
 EXPORTS = ['fnn_abi_version', 'fnn_last_error', 'fnn_create', 'fnn_destroy', 'fnn_weight_count', 'fnn_load_weights',
            'fnn_set_gaussian', 'fnn_predict_volume', 'fnn_predict_volume_ensemble', 'fnn_predict_labels',
            'fnn_set_label_rule', 'fnn_accumulator_channels', 'fnn_accumulate_patches', 'fnn_normalize_box', 'fnn_labels_box', 'fnn_feature_channels', 'fnn_patch_features', 'fnn_gather_box', 'fnn_pack_regions', 'fnn_unpack_regions', 'fnn_forward_patches', 'fnn_argmax_labels', 'fnn_nonzero_bbox', 'fnn_preprocess', 'fnn_revert_labels', 'fnn_export_probabilities', 'fnn_resample', 'fnn_compute_steps', 'fnn_plan_volume', 'fnn_fp8_e4m3_encode',
-           'fnn_set_profiling', 'fnn_get_profile', 'fnn_kernel_log', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d', 'fnn_op_quotient_check', 'fnn_op_last_kernels', 'fnn_clock_probe_start', 'fnn_clock_probe_stop']
+           'fnn_set_profiling', 'fnn_get_profile', 'fnn_kernel_log', 'fnn_profile_launches', 'fnn_layer_table', 'fnn_patch_work', 'fnn_op_conv3d', 'fnn_op_conv_transpose3d', 'fnn_op_quotient_check', 'fnn_op_last_kernels', 'fnn_clock_probe_start', 'fnn_clock_probe_stop']
 
 _lib = None
 
@@ -125,6 +125,9 @@ def load_library() -> C.CDLL:
     lib.fnn_get_profile.argtypes = [vp, C.POINTER(Profile)]
     lib.fnn_kernel_log.argtypes = [vp, C.c_char_p, i64]
     lib.fnn_kernel_log.restype = i64
+    for fn in (lib.fnn_profile_launches, lib.fnn_layer_table):
+        fn.argtypes = [vp, C.c_char_p, i64]
+        fn.restype = i64
     lib.fnn_patch_work.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     I3 = C.POINTER(C.c_int)
     lib.fnn_op_conv3d.argtypes = [i32, i32, I3, f32p, i32, f32p, f32p, C.c_float, f32p, i32, f32p, f32p, C.c_float,
@@ -363,6 +366,22 @@ class Engine:
         buf = C.create_string_buffer(int(n))
         self.lib.fnn_kernel_log(self.handle, buf, n)
         return [k for k in buf.value.decode().split('\n') if k]
+
+    def _text(self, fn):
+        n = fn(self.handle, None, 0)
+        buf = C.create_string_buffer(int(n))
+        fn(self.handle, buf, n)
+        return [r.split('\t') for r in buf.value.decode().split('\n') if r]
+
+    def profile_launches(self):
+        """Rows (layer, family, ms, flops, bytes, kernels) of every timed launch of the last profiled call."""
+        return [(int(r[0]), r[1], float(r[2]), float(r[3]), float(r[4]), r[5] if len(r) > 5 else '') for r in self._text(self.lib.fnn_profile_launches)]
+
+    def layer_table(self):
+        """The engine's layer plan: dicts with index, type, cin, cout, kernel, stride, in_dims, out_dims, flops, bytes, fused."""
+        keys = ('index', 'type', 'cin', 'cout', 'kernel', 'stride', 'in_dims', 'out_dims', 'flops', 'bytes', 'fused')
+        conv = (int, str, int, int, str, str, str, str, float, float, int)
+        return [dict((k, c(v)) for k, c, v in zip(keys, conv, r)) for r in self._text(self.lib.fnn_layer_table)]
 
     def patch_work(self):
         fl, by = C.c_double(), C.c_double()

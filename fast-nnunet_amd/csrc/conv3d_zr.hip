@@ -1844,6 +1844,8 @@ static int launch_zr8(ConvParams p, hipStream_t st) {
     }
     p.ident_ss = conv3d_identity_ss();
     if (!p.ident_ss || !p.oscale) return -2;
+    // one statistics row per tile: a plan that sized the rows for another tiling must not reach this kernel
+    if (p.stats_out && p.stats_slots < p.tiles_d * p.tiles_h * p.tiles_w) return -1;
     dim3 grid(p.N * p.tiles_d * p.tiles_h * p.tiles_w, (p.Cout / 16) / NB);
     fnn_note_kernel("conv3d_zr8_kernel<%d,%d>", NB, TD);
     hipLaunchKernelGGL((conv3d_zr8_kernel<NB, TD>), grid, dim3(256), lds, st, p);

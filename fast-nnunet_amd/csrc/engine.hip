@@ -130,8 +130,10 @@ struct fnn_engine {
     double head_flops = 0, patch_flops = 0, patch_act_bytes = 0;
     // profiling
     bool profiling = false;
-    struct Ev { hipEvent_t a, b; int family; double flops, bytes; };
+    struct Ev { hipEvent_t a, b; int family; double flops, bytes; int layer; size_t klog_lo, klog_hi; };
     std::vector<Ev> evs; size_t ev_used = 0;
+    int cur_layer = -1;                     // layer index of the launches being issued (-1: head / gather / finalize)
+    std::vector<std::string> launch_rows;   // fnn_profile_launches: one row per timed launch of the last profiled call
     fnn_profile prof{};
 };
 
@@ -443,17 +445,23 @@ int build_plan(fnn_engine *e) {
                 q.plan_N = e->max_batch; q.N = e->max_batch; q.Cout = L.cout_pad; q.chunks = L.chunks;
                 q.Do = L.out_dims[0]; q.Ho = L.out_dims[1]; q.Wo = L.out_dims[2];
                 q.kd = L.k[0]; q.kh = L.k[1]; q.kw = L.k[2]; q.sd = L.s[0]; q.sh = L.s[1]; q.sw = L.s[2];
+                // e4m3 operands: the stride-1 3x3x3 layers the fp8 ZR kernel takes (the strided depth-shift kernel is fp16 only).
+                // The probes see the SAME fp8 flag the launch will carry (the variant choice depends on it: the fp16-only
+                // six-row tiles) - packing, tile depth and statistics rows are then the launch's; a layer the fp8 pick refuses
+                // stays fp16 with whatever that pick gives it.
+                q.fp8 = a.precision == FNN_PREC_F8 && !L.fuse && T == 27 && L.s[0] == 1 && L.s[1] == 1 && L.s[2] == 1;
+                if (q.fp8 && fnn_knob("FNN_FP8_LEVELS")) {
+                    // sensitivity studies (tools/fp8_sensitivity.py): e4m3 operands only at the resolution levels of the bit mask
+                    // (level = how many times the patch's voxel count was divided by ~8 on the way to this layer's output)
+                    const double P = (double)a.patch[0] * a.patch[1] * a.patch[2];
+                    const int level = (int)std::lround(std::log2(P / (double)ovox) / 3.0);
+                    q.fp8 = ((atoi(fnn_knob("FNN_FP8_LEVELS")) >> level) & 1) != 0;
+                }
                 L.packing = L.fuse ? FNN_PACK_LINEAR : conv3d_packing(q);
+                if (q.fp8 && L.packing != FNN_PACK_ZR) { q.fp8 = 0; L.packing = conv3d_packing(q); }
+                L.fp8 = q.fp8 != 0;
             }
             L.ksteps = conv3d_ksteps(L.packing, T);
-            L.fp8 = a.precision == FNN_PREC_F8 && L.packing == FNN_PACK_ZR && L.s[0] == 1 && L.s[1] == 1 && L.s[2] == 1;   // (the strided depth-shift kernel is fp16 only)
-            if (L.fp8 && fnn_knob("FNN_FP8_LEVELS")) {
-                // sensitivity studies (tools/fp8_sensitivity.py): e4m3 operands only at the resolution levels of the bit mask
-                // (level = how many times the patch's voxel count was divided by ~8 on the way to this layer's output)
-                const double P = (double)a.patch[0] * a.patch[1] * a.patch[2];
-                const int level = (int)std::lround(std::log2(P / (double)ovox) / 3.0);
-                L.fp8 = ((atoi(fnn_knob("FNN_FP8_LEVELS")) >> level) & 1) != 0;
-            }
             L.w_off = wpk; wpk += (size_t)(L.cout_pad / 16) * L.chunks * L.ksteps * 512;
         } else if (L.type == Layer::TCONV) {
             const int taps = L.s[0] * L.s[1] * L.s[2];
@@ -471,6 +479,7 @@ int build_plan(fnn_engine *e) {
             q.plan_N = e->max_batch; q.N = e->max_batch; q.Cout = L.cout_pad; q.chunks = L.chunks;
             q.Do = L.out_dims[0]; q.Ho = L.out_dims[1]; q.Wo = L.out_dims[2];
             q.kd = L.k[0]; q.kh = L.k[1]; q.kw = L.k[2]; q.sd = L.s[0]; q.sh = L.s[1]; q.sw = L.s[2];
+            q.fp8 = L.fp8;
             L.stats_slots = conv3d_stats_slots(q);
         }
         L.stats_off = st; if (L.has_norm) st += (size_t)L.stats_slots * L.cout_pad * 2;
@@ -627,19 +636,31 @@ struct Scope {
         }
         idx = (int)e->ev_used++;
         e->evs[idx].family = family; e->evs[idx].flops = flops; e->evs[idx].bytes = bytes;
+        e->evs[idx].layer = e->cur_layer; e->evs[idx].klog_lo = e->evs[idx].klog_hi = e->klog.size();
         (void)hipEventRecord(e->evs[idx].a, st);
     }
-    ~Scope() { if (idx >= 0) (void)hipEventRecord(e->evs[idx].b, st); }
+    ~Scope() { if (idx >= 0) { (void)hipEventRecord(e->evs[idx].b, st); e->evs[idx].klog_hi = e->klog.size(); } }
 };
 
 void collect_profile(fnn_engine *e, int64_t n_patches) {
     fnn_profile &p = e->prof;
     p = fnn_profile{};
     p.n_patches = n_patches;
+    e->launch_rows.clear();
     for (size_t i = 0; i < e->ev_used; ++i) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, e->evs[i].a, e->evs[i].b) != hipSuccess) continue;
         p.total_ms += ms;
+        {
+            static const char *const fam[] = {"conv", "stem", "tconv", "head", "finalize"};
+            const fnn_engine::Ev &v = e->evs[i];
+            char row[320];
+            std::string names;
+            for (size_t k = v.klog_lo; k < v.klog_hi && k < e->klog.size(); ++k) { if (!names.empty()) names += " + "; names += e->klog[k]; }
+            snprintf(row, sizeof row, "%d\t%s\t%.6f\t%.6g\t%.6g\t%s", v.layer, fam[v.family >= 0 && v.family <= 4 ? v.family : 4],
+                     (double)ms, v.flops, v.bytes, names.c_str());
+            e->launch_rows.push_back(row);
+        }
         switch (e->evs[i].family) {
             case FAM_CONV: p.conv_ms += ms; p.conv_launches++; p.conv_flops += e->evs[i].flops; p.conv_bytes += e->evs[i].bytes; break;
             case FAM_STEM: p.stem_ms += ms; break;
@@ -684,8 +705,10 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
                   float *head_ss = nullptr, unsigned short *head_ssh = nullptr) {
     const FoldWeights &fw = e->folds[fold];
     HIPCHK(e, hipMemsetAsync(e->stats, 0, e->stats_doubles * e->max_batch * sizeof(double), st));
+    struct LayerMark { fnn_engine *e; ~LayerMark() { e->cur_layer = -1; } } mark{e};
     for (size_t li = 0; li < e->layers.size(); ++li) {
         const Layer &L = e->layers[li];
+        e->cur_layer = (int)li;
         f16 *out = e->act + L.out_off * e->max_batch;
         if (head_out && (int)li == e->head_src) out = head_out;
         double *stats_out = L.has_norm ? e->stats + L.stats_off * e->max_batch : nullptr;
@@ -1857,6 +1880,39 @@ int64_t fnn_kernel_log(const fnn_engine *e, char *buf, int64_t cap) {
     if (!e) return FNN_E_INVALID;
     std::string all;
     for (const std::string &k : e->klog) { all += k; all += '\n'; }
+    if (buf && cap > 0) {
+        const size_t n = std::min((size_t)cap - 1, all.size());
+        memcpy(buf, all.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)all.size() + 1;
+}
+
+int64_t fnn_profile_launches(const fnn_engine *e, char *buf, int64_t cap) {
+    if (!e) return FNN_E_INVALID;
+    std::string all;
+    for (const std::string &k : e->launch_rows) { all += k; all += '\n'; }
+    if (buf && cap > 0) {
+        const size_t n = std::min((size_t)cap - 1, all.size());
+        memcpy(buf, all.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)all.size() + 1;
+}
+
+int64_t fnn_layer_table(const fnn_engine *e, char *buf, int64_t cap) {
+    if (!e) return FNN_E_INVALID;
+    static const char *const ty[] = {"stem", "conv", "tconv", "pool", "combine"};
+    std::string all;
+    for (size_t li = 0; li < e->layers.size(); ++li) {
+        const Layer &L = e->layers[li];
+        char row[256];
+        snprintf(row, sizeof row, "%zu\t%s\t%d\t%d\t%dx%dx%d\t%dx%dx%d\t%dx%dx%d\t%dx%dx%d\t%.6g\t%.6g\t%d\n", li, ty[L.type],
+                 L.cin_real[0] + (L.n_src > 1 ? L.cin_real[1] : 0), L.cout_real, L.k[0], L.k[1], L.k[2], L.s[0], L.s[1], L.s[2],
+                 L.in_dims[0], L.in_dims[1], L.in_dims[2], L.out_dims[0], L.out_dims[1], L.out_dims[2], L.flops, L.bytes,
+                 L.virtual_out ? 1 : (L.fuse ? 2 : 0));
+        all += row;
+    }
     if (buf && cap > 0) {
         const size_t n = std::min((size_t)cap - 1, all.size());
         memcpy(buf, all.data(), n);

@@ -923,7 +923,9 @@ int launch_quotient_check(unsigned long long *counts, hipStream_t st) {         
 #define FNN_GATHER_PASS_HEADS 63                                   // heads per pass: 63 + the weight-sum row = 4 blocks of 16
 bool gather_ok(const GatherParams &p) {
     const int hblocks = (p.heads + 1 + 15) / 16;
-    return (hblocks <= 4 || p.n_pass > 1) && p.C <= 32 && p.C % 8 == 0 && (long long)p.PD * p.PH * p.PW < (1LL << 31) / 32 && p.n_eval <= 8 &&
+    return (hblocks <= 4 || p.n_pass > 1) && p.C <= 32 && p.C % 8 == 0 && (long long)p.PD * p.PH * p.PW < (1LL << 31) / 32 &&
+           (long long)p.PD * p.PH * p.PW * p.C * 2 < (1LL << 31) &&   // a slot's bytes stay below the staging's 0x80000000 "not fetched" offset
+           p.n_eval <= 8 &&
            (p.n_eval & (p.n_eval - 1)) == 0 &&                 // 1, 2, 4 or 8 evaluations (the mean over them is a multiply by 2^-k)
            ((p.nx <= 64 && p.ny <= 64 && p.nz <= 64) || p.windowed);   // a wave holds 64 of an axis' tile starts one per lane
 }

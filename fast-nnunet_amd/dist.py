@@ -580,7 +580,8 @@ class ShardedPredictor:
         from . import capi
         p = self.p
         key = (tuple(int(v) for v in x.shape[1:]), float(p.tile_step_size), self.world,
-               tuple(int(v) for v in p._spec.patch), int(p._spec.spatial_dims), id(p._spec))
+               tuple(int(v) for v in p._spec.patch), int(p._spec.spatial_dims),
+               int(p._spec.features[0]), int(p._spec.num_heads))      # the spec's content, not its id() (ids are reused)
         hit = self._plans.get(key)
         if hit is not None:
             self._plans.move_to_end(key)

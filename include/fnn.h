@@ -355,6 +355,16 @@ int fnn_get_profile(const fnn_engine *e, fnn_profile *out);
  * (with the terminating 0); writes at most `cap`.  No counterpart in the reference. */
 int64_t fnn_kernel_log(const fnn_engine *e, char *buf, int64_t cap);
 
+/* Per-launch rows of the same profiled call (measurement aid of bench.py --plan / tools/plan_sweep.py; additive in ABI 4,
+ * no counterpart in the reference): one line per timed launch, tab-separated -
+ *   layer index (-1: seg head / gather / finalize), family (conv | stem | tconv | head | finalize), milliseconds between
+ *   the launch's two HIP events, algorithmic 2*MACs, algorithmic HBM bytes, kernel variant(s) as in fnn_kernel_log.
+ * fnn_layer_table describes the layers those indices name: index, type, input channels, output channels, kernel, stride,
+ * input dims, output dims, 2*MACs per patch, algorithmic bytes per patch, 1 = computed inside its consumer / 2 = a
+ * consumer that recomputes its producer / 0.  Both return the bytes needed and write at most `cap`. */
+int64_t fnn_profile_launches(const fnn_engine *e, char *buf, int64_t cap);
+int64_t fnn_layer_table(const fnn_engine *e, char *buf, int64_t cap);
+
 /* Algorithmic work of one patch forward: 2*MACs of convs, transposed convs and
  * the seg head; ideal fp16 activation bytes (each activation written once and
  * read once).  SURVEY.md 8d. */
