@@ -337,6 +337,46 @@ def layer_table(engine, batch):
     return rows
 
 
+ALSO = [('C1 iso128_r2', ['--workload', 'iso128_r2']),
+        ('C4 iso128_teacher, 5-fold ensemble', ['--workload', 'iso128_teacher', '--folds', '5']),
+        ('C5 resenc160_r2 f16', ['--workload', 'resenc160_r2']),
+        ('C5 resenc160_r2 f8', ['--workload', 'resenc160_r2', '--dtype', 'f8'])]
+
+
+def also_block(device):
+    """The other single-GPU BASELINE configurations, 3 timed steps each (1 warm-up), every one in a process of its own
+    started AFTER this process has finished its GPU work (its memory is released first) - so that the driver's record
+    carries C1 / C4 / C5 next to the headline.  Child lines are trimmed to the fields a reader compares."""
+    import gc
+    import subprocess
+    gc.collect()
+    torch.cuda.empty_cache()
+    out = {}
+    for name, flags in ALSO:
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-also',
+               '--no-from-host'] + flags
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            if r.returncode != 0 or not line:
+                out[name] = {'error': (r.stderr or r.stdout)[-300:]}
+                continue
+            j = json.loads(line[-1])
+            rf = j.get('roofline', {})
+            out[name] = {'value': j['value'], 'unit': j['unit'], 'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'dtype': j['dtype'],
+                         'workload': j['config']['workload'], 'folds': j['config']['folds'],
+                         'frac': rf.get('frac'), 'achieved_tflops': rf.get('achieved'), 'clock_ghz': rf.get('clock_ghz'),
+                         'frac_at_clock': rf.get('frac_at_clock'), 'traffic_over_algorithmic': rf.get('traffic_over_algorithmic'),
+                         'hidden_by_batches_in_flight': rf.get('schedules', {}).get('hidden_by_batches_in_flight'),
+                         'wall_s': round(time.perf_counter() - t0, 1)}
+            if 'sec_per_volume_per_fold' in j:
+                out[name]['sec_per_volume'] = j['sec_per_volume']
+        except subprocess.TimeoutExpired:
+            out[name] = {'error': 'timeout'}
+    return out
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) BEFORE anything in
     this process touches the GPU, wait for them, and leave with the worst exit code.  Rank 0 prints the JSON line."""
@@ -383,6 +423,10 @@ def main():
                     help='test-time mirroring over all three axes (8 evaluations per patch; the reference default, off in the '
                          'bone_turbo .ini and in the bench line)')
     ap.add_argument('--layers', action='store_true', help='add the per-layer table of the profiled step (always on with --plan)')
+    ap.add_argument('--no-from-host', action='store_true', help='skip the steps that start from a host tensor (ms_per_step_from_host)')
+    ap.add_argument('--no-also', action='store_true',
+                    help='skip the `also` block (N = 1, default workload only: 3 timed steps each of the other single-GPU BASELINE '
+                         'configurations, each in a process of its own)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-clock-probe', action='store_true', help='skip the extra step that samples the shader clock (fnn_clock_probe_*)')
@@ -498,6 +542,36 @@ def main():
         del out
         dt_labels = timed(labels_fn, barrier, max(1, min(args.steps, 5)))   # the step that ends with the label map on every rank
 
+    from_host = None
+    if not distributed and not args.no_from_host and not w['plan'] and args.folds == 1:
+        # The same step as a reference caller sees it: the preprocessed volume is a CPU tensor (what the preprocessing iterator
+        # yields, data_iterators.py:116-117; `data.to(results_device)` at predict_from_raw_data.py:579).  The engine uploads it
+        # by x slabs on a copy stream under the first batches (engine.hip, stage_volume / upload_until).  Untimed extras.
+        def raw_copy(t):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d = t.to(device)
+            torch.cuda.synchronize()
+            del d
+            return (time.perf_counter() - t0) * 1e3
+        k = max(1, min(args.steps, 3))
+        vol_cpu = vol.cpu()
+        raw_pageable = min(raw_copy(vol_cpu) for _ in range(2))
+        fn = lambda: predictor.predict_sliding_window_return_logits(vol_cpu)
+        out = fn(); del out
+        dt_pageable = timed(fn, barrier, k) / k
+        vol_pin = vol_cpu.pin_memory()
+        raw_pinned = min(raw_copy(vol_pin) for _ in range(2))
+        fn = lambda: predictor.predict_sliding_window_return_logits(vol_pin)
+        out = fn(); del out
+        dt_pinned = timed(fn, barrier, k) / k
+        del vol_pin, vol_cpu
+        from_host = {'ms_per_step_pinned': round(dt_pinned * 1e3, 3), 'ms_per_step_pageable': round(dt_pageable * 1e3, 3),
+                     'raw_copy_ms_pinned': round(raw_pinned, 3), 'raw_copy_ms_pageable': round(raw_pageable, 3), 'steps': k,
+                     'volume_mib': round(vol.numel() * 4 / 2 ** 20, 1),
+                     'note': 'the same step with the volume handed over as a CPU tensor: uploaded by x slabs on a copy stream, a batch '
+                             'starts when the slabs under its patches have landed; raw_copy_ms = one torch .to(device) of the same tensor'}
+
     flops_patch, act_bytes_patch = predictor._engine.patch_work()
     assembly = {'labels': 'labels on the owner of each box, all_gather of the uint8 slabs: the label map on every rank',
                 'logits': 'all_gather of the fp16 logits of the owned boxes: the logits on every rank',
@@ -537,6 +611,11 @@ def main():
     if w['plan']:
         result['config']['plan'] = {'file': os.path.relpath(os.path.abspath(args.plan), ROOT), 'spacing': list(w['spacing']),
                                     'kernels': info['kernels'], 'strides': info['strides'], 'note': w['note']}
+    if from_host is not None:
+        result['ms_per_step_from_host'] = from_host['ms_per_step_pinned']
+        from_host['minus_resident_ms'] = {'pinned': round(from_host['ms_per_step_pinned'] - result['ms_per_step'], 3),
+                                          'pageable': round(from_host['ms_per_step_pageable'] - result['ms_per_step'], 3)}
+        result['from_host'] = from_host
     if args.folds > 1:
         result['sec_per_volume_per_fold'] = round(dt / args.steps / args.folds, 4)
         result['config']['ensemble'] = (f'{args.folds} resident folds, logits averaged on the device; value counts one patch forward per fold '
@@ -642,6 +721,12 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and not distributed and not args.no_also and not w['plan'] and args.workload == 'bone_turbo_r2' and args.folds == 1 \
+            and args.dtype == 'f16' and not args.mirror and args.accum == 'fp16' and args.volume == 512:
+        predictor._engine.close()                               # (every figure of this process is in `result` by now: its HBM goes back first)
+        predictor._engine = None
+        del vol
+        result['also'] = also_block(device)
     if rank == 0:                                              # last, so that the JSON is the last line on stdout
         sys.stderr.flush()
         print(json.dumps(result), flush=True)

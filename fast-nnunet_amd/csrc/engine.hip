@@ -18,13 +18,14 @@
 #include <algorithm>
 #include <climits>
 #include <vector>
+#include <thread>
 
 namespace {
 
 thread_local std::string g_err;
 
 struct Layer {
-    enum Type { STEM, CONV, TCONV, POOL, COMBINE } type;
+    enum Type { STEM, CONV, TCONV, POOL, COMBINE, GATHER } type;   // GATHER: the patches' input windows as an fp16 tensor (stem on the conv kernels)
     int n_src = 1;
     int cin_real[2] = {0, 0}, cin_pad[2] = {0, 0};
     int cout_real = 0, cout_pad = 0;
@@ -115,6 +116,23 @@ struct fnn_engine {
     int *origins_host = nullptr; size_t origins_host_cap = 0; hipEvent_t origins_ev = nullptr;   // pinned staging, as for steps_dev below
     void *acc = nullptr; size_t acc_bytes = 0;
     float *vol_tmp = nullptr; size_t vol_tmp_bytes = 0;
+    // A volume that arrives in HOST memory (the reference's callers hand over the CPU tensor of the preprocessing iterator,
+    // predict_from_raw_data.py:579 `data = data.to(results_device)`): it is uploaded by x slabs on a copy stream of the
+    // engine's, and a batch of patches starts as soon as the slabs under its patches have landed - the patch order is
+    // x-major (:532-537), so the slabs are needed in the order they travel.  Pinned source: DMA straight from it; pageable
+    // source: through a ring of pinned staging buffers filled by a few host threads.
+    struct Upload {
+        bool active = false, pinned_src = false;
+        const float *host = nullptr; float *dev = nullptr;
+        int C = 0; int64_t X = 0, Y = 0, Z = 0, slab_x = 1, issued_x = 0;
+        std::vector<hipEvent_t> landed;        // landed[i]: slab i is in HBM (events are kept between calls)
+        size_t n_slabs = 0;
+        hipStream_t st = nullptr;
+        static constexpr int RING = 3;
+        float *stage[RING] = {}; size_t stage_bytes = 0; hipEvent_t stage_free[RING] = {}; bool stage_used[RING] = {};
+        int next_stage = 0;
+        hipEvent_t go = nullptr;
+    } up;
     float *vol_pad = nullptr; size_t vol_pad_bytes = 0;
     void *out_tmp = nullptr; size_t out_tmp_bytes = 0;
     float *patch_buf = nullptr; size_t patch_buf_bytes = 0;
@@ -267,6 +285,28 @@ int build_plan(fnn_engine *e) {
         e->layers.push_back(L);
         return (int)e->layers.size() - 1;
     };
+    // The first conv of the network.  One input channel in 3-D: the stem kernels (conv3d_thin.hip / conv3d_row.hip: the window
+    // of the fp32 volume in LDS, one MFMA per 16 voxels).  More channels (multi-modal MR, a cascade's one-hot channels) or a
+    // `2d` configuration (depth-1 tiles: a sixteenth of that kernel's tile): the patches' windows are first written as an fp16
+    // tensor with the channels padded to 16 (patch_input_kernel, misc.hip) and the stem is an ordinary conv layer on the MFMA
+    // conv kernels - plan sweep, round 6: the generic multi-channel stem took 17 % (4 channels) to 55 % (14) of a forward.
+    auto add_stem = [&](int cin, int cout, const int32_t *k, const int *d) {
+        const bool via_conv = (cin >= 2 || d[0] < 8) && fnn_knob("FNN_STEM_DIRECT") == nullptr;       // (knob: A-B aid / the tests of the generic stem kernel)
+        const int c[2] = {cin, 0};
+        if (!via_conv) {
+            const int src[2] = {-1, -1};
+            return add_conv(Layer::STEM, 1, c, src, cout, k, one, d, d);
+        }
+        Layer G;
+        G.type = Layer::GATHER; G.n_src = 1; G.has_norm = false;
+        G.cin_real[0] = cin; G.cin_pad[0] = pad16(cin); G.cout_real = cin; G.cout_pad = pad16(cin);
+        for (int q = 0; q < 3; ++q) { G.in_dims[q] = d[q]; G.out_dims[q] = d[q]; }
+        e->layers.push_back(G);
+        const int src[2] = {(int)e->layers.size() - 1, -1};
+        const int li = add_conv(Layer::CONV, 1, c, src, cout, k, one, d, d);
+        e->layers[li].bytes += 2.0 * cin * (double)d[0] * d[1] * d[2];                  // the network input is fp32 in HBM
+        return li;
+    };
     if (a.kind == FNN_NET_PLAIN) {
         for (int s = 0; s < a.n_stages; ++s) {
             if (a.n_conv_enc[s] < 1) return fail(e, FNN_E_INVALID, "n_conv_per_stage must be >= 1");
@@ -274,8 +314,8 @@ int build_plan(fnn_engine *e) {
                 const int cin[2] = {prev_c, 0}, src[2] = {prev, -1};
                 const bool first = (s == 0 && i == 0);
                 const int *in_d = (i == 0 && s > 0) ? dims[s - 1] : dims[s];
-                prev = add_conv(first ? Layer::STEM : Layer::CONV, 1, cin, src, a.features[s], a.kernels[s],
-                                i == 0 ? a.strides[s] : one, in_d, dims[s]);
+                prev = first ? add_stem(prev_c, a.features[s], a.kernels[s], dims[s])
+                             : add_conv(Layer::CONV, 1, cin, src, a.features[s], a.kernels[s], i == 0 ? a.strides[s] : one, in_d, dims[s]);
                 prev_c = a.features[s];
             }
             enc_last[s] = prev;
@@ -284,8 +324,7 @@ int build_plan(fnn_engine *e) {
         // ResidualEncoderUNet: stem conv, then per stage n_conv_enc[s] BasicBlockD blocks
         //   y = LeakyReLU(norm(conv2(act(norm(conv1(x))))) + skip(x)),  skip = [AvgPool(stride)] [1x1x1 conv (no bias) + norm]
         {
-            const int cin[2] = {a.in_channels, 0}, src[2] = {-1, -1};
-            prev = add_conv(Layer::STEM, 1, cin, src, a.features[0], a.kernels[0], one, dims[0], dims[0]);
+            prev = add_stem(a.in_channels, a.features[0], a.kernels[0], dims[0]);
             prev_c = a.features[0];
         }
         for (int s = 0; s < a.n_stages; ++s) {
@@ -449,7 +488,8 @@ int build_plan(fnn_engine *e) {
                 // The probes see the SAME fp8 flag the launch will carry (the variant choice depends on it: the fp16-only
                 // six-row tiles) - packing, tile depth and statistics rows are then the launch's; a layer the fp8 pick refuses
                 // stays fp16 with whatever that pick gives it.
-                q.fp8 = a.precision == FNN_PREC_F8 && !L.fuse && T == 27 && L.s[0] == 1 && L.s[1] == 1 && L.s[2] == 1;
+                q.fp8 = a.precision == FNN_PREC_F8 && !L.fuse && T == 27 && L.s[0] == 1 && L.s[1] == 1 && L.s[2] == 1 &&
+                        !(L.src_layer[0] >= 0 && e->layers[L.src_layer[0]].type == Layer::GATHER);   // (the network input keeps fp16: the stem was never an fp8 layer)
                 if (q.fp8 && fnn_knob("FNN_FP8_LEVELS")) {
                     // sensitivity studies (tools/fp8_sensitivity.py): e4m3 operands only at the resolution levels of the bit mask
                     // (level = how many times the patch's voxel count was divided by ~8 on the way to this layer's output)
@@ -727,7 +767,7 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
             p.tiles_d = (p.PD + FNN_TILE_D - 1) / FNN_TILE_D;
             p.tiles_h = (p.PH + FNN_TILE_H - 1) / FNN_TILE_H;
             p.tiles_w = (p.PW + FNN_TILE_W - 1) / FNN_TILE_W;
-            Scope sc(e, st, FAM_STEM, L.flops * nb);
+            Scope sc(e, st, FAM_STEM, L.flops * nb, L.bytes * nb);
             if (L.virtual_out) p.out = nullptr;                       // statistics only: the consumer recomputes the values
             rc = launch_stem_mfma(p, fw.wpk + L.w_off2, nb, st);
         } else if (L.type == Layer::CONV) {
@@ -770,6 +810,17 @@ int forward_batch(fnn_engine *e, int fold, const float *vol, long long vol_batch
                 rc = launch_conv_thin(tp, st);
             } else
             rc = launch_conv3d(p, st);
+        } else if (L.type == Layer::GATHER) {
+            PatchInputParams p{};
+            p.vol = vol; p.vol_batch_stride = vol_batch_stride; p.C = L.cin_real[0]; p.Cpad = L.cout_pad;
+            p.X = vdim[0]; p.Y = vdim[1]; p.Z = vdim[2];
+            p.origins = origins_dev;
+            p.flip_d = flip[0]; p.flip_h = flip[1]; p.flip_w = flip[2];
+            p.PD = L.out_dims[0]; p.PH = L.out_dims[1]; p.PW = L.out_dims[2]; p.N = nb;
+            p.out = out;
+            if (L.chunk_major) { p.out_vs = 16; p.out_cs = 16LL * L.out_dims[0] * L.out_dims[1] * L.out_dims[2]; }
+            Scope sc(e, st, FAM_STEM, 0, 2.0 * nb * (2.0 * L.cin_real[0] + L.cout_pad) * L.out_dims[0] * L.out_dims[1] * L.out_dims[2]);
+            rc = launch_patch_input(p, st);
         } else if (L.type == Layer::POOL) {
             if (L.pool_fused) continue;                               // written by the COMBINE launch of its source
             PoolParams p{};
@@ -928,6 +979,8 @@ inline int no_autocast(fnn_engine *e, const fnn_opts *o, const char *who) {
 
 struct Box { int64_t lo[3], hi[3]; };
 
+int upload_until(fnn_engine *e, int64_t x_need, hipStream_t st);     // (below, next to stage_volume)
+
 inline int acc_hp(const fnn_arch_desc &a) { return (a.num_heads + 1 + 7) / 8 * 8; }
 
 // Runs the listed patches and accumulates into `acc`, which covers `box` of the padded volume
@@ -1017,6 +1070,11 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
             st = e->pipe[k];
             e->act = e->actp[k]; e->stats = e->statsp[k]; e->ss = e->ssp[k];
         }
+        if (e->up.active) {                                   // a volume still arriving from the host: the planes this batch reads
+            int64_t x_need = 0;                               // (un-padded volume: padded == shape along every axis here)
+            for (int b = 0; b < nb; ++b) x_need = std::max<int64_t>(x_need, (int64_t)vp.origins[ids[p0 + b] * 3] + a.patch[0]);
+            if (int rc = upload_until(e, x_need, st)) return rc;
+        }
         for (size_t ci = 0; ci <= (tta ? combos.size() : 0); ++ci) {
             int flip[3] = {0, 0, 0};
             if (ci > 0) for (int ax : combos[ci - 1]) flip[ax] = 1;
@@ -1072,19 +1130,109 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
     return 0;
 }
 
-// Brings the input volume onto the device and pads it when smaller than the patch.
+bool is_pinned_host_ptr(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+// host -> pinned staging with a few threads: one core's memcpy (~10 GB/s) is slower than the link
+void parallel_copy(float *dst, const float *src, size_t n) {
+    const size_t min_part = 1u << 20;                                          // floats
+    int parts = (int)std::min<size_t>(4, (n + min_part - 1) / min_part);
+    if (parts <= 1) { memcpy(dst, src, n * sizeof(float)); return; }
+    std::thread th[3];
+    const size_t per = (n + parts - 1) / parts;
+    for (int t = 1; t < parts; ++t) {
+        const size_t lo = per * t, hi = std::min(n, lo + per);
+        th[t - 1] = std::thread([=] { if (hi > lo) memcpy(dst + lo, src + lo, (hi - lo) * sizeof(float)); });
+    }
+    memcpy(dst, src, std::min(n, per) * sizeof(float));
+    for (int t = 1; t < parts; ++t) th[t - 1].join();
+}
+
+// Issues the upload of every slab that holds planes below x_need, then makes `st` wait for the last of them.
+int upload_until(fnn_engine *e, int64_t x_need, hipStream_t st) {
+    fnn_engine::Upload &u = e->up;
+    if (!u.active) return 0;
+    if (x_need > u.X) x_need = u.X;
+    if (x_need < 1) x_need = 1;
+    const size_t plane = (size_t)u.Y * u.Z;
+    while (u.issued_x < x_need) {
+        const int64_t x0 = u.issued_x, x1 = std::min(u.X, x0 + u.slab_x);
+        const size_t slab = (size_t)(x0 / u.slab_x), run = (size_t)(x1 - x0) * plane;
+        if (u.pinned_src) {
+            for (int c = 0; c < u.C; ++c)
+                HIPCHK(e, hipMemcpyAsync(u.dev + ((size_t)c * u.X + x0) * plane, u.host + ((size_t)c * u.X + x0) * plane,
+                                         run * sizeof(float), hipMemcpyHostToDevice, u.st));
+        } else {
+            const int k = u.next_stage;
+            u.next_stage = (k + 1) % fnn_engine::Upload::RING;
+            if (u.stage_used[k]) HIPCHK(e, hipEventSynchronize(u.stage_free[k]));          // its previous slab has left
+            for (int c = 0; c < u.C; ++c)
+                parallel_copy(u.stage[k] + (size_t)c * run, u.host + ((size_t)c * u.X + x0) * plane, run);
+            for (int c = 0; c < u.C; ++c)
+                HIPCHK(e, hipMemcpyAsync(u.dev + ((size_t)c * u.X + x0) * plane, u.stage[k] + (size_t)c * run,
+                                         run * sizeof(float), hipMemcpyHostToDevice, u.st));
+            HIPCHK(e, hipEventRecord(u.stage_free[k], u.st));
+            u.stage_used[k] = true;
+        }
+        HIPCHK(e, hipEventRecord(u.landed[slab], u.st));
+        u.issued_x = x1;
+    }
+    HIPCHK(e, hipStreamWaitEvent(st, u.landed[(size_t)((x_need - 1) / u.slab_x)], 0));
+    return 0;
+}
+
+// Brings the input volume onto the device and pads it when smaller than the patch.  `slabbed`: the caller's batches call
+// upload_until() for the planes they read (run_patches); otherwise the whole volume is waited for here.
 int stage_volume(fnn_engine *e, const float *vol, const int64_t shape[4], const VolPlan &vp, hipStream_t st,
-                 const float **vol_dev) {
+                 const float **vol_dev, bool slabbed = false) {
     const size_t nin = (size_t)shape[0] * shape[1] * shape[2] * shape[3];
     const float *src = vol;
+    const bool need_pad = vp.padded[0] != shape[1] || vp.padded[1] != shape[2] || vp.padded[2] != shape[3];
+    fnn_engine::Upload &u = e->up;
+    u.active = false;
     if (!is_device_ptr(vol)) {
         void *t = e->vol_tmp;
         if (int rc = ensure(e, &t, &e->vol_tmp_bytes, nin * sizeof(float))) return rc;
         e->vol_tmp = (float *)t;
-        HIPCHK(e, hipMemcpyAsync(e->vol_tmp, vol, nin * sizeof(float), hipMemcpyHostToDevice, st));
         src = e->vol_tmp;
+        u.host = vol; u.dev = e->vol_tmp; u.C = (int)shape[0]; u.X = shape[1]; u.Y = shape[2]; u.Z = shape[3];
+        u.pinned_src = is_pinned_host_ptr(vol);
+        const size_t plane_bytes = (size_t)u.C * u.Y * u.Z * sizeof(float);
+        const size_t slab_bytes = fnn_knob("FNN_UPLOAD_SLAB_BYTES") ? (size_t)atoll(fnn_knob("FNN_UPLOAD_SLAB_BYTES")) : (16u << 20);   // tests: many slabs in a small volume
+        u.slab_x = std::max<int64_t>(1, (int64_t)(slab_bytes / std::max<size_t>(1, plane_bytes)));     // ~16 MB per slab
+        u.n_slabs = (size_t)((u.X + u.slab_x - 1) / u.slab_x);
+        u.issued_x = 0;
+        if (!u.st) HIPCHK(e, hipStreamCreateWithFlags(&u.st, hipStreamNonBlocking));
+        if (!u.go) HIPCHK(e, hipEventCreateWithFlags(&u.go, hipEventDisableTiming));
+        while (u.landed.size() < u.n_slabs) {
+            hipEvent_t ev;
+            HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            u.landed.push_back(ev);
+        }
+        if (!u.pinned_src) {
+            const size_t need = (size_t)u.slab_x * plane_bytes;
+            if (u.stage_bytes < need) {
+                for (int k = 0; k < fnn_engine::Upload::RING; ++k) {
+                    if (u.stage[k]) { if (u.stage_used[k]) (void)hipEventSynchronize(u.stage_free[k]); (void)hipHostFree(u.stage[k]); u.stage[k] = nullptr; }
+                    u.stage_used[k] = false;
+                }
+                u.stage_bytes = 0;
+                for (int k = 0; k < fnn_engine::Upload::RING; ++k) {
+                    HIPCHK(e, hipHostMalloc((void **)&u.stage[k], need, hipHostMallocDefault));
+                    if (!u.stage_free[k]) HIPCHK(e, hipEventCreateWithFlags(&u.stage_free[k], hipEventDisableTiming));
+                }
+                u.stage_bytes = need;
+            }
+        }
+        // the copy stream starts behind whatever the caller's stream still does with the staging area
+        HIPCHK(e, hipEventRecord(u.go, st));
+        HIPCHK(e, hipStreamWaitEvent(u.st, u.go, 0));
+        u.active = true;
+        if (!slabbed || need_pad) { if (int rc = upload_until(e, u.X, st)) return rc; u.active = false; }
     }
-    const bool need_pad = vp.padded[0] != shape[1] || vp.padded[1] != shape[2] || vp.padded[2] != shape[3];
     if (need_pad) {
         const size_t npad = (size_t)shape[0] * vp.padded[0] * vp.padded[1] * vp.padded[2];
         void *t = e->vol_pad;
@@ -1289,7 +1437,8 @@ int predict_impl(fnn_engine *e, int fold0, int n_folds, const float *vol, const 
     VolPlan vp;
     if (plan_volume(a, shape + 1, o->tile_step_size, vp) != 0) return fail(e, FNN_E_INVALID, "invalid volume shape / step size");
     const float *vol_dev = nullptr;
-    if (int rc = stage_volume(e, vol, shape, vp, st, &vol_dev)) return rc;
+    if (int rc = stage_volume(e, vol, shape, vp, st, &vol_dev, true)) return rc;
+    struct UploadDone { fnn_engine *e; ~UploadDone() { e->up.active = false; } } upload_done{e};
     {
         std::vector<int64_t> all(vp.n_patches);
         for (int64_t i = 0; i < vp.n_patches; ++i) all[i] = i;
@@ -1431,6 +1580,13 @@ void fnn_destroy(fnn_engine *e) {
         if (k > 0) { (void)hipFree(e->actp[k]); (void)hipFree(e->statsp[k]); (void)hipFree(e->ssp[k]); }
     }
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
+    for (hipEvent_t ev : e->up.landed) (void)hipEventDestroy(ev);
+    for (int k = 0; k < fnn_engine::Upload::RING; ++k) {
+        if (e->up.stage[k]) (void)hipHostFree(e->up.stage[k]);
+        if (e->up.stage_free[k]) (void)hipEventDestroy(e->up.stage_free[k]);
+    }
+    if (e->up.go) (void)hipEventDestroy(e->up.go);
+    if (e->up.st) (void)hipStreamDestroy(e->up.st);
     if (e->steps_ev) (void)hipEventDestroy(e->steps_ev);
     if (e->origins_ev) (void)hipEventDestroy(e->origins_ev);
     if (e->steps_host) (void)hipHostFree(e->steps_host);
@@ -1454,7 +1610,7 @@ int fnn_load_weights(fnn_engine *e, int fold, const float *blob, int64_t count) 
     std::vector<uint16_t> wpk(e->wpk_halves, 0);
     std::vector<float> fp(e->fparam_floats, 0.f);
     for (const Layer &L : e->layers) {
-        if (L.type == Layer::POOL || L.type == Layer::COMBINE) continue;
+        if (L.type == Layer::POOL || L.type == Layer::COMBINE || L.type == Layer::GATHER) continue;
         const float *W = blob + L.blob_w;
         if (L.type == Layer::STEM) {
             const int T = L.k[0] * L.k[1] * L.k[2], C = L.cin_real[0];
@@ -1902,7 +2058,7 @@ int64_t fnn_profile_launches(const fnn_engine *e, char *buf, int64_t cap) {
 
 int64_t fnn_layer_table(const fnn_engine *e, char *buf, int64_t cap) {
     if (!e) return FNN_E_INVALID;
-    static const char *const ty[] = {"stem", "conv", "tconv", "pool", "combine"};
+    static const char *const ty[] = {"stem", "conv", "tconv", "pool", "combine", "input"};
     std::string all;
     for (size_t li = 0; li < e->layers.size(); ++li) {
         const Layer &L = e->layers[li];

@@ -298,6 +298,23 @@ static __device__ __forceinline__ f16x8 fnn_norm8(const f16x8 &x, const float (&
 #endif
 }
 
+// The network input of a batch of patches as an fp16 tensor: patch windows of the fp32 volume (mirroring applied), the
+// channel count padded to a multiple of 16 with zeros - what the stem conv of a multi-channel (or `2d`) configuration reads
+// through the regular MFMA conv kernels (misc.hip, patch_input_kernel).
+struct PatchInputParams {
+    const float *vol;            // [C][X][Y][Z] fp32 (the padded volume)
+    long long vol_batch_stride;  // elements between the volumes of consecutive batch items (0 = one volume)
+    int C, Cpad;
+    long long X, Y, Z;
+    const int *origins;          // [N][3] patch origin in the volume
+    int flip_d, flip_h, flip_w;  // test-time mirroring of the network input
+    int PD, PH, PW, N;
+    f16 *out;                    // [N][PD][PH][PW][Cpad], or chunk-major (out_vs, out_cs; 0 = channels-last)
+    int out_vs;
+    long long out_cs;
+};
+int launch_patch_input(const PatchInputParams &p, hipStream_t st);
+
 // Residual-encoder blocks (BasicBlockD): skip-path average pooling and the block's closing
 //   y = LeakyReLU( norm2(conv2) + skip )
 struct PoolParams {

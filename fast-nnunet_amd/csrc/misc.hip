@@ -207,6 +207,42 @@ static __device__ __forceinline__ void apply8(const SrcDesc &s, int n, int c0, c
     }
 }
 
+// Patch windows of the fp32 volume -> fp16 [N][PD][PH][PW][Cpad] (x rounded to fp16 once: the engine's contract for every
+// conv operand).  Thread = (voxel, 8-channel group); a wave's 64 voxels are consecutive along z, so each of its (up to 8)
+// channel-plane reads is 256 contiguous bytes and its 16-byte stores tile whole records.  The patch coordinates come from
+// 32-bit arithmetic (a patch has < 2^31 voxels); mirroring is the coordinate P - 1 - v.  Replaces the patch slicing
+// `data[sl]` of predict_from_raw_data.py:560-566 for stems that run on the MFMA conv kernels (engine.hip, Layer::GATHER).
+__global__ __launch_bounds__(256) void patch_input_kernel(const PatchInputParams p) {
+    const unsigned pvox = (unsigned)p.PD * p.PH * p.PW;
+    const unsigned cg = (unsigned)(p.Cpad >> 3);
+    const unsigned n = blockIdx.y / cg, g = blockIdx.y % cg;
+    const unsigned v = blockIdx.x * 256u + threadIdx.x;
+    if (v >= pvox) return;
+    const unsigned w = v % (unsigned)p.PW, t = v / (unsigned)p.PW, h = t % (unsigned)p.PH, d = t / (unsigned)p.PH;
+    const long long x = p.origins[n * 3 + 0] + (p.flip_d ? p.PD - 1 - (int)d : (int)d);
+    const long long y = p.origins[n * 3 + 1] + (p.flip_h ? p.PH - 1 - (int)h : (int)h);
+    const long long z = p.origins[n * 3 + 2] + (p.flip_w ? p.PW - 1 - (int)w : (int)w);
+    const float *src = p.vol + (size_t)n * p.vol_batch_stride + (size_t)((x * p.Y + y) * p.Z + z);
+    const size_t plane = (size_t)p.X * p.Y * p.Z;
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = (int)g * 8 + j;
+        o[j] = c < p.C ? (f16)src[(size_t)c * plane] : (f16)0.f;
+    }
+    const int c0 = (int)g * 8;
+    const size_t vs = p.out_vs ? (size_t)p.out_vs : (size_t)p.Cpad;
+    const size_t cs = p.out_vs ? (size_t)p.out_cs : 16;
+    *(f16x8 *)(p.out + (size_t)n * pvox * p.Cpad + (size_t)v * vs + (size_t)(c0 >> 4) * cs + (c0 & 15)) = o;
+}
+
+int launch_patch_input(const PatchInputParams &p, hipStream_t st) {
+    const unsigned pvox = (unsigned)p.PD * p.PH * p.PW;
+    fnn_note_kernel("patch_input_kernel");
+    hipLaunchKernelGGL(patch_input_kernel, dim3((pvox + 255) / 256, (unsigned)(p.N * (p.Cpad >> 3))), dim3(256), 0, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // skip path of a strided block: AvgPool3d(stride, stride) of the (transformed) block input.  Thread -> (voxel, 8-channel
 // group): the group runs fastest for a channels-last output, the voxel (inside a 16-channel chunk) for a chunk-major
 // one, so that a wave's stores are contiguous either way; element addresses by the one formula of fnn_device.h.

@@ -219,6 +219,15 @@ class nnUNetPredictor(object):
         return [tuple([slice(None), *[slice(s, s + p) for s, p in zip(st, patch)]])
                 for st in itertools.product(*steps)]
 
+    def _resident_or_host(self, t: torch.Tensor) -> torch.Tensor:
+        """float32, contiguous.  A CPU tensor (what the reference's callers hold: the preprocessing iterator's output,
+        data_iterators.py:116-117; moved with `data.to(results_device)` at :579) STAYS on the CPU: the engine uploads it by
+        x slabs on a copy stream and starts the first batch when the slabs under its patches have landed (pin the tensor
+        for a DMA straight from it; a pageable one goes through the engine's pinned staging ring)."""
+        if t.device.type == 'cpu':
+            return t.to(dtype=torch.float32).contiguous()
+        return t.to(device=self.device, dtype=torch.float32).contiguous()
+
     def _check_input(self, input_image):
         assert isinstance(input_image, torch.Tensor)
         assert input_image.ndim == 4, 'input_image must be a 4D np.ndarray or torch.Tensor (c, x, y, z)'
@@ -230,7 +239,7 @@ class nnUNetPredictor(object):
         """[C,X,Y,Z] preprocessed image -> fp16 logits [heads,X,Y,Z] (:634-680)."""
         self._check_input(input_image)
         with torch.cuda.device(self.device):
-            x = input_image.to(device=self.device, dtype=torch.float32).contiguous()
+            x = self._resident_or_host(input_image)
             out = torch.empty((self._spec.num_heads, *x.shape[1:]), dtype=torch.half, device=self.device)
             self._engine.predict_volume(x.data_ptr(), x.shape, self._opts(), out.data_ptr(), fold=self._active_fold)
         return out if self.perform_everything_on_device else out.cpu()
@@ -241,7 +250,7 @@ class nnUNetPredictor(object):
         reference: skips its 15 GiB device-to-host copy of a 61-class 512^3 volume)."""
         self._check_input(data)
         with torch.cuda.device(self.device):
-            x = data.to(device=self.device, dtype=torch.float32).contiguous()
+            x = self._resident_or_host(data)
             out = torch.empty((self._spec.num_heads, *x.shape[1:]), dtype=torch.half, device=self.device)
             self._engine.predict_volume(x.data_ptr(), x.shape, self._opts(), out.data_ptr(), n_folds=self._n_folds)
         if self.verbose:
@@ -321,7 +330,7 @@ class nnUNetPredictor(object):
         self._check_input(data)
         order, u16 = self._label_rule()
         with torch.cuda.device(self.device):
-            x = data.to(device=self.device, dtype=torch.float32).contiguous()
+            x = self._resident_or_host(data)
             self._engine.set_label_rule(order, uint16=u16)
             labels = torch.empty(x.shape[1:], dtype=torch.int16 if u16 else torch.uint8, device=self.device)
             self._engine.predict_labels(x.data_ptr(), x.shape, self._opts(), labels.data_ptr(), n_folds=self._n_folds)

@@ -482,3 +482,34 @@ def test_row_streaming_kernels_network_and_mirroring_match_the_oracle(patch):
     assert mr <= MAX_REL and rr <= RMSE_REL
     mr, rr = _report(f'row kernels {patch} mirrored volume vs tile kernels', vol[inner], vol_t[inner])
     assert mr <= 5e-3 and rr <= 3e-3
+
+
+# ------------------------------------------------------------------------- multi-channel stems: the two routes
+@pytest.mark.parametrize('cin,k0,patch', [(4, (3, 3, 3), (24, 32, 40)), (11, (3, 3, 3), (16, 24, 32)), (2, (1, 3, 3), (12, 40, 48))])
+def test_multi_channel_stem_on_the_conv_kernels_agrees_with_the_direct_stem_kernel(cin, k0, patch):
+    """Round 6: a stem with more than one input channel runs as patch_input_kernel (the patch windows as an fp16 tensor,
+    channels padded to 16) + an ordinary conv layer on the MFMA conv kernels; FNN_STEM_DIRECT=1 (read when the engine is
+    created) keeps the generic stem_mfma_kernel (groups of 8 channels from a raw window in LDS).  Same operands (x and w rounded
+    to fp16, fp32 accumulation), another summation order: the logits agree to a few fp16 roundings, and both are the oracle's
+    within the suite's tolerance."""
+    spec = UNetSpec('plain', cin, 3, [32, 64], [k0, (3, 3, 3)], [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
+    sd = synthetic_state_dict(spec, 654)
+    x = torch.randn(3, cin, *patch, generator=torch.Generator().manual_seed(17))
+    p = _predictor(spec, patch, [sd], batch=4)
+    a, ka = _forward_and_kernels(p, x)
+    os.environ['FNN_STEM_DIRECT'] = '1'
+    try:
+        pd = _predictor(spec, patch, [sd], batch=4)
+    finally:
+        del os.environ['FNN_STEM_DIRECT']
+    b, kb = _forward_and_kernels(pd, x)
+    assert 'patch_input_kernel' in ka and 'stem_mfma_kernel' not in ka, sorted(ka)
+    assert 'stem_mfma_kernel' in kb and 'patch_input_kernel' not in kb, sorted(kb)
+    err = float((a - b).abs().max()) / float(b.abs().max())
+    print(f'[stem {cin} ch {k0} {patch}] max |conv route - direct| / max |direct| = {err:.2e}   {sorted(k for k in ka if "conv" in k)}')
+    assert err <= 5e-3
+    torch.set_num_threads(8)
+    with torch.inference_mode():
+        ref = build_oracle(spec, sd)(x)
+    mr, rr = _report(f'stem {cin} ch on the conv kernels', a, ref)
+    assert mr <= MAX_REL and rr <= RMSE_REL

@@ -28,7 +28,7 @@ def is_cliff(r):
     """r: a row of bench.py's per-layer table.  HBM-side layers: at most 16 channels on the wide side of the layer."""
     if r['share'] <= 0.05 or not r['us']:
         return None
-    thin = min(r['cin'], r['cout']) <= 16 and r['type'].startswith(('conv', 'stem'))
+    thin = min(r['cin'], r['cout']) <= 16 and r['type'].startswith(('conv', 'stem', 'input'))
     if thin or r['type'].startswith('tconv'):
         if r['tbps'] is not None and r['tbps'] < 2.5 and (r['tflops'] or 0) < 0.10 * PEAK:
             return f"{r['tbps']:.2f} TB/s < 2.5"
