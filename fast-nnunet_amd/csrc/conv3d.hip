@@ -998,6 +998,7 @@ int launch_conv3d(const ConvParams &p_in, hipStream_t st) {
     p.tiles_h = (p.Ho + FNN_TILE_H - 1) / FNN_TILE_H;
     p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
     if (p.packing == FNN_PACK_ZR) return launch_conv3d_zr(p, st);      // weights are in that kernel's order
+    if (p.packing == FNN_PACK_ZP) return launch_conv2d_zp(p, st);
     {
         // 16-channel full-resolution (1, 3, 3) layers: the row-streaming kernel (conv3d_row.hip)
         ThinParams tp{};

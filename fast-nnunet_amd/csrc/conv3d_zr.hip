@@ -18,7 +18,7 @@
 #include <type_traits>
 #include <cstdlib>
 
-int conv3d_ksteps(int packing, int taps) { return packing == FNN_PACK_ZR ? 15 : (taps + 1) / 2; }
+int conv3d_ksteps(int packing, int taps) { return packing == FNN_PACK_ZR ? 15 : packing == FNN_PACK_ZP ? 9 : (taps + 1) / 2; }
 
 int conv3d_kstep_tap(int packing, int ks, int half, int taps) {
     if (packing == FNN_PACK_ZR) {
@@ -35,7 +35,7 @@ int conv3d_kstep_tap(int packing, int ks, int half, int taps) {
 // 32-channel group - half the store instructions of the 8-byte form, whole 64-byte runs (the stores of this kernel
 // delayed the next workgroup's loads in the texture-address path: a timing-only build without them ran 14 % faster).
 int conv3d_pack_cout(int packing, int nblk, int cb, int m) {
-    if (packing != FNN_PACK_ZR || nblk % 2 != 0) return cb * 16 + m;
+    if ((packing != FNN_PACK_ZR && packing != FNN_PACK_ZP) || nblk % 2 != 0) return cb * 16 + m;
     return (cb >> 1) * 32 + (m >> 2) * 8 + (cb & 1) * 4 + (m & 3);
 }
 
@@ -79,6 +79,7 @@ static bool zs_pick(const ConvParams &p);
 
 int conv3d_stats_slots(const ConvParams &p) {
     int nb, td;
+    if (conv2d_zp_ok(p)) return conv2d_zp_stats_slots(p);
     if (zs_pick(p)) return ((p.Do + 7) / 8) * ((p.Ho + 3) / 4) * ((p.Wo + 7) / 8);
     if (!zr_pick(p, nb, td)) return FNN_STAT_REPL;
     return ((p.Do + td - 1) / td) * ((p.Ho + 7) / 8) * ((p.Wo + 7) / 8);
@@ -86,6 +87,7 @@ int conv3d_stats_slots(const ConvParams &p) {
 
 int conv3d_packing(const ConvParams &p) {
     int nb, td;
+    if (conv2d_zp_ok(p)) return FNN_PACK_ZP;                  // (1, 3, 3) stride 1, cout blocks in pairs: conv2d_zp.hip
     return (zs_pick(p) || zr_pick(p, nb, td)) ? FNN_PACK_ZR : FNN_PACK_LINEAR;
 }
 

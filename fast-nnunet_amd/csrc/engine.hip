@@ -484,6 +484,8 @@ int build_plan(fnn_engine *e) {
                 q.plan_N = e->max_batch; q.N = e->max_batch; q.Cout = L.cout_pad; q.chunks = L.chunks;
                 q.Do = L.out_dims[0]; q.Ho = L.out_dims[1]; q.Wo = L.out_dims[2];
                 q.kd = L.k[0]; q.kh = L.k[1]; q.kw = L.k[2]; q.sd = L.s[0]; q.sh = L.s[1]; q.sw = L.s[2];
+                q.n_src = L.n_src; q.src[0].C = L.cin_pad[0]; q.src[1].C = L.n_src > 1 ? L.cin_pad[1] : 0;
+                q.Di = L.in_dims[0]; q.Hi = L.in_dims[1]; q.Wi = L.in_dims[2];
                 // e4m3 operands: the stride-1 3x3x3 layers the fp8 ZR kernel takes (the strided depth-shift kernel is fp16 only).
                 // The probes see the SAME fp8 flag the launch will carry (the variant choice depends on it: the fp16-only
                 // six-row tiles) - packing, tile depth and statistics rows are then the launch's; a layer the fp8 pick refuses
@@ -501,6 +503,7 @@ int build_plan(fnn_engine *e) {
                 if (q.fp8 && L.packing != FNN_PACK_ZR) { q.fp8 = 0; L.packing = conv3d_packing(q); }
                 L.fp8 = q.fp8 != 0;
             }
+            if (L.packing == FNN_PACK_ZP) L.chunks = conv_zp_chunks(L.cin_pad[0], L.n_src > 1 ? L.cin_pad[1] : 0);   // 32-channel chunks
             L.ksteps = conv3d_ksteps(L.packing, T);
             L.w_off = wpk; wpk += (size_t)(L.cout_pad / 16) * L.chunks * L.ksteps * 512;
         } else if (L.type == Layer::TCONV) {
@@ -520,6 +523,9 @@ int build_plan(fnn_engine *e) {
             q.Do = L.out_dims[0]; q.Ho = L.out_dims[1]; q.Wo = L.out_dims[2];
             q.kd = L.k[0]; q.kh = L.k[1]; q.kw = L.k[2]; q.sd = L.s[0]; q.sh = L.s[1]; q.sw = L.s[2];
             q.fp8 = L.fp8;
+            q.n_src = L.n_src; q.src[0].C = L.cin_pad[0]; q.src[1].C = L.n_src > 1 ? L.cin_pad[1] : 0;
+            q.Di = L.in_dims[0]; q.Hi = L.in_dims[1]; q.Wi = L.in_dims[2];
+            if (L.packing == FNN_PACK_ZP) q.chunks = (L.cin_pad[0] + (L.n_src > 1 ? L.cin_pad[1] : 0)) / 16;
             L.stats_slots = conv3d_stats_slots(q);
         }
         L.stats_off = st; if (L.has_norm) st += (size_t)L.stats_slots * L.cout_pad * 2;
@@ -1632,7 +1638,10 @@ int fnn_load_weights(fnn_engine *e, int fold, const float *blob, int64_t count) 
                             }
             }
         } else if (L.type == Layer::CONV) {
-            if (L.fp8) pack_conv_fp8(L, W, (uint8_t *)(wpk.data() + L.w_off), fp.data() + L.oscale_off);
+            if (L.packing == FNN_PACK_ZP)
+                conv_zp_pack(W, L.cout_real, L.cout_pad, L.cin_real[0], L.cin_pad[0], L.n_src > 1 ? L.cin_real[1] : 0,
+                             L.n_src > 1 ? L.cin_pad[1] : 0, wpk.data() + L.w_off);
+            else if (L.fp8) pack_conv_fp8(L, W, (uint8_t *)(wpk.data() + L.w_off), fp.data() + L.oscale_off);
             else pack_conv(L, W, wpk.data() + L.w_off);
         } else {
             pack_tconv(L, W, wpk.data() + L.w_off);

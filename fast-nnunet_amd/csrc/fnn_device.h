@@ -87,6 +87,15 @@ struct ConvParams {
 //                     offset dz (in-plane tap 9 = zero padding) - the order conv3d_zr_kernel walks.
 #define FNN_PACK_LINEAR 0
 #define FNN_PACK_ZR 1
+//   FNN_PACK_ZP     : (1, 3, 3) stride 1, conv2d_zp.hip: chunks of 32 input channels (never across the two sources), 9 k-steps
+//                     per chunk, k-step dx * 3 + dy = the 32 channels of tap (dy, dx); ConvParams::chunks counts THESE chunks.
+#define FNN_PACK_ZP 2
+int conv_zp_chunks(int cin_pad0, int cin_pad1);
+void conv_zp_pack(const float *W, int cout_real, int cout_pad, int cin_real0, int cin_pad0, int cin_real1, int cin_pad1, unsigned short *dst);
+struct ConvParams;
+bool conv2d_zp_ok(const ConvParams &p);
+int conv2d_zp_stats_slots(const ConvParams &p);
+int launch_conv2d_zp(const ConvParams &p, hipStream_t st);
 
 struct StemParams {
     const float *vol;            // [C][X][Y][Z] fp32 (the padded volume)

@@ -130,7 +130,10 @@ int fnn_op_conv3d(int device, int n, const int dims[3],
     p.tiles_w = (p.Wo + FNN_TILE_W - 1) / FNN_TILE_W;
     p.tile_d = FNN_TILE_D;
     // pack weights [cout][cin_tot][T] -> [cb][chunk][ks][lane][8]
+    if (p.packing == FNN_PACK_ZP) p.chunks = conv_zp_chunks(cp1, cp2);
     std::vector<uint16_t> wp((size_t)(cop / 16) * p.chunks * p.ksteps * 512, 0);
+    if (p.packing == FNN_PACK_ZP) conv_zp_pack(w, cout, cop, cin, cp1, x2 ? cin2 : 0, cp2, wp.data());
+    else
     for (int cb = 0; cb < cop / 16; ++cb)
         for (int ch = 0; ch < p.chunks; ++ch)
             for (int ks = 0; ks < p.ksteps; ++ks)

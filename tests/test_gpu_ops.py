@@ -731,3 +731,65 @@ def test_conv_transpose3d_random_layers(seed):
     assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max())), what
     y2 = capi.op_conv_transpose3d(x.numpy(), w.numpy(), b.numpy(), stride)
     _check(y2, F.conv_transpose3d(x, w, b, stride), what)
+
+
+# ---------------------------------------------------------------------------- conv2d_zp_kernel: (1, 3, 3) layers of >= 32 channels
+# n, cin, cin2 (second source), cout, dims, expected variant <rows per wave, waves along the columns>
+ZP_CASES = [
+    (2, 32, 0, 32, (1, 64, 64), '8,4'),          # 2-D plane, whole 8 x 64 tiles
+    (3, 64, 0, 32, (1, 37, 83), '8,4'),          # ragged rows and columns, two chunks
+    (2, 32, 32, 64, (2, 24, 40), '8,4'),         # two sources, depth 2, two cout pairs
+    (2, 48, 16, 32, (3, 21, 30), '8,2'),         # sources of 48 and 16 channels: half-empty last chunks, 16 x 32 tiles
+    (4, 128, 0, 64, (1, 32, 32), '8,2'),
+    (4, 96, 0, 96, (1, 16, 16), '4,1'),          # 16 x 16 tiles, three cout pairs
+    (8, 160, 160, 64, (1, 8, 8), '4,1'),         # plane smaller than the tile
+    (6, 64, 0, 64, (2, 4, 4), '4,1'),
+    (2, 16, 0, 32, (2, 33, 70), '8,4'),          # a single 16-channel source (a stem on the conv kernels): half a chunk
+    (1, 4, 0, 32, (1, 40, 48), '8,4'),           # channel padding 4 -> 16
+]
+
+
+@pytest.mark.parametrize('n,cin,cin2,cout,dims,variant', ZP_CASES, ids=lambda v: str(v).replace(' ', ''))
+def test_conv2d_plane_kernel(n, cin, cin2, cout, dims, variant):
+    """Round 6: conv2d_zp_kernel against torch's fp32 conv on the same fp16-rounded operands - identity input (statistics
+    checked), then InstanceNorm + LeakyReLU on load; two sources; the variant the launch rule must pick."""
+    from fast_nnunet_amd import capi
+    k, st = (1, 3, 3), (1, 1, 1)
+    g = torch.Generator().manual_seed(31 + cin + cin2 + cout + dims[1])
+    x = _h(torch.randn(n, cin, *dims, generator=g) * 2 + 0.5)
+    x2 = _h(torch.randn(n, cin2, *dims, generator=g) * 1.5 - 0.3) if cin2 else None
+    w = _h(torch.randn(cout, cin + cin2, *k, generator=g) / ((cin + cin2) * 9) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    y, stats = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), k, st, x2=None if x2 is None else x2.numpy(), want_stats=True)
+    assert capi.op_last_kernels() == [f'conv2d_zp_kernel<{variant}>'], capi.op_last_kernels()
+    cat = x if x2 is None else torch.cat((x, x2), 1)
+    _check(y, F.conv3d(cat, w, b, 1, (0, 1, 1)), 'conv2d zp')
+    y64 = y.astype(np.float64)
+    assert np.allclose(stats[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    assert np.allclose(stats[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+    kw = {}
+    xn = _h(F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01))
+    if x2 is not None:
+        gamma2, beta2 = torch.rand(cin2, generator=g) + 0.5, torch.randn(cin2, generator=g) * 0.1
+        kw = dict(x2=x2.numpy(), gamma2=gamma2.numpy(), beta2=beta2.numpy(), slope2=0.01)
+        xn = torch.cat((xn, _h(F.leaky_relu(F.instance_norm(x2, weight=gamma2, bias=beta2, eps=1e-5), 0.01))), 1)
+    y = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), k, st, gamma=gamma.numpy(), beta=beta.numpy(), slope=0.01, **kw)
+    ref = F.conv3d(xn, w, b, 1, (0, 1, 1))
+    assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_conv2d_plane_kernel_operand_map_with_exact_integers():
+    """Small integers (every product and sum exact in fp16 / fp32): a wrong tap, channel or output-channel permutation cannot
+    hide behind a tolerance."""
+    from fast_nnunet_amd import capi
+    g = torch.Generator().manual_seed(5)
+    n, cin, cout, dims = 2, 64, 64, (2, 19, 70)
+    x = torch.randint(-3, 4, (n, cin, *dims), generator=g).float()
+    w = torch.randint(-2, 3, (cout, cin, 1, 3, 3), generator=g).float()
+    b = torch.randint(-5, 6, (cout,), generator=g).float()
+    y = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (1, 3, 3), (1, 1, 1))
+    assert capi.op_last_kernels() == ['conv2d_zp_kernel<8,4>']
+    ref = F.conv3d(x, w, b, 1, (0, 1, 1))
+    assert float(ref.abs().max()) < 2048
+    assert np.array_equal(y, ref.numpy())
