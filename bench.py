@@ -169,14 +169,20 @@ def resolve_workload(args):
         if 'batch' in j and not args.batch_given:
             args.batch = int(j['batch'])
         return w
-    spacing, patch, heads, r = WORKLOADS[args.workload]
-    return dict(name=args.workload, spacing=spacing, patch=patch, heads=heads, r=r, in_channels=1,
-                resenc=args.workload.startswith('resenc'), volume=(args.volume,) * 3, max_features=320, plan=False, note='')
+    return named_workload(args.workload, args.volume)
+
+
+def named_workload(name, volume=512):
+    spacing, patch, heads, r = WORKLOADS[name]
+    return dict(name=name, spacing=spacing, patch=patch, heads=heads, r=r, in_channels=1,
+                resenc=name.startswith('resenc'), volume=(volume,) * 3, max_features=320, plan=False, note='')
 
 
 def build_predictor(w, device, batch, accumulate_in, compute_dtype='f16', mirror=False, folds=1):
     from fast_nnunet_amd import nnUNetPredictor
     from fast_nnunet_amd.plans import PlansManager
+    if isinstance(w, str):                                      # a BASELINE workload by name
+        w = named_workload(w)
     spacing, patch, heads, r, in_ch = w['spacing'], w['patch'], w['heads'], w['r'], w['in_channels']
     strides, kernels = plan_topology(spacing, patch)
     n = len(strides)

@@ -23,8 +23,11 @@ FNN_LABEL_U8, FNN_LABEL_U16 = 0, 1
 FNN_NORM_NONE, FNN_NORM_ZSCORE, FNN_NORM_CT, FNN_NORM_RESCALE01, FNN_NORM_RGB01 = 0, 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# FNN_LIB: another build of the same library (A-B comparisons of two builds inside one GPU session)
-LIB_PATH = os.environ.get('FNN_LIB') or os.path.join(_HERE, 'csrc', 'libfnn_hip.so')
+# FNN_LIB: another build of the same library (A-B comparisons of two builds inside one GPU session) - like every FNN_* switch
+# of the library itself (csrc/misc.hip, fnn_knob) honoured only next to FNN_KNOBS=1: an embedding process's environment
+# does not choose the code that runs
+_KNOBS = os.environ.get('FNN_KNOBS', '0') not in ('', '0')
+LIB_PATH = (os.environ.get('FNN_LIB') if _KNOBS else None) or os.path.join(_HERE, 'csrc', 'libfnn_hip.so')
 
 
 class ArchDesc(C.Structure):

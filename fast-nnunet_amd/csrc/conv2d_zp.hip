@@ -67,12 +67,21 @@ static bool zp_pick(const ConvParams &p, int &wc, int &th) {
     return false;                                             // (the A-B build with fp32 normalise-on-load keeps the linear-tap kernels)
 #endif
     static const bool off = fnn_knob("FNN_NO_ZP") != nullptr;                       // A-B aid
-    if (off || p.kd != 1 || p.kh != 3 || p.kw != 3 || p.sd != 1 || p.sh != 1 || p.sw != 1 || p.fp8) return false;
+    if (off || p.kd != 1 || p.kh != 3 || p.kw != 3 || p.sd != 1 || p.fp8) return false;
+    const bool strided = p.sh == 2 && p.sw == 2;
+    if (!strided && !(p.sh == 1 && p.sw == 1)) return false;
+    if (strided && fnn_knob("FNN_NO_ZPS") != nullptr) return false;                 // A-B aid
     if (p.Cout % 32 != 0) return false;                                             // cout blocks in pairs
     const long long vox = (long long)p.Do * p.Ho * p.Wo;
     const int cmax = p.src[0].C > p.src[1].C ? p.src[0].C : p.src[1].C;
     // 32-bit byte offsets inside a batch item, and the 0x80000000 "not fetched" offset must lie beyond every tensor
     if (vox * 2 * (cmax > 0 ? cmax : 16) >= (1ll << 31) || vox * 2 * p.Cout >= (1ll << 31) || vox >= (1 << 24)) return false;
+    if (strided) {                                                                  // conv2d_zps_kernel: 8 x 32 or 16 x 16 output tiles
+        const long long ivox = (long long)p.Di * p.Hi * p.Wi;
+        if (ivox * 2 * (cmax > 0 ? cmax : 16) >= (1ll << 31) || ivox >= (1 << 24)) return false;
+        wc = p.Wo > 16 ? 2 : 1; th = 4;
+        return true;
+    }
     if (p.Wo > 32) { wc = 4; th = 8; }
     else if (p.Wo > 16) { wc = 2; th = 8; }
     else { wc = 1; th = 4; }
@@ -84,7 +93,7 @@ bool conv2d_zp_ok(const ConvParams &p) { int wc, th; return zp_pick(p, wc, th); 
 int conv2d_zp_stats_slots(const ConvParams &p) {
     int wc, th;
     if (!zp_pick(p, wc, th)) return FNN_STAT_REPL;
-    const int rows = (4 / wc) * th, cols = wc * 16;
+    const int rows = (4 / wc) * th, cols = wc * 16;             // (the strided kernel: th = 4 -> 8 x 32 or 16 x 16)
     return p.Do * ((p.Ho + rows - 1) / rows) * ((p.Wo + cols - 1) / cols);
 }
 
@@ -348,6 +357,271 @@ int launch_zp(ConvParams p, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// ----------------------------------------------------------------------------
+// stride (1, 2, 2): the down-sampling conv of a (1, 3, 3) stage
+// ----------------------------------------------------------------------------
+// out[j][x] = sum w[dy][dx] in[2 j + dy - 1][2 x + dx - 1].  The halo image keeps the EVEN and the ODD input columns of a
+// row in lines of their own: tap dx = 0 reads odd column x - 1, dx = 1 even column x, dx = 2 odd column x - a wave's
+// fragment is again 16 consecutive 16-byte slots of four congruent lines (conflict free), not a stride-2 walk.  A workgroup
+// stages (2 ROWS + 1) x (2 COLS + 1) input voxels for ROWS x COLS outputs - four times the bytes per MFMA of the stride-1
+// kernel - so it keeps NB = 4 cout blocks (64 output channels) per staged image where the layer has them (a down-sampling
+// conv has twice its input's channels: every cout group re-reads the whole input), and one workgroup per CU (124 KB).
+// Same packing (FNN_PACK_ZP), staging arithmetic, epilogue and statistics rows as conv2d_zp_kernel.
+template <int NB, int WC>
+__global__ __launch_bounds__(256, 1) void conv2d_zps_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TH = 4;
+    constexpr int WR = 4 / WC;
+    constexpr int ROWS = WR * TH, COLS = WC * 16;             // output tile: 8 x 32 or 16 x 16
+    constexpr int IH = 2 * ROWS + 1, ICOLS = 2 * COLS + 1;    // input halo
+    constexpr int EOFF = 0, OOFF = COLS * 16 + 64;            // even-column slots, then (64 B further: other banks for the stores) odd-column slots
+    constexpr int QP = ((OOFF + (COLS + 1) * 16 + 255) / 256) * 256;
+    constexpr int ROWB = 4 * QP;
+    constexpr int ABYTES = IH * ROWB;
+    constexpr int RPP = 2 / WC;                               // input rows staged per pass: 128 WC threads per row
+    constexpr int NP = (IH + RPP - 1) / RPP;
+    constexpr int KS = 9, WB = KS * 64, WPB = (WB + 255) / 256;
+    static_assert(IH <= 64, "the extra input column of every row fits the 64 threads of a channel group");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int t;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        t = __builtin_amdgcn_readfirstlane((xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx);
+    }
+    const int tile_in_item = __builtin_amdgcn_readfirstlane(t % (p.Do * p.tiles_h * p.tiles_w));
+    const int tw = __builtin_amdgcn_readfirstlane(t % p.tiles_w); t = __builtin_amdgcn_readfirstlane(t / p.tiles_w);
+    const int th = __builtin_amdgcn_readfirstlane(t % p.tiles_h); t = __builtin_amdgcn_readfirstlane(t / p.tiles_h);
+    const int d = __builtin_amdgcn_readfirstlane(t % p.Do);
+    const int n = __builtin_amdgcn_readfirstlane(t / p.Do);
+    const int cb0 = blockIdx.y * NB;
+    const int oh0 = th * ROWS, ow0 = tw * COLS;
+    const int wr = wave / WC, wcol = wave % WC;
+
+    char *sA = smem;
+    char *sW = smem + ABYTES;                                 // [NB][9][64 lanes][16 B]
+
+    // ---- staging: thread = (input column ci of the halo row, 8-channel group); input column ci is image column 2 ow0 - 1 + ci:
+    // ci even -> an ODD column, slot ci / 2 of the odd line; ci odd -> an even column, slot (ci - 1) / 2 of the even line
+    const int rp = __builtin_amdgcn_readfirstlane(tid / (128 * WC));
+    const int tt = tid % (128 * WC);
+    const int cg4 = tt / (64 * WC), ci = (tt % (64 * WC)) >> 1, half = tt & 1;
+    const int q_st = cg4 * 2 + half;
+    const int gw = 2 * ow0 - 1 + ci;
+    const bool ok_w = (unsigned)gw < (unsigned)p.Wi;
+    const int lds_main = q_st * QP + ((ci & 1) ? EOFF + (ci >> 1) * 16 : OOFF + (ci >> 1) * 16);
+    // the last input column (ci = 2 COLS, odd line slot COLS) of every halo row: IH items per channel group
+    const int i64 = rp * (32 * WC) + ci;                      // 0 .. 63 within the channel group
+    const bool has_x = i64 < IH;
+    const int gh_x = 2 * oh0 - 1 + i64, gw_x = 2 * ow0 - 1 + 2 * COLS;
+    const bool ok_x = has_x & ((unsigned)gh_x < (unsigned)p.Hi) & ((unsigned)gw_x < (unsigned)p.Wi);
+    const int lds_x = i64 * ROWB + q_st * QP + OOFF + COLS * 16;
+
+    f32x4 acc[TH][NB];
+    zp_u32x4 xr[NP], xx, wrg[NB][WPB], ssv[2];
+    float slope_next = 1.f;
+    __amdgpu_buffer_rsrc_t rx, rw[NB];
+    unsigned voff = 0x80000000u, voff_x = 0x80000000u, row_bytes = 0, plane_off = 0;
+    bool ch_ok = true;
+
+    const int n0 = (p.src[0].C + 31) >> 5;
+    auto prep = [&](int ch) {
+        const int s = ch < n0 ? 0 : 1;
+        const int c_uni = (s ? ch - n0 : ch) * 32;
+        const int sC = p.src[s].C;
+        const int vs = FNN_VS(p.src[s]);
+        const long long cs = FNN_CS(p.src[s]);
+        const unsigned item_bytes = (unsigned)p.Di * p.Hi * p.Wi * sC * 2;
+        const f16 *sp = p.src[s].ptr + (size_t)n * (item_bytes >> 1) + (c_uni >> 4) * cs;
+        rx = __builtin_amdgcn_make_buffer_rsrc((void *)sp, 0, item_bytes - (unsigned)((c_uni >> 4) * cs * 2), 0x00020000);
+        slope_next = p.src[s].slope;
+        ch_ok = c_uni + 8 * q_st < sC;
+        {
+            const int cq = ch_ok ? c_uni + 8 * q_st : 0;
+            const unsigned short *q = p.src[s].ssh ? p.src[s].ssh + ((size_t)n * sC + cq) * 2 : p.ident_ssh + cq * 2;
+            const zp_u32x4 *qv = (const zp_u32x4 *)q;
+            ssv[0] = qv[0]; ssv[1] = qv[1];
+        }
+        const unsigned piece = (unsigned)cg4 * (unsigned)(cs * 2) + (unsigned)half * 16u;
+        voff = (ok_w & ch_ok) ? (unsigned)gw * (unsigned)(vs * 2) + piece : 0x80000000u;
+        voff_x = (ok_x & ch_ok) ? (unsigned)(gh_x * p.Wi + gw_x) * (unsigned)(vs * 2) + piece : 0x80000000u;
+        row_bytes = (unsigned)p.Wi * vs * 2;
+        plane_off = (unsigned)d * (unsigned)p.Hi * row_bytes;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const f16 *wp = p.wpk + ((size_t)((cb0 + nb) * p.chunks + ch) * WB) * 8;
+            rw[nb] = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, WB * 16, 0x00020000);
+        }
+    };
+    auto load_part = [&](int part) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            if (u * 3 / NP != part) continue;
+            int gh = 2 * oh0 - 1 + u * RPP + rp;
+            gh = gh < 0 ? 0 : (gh >= p.Hi ? p.Hi - 1 : gh);
+            xr[u] = __builtin_bit_cast(zp_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, plane_off + (unsigned)gh * row_bytes, 0));
+        }
+        if (part == 2) xx = __builtin_bit_cast(zp_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff_x, plane_off, 0));
+#pragma unroll
+        for (int e = 0; e < NB * WPB; ++e) {
+            if (e * 3 / (NB * WPB) != part) continue;
+            const int nb = e / WPB, u = e % WPB;
+            wrg[nb][u] = __builtin_bit_cast(zp_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw[nb], tid * 16, u * (256 * 16), 0));
+        }
+    };
+    auto commit = [&]() {
+        const f16 slope_h = (f16)slope_next;
+        const zp_u32x4 zero4 = {0u, 0u, 0u, 0u};
+        const bool okm = ok_w & ch_ok, okx = ok_x & ch_ok;
+        {
+            const f16x8 sc_h = __builtin_bit_cast(f16x8, okm ? ssv[0] : zero4), sh_h = __builtin_bit_cast(f16x8, okm ? ssv[1] : zero4);
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int row = u * RPP + rp;
+                if (NP * RPP > IH && row >= IH) continue;
+                const int gh = 2 * oh0 - 1 + row;
+                f16x8 o = __builtin_bit_cast(f16x8, xr[u]) * sc_h + sh_h;
+                o = __builtin_elementwise_max(o, o * slope_h);
+                if ((unsigned)gh >= (unsigned)p.Hi) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                *(f16x8 *)(sA + row * ROWB + lds_main) = o;
+            }
+        }
+        if (has_x) {
+            const f16x8 sc_h = __builtin_bit_cast(f16x8, okx ? ssv[0] : zero4), sh_h = __builtin_bit_cast(f16x8, okx ? ssv[1] : zero4);
+            f16x8 o = __builtin_bit_cast(f16x8, xx) * sc_h + sh_h;
+            o = __builtin_elementwise_max(o, o * slope_h);
+            *(f16x8 *)(sA + lds_x) = o;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int u = 0; u < WPB; ++u)
+                if (u + 1 < WPB || wave == 0) *(zp_u32x4 *)(sW + ((nb * WB + u * 256) + tid) * 16) = wrg[nb][u];
+    };
+    // MFMA "B" operand of output column x = wcol 16 + r, tap dx: dx = 0 -> odd slot x, dx = 1 -> even slot x, dx = 2 -> odd slot x + 1
+    const int bbase = (2 * wr * TH) * ROWB + (lane >> 4) * QP + (wcol * 16 + (lane & 15)) * 16;
+    auto kloop = [&](bool prefetch) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            if (prefetch) load_part(dx);
+            const char *bp = sA + bbase + (dx == 1 ? EOFF : OOFF + (dx == 2 ? 16 : 0));
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                f16x8 wf[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wf[nb] = *(const f16x8 *)(sW + ((nb * KS + dx * 3 + dy) * 64 + lane) * 16);
+#pragma unroll
+                for (int j = 0; j < TH; ++j) {
+                    const f16x8 xf = *(const f16x8 *)(bp + (2 * j + dy) * ROWB);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nb], xf, acc[j][nb], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    prep(0);
+#pragma unroll
+    for (int part = 0; part < 3; ++part) load_part(part);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        f32x4 b0[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b0[nb] = *(const f32x4 *)(p.bias + (cb0 + (nb & ~1)) * 16 + (lane >> 4) * 8 + (nb & 1) * 4);
+#pragma unroll
+        for (int j = 0; j < TH; ++j)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[j][nb] = b0[nb];
+    }
+    commit();
+    __syncthreads();
+    for (int ch = 0; ch + 1 < p.chunks; ++ch) {
+        prep(ch + 1);
+        kloop(true);
+        __syncthreads();
+        commit();
+        __syncthreads();
+    }
+    kloop(false);
+    __syncthreads();
+
+    // ---- epilogue: per pair of cout blocks one 16-byte store per (voxel, lane); statistics per pair
+    {
+        const int q = lane >> 4, r = lane & 15;
+        const unsigned item_bytes = (unsigned)p.Do * p.Ho * p.Wo * p.Cout * 2;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)n * (item_bytes >> 1), 0, item_bytes, 0x00020000);
+        const unsigned ovs2 = (unsigned)FNN_OVS(p) * 2;
+        const int ow = ow0 + wcol * 16 + r;
+        const bool ok_c = ow < p.Wo;
+        const f16x2 ones = {(f16)1.f, (f16)1.f};
+#pragma unroll
+        for (int pr2 = 0; pr2 < NB / 2; ++pr2) {
+            const unsigned coff = (unsigned)(cb0 + 2 * pr2 + (q >> 1)) * (unsigned)(FNN_OCS(p) * 2) + (unsigned)(q & 1) * 16;
+            float t1[2][4], t2[2][4];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
+#pragma unroll
+            for (int jr = 0; jr < TH; jr += 2) {
+                f16x8 o[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int oh = oh0 + wr * TH + jr + h;
+                    const bool ok = ok_c && oh < p.Ho;
+                    const unsigned vo = ok ? (unsigned)((d * p.Ho + oh) * p.Wo + ow) * ovs2 + coff : 0x80000000u;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[h][nb * 4 + j] = (f16)acc[jr + h][2 * pr2 + nb][j];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(zp_i32x4, o[h]), rsrc, vo, 0, 0);
+                    if (!ok) o[h] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f16x2 pr = {o[0][nb * 4 + j], o[1][nb * 4 + j]};
+                        t1[nb][j] = __builtin_amdgcn_fdot2(pr, ones, t1[nb][j], false);
+                        t2[nb][j] = __builtin_amdgcn_fdot2(pr, pr, t2[nb][j], false);
+                    }
+            }
+            if (p.stats_out) {
+                if (pr2 > 0) __syncthreads();                 // the previous pair's sums have been read out of the scratch
+                stats_to_global<2, true, true, 4>(p, t1, t2, (float *)smem, n, cb0 + 2 * pr2, wave, lane, tid, tile_in_item);
+            }
+        }
+    }
+}
+
+template <int NB, int WC>
+int launch_zps(ConvParams p, hipStream_t st) {
+    constexpr int WR = 4 / WC, ROWS = WR * 4, COLS = WC * 16, IH = 2 * ROWS + 1;
+    constexpr int OOFF = COLS * 16 + 64, QP = ((OOFF + (COLS + 1) * 16 + 255) / 256) * 256;
+    const size_t lds = (size_t)IH * 4 * QP + (size_t)NB * 9 * 1024;
+    p.tiles_d = p.Do;
+    p.tiles_h = (p.Ho + ROWS - 1) / ROWS;
+    p.tiles_w = (p.Wo + COLS - 1) / COLS;
+    if (p.stats_out && p.stats_slots < p.Do * p.tiles_h * p.tiles_w) return -1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)conv2d_zps_kernel<NB, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    p.ident_ss = conv3d_identity_ss();
+    p.ident_ssh = conv3d_identity_ssh();
+    if (!p.ident_ss || !p.ident_ssh) return -2;
+    const long long tiles = (long long)p.N * p.Do * p.tiles_h * p.tiles_w;
+    if (tiles >= (1ll << 31)) return -1;
+    dim3 grid((unsigned)tiles, (p.Cout / 16) / NB);
+    fnn_note_kernel("conv2d_zps_kernel<%d,%d>", NB, WC);
+    hipLaunchKernelGGL((conv2d_zps_kernel<NB, WC>), grid, dim3(256), lds, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 }  // namespace
 
 // Runs the layer; the weights must have been packed as FNN_PACK_ZP and p.chunks = conv_zp_chunks(...).
@@ -355,6 +629,11 @@ int launch_conv2d_zp(const ConvParams &p, hipStream_t st) {
     int wc, th;
     if (p.packing != FNN_PACK_ZP || p.ksteps != 9 || !zp_pick(p, wc, th)) return -1;
     if (p.chunks != conv_zp_chunks(p.src[0].C, p.n_src > 1 ? p.src[1].C : 0)) return -1;
+    if (p.sh == 2) {
+        const bool four = (p.Cout / 16) % 4 == 0;
+        if (wc == 2) return four ? launch_zps<4, 2>(p, st) : launch_zps<2, 2>(p, st);
+        return four ? launch_zps<4, 1>(p, st) : launch_zps<2, 1>(p, st);
+    }
     if (wc == 4) return launch_zp<8, 4>(p, st);
     if (wc == 2) return launch_zp<8, 2>(p, st);
     return launch_zp<4, 1>(p, st);

@@ -16,8 +16,8 @@ them.  Here the engine is built the way ``bench.py`` builds it and
 * the other BASELINE workloads get the same whole-step comparison on their corner box: C1 student 128^3, C4 teacher
   128^3, C5 ResEnc student 160^3 in f16 (usual gate) and f8 (its stated budget).
 
-Tolerance = the suite's fp16-MFMA-vs-fp32 gate (test_gpu_predictor.py): max |err| <= 1e-2 max|ref|, relative RMSE <=
-5e-3; labels equal wherever the top-1 / top-2 margin exceeds twice the measured error.  The reference lines under
+Tolerance = the suite's fp16-MFMA-vs-fp32 gate (test_gpu_predictor.py MAX_REL, RMSE_REL): max |err| <= 6e-3 max|ref|, relative
+RMSE <= 3.5e-3; labels equal wherever the top-1 / top-2 margin exceeds twice the measured error.  The reference lines under
 test: predict_from_raw_data.py:541-631; networks nnUNetDistillationTrainer.py:141-173, 248-266.
 """
 import time

@@ -793,3 +793,58 @@ def test_conv2d_plane_kernel_operand_map_with_exact_integers():
     ref = F.conv3d(x, w, b, 1, (0, 1, 1))
     assert float(ref.abs().max()) < 2048
     assert np.array_equal(y, ref.numpy())
+
+
+# n, cin, cin2, cout, input dims, expected variant <cout blocks per workgroup, waves along the columns>
+ZPS_CASES = [
+    (2, 32, 0, 64, (1, 64, 64), '4,2'),          # 2-D down-sampling conv: 32 x 32 outputs, 64 output channels in one group
+    (3, 32, 0, 32, (2, 37, 83), '2,2'),          # odd input sizes (ragged rows / columns), one cout pair
+    (2, 64, 0, 128, (1, 128, 96), '4,2'),        # several tiles per plane, two chunks, two cout groups
+    (2, 48, 16, 96, (2, 30, 44), '2,2'),         # two sources with half-empty last chunks, three cout pairs
+    (4, 128, 0, 256, (1, 32, 32), '4,1'),        # 16 x 16 outputs
+    (8, 96, 0, 64, (1, 9, 7), '4,1'),            # a plane smaller than the tile, odd sizes
+    (2, 16, 0, 32, (3, 40, 66), '2,2'),          # a single 16-channel source
+]
+
+
+@pytest.mark.parametrize('n,cin,cin2,cout,dims,variant', ZPS_CASES, ids=lambda v: str(v).replace(' ', ''))
+def test_conv2d_plane_kernel_strided(n, cin, cin2, cout, dims, variant):
+    """conv2d_zps_kernel ((1, 3, 3) taps, stride (1, 2, 2)) against torch's fp32 conv on the same fp16-rounded operands."""
+    from fast_nnunet_amd import capi
+    k, st = (1, 3, 3), (1, 2, 2)
+    g = torch.Generator().manual_seed(57 + cin + cin2 + cout + dims[1])
+    x = _h(torch.randn(n, cin, *dims, generator=g) * 2 + 0.5)
+    x2 = _h(torch.randn(n, cin2, *dims, generator=g) * 1.5 - 0.3) if cin2 else None
+    w = _h(torch.randn(cout, cin + cin2, *k, generator=g) / ((cin + cin2) * 9) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    y, stats = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), k, st, x2=None if x2 is None else x2.numpy(), want_stats=True)
+    assert capi.op_last_kernels() == [f'conv2d_zps_kernel<{variant}>'], capi.op_last_kernels()
+    cat = x if x2 is None else torch.cat((x, x2), 1)
+    _check(y, F.conv3d(cat, w, b, st, (0, 1, 1)), 'conv2d zps')
+    y64 = y.astype(np.float64)
+    assert np.allclose(stats[..., 0], y64.sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    assert np.allclose(stats[..., 1], (y64 ** 2).sum((2, 3, 4)), rtol=1e-6, atol=1e-3)
+    gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+    kw = {}
+    xn = _h(F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.01))
+    if x2 is not None:
+        gamma2, beta2 = torch.rand(cin2, generator=g) + 0.5, torch.randn(cin2, generator=g) * 0.1
+        kw = dict(x2=x2.numpy(), gamma2=gamma2.numpy(), beta2=beta2.numpy(), slope2=0.01)
+        xn = torch.cat((xn, _h(F.leaky_relu(F.instance_norm(x2, weight=gamma2, bias=beta2, eps=1e-5), 0.01))), 1)
+    y = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), k, st, gamma=gamma.numpy(), beta=beta.numpy(), slope=0.01, **kw)
+    ref = F.conv3d(xn, w, b, st, (0, 1, 1))
+    assert np.abs(y - ref.numpy()).max() <= 6e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_conv2d_plane_kernel_strided_operand_map_with_exact_integers():
+    from fast_nnunet_amd import capi
+    g = torch.Generator().manual_seed(6)
+    n, cin, cout, dims = 2, 64, 128, (2, 21, 70)
+    x = torch.randint(-3, 4, (n, cin, *dims), generator=g).float()
+    w = torch.randint(-2, 3, (cout, cin, 1, 3, 3), generator=g).float()
+    b = torch.randint(-5, 6, (cout,), generator=g).float()
+    y = capi.op_conv3d(x.numpy(), w.numpy(), b.numpy(), (1, 3, 3), (1, 2, 2))
+    assert capi.op_last_kernels() == ['conv2d_zps_kernel<4,2>']
+    ref = F.conv3d(x, w, b, (1, 2, 2), (0, 1, 1))
+    assert float(ref.abs().max()) < 2048
+    assert np.array_equal(y, ref.numpy())

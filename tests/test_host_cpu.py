@@ -451,3 +451,72 @@ def test_committed_counter_traffic_belongs_to_the_kernel_sources_in_the_tree():
     assert doc.get('csrc_sha256') == bench.csrc_sha256(), \
         f'profiles/{bench.TRAFFIC_FILE} was captured on other kernel sources: re-run tools/capture.sh (FNN_ROUND) and commit it'
     assert any(k.startswith('bone_turbo_r2|f16|mirror=0|fp16|') for k in doc.get('workloads', {}))
+
+
+def test_the_library_reads_its_environment_only_through_the_knob_switch():
+    """a production libfnn_hip.so must not change kernels because an unrelated process exported FNN_PIPES.
+    Every FNN_* variable of the HIP sources is read through fnn_knob() (csrc/misc.hip), which answers nullptr unless
+    FNN_KNOBS is set to something other than 0; the only direct getenv calls are that switch itself and the timing-only
+    FNN_ZR_TMODE inside `#ifdef FNN_TMODE` (a diagnostic build that is never shipped).  The Python side reads FNN_LIB behind the
+    same switch.  Scans the sources."""
+    src_dir = os.path.join(ROOT, 'fast-nnunet_amd', 'csrc')
+    direct, knobs = [], set()
+    for name in sorted(os.listdir(src_dir)):
+        if not name.endswith(('.hip', '.h')):
+            continue
+        text = open(os.path.join(src_dir, name)).read()
+        depth_tmode = 0
+        for ln, line in enumerate(text.splitlines(), 1):
+            s = line.strip()
+            if s.startswith('#ifdef FNN_TMODE'):
+                depth_tmode += 1
+            elif s.startswith('#endif') and depth_tmode:
+                depth_tmode -= 1
+            code = line.split('//')[0]
+            for m in re.finditer(r'\bgetenv\s*\(\s*("?)([A-Za-z_0-9]*)', code):
+                direct.append((name, ln, m.group(2), depth_tmode > 0))
+            knobs.update(re.findall(r'fnn_knob\("([A-Z0-9_]+)"\)', code))
+    allowed = {('misc.hip', 'FNN_KNOBS'), ('misc.hip', 'name')}
+    for name, ln, var, in_tmode in direct:
+        assert in_tmode or (name, var) in allowed, f'{name}:{ln} reads {var or "the environment"} without the FNN_KNOBS switch'
+    body = open(os.path.join(src_dir, 'misc.hip')).read()
+    m = re.search(r'const char \*fnn_knob\(const char \*name\) \{(.*?)\n\}', body, re.S)
+    assert m and 'getenv("FNN_KNOBS")' in m.group(1) and 'on ? getenv(name) : nullptr' in m.group(1)
+    assert len(knobs) >= 40 and all(k.startswith('FNN_') for k in knobs)
+    # the Python binding: FNN_LIB only next to the switch; nothing else of the package reads FNN_* variables
+    pkg = os.path.join(ROOT, 'fast-nnunet_amd')
+    for name in sorted(os.listdir(pkg)):
+        if name.endswith('.py'):
+            for var in re.findall(r"environ(?:\.get)?[\(\[]\s*'(FNN_[A-Z0-9_]+)'", open(os.path.join(pkg, name)).read()):
+                assert (name, var) in {('capi.py', 'FNN_KNOBS'), ('capi.py', 'FNN_LIB')}, (name, var)
+    capi_src = open(os.path.join(pkg, 'capi.py')).read()
+    assert "os.environ.get('FNN_LIB') if _KNOBS else None" in capi_src
+
+
+def test_sweep_plans_get_the_reference_planners_topology(golden_dir):
+    """tools/plans/*.json (the plan sweep): bench.py's restatement of get_pool_and_conv_props agrees with the
+    oracle's on every plan of the sweep, and both with the reference-made tests/golden/topology.json where a plan's
+    (spacing, patch) is one of its cases."""
+    import glob
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle.topology import plan_pool_and_kernels as oracle_plan
+    golden = {(tuple(c['spacing']), tuple(c['patch'])): c for c in json.load(open(os.path.join(golden_dir, 'topology.json')))}
+    plans = sorted(glob.glob(os.path.join(ROOT, 'tools', 'plans', '*.json')))
+    assert len(plans) >= 10
+    hit = 0
+    for pf in plans:
+        j = json.load(open(pf))
+        strides, kernels = bench.plan_topology(j['spacing'], j['patch'])
+        o = oracle_plan(tuple(float(v) for v in j['spacing']), tuple(int(v) for v in j['patch']))
+        assert [list(s) for s in o[0]] == strides and [list(k) for k in o[1]] == kernels, pf
+        g = golden.get((tuple(float(v) for v in j['spacing']), tuple(int(v) for v in j['patch'])))
+        if g is not None:
+            hit += 1
+            assert g['strides'] == strides and g['kernels'] == kernels, pf
+        # the patch is divisible by the total stride (the planner pads it so: network_topology.py:96-108)
+        for a in range(len(j['patch'])):
+            total = int(np.prod([s[a] for s in strides]))
+            assert j['patch'][a] % total == 0, (pf, a)
+    assert hit >= 1
