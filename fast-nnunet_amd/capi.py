@@ -128,9 +128,11 @@ def load_library() -> C.CDLL:
     lib.fnn_get_profile.argtypes = [vp, C.POINTER(Profile)]
     lib.fnn_kernel_log.argtypes = [vp, C.c_char_p, i64]
     lib.fnn_kernel_log.restype = i64
-    for fn in (lib.fnn_profile_launches, lib.fnn_layer_table):
-        fn.argtypes = [vp, C.c_char_p, i64]
-        fn.restype = i64
+    for name in ('fnn_profile_launches', 'fnn_layer_table'):       # (absent from an older build picked with FNN_LIB for an A-B)
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.argtypes = [vp, C.c_char_p, i64]
+            fn.restype = i64
     lib.fnn_patch_work.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     I3 = C.POINTER(C.c_int)
     lib.fnn_op_conv3d.argtypes = [i32, i32, I3, f32p, i32, f32p, f32p, C.c_float, f32p, i32, f32p, f32p, C.c_float,
