@@ -67,6 +67,7 @@ static bool zp_pick(const ConvParams &p, int &wc, int &th) {
     return false;                                             // (the A-B build with fp32 normalise-on-load keeps the linear-tap kernels)
 #endif
     static const bool off = fnn_knob("FNN_NO_ZP") != nullptr;                       // A-B aid
+    if (fnn_knob("FNN_CONV_V1") != nullptr) return false;                           // (read per call: the test of the generic kernel)
     if (off || p.kd != 1 || p.kh != 3 || p.kw != 3 || p.sd != 1 || p.fp8) return false;
     const bool strided = p.sh == 2 && p.sw == 2;
     if (!strided && !(p.sh == 1 && p.sw == 1)) return false;

@@ -101,7 +101,7 @@ struct fnn_engine {
     // HBM-bound (thin full-resolution convs, seg head) and MFMA-bound kernels; with the following batches' forwards on
     // the other streams they overlap.  The heads stay ordered (events), so the accumulation order - and with it every
     // rounding - is the reference's.  288 GB of HBM make the extra arenas free.
-    static constexpr int MAXP = 4;
+    static constexpr int MAXP = 8;
     int n_pipe = 0;                         // arenas / streams allocated (0 until the first multi-batch run)
     f16 *actp[MAXP] = {}; double *statsp[MAXP] = {}; float *ssp[MAXP] = {};      // [0] aliases act / stats / ss
     hipStream_t pipe[MAXP] = {};
@@ -1027,8 +1027,20 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
     const bool pipelined = !no_pipe && (!tta || keep_features) && !e->profiling && np > B;
     f16 *const act0 = e->act; double *const stats0 = e->stats; float *const ss0 = e->ss;
     static const int want_pipes = fnn_knob("FNN_PIPES") ? atoi(fnn_knob("FNN_PIPES")) : 3;
-    const int NP = want_pipes < 2 ? 2 : (want_pipes > fnn_engine::MAXP ? fnn_engine::MAXP : want_pipes);
+    int NP = want_pipes < 2 ? 2 : (want_pipes > fnn_engine::MAXP ? fnn_engine::MAXP : want_pipes);
     if (pipelined) {
+        if (e->n_pipe < NP) {
+            // the arenas of the batches in flight take at most a quarter of the device's memory (a full-width teacher's is 29 GB
+            // at batch 32) and never what is not free: fewer batches in flight then, not a failed call
+            const size_t arena = e->act_halves * e->max_batch * sizeof(f16) + e->stats_doubles * e->max_batch * sizeof(double) +
+                                 (e->ss_count * e->max_batch * 3 + 8) * sizeof(float);
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && arena > 0) {
+                const long long by_total = (long long)(total_b / 4 / arena), by_free = (long long)(free_b * 8 / 10 / arena) + e->n_pipe;
+                const long long cap = std::max<long long>(2, std::min(by_total, by_free));
+                if (NP > cap) NP = (int)std::max<long long>(cap, e->n_pipe);
+            }
+        }
         if (e->n_pipe < NP) {
             if (!e->ev_start) HIPCHK(e, hipEventCreateWithFlags(&e->ev_start, hipEventDisableTiming));
             for (int k = e->n_pipe; k < NP; ++k) {
