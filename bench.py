@@ -529,20 +529,24 @@ def main():
         # one extra, identical, UNTIMED step beside the clock probe (one sleeping wave, fnn_clock_probe_*): the shader clock the
         # device holds under this step.  Not in the timed region (it costs ~0.5 % there) and not in the profiled step below
         # (it stretches the per-launch durations by ~4 %, measured: 734 -> 700 TFLOP/s)
-        barrier()
-        torch.cuda.synchronize()
-        probe = capi.clock_probe_start(local_rank, min(30.0, 4.0 * step_est))
-        out = step_fn()                                          # (returns when the volume is done: the engine's entry points are synchronous)
-        clock['ghz'], clock['seconds'] = capi.clock_probe_stop(probe)   # raises the probe's flag and waits for ITS stream only
-        del out
-        torch.cuda.synchronize()
-        # the sample only counts when the probed step ran like the timed ones: with fewer hardware queues than streams (HIP
-        # initialised before main() set GPU_MAX_HW_QUEUES - a profiler's preload, an embedding process) the probe shares a queue
-        # with an engine stream and the step waits behind it; then the clock is that of a stalled device
         step_timed = dt / args.steps
-        if not (0.85 * step_timed <= clock['seconds'] <= 1.15 * step_timed):
-            clock = {'rejected': f"probed step took {clock['seconds']:.3f} s against {step_timed:.3f} s timed: the probe disturbed the step "
-                                 f"(GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}), sample dropped"}
+        for attempt in range(3):                                 # (a short step's duration jitters by more than the gate: sampled again)
+            barrier()
+            torch.cuda.synchronize()
+            probe = capi.clock_probe_start(local_rank, min(30.0, 4.0 * step_est))
+            out = step_fn()                                      # (returns when the volume is done: the engine's entry points are synchronous)
+            clock['ghz'], clock['seconds'] = capi.clock_probe_stop(probe)   # raises the probe's flag and waits for ITS stream only
+            del out
+            torch.cuda.synchronize()
+            # the sample only counts when the probed step ran like the timed ones: with fewer hardware queues than streams (HIP
+            # initialised before main() set GPU_MAX_HW_QUEUES - a profiler's preload, an embedding process) the probe shares a queue
+            # with an engine stream and the step waits behind it; then the clock is that of a stalled device
+            tol = 0.15 if args.steps >= 3 else 0.35               # (one or two timed steps are themselves a noisy yardstick)
+            if (1 - tol) * step_timed <= clock['seconds'] <= (1 + tol) * step_timed:
+                break
+            if attempt == 2:
+                clock = {'rejected': f"probed step took {clock['seconds']:.3f} s against {step_timed:.3f} s timed: the probe disturbed the step "
+                                     f"(GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}), sample dropped"}
     if distributed and args.gather != 'labels':
         out = labels_fn()                                        # (one untimed call: first-use allocations of this entry point)
         del out

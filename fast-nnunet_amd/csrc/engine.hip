@@ -1026,17 +1026,17 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
     static const bool no_pipe = fnn_knob("FNN_NO_PIPELINE") != nullptr;                // A-B aid
     const bool pipelined = !no_pipe && (!tta || keep_features) && !e->profiling && np > B;
     f16 *const act0 = e->act; double *const stats0 = e->stats; float *const ss0 = e->ss;
-    static const int want_pipes = fnn_knob("FNN_PIPES") ? atoi(fnn_knob("FNN_PIPES")) : 3;
+    static const int want_pipes = fnn_knob("FNN_PIPES") ? atoi(fnn_knob("FNN_PIPES")) : 4;   // round 6: four beat three by 0.3-0.9 % on C1 / C2 / C4 / C5 (profiles/r06_pipes_sweep.txt); beyond four: nothing
     int NP = want_pipes < 2 ? 2 : (want_pipes > fnn_engine::MAXP ? fnn_engine::MAXP : want_pipes);
     if (pipelined) {
         if (e->n_pipe < NP) {
-            // the arenas of the batches in flight take at most a quarter of the device's memory (a full-width teacher's is 29 GB
-            // at batch 32) and never what is not free: fewer batches in flight then, not a failed call
+            // the arenas of the batches in flight take at most half of the device's memory (a full-width teacher's is 29 GB at
+            // batch 32, the 160^3 ResEnc student's 45 GB) and never what is not free: fewer batches in flight then, not a failed call
             const size_t arena = e->act_halves * e->max_batch * sizeof(f16) + e->stats_doubles * e->max_batch * sizeof(double) +
                                  (e->ss_count * e->max_batch * 3 + 8) * sizeof(float);
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && arena > 0) {
-                const long long by_total = (long long)(total_b / 4 / arena), by_free = (long long)(free_b * 8 / 10 / arena) + e->n_pipe;
+                const long long by_total = (long long)(total_b / 2 / arena), by_free = (long long)(free_b * 8 / 10 / arena) + e->n_pipe;
                 const long long cap = std::max<long long>(2, std::min(by_total, by_free));
                 if (NP > cap) NP = (int)std::max<long long>(cap, e->n_pipe);
             }
@@ -1552,7 +1552,13 @@ const char *fnn_last_error(const fnn_engine *e) { return e ? e->err.c_str() : g_
 
 int fnn_create(const fnn_arch_desc *arch, int device, int max_batch, fnn_engine **out) {
     if (!arch || !out) return fail(nullptr, FNN_E_INVALID, "NULL argument");
-    if (max_batch < 1 || max_batch > 64) return fail(nullptr, FNN_E_INVALID, "max_batch must be 1..64");
+    // up to 64 patches per forward, or - small patches (a 40 x 56 x 40 plan, a 2-D slice) - as many as give a forward 2^27 voxels
+    // (64 patches of 128^3), at most 512: the deep layers of a small patch have too few voxels per item to fill the chip
+    {
+        const long long pv = (long long)arch->patch[0] * arch->patch[1] * arch->patch[2];
+        const long long cap = pv > 0 ? std::max<long long>(64, std::min<long long>(512, (1ll << 27) / pv)) : 64;
+        if (max_batch < 1 || max_batch > cap) return fail(nullptr, FNN_E_INVALID, "max_batch must be 1..%lld for this patch size", cap);
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, FNN_E_HIP, "no HIP device is available: the MI355X engine has no CPU fallback");
