@@ -63,7 +63,6 @@ static bool zr_pick(const ConvParams &p, int &nb, int &td, int *th_out = nullptr
     if (nb == 2 && !p.fp8 && p.Ho <= 6 && p.Wo <= 8 && p.Do >= 10 && p.Do % 10 == 0 && fnn_knob("FNN_NO_ZR6") == nullptr &&
         (long long)plan_n * (p.Do / 10) * (nblk / 2) >= 160) {
         td = 10;
-        if (fnn_knob("FNN_ZR6_TD4") != nullptr) td = 4;      // experiment (round 6): 4 x 6 x 8 tiles - 2.5 x the workgroups, three per CU
         if (th_out) *th_out = 6;
         return true;
     }
@@ -1960,7 +1959,7 @@ int launch_conv3d_zr(const ConvParams &p, hipStream_t st) {
     int nb, td, th;
     if (p.packing == FNN_PACK_ZR && p.ksteps == 15 && zs_pick(p)) return launch_zs(p, st);
     if (p.packing != FNN_PACK_ZR || p.ksteps != 15 || !zr_pick(p, nb, td, &th)) return -1;
-    if (th == 6) return td == 4 ? launch_zr<2, 4, 6>(p, st) : launch_zr<2, 10, 6>(p, st);
+    if (th == 6) return launch_zr<2, 10, 6>(p, st);
     if (p.fp8) {
         if (nb == 2) return td == 8 ? launch_zr8<2, 8>(p, st) : launch_zr8<2, 4>(p, st);
         return td == 8 ? launch_zr8<1, 8>(p, st) : launch_zr8<1, 4>(p, st);
