@@ -804,6 +804,7 @@ ZPS_CASES = [
     (4, 128, 0, 256, (1, 32, 32), '4,1'),        # 16 x 16 outputs
     (8, 96, 0, 64, (1, 9, 7), '4,1'),            # a plane smaller than the tile, odd sizes
     (2, 16, 0, 32, (3, 40, 66), '2,2'),          # a single 16-channel source
+    (3, 64, 0, 96, (2, 20, 18), '2,1'),          # 16 x 16 tiles, cout blocks in pairs (96 = 3 x 32)
 ]
 
 

@@ -4,7 +4,7 @@
 # (separate runs, no trace domains next to --pmc), the MFMA-busy pass, and the plain bench line.  Every pass under `timeout`.
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
-round=${FNN_ROUND:-r05}
+round=${FNN_ROUND:-r06}
 out=$root/gpurun_out/cap_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
@@ -15,16 +15,16 @@ echo "workload key: $key"
 # per-kernel durations and counters are taken with the pipelining off: kernels of the internal streams otherwise overlap
 # and the trace reports their stretched durations.  The headline bench line below has it on.
 export FNN_KNOBS=1 FNN_NO_PIPELINE=1
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --no-cpu-baseline --no-clock-probe --steps 3 --warmup 1 "$@" > $out/trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --no-cpu-baseline --no-clock-probe --no-also --no-from-host --steps 3 --warmup 1 "$@" > $out/trace.log 2>&1
 if [ -z "$SKIP_PMC" ]; then
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 --output-format csv -d $out/pmc_mfma -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline "$@" > $out/pmc_mfma.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 --output-format csv -d $out/pmc_mfma -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-also --no-from-host "$@" > $out/pmc_mfma.log 2>&1
 m=$(find $out/pmc_mfma -name "*counter_collection.csv" | head -1)
 mk=$(find $out/pmc_mfma -name "*kernel_trace.csv" | head -1)
 python3 $root/tools/pmc_summary.py $m > $out/pmc_mfma_summary.txt 2>&1
 python3 $root/tools/clock_summary.py $mk $m > $out/clock_summary.txt 2>&1
 rm -rf $out/pmc_mfma
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline "$@" > $out/pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-also --no-from-host "$@" > $out/pmc_$c.log 2>&1
 done
 fi
 cd $root

@@ -8,7 +8,7 @@ export FNN_KNOBS=1 FNN_NO_PIPELINE=1
 i=0
 for grp in "$@"; do
   d=$root/gpurun_out/pmc_${tag}_$i
-  rocprofv3 --pmc $grp --output-format csv -d $d -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $d.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $d -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-also --no-from-host > $d.log 2>&1
   f=$(find $d -name "*counter_collection.csv" | head -1)
   python3 $root/tools/pmc_summary.py $f > $root/gpurun_out/pmc_${tag}_$i.txt 2>&1
   rm -rf $d

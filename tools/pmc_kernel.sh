@@ -9,7 +9,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $line --output-format csv -d $out/p$i -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline "$@" > $out/p$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $line --output-format csv -d $out/p$i -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-also --no-from-host "$@" > $out/p$i.log 2>&1
   f=$(find $out/p$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 $root/tools/pmc_avg.py $f "$kn"
   rm -rf $out/p$i
