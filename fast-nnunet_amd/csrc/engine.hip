@@ -291,7 +291,7 @@ int build_plan(fnn_engine *e) {
     // tensor with the channels padded to 16 (patch_input_kernel, misc.hip) and the stem is an ordinary conv layer on the MFMA
     // conv kernels - plan sweep, round 6: the generic multi-channel stem took 17 % (4 channels) to 55 % (14) of a forward.
     auto add_stem = [&](int cin, int cout, const int32_t *k, const int *d) {
-        const bool via_conv = (cin >= 2 || d[0] < 8) && fnn_knob("FNN_STEM_DIRECT") == nullptr;       // (knob: A-B aid / the tests of the generic stem kernel)
+        const bool via_conv = (cin >= 2 || a.spatial_dims == 2) && fnn_knob("FNN_STEM_DIRECT") == nullptr;   // (knob: A-B aid / the tests of the generic stem kernel)
         const int c[2] = {cin, 0};
         if (!via_conv) {
             const int src[2] = {-1, -1};

@@ -513,3 +513,32 @@ def test_multi_channel_stem_on_the_conv_kernels_agrees_with_the_direct_stem_kern
         ref = build_oracle(spec, sd)(x)
     mr, rr = _report(f'stem {cin} ch on the conv kernels', a, ref)
     assert mr <= MAX_REL and rr <= RMSE_REL
+
+
+def test_per_launch_profile_rows_and_layer_table():
+    """fnn_profile_launches / fnn_layer_table (round 6, the plan sweep's per-layer tables): one row per timed launch of the
+    profiled call - layer index, family, milliseconds, algorithmic work, kernel variant(s) - consistent with fnn_kernel_log and
+    with the layer plan; a multi-channel stem shows as an `input` layer + a conv layer."""
+    spec = UNetSpec('plain', 2, 3, [32, 64], [(1, 3, 3), (3, 3, 3)], [(1, 1, 1), (1, 2, 2)], [2, 2], [2])
+    patch = (8, 48, 64)
+    p = _predictor(spec, patch, [synthetic_state_dict(spec, 9)], batch=2)
+    x = torch.randn(2, 2, *patch, generator=torch.Generator().manual_seed(2))
+    p._engine.set_profiling(True)
+    try:
+        p.forward_patches(x)
+        rows = p._engine.profile_launches()
+        klog = p._engine.kernel_log()
+    finally:
+        p._engine.set_profiling(False)
+    layers = p._engine.layer_table()
+    assert [L['type'] for L in layers][:2] == ['input', 'conv'] and layers[0]['cin'] == 2 and layers[1]['cout'] == 32
+    assert layers[1]['kernel'] == '1x3x3' and layers[1]['out_dims'] == '8x48x64'
+    named = [k for r in rows for k in r[5].split(' + ') if k]
+    assert named == klog                                            # every noted kernel belongs to exactly one timed launch
+    by_layer = {r[0]: r for r in rows if r[0] >= 0}
+    assert set(by_layer) == {L['index'] for L in layers if L['fused'] != 1}
+    for li, (layer, fam, ms, flops, by, kern) in by_layer.items():
+        assert ms > 0 and kern
+        if layers[li]['type'] == 'conv':
+            assert fam == 'conv' and abs(flops - 2 * layers[li]['flops']) < 1e-6 * flops      # two patches in the batch
+    assert by_layer[0][5] == 'patch_input_kernel' and by_layer[1][5].startswith('conv2d_zp_kernel')
