@@ -375,6 +375,9 @@ int launch_zp(ConvParams p, hipStream_t st) {
 // kernel - so it keeps NB = 4 cout blocks (64 output channels) per staged image where the layer has them (a down-sampling
 // conv has twice its input's channels: every cout group re-reads the whole input), and one workgroup per CU (124 KB).
 // Same packing (FNN_PACK_ZP), staging arithmetic, epilogue and statistics rows as conv2d_zp_kernel.
+// Measured and dropped (round 6): 4 x 32 tiles with two cout blocks for layers of one or two chunks - 64 KB, two workgroups per CU, so that a
+// single-chunk tile has a neighbour to hide its load latency behind: SLOWER, 32 -> 64 at 256^2 575 -> 736 us, 64 -> 128 527 -> 600 us, the thick-slice
+// plan's 32 -> 64 1677 -> 2174 us (profiles/r06_zps_th2_ab.txt): half the MFMAs per staged byte and a 9 / 4 instead of 17 / 8 halo cost more than the overlap buys.
 template <int NB, int WC>
 __global__ __launch_bounds__(256, 1) void conv2d_zps_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

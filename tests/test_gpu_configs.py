@@ -540,5 +540,5 @@ def test_per_launch_profile_rows_and_layer_table():
     for li, (layer, fam, ms, flops, by, kern) in by_layer.items():
         assert ms > 0 and kern
         if layers[li]['type'] == 'conv':
-            assert fam == 'conv' and abs(flops - 2 * layers[li]['flops']) < 1e-6 * flops      # two patches in the batch
+            assert fam == 'conv' and abs(flops - 2 * layers[li]['flops']) < 1e-5 * flops      # two patches in the batch (six printed digits)
     assert by_layer[0][5] == 'patch_input_kernel' and by_layer[1][5].startswith('conv2d_zp_kernel')
