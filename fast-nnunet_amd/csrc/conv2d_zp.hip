@@ -78,7 +78,10 @@ static bool zp_pick(const ConvParams &p, int &wc, int &th) {
     const bool strided = p.sh == 2 && p.sw == 2;
     if (!strided && !(p.sh == 1 && p.sw == 1)) return false;
     if (strided && fnn_knob("FNN_NO_ZPS") != nullptr) return false;                 // A-B aid
-    if (p.Cout % 32 != 0) return false;                                             // cout blocks in pairs
+    // cout blocks in pairs; an odd number of blocks (16 output channels: the full-resolution level of an r = 2 student) one at a
+    // time, only where no other kernel fits - depth < 4, i.e. `2d` configurations (at depth >= 4 the persistent 4 x 8 x 8 kernels
+    // reach 4 TB/s on those layers) - and not strided (a down-sampling conv doubles its channels)
+    if (p.Cout % 32 != 0 && (strided || p.Do >= 4 || p.Cout % 16 != 0)) return false;
     const long long vox = (long long)p.Do * p.Ho * p.Wo;
     const int cmax = p.src[0].C > p.src[1].C ? p.src[0].C : p.src[1].C;
     // 32-bit byte offsets inside a batch item, and the 0x80000000 "not fetched" offset must lie beyond every tensor
@@ -109,10 +112,9 @@ namespace {
 typedef unsigned zp_u32x4 __attribute__((ext_vector_type(4)));
 typedef int zp_i32x4 __attribute__((ext_vector_type(4)));
 
-template <int TH, int WC>
+template <int TH, int WC, int NB = 2>
 __global__ __launch_bounds__(256, 2) void conv2d_zp_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NB = 2;
     constexpr int WR = 4 / WC;                                // waves along the rows
     constexpr int ROWS = WR * TH, COLS = WC * 16;             // output tile
     constexpr int IH = ROWS + 2, IWC = COLS + 2;              // halo image
@@ -279,7 +281,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_zp_kernel(const ConvParams p) {
         // the bias is where the accumulators start: lane quarter q holds channels q * 8 + nb * 4 .. + 3 of the block pair
         f32x4 b0[NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) b0[nb] = *(const f32x4 *)(p.bias + cb0 * 16 + (lane >> 4) * 8 + nb * 4);
+        for (int nb = 0; nb < NB; ++nb)
+            b0[nb] = *(const f32x4 *)(p.bias + cb0 * 16 + (NB == 2 ? (lane >> 4) * 8 + nb * 4 : (lane >> 4) * 4));   // (NB = 1: the plain channel order)
 #pragma unroll
         for (int j = 0; j < TH; ++j)
 #pragma unroll
@@ -312,6 +315,33 @@ __global__ __launch_bounds__(256, 2) void conv2d_zp_kernel(const ConvParams p) {
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { t1[nb][j] = 0.f; t2[nb][j] = 0.f; }
+        if constexpr (NB == 1) {
+            // one cout block: lane (r, q) holds channels 4 q .. + 3 of its voxel in rows jr and jr + 1; v_permlane16_swap (pair_to_b128) turns the
+            // two rows' 8-byte pieces into ONE 16-byte store per lane - channels 8 (q >> 1) .. + 7 of voxel r of row jr + (q & 1)
+            const unsigned coff1 = (unsigned)cb0 * (unsigned)(FNN_OCS(p) * 2) + (unsigned)(q >> 1) * 16;
+#pragma unroll
+            for (int jr = 0; jr < TH; jr += 2) {
+                f16x4 o[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int oh = oh0 + wr * TH + jr + h;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[h][j] = (f16)acc[jr + h][0][j];
+                    if (!(ok_c && oh < p.Ho)) o[h] = (f16x4){0, 0, 0, 0};
+                }
+                const int ohs = oh0 + wr * TH + jr + (q & 1);
+                const unsigned vo = (ok_c && ohs < p.Ho) ? (unsigned)((d * p.Ho + ohs) * p.Wo + ow) * ovs2 + coff1 : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(zp_i32x4, pair_to_b128(o[0], o[1])), rsrc, vo, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f16x2 pr = {o[0][j], o[1][j]};
+                    t1[0][j] = __builtin_amdgcn_fdot2(pr, ones, t1[0][j], false);
+                    t2[0][j] = __builtin_amdgcn_fdot2(pr, pr, t2[0][j], false);
+                }
+            }
+            if (p.stats_out) stats_to_global<1, true, false, 4>(p, t1, t2, (float *)smem, n, cb0, wave, lane, tid, tile_in_item);
+            return;
+        }
 #pragma unroll
         for (int jr = 0; jr < TH; jr += 2) {
             f16x8 o[2];
@@ -340,18 +370,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_zp_kernel(const ConvParams p) {
     }
 }
 
-template <int TH, int WC>
+template <int TH, int WC, int NB = 2>
 int launch_zp(ConvParams p, hipStream_t st) {
     constexpr int WR = 4 / WC, ROWS = WR * TH, COLS = WC * 16, IH = ROWS + 2, IWC = COLS + 2;
     constexpr int QP = ((IWC * 16 + 64 + 255) / 256) * 256;
-    const size_t lds = (size_t)IH * 4 * QP + 2 * 9 * 1024;
+    const size_t lds = (size_t)IH * 4 * QP + NB * 9 * 1024;
     p.tiles_d = p.Do;
     p.tiles_h = (p.Ho + ROWS - 1) / ROWS;
     p.tiles_w = (p.Wo + COLS - 1) / COLS;
     if (p.stats_out && p.stats_slots < p.Do * p.tiles_h * p.tiles_w) return -1;   // (a plan sized for another tiling)
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)conv2d_zp_kernel<TH, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv2d_zp_kernel<TH, WC, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     p.ident_ss = conv3d_identity_ss();
@@ -359,9 +389,9 @@ int launch_zp(ConvParams p, hipStream_t st) {
     if (!p.ident_ss || !p.ident_ssh) return -2;
     const long long tiles = (long long)p.N * p.Do * p.tiles_h * p.tiles_w;
     if (tiles >= (1ll << 31)) return -1;
-    dim3 grid((unsigned)tiles, (p.Cout / 16) / 2);
-    fnn_note_kernel("conv2d_zp_kernel<%d,%d>", TH, WC);
-    hipLaunchKernelGGL((conv2d_zp_kernel<TH, WC>), grid, dim3(256), lds, st, p);
+    dim3 grid((unsigned)tiles, (p.Cout / 16) / NB);
+    if (NB == 2) fnn_note_kernel("conv2d_zp_kernel<%d,%d>", TH, WC); else fnn_note_kernel("conv2d_zp_kernel<%d,%d,%d>", TH, WC, NB);
+    hipLaunchKernelGGL((conv2d_zp_kernel<TH, WC, NB>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -646,6 +676,11 @@ int launch_conv2d_zp(const ConvParams &p, hipStream_t st) {
         const bool four = (p.Cout / 16) % 4 == 0;
         if (wc == 2) return four ? launch_zps<4, 2>(p, st) : launch_zps<2, 2>(p, st);
         return four ? launch_zps<4, 1>(p, st) : launch_zps<2, 1>(p, st);
+    }
+    if ((p.Cout / 16) % 2 != 0) {                             // an odd number of cout blocks: one per workgroup
+        if (wc == 4) return launch_zp<8, 4, 1>(p, st);
+        if (wc == 2) return launch_zp<8, 2, 1>(p, st);
+        return launch_zp<4, 1, 1>(p, st);
     }
     if (wc == 4) return launch_zp<8, 4>(p, st);
     if (wc == 2) return launch_zp<8, 2>(p, st);

@@ -746,6 +746,12 @@ ZP_CASES = [
     (6, 64, 0, 64, (2, 4, 4), '4,1'),
     (2, 16, 0, 32, (2, 33, 70), '8,4'),          # a single 16-channel source (a stem on the conv kernels): half a chunk
     (1, 4, 0, 32, (1, 40, 48), '8,4'),           # channel padding 4 -> 16
+    # one cout block per workgroup (16 output channels - the full-resolution level of a `2d` r = 2 student - or an odd block count)
+    (2, 16, 0, 16, (1, 64, 96), '8,4,1'),
+    (3, 16, 16, 16, (1, 37, 83), '8,4,1'),       # decoder conv of that level: two 16-channel sources = two half-empty chunks, ragged tiles
+    (2, 1, 0, 16, (2, 24, 40), '8,4,1'),         # a 1-channel stem on the conv kernels, depth 2
+    (4, 64, 0, 48, (1, 32, 20), '8,2,1'),        # three cout blocks
+    (4, 32, 0, 16, (3, 9, 12), '4,1,1'),
 ]
 
 

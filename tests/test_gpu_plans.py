@@ -53,6 +53,7 @@ def test_plan_forward_matches_fp32_oracle(plan):
     # 512^2 plan measures 5.7e-3 / 4.9e-3 on the plane kernels and 4.7e-3 / 4.3e-3 on the linear-tap kernels they replace
     # (FNN_NO_ZP=1, profiles/r06_plans_parity.txt) - a property of the fp16 chain, not of a kernel: 1.5 x the gate, like the deep
     # random topologies of test_gpu_predictor.py
-    k = 1.5 if nd == 2 else 1.0
+    # (the 7-stage thick-slice r = 2 student likewise: 3.8e-3 / 3.8e-3 on the tree, 4.0e-3 / 3.7e-3 with FNN_NO_ZP=1)
+    k = 1.5 if nd == 2 or n >= 7 else 1.0
     assert mr <= k * MAX_REL and rr <= k * RMSE_REL
     assert not any('generic' in name for name in p._engine.kernel_log()), p._engine.kernel_log()
