@@ -363,7 +363,7 @@ def also_block(device):
                '--no-from-host'] + flags
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
             if r.returncode != 0 or not line:
                 out[name] = {'error': (r.stderr or r.stdout)[-300:]}
