@@ -40,7 +40,8 @@ python tools/traffic.py $f $w $root/gpurun_out/${round}_traffic.json "$key" > $o
 fi
 unset FNN_NO_PIPELINE
 cp $root/gpurun_out/${round}_traffic.json $root/profiles/${round}_traffic.json 2>/dev/null   # so that the bench line below quotes it
-timeout 900 python bench.py "$@" 2> $out/bench.err | grep "^{" > $out/bench.json
+extra=""; [[ "$*" == *--plan* ]] && extra="--no-cpu-baseline"          # (a plan line: no CPU leg - its oracle forward of a full-width teacher patch takes minutes)
+timeout 900 python bench.py $extra "$@" 2> $out/bench.err | grep "^{" > $out/bench.json
 rm -rf $out/trace $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
 tail -1 $out/bench.json | cut -c1-1200
 head -14 $out/trace_summary.txt

@@ -3,7 +3,7 @@
 #   bash tools/install_capture.sh      - copies the per-workload capture files and the counter-traffic file into profiles/ under the round's names
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 R=${FNN_ROUND:-r06}
-for t in bone iso128_r2 iso128_teacher resenc160_r2 resenc160_r2_f8 bone_autocast bone_mirror; do
+for t in bone iso128_r2 iso128_teacher resenc160_r2 resenc160_r2_f8 bone_autocast bone_mirror plan_plane2d_512_r1 plan_brats_128_c4_r1 plan_prostate_20x320x256_r1; do
   d=gpurun_out/cap_$t
   [ -d $d ] || { echo "missing $d"; continue; }
   for f in bench.json kernel_stats.csv trace_summary.txt layers.txt clock_summary.txt pmc_mfma_summary.txt; do
