@@ -210,50 +210,38 @@ static __device__ __forceinline__ void apply8(const SrcDesc &s, int n, int c0, c
 // Patch windows of the fp32 volume -> fp16 [N][PD][PH][PW][Cpad] (x rounded to fp16 once: the engine's contract for every
 // conv operand).  Thread = (voxel, 8-channel group); a wave's 64 voxels are consecutive along z, so each of its (up to 8)
 // channel-plane reads is 256 contiguous bytes and its 16-byte stores tile whole records.  The patch coordinates come from
-// 32-bit arithmetic (a patch has < 2^31 voxels); mirroring is the coordinate P - 1 - v; four voxels per thread, their loads in flight together.  Replaces the patch slicing
+// 32-bit arithmetic (a patch has < 2^31 voxels); mirroring is the coordinate P - 1 - v.  (Measured, round 6: four voxels per thread with all
+// their loads in flight - 2 channels at 20 x 320 x 256 915 -> 690 us, 14 channels at 128^3 1765 -> 1670 us, but 4 channels at 128^3 1258 -> 1337 us and one
+// channel at 512^2 152 -> 275 us: profiles/r06_plan_sweep_patch_input_u4.txt - not kept.)  Replaces the patch slicing
 // `data[sl]` of predict_from_raw_data.py:560-566 for stems that run on the MFMA conv kernels (engine.hip, Layer::GATHER).
-#define FNN_PIN_U 4                                                    // voxels per thread (256 apart): every load of a thread in flight together
 __global__ __launch_bounds__(256) void patch_input_kernel(const PatchInputParams p) {
     const unsigned pvox = (unsigned)p.PD * p.PH * p.PW;
     const unsigned cg = (unsigned)(p.Cpad >> 3);
     const unsigned n = blockIdx.y / cg, g = blockIdx.y % cg;
-    const unsigned v0 = blockIdx.x * (256u * FNN_PIN_U) + threadIdx.x;
-    const int c0 = (int)g * 8;
-    const int nreal = p.C - c0 < 8 ? (p.C - c0 < 0 ? 0 : p.C - c0) : 8;   // real channels of this group (uniform)
+    const unsigned v = blockIdx.x * 256u + threadIdx.x;
+    if (v >= pvox) return;
+    const unsigned w = v % (unsigned)p.PW, t = v / (unsigned)p.PW, h = t % (unsigned)p.PH, d = t / (unsigned)p.PH;
+    const long long x = p.origins[n * 3 + 0] + (p.flip_d ? p.PD - 1 - (int)d : (int)d);
+    const long long y = p.origins[n * 3 + 1] + (p.flip_h ? p.PH - 1 - (int)h : (int)h);
+    const long long z = p.origins[n * 3 + 2] + (p.flip_w ? p.PW - 1 - (int)w : (int)w);
+    const float *src = p.vol + (size_t)n * p.vol_batch_stride + (size_t)((x * p.Y + y) * p.Z + z);
     const size_t plane = (size_t)p.X * p.Y * p.Z;
-    const float *vol = p.vol + (size_t)n * p.vol_batch_stride + (size_t)c0 * plane;
-    const long long ox = p.origins[n * 3 + 0], oy = p.origins[n * 3 + 1], oz = p.origins[n * 3 + 2];
-    float x[FNN_PIN_U][8];
+    f16x8 o;
 #pragma unroll
-    for (int u = 0; u < FNN_PIN_U; ++u) {
-        const unsigned v = v0 + 256u * u;
-        const unsigned vv = v < pvox ? v : pvox - 1;                     // clamped: always a valid address
-        const unsigned w = vv % (unsigned)p.PW, t = vv / (unsigned)p.PW, h = t % (unsigned)p.PH, d = t / (unsigned)p.PH;
-        const long long xx = ox + (p.flip_d ? p.PD - 1 - (int)d : (int)d);
-        const long long yy = oy + (p.flip_h ? p.PH - 1 - (int)h : (int)h);
-        const long long zz = oz + (p.flip_w ? p.PW - 1 - (int)w : (int)w);
-        const float *src = vol + (size_t)((xx * p.Y + yy) * p.Z + zz);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[u][j] = j < nreal ? src[(size_t)j * plane] : 0.f;
+    for (int j = 0; j < 8; ++j) {
+        const int c = (int)g * 8 + j;
+        o[j] = c < p.C ? (f16)src[(size_t)c * plane] : (f16)0.f;
     }
+    const int c0 = (int)g * 8;
     const size_t vs = p.out_vs ? (size_t)p.out_vs : (size_t)p.Cpad;
     const size_t cs = p.out_vs ? (size_t)p.out_cs : 16;
-    f16 *outn = p.out + (size_t)n * pvox * p.Cpad + (size_t)(c0 >> 4) * cs + (c0 & 15);
-#pragma unroll
-    for (int u = 0; u < FNN_PIN_U; ++u) {
-        const unsigned v = v0 + 256u * u;
-        if (v >= pvox) continue;
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (f16)x[u][j];
-        *(f16x8 *)(outn + (size_t)v * vs) = o;
-    }
+    *(f16x8 *)(p.out + (size_t)n * pvox * p.Cpad + (size_t)v * vs + (size_t)(c0 >> 4) * cs + (c0 & 15)) = o;
 }
 
 int launch_patch_input(const PatchInputParams &p, hipStream_t st) {
     const unsigned pvox = (unsigned)p.PD * p.PH * p.PW;
     fnn_note_kernel("patch_input_kernel");
-    hipLaunchKernelGGL(patch_input_kernel, dim3((pvox + 256 * FNN_PIN_U - 1) / (256 * FNN_PIN_U), (unsigned)(p.N * (p.Cpad >> 3))), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(patch_input_kernel, dim3((pvox + 255) / 256, (unsigned)(p.N * (p.Cpad >> 3))), dim3(256), 0, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
