@@ -112,7 +112,8 @@ int fnn_abi_version(void);
 const char *fnn_last_error(const fnn_engine *e);             /* e may be NULL */
 
 /* Replaces network construction in initialize_from_trained_model_folder
- * (:104-118) / manual_initialization (:131-154). */
+ * (:104-118) / manual_initialization (:131-154).  max_batch: patches per forward the engine is planned for (the kernel
+ * variants are chosen for it): 1 .. 64, or - small patches - as many as give a forward 2^27 voxels, at most 512. */
 int fnn_create(const fnn_arch_desc *arch, int device, int max_batch, fnn_engine **out);
 void fnn_destroy(fnn_engine *e);
 

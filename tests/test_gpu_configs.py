@@ -542,3 +542,35 @@ def test_per_launch_profile_rows_and_layer_table():
         if layers[li]['type'] == 'conv':
             assert fam == 'conv' and abs(flops - 2 * layers[li]['flops']) < 1e-5 * flops      # two patches in the batch (six printed digits)
     assert by_layer[0][5] == 'patch_input_kernel' and by_layer[1][5].startswith('conv2d_zp_kernel')
+
+
+@pytest.mark.parametrize('planned', [32, 24, 16])
+def test_fp8_on_the_160_channel_stage_where_the_f16_pick_uses_six_row_tiles(planned):
+    """a 160-channel stage at 20 x 6 x 6 - the benchmark net's own - with compute_dtype='f8'.  The f16 launch rule
+    takes 10 x 6 x 8 tiles there (two statistics rows per item), the e4m3 kernel 8 x 8 x 8 (three) or four-plane tiles (five): the
+    plan's probes now carry the fp8 flag the launch carries, so the rows it sizes are the rows the kernel writes (a plan sized for
+    the f16 tiling let row 2 of item n overwrite row 0 of item n + 1: wrong InstanceNorm scales and a write past the layer's
+    region); planned batches 32 / 24 / 16 pick td = 8 / td = 4 / fall back to f16 for that layer.  Budget as the other fp8
+    tests, every item of a full batch checked (a trampled statistics row shows in the items behind the first)."""
+    spec = UNetSpec('plain', 1, 2, [16, 160], [(3, 3, 3)] * 2, [(1, 1, 1), (2, 2, 2)], [2, 2], [2])
+    patch = (40, 12, 12)
+    sd = synthetic_state_dict(spec, 815)
+    n = min(planned, 8)
+    x = torch.randn(n, 1, *patch, generator=torch.Generator().manual_seed(83))
+    torch.set_num_threads(8)
+    with torch.inference_mode():
+        ref = build_oracle(spec, sd)(x)
+    p8 = _fp8_predictor(spec, patch, [sd], batch=planned)
+    p8._engine.set_profiling(True)
+    try:
+        got8 = p8.forward_patches(x).cpu()
+        kernels = sorted(set(p8._engine.kernel_log()))
+    finally:
+        p8._engine.set_profiling(False)
+    print(f'[f8 160-channel stage, planned batch {planned}] {kernels}')
+    assert bool(torch.isfinite(got8).all())
+    for i in range(n):                                                      # per item: the statistics rows of every item are its own
+        err = float((got8[i] - ref[i]).pow(2).mean().sqrt() / ref[i].pow(2).mean().sqrt())
+        assert err <= FP8_RMSE, (i, err)
+    single = p8.forward_patches(x[n - 1:n]).cpu()                           # a patch's result does not depend on its place in the batch
+    assert float((single - got8[n - 1:n]).abs().max()) <= 2e-2 * float(ref.abs().max())
