@@ -149,6 +149,7 @@ struct TconvParams {
     int ksteps;                  // ceil(Cin / 32)
     int nblk;                    // Cout / 16
     int row_store;               // set by launch_tconv: pairs of w-phase taps stored as contiguous rows
+    int lds_w;                   // set by launch_tconv: >= 4 k-steps - the weight fragments of a k-step once per workgroup through LDS
 };
 
 struct HeadParams {

@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void tconv_mfma_kernel(const TconvParams p)
 
     load_scale_shift(p.src, n, sSS, tid, 256);
     __syncthreads();
-    if (v0 >= vox_in) return;
+    if (v0 >= vox_in && !p.lds_w) return;                              // (with the weights through LDS every wave keeps the k-loop's barriers; its stores are guarded)
 
     f32x4 acc[MB][TG][NBT];
     const int r = lane & 15, q = lane >> 4;
@@ -511,8 +511,62 @@ __global__ __launch_bounds__(256, 2) void tconv_mfma_kernel(const TconvParams p)
                     acc[mb][tg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tg][nb], xf[mb],
                                           FIRST ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mb][tg][nb], 0, 0, 0);
     };
-    kstep(0, std::true_type{});
-    for (int ks = 1; ks < p.ksteps; ++ks) kstep(ks, std::false_type{});
+    if (!p.lds_w) {
+        kstep(0, std::true_type{});
+        for (int ks = 1; ks < p.ksteps; ++ks) kstep(ks, std::false_type{});
+    } else {
+        // Layers with four and more k-steps (>= 128 input channels: the matrix-bound transposed convs in the middle of the decoder): the workgroup's
+        // four waves multiply the SAME TG x NBT weight fragments per k-step - each wave loading them from L2 was four times the traffic, and with the
+        // activation fragments 96 B per clock and CU against the 64 the L2 delivers (270-280 TFLOP/s whatever the layer).  Here the fragments of
+        // k-step ks + 1 are fetched once per workgroup (16 B per thread and 256 fragment elements) while k-step ks multiplies, and go through a
+        // double-buffered LDS image; one barrier per k-step.  Same k order, same accumulators: the same bits.
+        constexpr int NW = TG * NBT, WPT = (NW * 64 + 255) / 256;           // fragments per k-step; 16-byte elements per thread
+        typedef unsigned tc_u32x4 __attribute__((ext_vector_type(4)));
+        tc_u32x4 *sWt = (tc_u32x4 *)(smem + (((size_t)p.src.C * 8 + 15) & ~(size_t)15));   // [2][NW][64]
+        tc_u32x4 wreg[WPT];
+        auto wload = [&](int ks) {
+#pragma unroll
+            for (int u = 0; u < WPT; ++u) {
+                const int e = tid + 256 * u, f = e >> 6, l = e & 63, tg = f / NBT, nb = f - tg * NBT;
+                if (NW * 64 % 256 == 0 || e < NW * 64)
+                    wreg[u] = *(const tc_u32x4 *)(p.wpk + ((((size_t)(tap0 + tg) * p.nblk + cb0 + nb) * p.ksteps + ks) * 64 + l) * 8);
+            }
+        };
+        auto wstore = [&](int buf) {
+#pragma unroll
+            for (int u = 0; u < WPT; ++u) {
+                const int e = tid + 256 * u;
+                if (NW * 64 % 256 == 0 || e < NW * 64) sWt[buf * (NW * 64) + e] = wreg[u];
+            }
+        };
+        auto kstep_l = [&](int ks, auto first_c) {
+            constexpr bool FIRST = decltype(first_c)::value;
+            if (ks + 1 < p.ksteps) wload(ks + 1);
+            f16x8 xf[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int v = v0 + mb * 16 + r;
+                xf[mb] = load_act_frag(p.src, (size_t)(v < vox_in ? v : vox_in - 1), true, ks * 32 + q * 8, sSS, (size_t)n * vox_in * p.src.C);
+            }
+            const tc_u32x4 *wb = sWt + (ks & 1) * (NW * 64) + lane;
+#pragma unroll
+            for (int tg = 0; tg < TG; ++tg)
+#pragma unroll
+                for (int nb = 0; nb < NBT; ++nb) {
+                    const f16x8 wf = __builtin_bit_cast(f16x8, wb[(tg * NBT + nb) * 64]);
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        acc[mb][tg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[mb], FIRST ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mb][tg][nb], 0, 0, 0);
+                }
+            if (ks + 1 < p.ksteps) wstore((ks + 1) & 1);
+            __syncthreads();
+        };
+        wload(0);
+        wstore(0);
+        __syncthreads();
+        kstep_l(0, std::true_type{});
+        for (int ks = 1; ks < p.ksteps; ++ks) kstep_l(ks, std::false_type{});
+    }
 
     const int Ho = p.Hi * p.sh, Wo = p.Wi * p.sw;
     float4 bv[NBT];
@@ -599,7 +653,7 @@ int launch_tconv(const TconvParams &p, hipStream_t st) {
     const int vox_in = p.Di * p.Hi * p.Wi;
     if ((long long)p.Di * p.Hi * p.Wi > (1 << 24)) return -1;       // the kernel's float-reciprocal index arithmetic
     const int taps = p.sd * p.sh * p.sw;
-    const size_t lds = (size_t)p.src.C * 8;
+    size_t lds = (size_t)p.src.C * 8;
     // accumulators: 4 column blocks x TG taps x NBT cout blocks x 4 registers; keep TG * NBT <= 4
     const int nbt = (p.nblk % 2 == 0) ? 2 : 1;
     // two cout blocks x 4 taps held 128 accumulator registers (276 VGPRs: one wave per SIMD); two taps: 152, three waves
@@ -616,6 +670,8 @@ int launch_tconv(const TconvParams &p, hipStream_t st) {
     // (FNN_TCONV_NO_ROWSTORE: A-B aid): transposed convs 8.1 -> 7.7 ms per benchmark volume, teacher 26.7 -> 25.6; two column
     // blocks per wave at four waves per SIMD (98 registers) next to it: 8.35 - dropped
     pp.row_store = p.sw == 2 && nbt == 2 && tg % 2 == 0 && fnn_knob("FNN_TCONV_NO_ROWSTORE") == nullptr;
+    pp.lds_w = p.ksteps >= 4 && fnn_knob("FNN_TCONV_NO_LDSW") == nullptr;      // (knob: A-B aid) the weight fragments once per workgroup through LDS
+    if (pp.lds_w) lds = ((lds + 15) & ~(size_t)15) + (size_t)2 * tg * nbt * 1024;
 #define FNN_TCONV(NBTv, TGv) do { fnn_note_kernel("tconv_mfma_kernel<%d,%d>", NBTv, TGv); hipLaunchKernelGGL((tconv_mfma_kernel<NBTv, TGv>), grid, dim3(256), lds, st, pp); } while (0)
     if (nbt == 2) { if (tg == 4) FNN_TCONV(2, 4); else FNN_TCONV(2, 2); }
     else          { if (tg == 4) FNN_TCONV(1, 4); else FNN_TCONV(1, 2); }
