@@ -716,7 +716,7 @@ def main():
                               'finalize': round(pr.finalize_ms, 2)},
             'whole_net_tflops': round(flops_patch * n_patches * args.folds / (dt / args.steps) / 1e12, 2),
             # `achieved` / `frac` describe the PROFILED step (one stream, events around every launch); `value` the timed steps
-            # (three batches in flight on the engine's streams).  Both schedules side by side:
+            # (four batches in flight on the engine's streams).  Both schedules side by side:
             'schedules': {'profiled_step_kernel_ms_sum': round(pr.total_ms, 2), 'profiled_step_family_ms': round(pr.conv_ms, 2),
                           'timed_step_ms': round(dt / args.steps * 1e3, 2),
                           'hidden_by_batches_in_flight': round(1.0 - (dt / args.steps * 1e3) / pr.total_ms, 4) if pr.total_ms > 0 else None,

@@ -97,7 +97,7 @@ struct fnn_engine {
     double *stats = nullptr;
     float *ss = nullptr;                    // [layer][max_batch][2][C]
     // Batches in flight (fnn_accumulate / predict): one activation arena and one internal stream per batch in flight
-    // (three by default, FNN_PIPES = 2..4; measured 2 -> 3: +1.5 %, 4: no better).  The network alternates between
+    // (four by default since round 6, FNN_PIPES = 2..8; measured 2 -> 3: +1.5 %, 3 -> 4: +0.3 ... +0.9 %, beyond: nothing).  The network alternates between
     // HBM-bound (thin full-resolution convs, seg head) and MFMA-bound kernels; with the following batches' forwards on
     // the other streams they overlap.  The heads stay ordered (events), so the accumulation order - and with it every
     // rounding - is the reference's.  288 GB of HBM make the extra arenas free.

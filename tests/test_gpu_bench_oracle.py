@@ -1,7 +1,7 @@
 """The benchmark's own launches against the oracle, at the benchmark's own geometry ("parity first" #1).
 
 ``bench.py`` quotes its number on one engine configuration per workload: the network of ``bench.build_predictor``
-planned for 32 patches per forward, a 512^3 synthetic CT, three batches in flight.  Which kernel variant a layer gets
+planned for 32 patches per forward, a 512^3 synthetic CT, several batches in flight.  Which kernel variant a layer gets
 depends on exactly those things (planned batch, tile count, row length), so small-shape parity says nothing about
 them.  Here the engine is built the way ``bench.py`` builds it and
 

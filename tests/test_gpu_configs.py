@@ -157,7 +157,7 @@ def test_c4_teacher_full_size_patch_five_folds_constant_networks():
 
 def test_c4_teacher_full_size_patch_is_bit_stable_and_batch_independent():
     """Random teacher weights at the full 128^3 patch: every kernel variant the teacher's widths select runs with
-    three batches in flight; two runs and a run with other batch boundaries must agree bit for bit."""
+    several batches in flight; two runs and a run with other batch boundaries must agree bit for bit."""
     patch = (128, 128, 128)
     p = _predictor(TEACHER, patch, [synthetic_state_dict(TEACHER, 77)], batch=8)
     vol = torch.randn((1, 256, 256, 256), generator=torch.Generator().manual_seed(1))

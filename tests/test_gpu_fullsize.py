@@ -61,7 +61,7 @@ def test_full_size_volume_constant_network_returns_the_head_bias_everywhere():
         worst = max(worst, float((o[m:-m, m:-m, m:-m] - c[h]).abs().max()) / max(abs(float(c[h])), 0.25))
     print(f'worst relative deviation from the head bias: interior {worst:.2e}, whole volume {worst_border:.2e}')
     assert worst <= 6e-3 and worst_border <= 0.51
-    # a second run over the same volume reproduces the first bit for bit (three batches in flight, 600 patches)
+    # a second run over the same volume reproduces the first bit for bit (several batches in flight, 600 patches)
     again = p.predict_sliding_window_return_logits(vol)
     assert torch.equal(out, again)
     del out, again
