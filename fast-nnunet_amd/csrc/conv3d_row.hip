@@ -864,7 +864,11 @@ int launch_row_t(ThinParams tp, hipStream_t st) {
         attr_set = true;
     }
     int per_cu = (int)((160 * 1024) / lds);
-    int cap = CH == 1 ? (NBLK <= 8 ? 3 : 2) : (NBLK <= 8 ? 2 : 1);
+    // persistent workgroups per CU.  One chunk, rows of <= 128 voxels: LDS would take three, TWO are faster (round 6, profiles/r06_row_wpc.txt,
+    // r06_row1_wpc_ab.txt: the 16 -> 16 layer at 160 x 96 x 96 609-620 us at three, 564-595 at two, 712 at one; the step does not notice; the fused
+    // stem kernel below is the other way round: 591 us at three, 665 at two)
+    static const bool row1_three = fnn_knob("FNN_ROW1_WPC3") != nullptr;                       // A-B aid: the cap of rounds 2-5
+    int cap = CH == 1 ? (NBLK <= 8 ? (row1_three ? 3 : 2) : 2) : (NBLK <= 8 ? 2 : 1);
     static const int wpc_knob = fnn_knob("FNN_ROW_WPC") ? atoi(fnn_knob("FNN_ROW_WPC")) : 0;      // A-B aid: fewer persistent workgroups per CU (room for another stream's kernels)
     if (wpc_knob > 0 && wpc_knob < cap) cap = wpc_knob;
     if (per_cu > cap) per_cu = cap;
