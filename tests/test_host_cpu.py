@@ -520,3 +520,20 @@ def test_sweep_plans_get_the_reference_planners_topology(golden_dir):
             total = int(np.prod([s[a] for s in strides]))
             assert j['patch'][a] % total == 0, (pf, a)
     assert hit >= 1
+
+
+def test_patches_per_forward_bound_follows_the_patch_size(capi):
+    """fnn_create: 1 .. 64 patches per forward, or - small patches - as many as give a forward 2^27 voxels, at most 512 (round 6: the deep layers
+    of a 40 x 56 x 40 plan or a 2-D slice have too few voxels per item).  The bound is checked before any device is touched."""
+    from fast_nnunet_amd.arch import spec_from_state_dict
+    small = spec_from_state_dict(synthetic_state_dict(toy_unet_spec(1, 3)), (16, 16, 32))        # 8192 voxels: 512 allowed
+    with pytest.raises(AssertionError, match=r"max_batch must be 1\.\.512"):
+        capi.Engine(small.to_desc(), 0, 513)
+    with pytest.raises(AssertionError, match=r"max_batch must be 1\.\.512"):
+        capi.Engine(small.to_desc(), 0, 0)
+    big = spec_from_state_dict(synthetic_state_dict(toy_unet_spec(1, 3)), (160, 160, 160))      # 4.1 M voxels: 64
+    with pytest.raises(AssertionError, match=r"max_batch must be 1\.\.64"):
+        capi.Engine(big.to_desc(), 0, 65)
+    mid = spec_from_state_dict(synthetic_state_dict(toy_unet_spec(1, 3)), (64, 128, 128))       # 1 M voxels: 2^27 / 2^20 = 128
+    with pytest.raises(AssertionError, match=r"max_batch must be 1\.\.128"):
+        capi.Engine(mid.to_desc(), 0, 129)
