@@ -84,3 +84,23 @@ def test_host_volume_through_the_accumulate_path_and_fp32_input_dtypes(small_sla
     ref = p.predict_sliding_window_return_logits(vol.cuda())
     got = p.predict_sliding_window_return_logits(vol.double())
     assert np.array_equal(_bits(got), _bits(ref))
+
+
+def test_host_volume_with_the_gather_ring_and_with_the_gather_off(small_slabs, monkeypatch):
+    """The ring form of the gather path (one run_patches call per x layer, a gather launch per output slab: FNN_GATHER_RING) and the
+    accumulate path (FNN_NO_GATHER, read when the engine is created) take their patches from a volume that is still arriving."""
+    spec, patch = toy_unet_spec(1, 3), (16, 16, 32)
+    sd = synthetic_state_dict(spec, 13)
+    vol = torch.randn((1, 72, 40, 72), generator=torch.Generator().manual_seed(8))
+    p = _predictor(spec, patch, [sd], batch=4)
+    ref = p.predict_sliding_window_return_logits(vol.cuda())
+    monkeypatch.setenv('FNN_GATHER_RING', '2')
+    got = p.predict_sliding_window_return_logits(vol)
+    assert np.array_equal(_bits(got), _bits(ref))
+    got = p.predict_sliding_window_return_logits(vol.pin_memory())
+    assert np.array_equal(_bits(got), _bits(ref))
+    monkeypatch.delenv('FNN_GATHER_RING')
+    monkeypatch.setenv('FNN_NO_GATHER', '1')
+    q = _predictor(spec, patch, [sd], batch=4)
+    assert np.array_equal(_bits(q.predict_sliding_window_return_logits(vol)), _bits(q.predict_sliding_window_return_logits(vol.cuda())))
+    assert np.array_equal(_bits(q.predict_sliding_window_return_logits(vol)), _bits(ref))
