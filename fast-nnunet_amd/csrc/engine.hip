@@ -124,9 +124,15 @@ struct fnn_engine {
     struct Upload {
         bool active = false, pinned_src = false;
         const float *host = nullptr; float *dev = nullptr;
-        int C = 0; int64_t X = 0, Y = 0, Z = 0, slab_x = 1, issued_x = 0;
-        std::vector<hipEvent_t> landed;        // landed[i]: slab i is in HBM (events are kept between calls)
-        size_t n_slabs = 0;
+        int C = 0; int64_t X = 0, Y = 0, Z = 0;
+        // the volume travels in tiles of slab_x planes x slab_y rows x the whole z extent (x-major patch order: the first batch's
+        // patches cover the first x layer and a part of y - it starts when THOSE tiles have landed, not the whole layer)
+        int64_t slab_x = 1, slab_y = 1, nxs = 0, nyb = 0;
+        std::vector<char> issued;              // [nxs][nyb]
+        size_t n_issued = 0;
+        std::vector<hipEvent_t> landed;        // event pool (kept between calls): one per upload_box call that issued something
+        size_t ev_next = 0;
+        hipEvent_t last = nullptr;             // the youngest recorded event: everything issued so far lies in front of it
         hipStream_t st = nullptr;
         static constexpr int RING = 3;
         float *stage[RING] = {}; size_t stage_bytes = 0; hipEvent_t stage_free[RING] = {}; bool stage_used[RING] = {};
@@ -985,7 +991,7 @@ inline int no_autocast(fnn_engine *e, const fnn_opts *o, const char *who) {
 
 struct Box { int64_t lo[3], hi[3]; };
 
-int upload_until(fnn_engine *e, int64_t x_need, hipStream_t st);     // (below, next to stage_volume)
+int upload_box(fnn_engine *e, int64_t x_lo, int64_t x_hi, int64_t y_lo, int64_t y_hi, hipStream_t st);     // (below, next to stage_volume)
 
 inline int acc_hp(const fnn_arch_desc &a) { return (a.num_heads + 1 + 7) / 8 * 8; }
 
@@ -1088,10 +1094,14 @@ int run_patches(fnn_engine *e, int fold, const float *vol_dev, const VolPlan &vp
             st = e->pipe[k];
             e->act = e->actp[k]; e->stats = e->statsp[k]; e->ss = e->ssp[k];
         }
-        if (e->up.active) {                                   // a volume still arriving from the host: the planes this batch reads
-            int64_t x_need = 0;                               // (un-padded volume: padded == shape along every axis here)
-            for (int b = 0; b < nb; ++b) x_need = std::max<int64_t>(x_need, (int64_t)vp.origins[ids[p0 + b] * 3] + a.patch[0]);
-            if (int rc = upload_until(e, x_need, st)) return rc;
+        if (e->up.active) {                                   // a volume still arriving from the host: the box this batch's patches read
+            int64_t lo[2] = {INT64_MAX, INT64_MAX}, hi[2] = {0, 0};   // (un-padded volume: padded == shape along every axis here)
+            for (int b = 0; b < nb; ++b)
+                for (int d = 0; d < 2; ++d) {
+                    const int64_t o0 = vp.origins[ids[p0 + b] * 3 + d];
+                    lo[d] = std::min(lo[d], o0); hi[d] = std::max(hi[d], o0 + a.patch[d]);
+                }
+            if (int rc = upload_box(e, lo[0], hi[0], lo[1], hi[1], st)) return rc;
         }
         for (size_t ci = 0; ci <= (tta ? combos.size() : 0); ++ci) {
             int flip[3] = {0, 0, 0};
@@ -1169,41 +1179,72 @@ void parallel_copy(float *dst, const float *src, size_t n) {
     for (int t = 1; t < parts; ++t) th[t - 1].join();
 }
 
-// Issues the upload of every slab that holds planes below x_need, then makes `st` wait for the last of them.
-int upload_until(fnn_engine *e, int64_t x_need, hipStream_t st) {
+// Issues the upload of every tile of [x_lo, x_hi) x [y_lo, y_hi) (planes x rows, whole z extent) that has not left yet, then makes `st` wait
+// for everything issued so far (one copy stream: in order).
+int upload_box(fnn_engine *e, int64_t x_lo, int64_t x_hi, int64_t y_lo, int64_t y_hi, hipStream_t st) {
     fnn_engine::Upload &u = e->up;
     if (!u.active) return 0;
-    if (x_need > u.X) x_need = u.X;
-    if (x_need < 1) x_need = 1;
-    const size_t plane = (size_t)u.Y * u.Z;
-    while (u.issued_x < x_need) {
-        const int64_t x0 = u.issued_x, x1 = std::min(u.X, x0 + u.slab_x);
-        const size_t slab = (size_t)(x0 / u.slab_x), run = (size_t)(x1 - x0) * plane;
-        if (u.pinned_src) {
-            for (int c = 0; c < u.C; ++c)
-                HIPCHK(e, hipMemcpyAsync(u.dev + ((size_t)c * u.X + x0) * plane, u.host + ((size_t)c * u.X + x0) * plane,
-                                         run * sizeof(float), hipMemcpyHostToDevice, u.st));
-        } else {
-            const int k = u.next_stage;
-            u.next_stage = (k + 1) % fnn_engine::Upload::RING;
-            if (u.stage_used[k]) HIPCHK(e, hipEventSynchronize(u.stage_free[k]));          // its previous slab has left
-            for (int c = 0; c < u.C; ++c)
-                parallel_copy(u.stage[k] + (size_t)c * run, u.host + ((size_t)c * u.X + x0) * plane, run);
-            for (int c = 0; c < u.C; ++c)
-                HIPCHK(e, hipMemcpyAsync(u.dev + ((size_t)c * u.X + x0) * plane, u.stage[k] + (size_t)c * run,
-                                         run * sizeof(float), hipMemcpyHostToDevice, u.st));
-            HIPCHK(e, hipEventRecord(u.stage_free[k], u.st));
-            u.stage_used[k] = true;
+    x_lo = std::max<int64_t>(0, x_lo); y_lo = std::max<int64_t>(0, y_lo);
+    x_hi = std::min(u.X, x_hi); y_hi = std::min(u.Y, y_hi);
+    if (x_hi <= x_lo || y_hi <= y_lo) { x_lo = 0; x_hi = std::min<int64_t>(u.X, 1); y_lo = 0; y_hi = std::min<int64_t>(u.Y, 1); }
+    const size_t row = (size_t)u.Z, pitch = (size_t)u.Y * u.Z * sizeof(float);
+    bool any = false;
+    for (int64_t xs = x_lo / u.slab_x; xs <= (x_hi - 1) / u.slab_x && u.n_issued < u.issued.size(); ++xs)
+        for (int64_t yb = y_lo / u.slab_y; yb <= (y_hi - 1) / u.slab_y; ++yb) {
+            char &done = u.issued[(size_t)(xs * u.nyb + yb)];
+            if (done) continue;
+            done = 1; ++u.n_issued; any = true;
+            const int64_t x0 = xs * u.slab_x, x1 = std::min(u.X, x0 + u.slab_x), y0 = yb * u.slab_y, y1 = std::min(u.Y, y0 + u.slab_y);
+            const size_t width = (size_t)(y1 - y0) * row * sizeof(float), height = (size_t)(x1 - x0);
+            const bool whole_rows = y0 == 0 && y1 == u.Y;     // the tile is one contiguous run
+            if (u.pinned_src) {
+                for (int c = 0; c < u.C; ++c) {
+                    const size_t off = (((size_t)c * u.X + x0) * u.Y + y0) * row;
+                    if (whole_rows) HIPCHK(e, hipMemcpyAsync(u.dev + off, u.host + off, width * height, hipMemcpyHostToDevice, u.st));
+                    else HIPCHK(e, hipMemcpy2DAsync(u.dev + off, pitch, u.host + off, pitch, width, height, hipMemcpyHostToDevice, u.st));
+                }
+            } else {
+                const int k = u.next_stage;
+                u.next_stage = (k + 1) % fnn_engine::Upload::RING;
+                if (u.stage_used[k]) HIPCHK(e, hipEventSynchronize(u.stage_free[k]));          // its previous tile has left
+                const size_t tile = width / sizeof(float) * height;                            // floats per channel, packed
+                for (int c = 0; c < u.C; ++c) {
+                    const float *src0 = u.host + (((size_t)c * u.X + x0) * u.Y + y0) * row;
+                    float *dst0 = u.stage[k] + (size_t)c * tile;
+                    if (whole_rows) { parallel_copy(dst0, src0, tile); continue; }               // one contiguous run
+                    // rows y0 .. y1 of every plane of the tile: the planes shared out over a few host threads
+                    const size_t wf = width / sizeof(float), pf = pitch / sizeof(float);
+                    const int parts = (int)std::min<size_t>(4, std::max<size_t>(1, tile / (1u << 18)));
+                    auto planes = [=](size_t h0, size_t h1) { for (size_t hx = h0; hx < h1; ++hx) memcpy(dst0 + hx * wf, src0 + hx * pf, wf * sizeof(float)); };
+                    std::thread th[3];
+                    const size_t per = (height + parts - 1) / parts;
+                    for (int t = 1; t < parts; ++t) th[t - 1] = std::thread(planes, std::min(height, per * t), std::min(height, per * (t + 1)));
+                    planes(0, std::min(height, per));
+                    for (int t = 1; t < parts; ++t) th[t - 1].join();
+                }
+                for (int c = 0; c < u.C; ++c) {
+                    const size_t off = (((size_t)c * u.X + x0) * u.Y + y0) * row;
+                    HIPCHK(e, hipMemcpy2DAsync(u.dev + off, pitch, u.stage[k] + (size_t)c * tile, width, width, height, hipMemcpyHostToDevice, u.st));
+                }
+                HIPCHK(e, hipEventRecord(u.stage_free[k], u.st));
+                u.stage_used[k] = true;
+            }
         }
-        HIPCHK(e, hipEventRecord(u.landed[slab], u.st));
-        u.issued_x = x1;
+    if (any) {
+        if (u.ev_next == u.landed.size()) {
+            hipEvent_t ev;
+            HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            u.landed.push_back(ev);
+        }
+        u.last = u.landed[u.ev_next++];
+        HIPCHK(e, hipEventRecord(u.last, u.st));
     }
-    HIPCHK(e, hipStreamWaitEvent(st, u.landed[(size_t)((x_need - 1) / u.slab_x)], 0));
+    if (u.last) HIPCHK(e, hipStreamWaitEvent(st, u.last, 0));
     return 0;
 }
 
 // Brings the input volume onto the device and pads it when smaller than the patch.  `slabbed`: the caller's batches call
-// upload_until() for the planes they read (run_patches); otherwise the whole volume is waited for here.
+// upload_box() for the box their patches read (run_patches); otherwise the whole volume is waited for here.
 int stage_volume(fnn_engine *e, const float *vol, const int64_t shape[4], const VolPlan &vp, hipStream_t st,
                  const float **vol_dev, bool slabbed = false) {
     const size_t nin = (size_t)shape[0] * shape[1] * shape[2] * shape[3];
@@ -1218,20 +1259,18 @@ int stage_volume(fnn_engine *e, const float *vol, const int64_t shape[4], const 
         src = e->vol_tmp;
         u.host = vol; u.dev = e->vol_tmp; u.C = (int)shape[0]; u.X = shape[1]; u.Y = shape[2]; u.Z = shape[3];
         u.pinned_src = is_pinned_host_ptr(vol);
-        const size_t plane_bytes = (size_t)u.C * u.Y * u.Z * sizeof(float);
-        const size_t slab_bytes = fnn_knob("FNN_UPLOAD_SLAB_BYTES") ? (size_t)atoll(fnn_knob("FNN_UPLOAD_SLAB_BYTES")) : (16u << 20);   // tests: many slabs in a small volume
-        u.slab_x = std::max<int64_t>(1, (int64_t)(slab_bytes / std::max<size_t>(1, plane_bytes)));     // ~16 MB per slab
-        u.n_slabs = (size_t)((u.X + u.slab_x - 1) / u.slab_x);
-        u.issued_x = 0;
+        // tiles of ~4 MiB per channel: an eighth of the rows (at least 16) x as many planes as fill the tile
+        const size_t slab_bytes = fnn_knob("FNN_UPLOAD_SLAB_BYTES") ? (size_t)atoll(fnn_knob("FNN_UPLOAD_SLAB_BYTES")) : (4u << 20);   // tests: many tiles in a small volume
+        u.slab_y = fnn_knob("FNN_UPLOAD_WHOLE_ROWS") ? u.Y : std::min<int64_t>(u.Y, std::max<int64_t>(16, (u.Y + 7) / 8));          // (knob: x slabs only - the first form)
+        const size_t rows_bytes = (size_t)u.slab_y * u.Z * sizeof(float);
+        u.slab_x = std::max<int64_t>(1, (int64_t)(slab_bytes / std::max<size_t>(1, rows_bytes)));
+        u.nxs = (u.X + u.slab_x - 1) / u.slab_x; u.nyb = (u.Y + u.slab_y - 1) / u.slab_y;
+        u.issued.assign((size_t)(u.nxs * u.nyb), 0);
+        u.n_issued = 0; u.ev_next = 0; u.last = nullptr;
         if (!u.st) HIPCHK(e, hipStreamCreateWithFlags(&u.st, hipStreamNonBlocking));
         if (!u.go) HIPCHK(e, hipEventCreateWithFlags(&u.go, hipEventDisableTiming));
-        while (u.landed.size() < u.n_slabs) {
-            hipEvent_t ev;
-            HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            u.landed.push_back(ev);
-        }
         if (!u.pinned_src) {
-            const size_t need = (size_t)u.slab_x * plane_bytes;
+            const size_t need = (size_t)u.C * u.slab_x * rows_bytes;
             if (u.stage_bytes < need) {
                 for (int k = 0; k < fnn_engine::Upload::RING; ++k) {
                     if (u.stage[k]) { if (u.stage_used[k]) (void)hipEventSynchronize(u.stage_free[k]); (void)hipHostFree(u.stage[k]); u.stage[k] = nullptr; }
@@ -1249,7 +1288,7 @@ int stage_volume(fnn_engine *e, const float *vol, const int64_t shape[4], const 
         HIPCHK(e, hipEventRecord(u.go, st));
         HIPCHK(e, hipStreamWaitEvent(u.st, u.go, 0));
         u.active = true;
-        if (!slabbed || need_pad) { if (int rc = upload_until(e, u.X, st)) return rc; u.active = false; }
+        if (!slabbed || need_pad) { if (int rc = upload_box(e, 0, u.X, 0, u.Y, st)) return rc; u.active = false; }
     }
     if (need_pad) {
         const size_t npad = (size_t)shape[0] * vp.padded[0] * vp.padded[1] * vp.padded[2];
