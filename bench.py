@@ -556,7 +556,7 @@ def main():
     if not distributed and not args.no_from_host and not w['plan'] and args.folds == 1:
         # The same step as a reference caller sees it: the preprocessed volume is a CPU tensor (what the preprocessing iterator
         # yields, data_iterators.py:116-117; `data.to(results_device)` at predict_from_raw_data.py:579).  The engine uploads it
-        # by x slabs on a copy stream under the first batches (engine.hip, stage_volume / upload_until).  Untimed extras.
+        # in tiles on a copy stream under the first batches (engine.hip, stage_volume / upload_box).  Untimed extras.
         def raw_copy(t):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -579,8 +579,8 @@ def main():
         from_host = {'ms_per_step_pinned': round(dt_pinned * 1e3, 3), 'ms_per_step_pageable': round(dt_pageable * 1e3, 3),
                      'raw_copy_ms_pinned': round(raw_pinned, 3), 'raw_copy_ms_pageable': round(raw_pageable, 3), 'steps': k,
                      'volume_mib': round(vol.numel() * 4 / 2 ** 20, 1),
-                     'note': 'the same step with the volume handed over as a CPU tensor: uploaded by x slabs on a copy stream, a batch '
-                             'starts when the slabs under its patches have landed; raw_copy_ms = one torch .to(device) of the same tensor'}
+                     'note': 'the same step with the volume handed over as a CPU tensor: uploaded in tiles (planes x rows) on a copy stream, a batch '
+                             'starts when the tiles under its patches have landed; raw_copy_ms = one torch .to(device) of the same tensor'}
 
     flops_patch, act_bytes_patch = predictor._engine.patch_work()
     assembly = {'labels': 'labels on the owner of each box, all_gather of the uint8 slabs: the label map on every rank',
