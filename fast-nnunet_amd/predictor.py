@@ -222,7 +222,7 @@ class nnUNetPredictor(object):
     def _resident_or_host(self, t: torch.Tensor) -> torch.Tensor:
         """float32, contiguous.  A CPU tensor (what the reference's callers hold: the preprocessing iterator's output,
         data_iterators.py:116-117; moved with `data.to(results_device)` at :579) STAYS on the CPU: the engine uploads it by
-        x slabs on a copy stream and starts the first batch when the slabs under its patches have landed (pin the tensor
+        tiles (planes x rows) on a copy stream and starts a batch when the tiles under its patches have landed (pin the tensor
         for a DMA straight from it; a pageable one goes through the engine's pinned staging ring)."""
         if t.device.type == 'cpu':
             return t.to(dtype=torch.float32).contiguous()

@@ -144,8 +144,8 @@ int fnn_set_gaussian(fnn_engine *e, const uint16_t *half_bits, int64_t count);
  * normalise -> un-pad.  vol: float32 [C,X,Y,Z]; out: [heads,X,Y,Z] of
  * opts->out_dtype.  FNN_E_INF if the normalised logits contain inf.
  * vol may be DEVICE memory (read in place) or HOST memory - what the reference's callers hold
- * (`data = data.to(results_device)`, :579): a host volume is uploaded by x slabs on a copy stream of the
- * engine's and a batch of patches starts when the slabs under its patches have landed (the patch order is
+ * (`data = data.to(results_device)`, :579): a host volume is uploaded in tiles (planes x rows) on a copy stream of the
+ * engine's and a batch of patches starts when the tiles under its patches have landed (the patch order is
  * x-major, :532-537); pinned host memory is read by DMA directly, pageable memory through pinned staging. */
 int fnn_predict_volume(fnn_engine *e, int fold, const float *vol, const int64_t shape[4],
                        const fnn_opts *opts, void *out_logits);

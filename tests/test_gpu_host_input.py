@@ -1,6 +1,6 @@
 """The step as a reference caller sees it: the preprocessed volume is a CPU tensor (the reference's
 ``predict_sliding_window_return_logits`` receives what the preprocessing iterator yields, data_iterators.py:116-117, and moves
-it with ``data.to(results_device)``, predict_from_raw_data.py:579).  The engine uploads a host volume by x slabs on a copy
+it with ``data.to(results_device)``, predict_from_raw_data.py:579).  The engine uploads a host volume in tiles (planes x rows) on a copy
 stream and starts a batch when the slabs under its patches have landed (engine.hip: stage_volume / upload_until); the result
 must be the resident volume's, bit for bit - pageable and pinned, one and many channels, many slabs per volume, with
 mirroring, folds, the label entry point, and a volume smaller than the patch (padded after a whole upload)."""
