@@ -112,14 +112,17 @@ namespace {
 typedef unsigned zp_u32x4 __attribute__((ext_vector_type(4)));
 typedef int zp_i32x4 __attribute__((ext_vector_type(4)));
 
-template <int TH, int WC, int NB = 2>
-__global__ __launch_bounds__(256, 2) void conv2d_zp_kernel(const ConvParams p) {
+// HALF: every source has 16 channels (the full-resolution level of an r = 2 student, a stem on the conv kernels): only the two lines of a chunk's
+// lower record are kept (conv2d_zps_kernel below: k-groups 1 and 3 read the lines of 0 and 2 - finite values times zero weights), the image is half as
+// large and, with one cout block, three workgroups fit a CU.
+template <int TH, int WC, int NB = 2, bool HALF = false>
+__global__ __launch_bounds__(256, HALF && NB == 1 ? 3 : 2) void conv2d_zp_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WR = 4 / WC;                                // waves along the rows
     constexpr int ROWS = WR * TH, COLS = WC * 16;             // output tile
     constexpr int IH = ROWS + 2, IWC = COLS + 2;              // halo image
     constexpr int QP = ((IWC * 16 + 64 + 255) / 256) * 256;   // bytes of one (row, k-group) line (+ the 64-byte shift of lines 2, 3)
-    constexpr int ROWB = 4 * QP;
+    constexpr int ROWB = (HALF ? 2 : 4) * QP;
     constexpr int ABYTES = IH * ROWB;
     constexpr int RPP = 4 / WC;                               // halo rows staged per pass (one per group of 64 WC threads)
     constexpr int NP = (IH + RPP - 1) / RPP;                  // passes
@@ -154,11 +157,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_zp_kernel(const ConvParams p) {
     const int q_st = cg4 * 2 + half;                          // channels 8 q_st .. + 7 of the 32-channel chunk
     const int gw = ow0 - 1 + col;
     const bool ok_w = (unsigned)gw < (unsigned)p.Wi;
-    const int line_st = (half * 2 + cg4) * QP + half * 64;  // this thread's k-group line (file header)
+    const int line_st = HALF ? half * QP + half * 64 : (half * 2 + cg4) * QP + half * 64;  // this thread's k-group line (file header)
+    const bool stager = !(HALF && cg4);                      // HALF: the threads of the upper record stage nothing
     const int lds_main = line_st + col * 16;
     // the two extra columns (COLS, COLS + 1) of every halo row: 2 IH items per channel group, spread over its 64 threads
     const int i64 = rp * (16 * WC) + col;
-    const bool has_x = i64 < IH * 2;
+    const bool has_x = i64 < IH * 2 && stager;
     const int xu = i64 >> 1, xcol = COLS + (i64 & 1);
     const int gh_x = oh0 - 1 + xu, gw_x = ow0 - 1 + xcol;
     const bool ok_x = has_x & ((unsigned)gh_x < (unsigned)p.Hi) & ((unsigned)gw_x < (unsigned)p.Wi);
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_zp_kernel(const ConvParams p) {
         const f16 *sp = p.src[s].ptr + (size_t)n * (item_bytes >> 1) + (c_uni >> 4) * cs;
         rx = __builtin_amdgcn_make_buffer_rsrc((void *)sp, 0, item_bytes - (unsigned)((c_uni >> 4) * cs * 2), 0x00020000);
         slope_next = p.src[s].slope;
-        ch_ok = c_uni + 8 * q_st < sC;                        // (the upper half of a source's last 16-channel chunk does not exist)
+        ch_ok = c_uni + 8 * q_st < sC && stager;                        // (the upper half of a source's last 16-channel chunk does not exist)
         {
             const int cq = ch_ok ? c_uni + 8 * q_st : 0;
             const unsigned short *q = p.src[s].ssh ? p.src[s].ssh + ((size_t)n * sC + cq) * 2 : p.ident_ssh + cq * 2;
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_zp_kernel(const ConvParams p) {
                 f16x8 o = __builtin_bit_cast(f16x8, xr[u]) * sc_h + sh_h;
                 o = __builtin_elementwise_max(o, o * slope_h);
                 if ((unsigned)gh >= (unsigned)p.Hi) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};      // scalar condition: a row above / below the tensor
-                *(f16x8 *)(sA + row * ROWB + lds_main) = o;
+                if (stager) *(f16x8 *)(sA + row * ROWB + lds_main) = o;
             }
         }
         if (has_x) {
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_zp_kernel(const ConvParams p) {
                 if (u + 1 < WPB || wave == 0) *(zp_u32x4 *)(sW + ((nb * WB + u * 256) + tid) * 16) = wrg[nb][u];
     };
     // MFMA "B" operand: lane (r = column of the wave's block, q = 8-channel group)
-    const int boff = (wr * TH) * ROWB + (lane >> 4) * QP + (lane >> 5) * 64 + (wcol * 16 + (lane & 15)) * 16;
+    const int boff = (wr * TH) * ROWB + (HALF ? (lane >> 5) : (lane >> 4)) * QP + (lane >> 5) * 64 + (wcol * 16 + (lane & 15)) * 16;
     auto kloop = [&](bool prefetch) {
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
@@ -370,18 +374,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_zp_kernel(const ConvParams p) {
     }
 }
 
-template <int TH, int WC, int NB = 2>
+template <int TH, int WC, int NB = 2, bool HALF = false>
 int launch_zp(ConvParams p, hipStream_t st) {
     constexpr int WR = 4 / WC, ROWS = WR * TH, COLS = WC * 16, IH = ROWS + 2, IWC = COLS + 2;
     constexpr int QP = ((IWC * 16 + 64 + 255) / 256) * 256;
-    const size_t lds = (size_t)IH * 4 * QP + NB * 9 * 1024;
+    const size_t lds = (size_t)IH * (HALF ? 2 : 4) * QP + NB * 9 * 1024;
     p.tiles_d = p.Do;
     p.tiles_h = (p.Ho + ROWS - 1) / ROWS;
     p.tiles_w = (p.Wo + COLS - 1) / COLS;
     if (p.stats_out && p.stats_slots < p.Do * p.tiles_h * p.tiles_w) return -1;   // (a plan sized for another tiling)
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)conv2d_zp_kernel<TH, WC, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv2d_zp_kernel<TH, WC, NB, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     p.ident_ss = conv3d_identity_ss();
@@ -390,8 +394,9 @@ int launch_zp(ConvParams p, hipStream_t st) {
     const long long tiles = (long long)p.N * p.Do * p.tiles_h * p.tiles_w;
     if (tiles >= (1ll << 31)) return -1;
     dim3 grid((unsigned)tiles, (p.Cout / 16) / NB);
-    if (NB == 2) fnn_note_kernel("conv2d_zp_kernel<%d,%d>", TH, WC); else fnn_note_kernel("conv2d_zp_kernel<%d,%d,%d>", TH, WC, NB);
-    hipLaunchKernelGGL((conv2d_zp_kernel<TH, WC, NB>), grid, dim3(256), lds, st, p);
+    if (NB == 2 && !HALF) fnn_note_kernel("conv2d_zp_kernel<%d,%d>", TH, WC);
+    else fnn_note_kernel(HALF ? "conv2d_zp_kernel<%d,%d,%d,half>" : "conv2d_zp_kernel<%d,%d,%d>", TH, WC, NB);
+    hipLaunchKernelGGL((conv2d_zp_kernel<TH, WC, NB, HALF>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -408,8 +413,11 @@ int launch_zp(ConvParams p, hipStream_t st) {
 // Measured and dropped (round 6): 4 x 32 tiles with two cout blocks for layers of one or two chunks - 64 KB, two workgroups per CU, so that a
 // single-chunk tile has a neighbour to hide its load latency behind: SLOWER, 32 -> 64 at 256^2 575 -> 736 us, 64 -> 128 527 -> 600 us, the thick-slice
 // plan's 32 -> 64 1677 -> 2174 us (profiles/r06_zps_th2_ab.txt): half the MFMAs per staged byte and a 9 / 4 instead of 17 / 8 halo cost more than the overlap buys.
-template <int NB, int WC>
-__global__ __launch_bounds__(256, 1) void conv2d_zps_kernel(const ConvParams p) {
+// HALF: one source of 16 channels (the first down-sampling conv of an r = 2 student) - the chunk's upper 16 channels do not exist (their
+// weights are zero): only the two lines of the lower record are kept (k-groups 1 and 3 read the lines of 0 and 2: finite values times zero), the
+// image is half as large - 62 KB with two cout blocks - and TWO workgroups fit a CU: a single-chunk tile has a neighbour to hide its loads behind.
+template <int NB, int WC, bool HALF = false>
+__global__ __launch_bounds__(256, HALF ? 2 : 1) void conv2d_zps_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TH = 4;
     constexpr int WR = 4 / WC;
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void conv2d_zps_kernel(const ConvParams p) 
     constexpr int EOFF = 0, OOFF = COLS * 16 + 32;            // even-column slots, then odd-column slots 32 B off the stores' 128-byte bank period:
                                                               // a store group's four columns (odd, even, odd, even) x two halves (64 B apart) = eight slots
     constexpr int QP = ((OOFF + (COLS + 1) * 16 + 64 + 255) / 256) * 256;
-    constexpr int ROWB = 4 * QP;
+    constexpr int ROWB = (HALF ? 2 : 4) * QP;
     constexpr int ABYTES = IH * ROWB;
     constexpr int RPP = 2 / WC;                               // input rows staged per pass: 128 WC threads per row
     constexpr int NP = (IH + RPP - 1) / RPP;
@@ -452,11 +460,12 @@ __global__ __launch_bounds__(256, 1) void conv2d_zps_kernel(const ConvParams p) 
     const int q_st = cg4 * 2 + half;
     const int gw = 2 * ow0 - 1 + ci;
     const bool ok_w = (unsigned)gw < (unsigned)p.Wi;
-    const int line_st = (half * 2 + cg4) * QP + half * 64;
+    const int line_st = HALF ? half * QP + half * 64 : (half * 2 + cg4) * QP + half * 64;
+    const bool stager = !(HALF && cg4);                      // HALF: the threads of the upper record stage nothing
     const int lds_main = line_st + ((ci & 1) ? EOFF + (ci >> 1) * 16 : OOFF + (ci >> 1) * 16);
     // the last input column (ci = 2 COLS, odd line slot COLS) of every halo row: IH items per channel group
     const int i64 = rp * (32 * WC) + ci;                      // 0 .. 63 within the channel group
-    const bool has_x = i64 < IH;
+    const bool has_x = i64 < IH && stager;
     const int gh_x = 2 * oh0 - 1 + i64, gw_x = 2 * ow0 - 1 + 2 * COLS;
     const bool ok_x = has_x & ((unsigned)gh_x < (unsigned)p.Hi) & ((unsigned)gw_x < (unsigned)p.Wi);
     const int lds_x = i64 * ROWB + line_st + OOFF + COLS * 16;
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(256, 1) void conv2d_zps_kernel(const ConvParams p) 
         const f16 *sp = p.src[s].ptr + (size_t)n * (item_bytes >> 1) + (c_uni >> 4) * cs;
         rx = __builtin_amdgcn_make_buffer_rsrc((void *)sp, 0, item_bytes - (unsigned)((c_uni >> 4) * cs * 2), 0x00020000);
         slope_next = p.src[s].slope;
-        ch_ok = c_uni + 8 * q_st < sC;
+        ch_ok = c_uni + 8 * q_st < sC && stager;
         {
             const int cq = ch_ok ? c_uni + 8 * q_st : 0;
             const unsigned short *q = p.src[s].ssh ? p.src[s].ssh + ((size_t)n * sC + cq) * 2 : p.ident_ssh + cq * 2;
@@ -527,7 +536,7 @@ __global__ __launch_bounds__(256, 1) void conv2d_zps_kernel(const ConvParams p) 
                 f16x8 o = __builtin_bit_cast(f16x8, xr[u]) * sc_h + sh_h;
                 o = __builtin_elementwise_max(o, o * slope_h);
                 if ((unsigned)gh >= (unsigned)p.Hi) o = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                *(f16x8 *)(sA + row * ROWB + lds_main) = o;
+                if (stager) *(f16x8 *)(sA + row * ROWB + lds_main) = o;
             }
         }
         if (has_x) {
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(256, 1) void conv2d_zps_kernel(const ConvParams p) 
                 if (u + 1 < WPB || wave == 0) *(zp_u32x4 *)(sW + ((nb * WB + u * 256) + tid) * 16) = wrg[nb][u];
     };
     // MFMA "B" operand of output column x = wcol 16 + r, tap dx: dx = 0 -> odd slot x, dx = 1 -> even slot x, dx = 2 -> odd slot x + 1
-    const int bbase = (2 * wr * TH) * ROWB + (lane >> 4) * QP + (lane >> 5) * 64 + (wcol * 16 + (lane & 15)) * 16;
+    const int bbase = (2 * wr * TH) * ROWB + (HALF ? (lane >> 5) : (lane >> 4)) * QP + (lane >> 5) * 64 + (wcol * 16 + (lane & 15)) * 16;
     auto kloop = [&](bool prefetch) {
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
@@ -640,18 +649,18 @@ __global__ __launch_bounds__(256, 1) void conv2d_zps_kernel(const ConvParams p) 
     }
 }
 
-template <int NB, int WC>
+template <int NB, int WC, bool HALF = false>
 int launch_zps(ConvParams p, hipStream_t st) {
     constexpr int WR = 4 / WC, ROWS = WR * 4, COLS = WC * 16, IH = 2 * ROWS + 1;
     constexpr int OOFF = COLS * 16 + 32, QP = ((OOFF + (COLS + 1) * 16 + 64 + 255) / 256) * 256;
-    const size_t lds = (size_t)IH * 4 * QP + (size_t)NB * 9 * 1024;
+    const size_t lds = (size_t)IH * (HALF ? 2 : 4) * QP + (size_t)NB * 9 * 1024;
     p.tiles_d = p.Do;
     p.tiles_h = (p.Ho + ROWS - 1) / ROWS;
     p.tiles_w = (p.Wo + COLS - 1) / COLS;
     if (p.stats_out && p.stats_slots < p.Do * p.tiles_h * p.tiles_w) return -1;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)conv2d_zps_kernel<NB, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv2d_zps_kernel<NB, WC, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     p.ident_ss = conv3d_identity_ss();
@@ -660,8 +669,8 @@ int launch_zps(ConvParams p, hipStream_t st) {
     const long long tiles = (long long)p.N * p.Do * p.tiles_h * p.tiles_w;
     if (tiles >= (1ll << 31)) return -1;
     dim3 grid((unsigned)tiles, (p.Cout / 16) / NB);
-    fnn_note_kernel("conv2d_zps_kernel<%d,%d>", NB, WC);
-    hipLaunchKernelGGL((conv2d_zps_kernel<NB, WC>), grid, dim3(256), lds, st, p);
+    fnn_note_kernel(HALF ? "conv2d_zps_kernel<%d,%d,half>" : "conv2d_zps_kernel<%d,%d>", NB, WC);
+    hipLaunchKernelGGL((conv2d_zps_kernel<NB, WC, HALF>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -674,13 +683,26 @@ int launch_conv2d_zp(const ConvParams &p, hipStream_t st) {
     if (p.chunks != conv_zp_chunks(p.src[0].C, p.n_src > 1 ? p.src[1].C : 0)) return -1;
     if (p.sh == 2) {
         const bool four = (p.Cout / 16) % 4 == 0;
+        const bool half16 = p.n_src == 1 && p.src[0].C == 16 && !four && fnn_knob("FNN_ZPS_NO_HALF") == nullptr;   // (knob: A-B aid)
+        if (half16) return wc == 2 ? launch_zps<2, 2, true>(p, st) : launch_zps<2, 1, true>(p, st);
         if (wc == 2) return four ? launch_zps<4, 2>(p, st) : launch_zps<2, 2>(p, st);
         return four ? launch_zps<4, 1>(p, st) : launch_zps<2, 1>(p, st);
     }
+    const bool half16 = p.src[0].C == 16 && (p.n_src < 2 || p.src[1].C == 16) && fnn_knob("FNN_ZP_NO_HALF") == nullptr;   // (knob: A-B aid)
     if ((p.Cout / 16) % 2 != 0) {                             // an odd number of cout blocks: one per workgroup
+        if (half16) {
+            if (wc == 4) return launch_zp<8, 4, 1, true>(p, st);
+            if (wc == 2) return launch_zp<8, 2, 1, true>(p, st);
+            return launch_zp<4, 1, 1, true>(p, st);
+        }
         if (wc == 4) return launch_zp<8, 4, 1>(p, st);
         if (wc == 2) return launch_zp<8, 2, 1>(p, st);
         return launch_zp<4, 1, 1>(p, st);
+    }
+    if (half16) {
+        if (wc == 4) return launch_zp<8, 4, 2, true>(p, st);
+        if (wc == 2) return launch_zp<8, 2, 2, true>(p, st);
+        return launch_zp<4, 1, 2, true>(p, st);
     }
     if (wc == 4) return launch_zp<8, 4>(p, st);
     if (wc == 2) return launch_zp<8, 2>(p, st);

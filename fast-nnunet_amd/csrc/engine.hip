@@ -117,9 +117,9 @@ struct fnn_engine {
     void *acc = nullptr; size_t acc_bytes = 0;
     float *vol_tmp = nullptr; size_t vol_tmp_bytes = 0;
     // A volume that arrives in HOST memory (the reference's callers hand over the CPU tensor of the preprocessing iterator,
-    // predict_from_raw_data.py:579 `data = data.to(results_device)`): it is uploaded by x slabs on a copy stream of the
-    // engine's, and a batch of patches starts as soon as the slabs under its patches have landed - the patch order is
-    // x-major (:532-537), so the slabs are needed in the order they travel.  Pinned source: DMA straight from it; pageable
+    // predict_from_raw_data.py:579 `data = data.to(results_device)`): it is uploaded in tiles (planes x rows) on a copy stream of
+    // the engine's, and a batch of patches starts as soon as the tiles under its patches have landed - the patch order is
+    // x-major, y next (:532-537), so the tiles are needed roughly in the order they travel.  Pinned source: DMA straight from it; pageable
     // source: through a ring of pinned staging buffers filled by a few host threads.
     struct Upload {
         bool active = false, pinned_src = false;

@@ -744,12 +744,17 @@ ZP_CASES = [
     (4, 96, 0, 96, (1, 16, 16), '4,1'),          # 16 x 16 tiles, three cout pairs
     (8, 160, 160, 64, (1, 8, 8), '4,1'),         # plane smaller than the tile
     (6, 64, 0, 64, (2, 4, 4), '4,1'),
-    (2, 16, 0, 32, (2, 33, 70), '8,4'),          # a single 16-channel source (a stem on the conv kernels): half a chunk
-    (1, 4, 0, 32, (1, 40, 48), '8,4'),           # channel padding 4 -> 16
+    (2, 16, 0, 32, (2, 33, 70), '8,4,2,half'),   # a single 16-channel source (a stem on the conv kernels): the half image
+    (1, 4, 0, 32, (1, 40, 48), '8,4,2,half'),    # channel padding 4 -> 16
     # one cout block per workgroup (16 output channels - the full-resolution level of a `2d` r = 2 student - or an odd block count)
-    (2, 16, 0, 16, (1, 64, 96), '8,4,1'),
-    (3, 16, 16, 16, (1, 37, 83), '8,4,1'),       # decoder conv of that level: two 16-channel sources = two half-empty chunks, ragged tiles
-    (2, 1, 0, 16, (2, 24, 40), '8,4,1'),         # a 1-channel stem on the conv kernels, depth 2
+    (2, 16, 0, 16, (1, 64, 96), '8,4,1,half'),
+    (3, 16, 16, 16, (1, 37, 83), '8,4,1,half'),  # decoder conv of that level: two 16-channel sources = two half chunks, ragged tiles
+    (2, 1, 0, 16, (2, 24, 40), '8,4,1,half'),    # a 1-channel stem on the conv kernels, depth 2
+    (3, 16, 0, 16, (1, 20, 30), '8,2,1,half'),
+    (3, 16, 0, 32, (1, 12, 14), '4,1,2,half'),
+    (2, 16, 0, 32, (1, 20, 30), '8,2,2,half'),
+    (3, 16, 0, 16, (2, 10, 12), '4,1,1,half'),
+    (2, 32, 0, 16, (1, 40, 64), '8,4,1'),        # one cout block, a whole 32-channel chunk
     (4, 64, 0, 48, (1, 32, 20), '8,2,1'),        # three cout blocks
     (4, 32, 0, 16, (3, 9, 12), '4,1,1'),
 ]
@@ -809,7 +814,9 @@ ZPS_CASES = [
     (2, 48, 16, 96, (2, 30, 44), '2,2'),         # two sources with half-empty last chunks, three cout pairs
     (4, 128, 0, 256, (1, 32, 32), '4,1'),        # 16 x 16 outputs
     (8, 96, 0, 64, (1, 9, 7), '4,1'),            # a plane smaller than the tile, odd sizes
-    (2, 16, 0, 32, (3, 40, 66), '2,2'),          # a single 16-channel source
+    (2, 16, 0, 32, (3, 40, 66), '2,2,half'),     # a single 16-channel source: the half image, two workgroups per CU
+    (3, 9, 0, 32, (1, 20, 18), '2,1,half'),      # ... 16 x 16 tiles, channel padding 9 -> 16
+    (2, 16, 0, 64, (2, 34, 40), '4,2'),          # 16 channels into 64: the whole image with four cout blocks
     (3, 64, 0, 96, (2, 20, 18), '2,1'),          # 16 x 16 tiles, cout blocks in pairs (96 = 3 x 32)
 ]
 
