@@ -333,10 +333,20 @@ def layer_table(engine, batch):
         if L['type'] == 'tconv':                                        # (the engine prices transposed convs' bytes as 0: priced here)
             vi, vo = np.prod([int(v) for v in L['in_dims'].split('x')]), np.prod([int(v) for v in L['out_dims'].split('x')])
             by = 2.0 * (L['cin'] * vi + L['cout'] * vo) * (flops / L['flops'] if L['flops'] else batch)
-        rows.append({'layer': li, 'type': L['type'] + ('+producer' if L['fused'] == 2 else ''), 'cin': L['cin'], 'cout': L['cout'],
-                     'kernel': L['kernel'], 'stride': L['stride'], 'out': L['out_dims'], 'picked': runs[0][3], 'us': round(ms * 1e3, 1),
-                     'tflops': round(flops / (ms * 1e-3) / 1e12, 1) if ms > 0 else None,
-                     'tbps': round(by / (ms * 1e-3) / 1e12, 2) if ms > 0 and by else None})
+        row = {'layer': li, 'type': L['type'] + ('+producer' if L['fused'] == 2 else ''), 'cin': L['cin'], 'cout': L['cout'],
+               'kernel': L['kernel'], 'stride': L['stride'], 'out': L['out_dims'], 'picked': runs[0][3], 'us': round(ms * 1e3, 1),
+               'tflops': round(flops / (ms * 1e-3) / 1e12, 1) if ms > 0 else None,
+               'tbps': round(by / (ms * 1e-3) / 1e12, 2) if ms > 0 and by else None}
+        # tensors are stored with their channels padded to 16: what a layer with fewer channels really moves (conv / tconv: fp16 in and out;
+        # the input layer: fp32 in, padded fp16 out) - next to the algorithmic figure, not instead of it
+        if ms > 0 and L['type'] in ('conv', 'tconv', 'input') and (L['cin'] % 16 or L['cout'] % 16):
+            pad = lambda c: (c + 15) // 16 * 16
+            vi, vo = np.prod([int(v) for v in L['in_dims'].split('x')]), np.prod([int(v) for v in L['out_dims'].split('x')])
+            n_items = flops / L['flops'] if L['flops'] else batch
+            cin_stored = 2 * pad(L['cout']) if (L['type'] == 'conv' and L['cin'] == 2 * L['cout']) else pad(L['cin'])   # (a decoder conv's two sources are padded one by one)
+            real = (4.0 * L['cin'] * vi + 2.0 * pad(L['cout']) * vo) if L['type'] == 'input' else 2.0 * (cin_stored * vi + pad(L['cout']) * vo)
+            row['tbps_padded'] = round(real * n_items / (ms * 1e-3) / 1e12, 2)
+        rows.append(row)
     tot = sum(r['us'] for r in rows) or 1.0
     for r in rows:
         r['share'] = round(r['us'] / tot, 4)

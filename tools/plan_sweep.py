@@ -31,7 +31,8 @@ def is_cliff(r):
     thin = min(r['cin'], r['cout']) <= 16 and r['type'].startswith(('conv', 'stem', 'input'))
     if thin or r['type'].startswith('tconv'):
         if r['tbps'] is not None and r['tbps'] < 2.5 and (r['tflops'] or 0) < 0.10 * PEAK:
-            return f"{r['tbps']:.2f} TB/s < 2.5"
+            pad = f" (with the channels padded to 16 as stored: {r['tbps_padded']:.2f} TB/s)" if r.get('tbps_padded') else ''
+            return f"{r['tbps']:.2f} TB/s < 2.5{pad}"
         return None
     if r['type'].startswith('conv') and r['tflops'] is not None and r['tflops'] < 0.10 * PEAK:
         return f"{r['tflops']:.0f} TFLOP/s < {0.10 * PEAK:.0f}"
@@ -52,9 +53,10 @@ def fmt_plan(j):
     out.append(f"   {'layer':>5} {'type':<14} {'cin':>4} {'cout':>4} {'k':<6} {'s':<6} {'out':<12} {'us':>8} {'share':>6} {'TFLOP/s':>8} {'TB/s':>6}  kernel")
     for r in j.get('layers', []):
         mark = '  <-- CLIFF: ' + is_cliff(r) if is_cliff(r) else ''
+        padded = f" [{r['tbps_padded']} TB/s as stored]" if r.get('tbps_padded') else ''
         out.append(f"   {r['layer']:>5} {r['type']:<14} {r['cin']:>4} {r['cout']:>4} {r['kernel']:<6} {r['stride']:<6} {r['out']:<12} "
                    f"{r['us']:>8.1f} {100 * r['share']:>5.1f}% {r['tflops'] if r['tflops'] is not None else '-':>8} "
-                   f"{r['tbps'] if r['tbps'] is not None else '-':>6}  {r['picked']}{mark}")
+                   f"{r['tbps'] if r['tbps'] is not None else '-':>6}  {r['picked']}{padded}{mark}")
     return out
 
 
